@@ -1,0 +1,45 @@
+"""Env / config registry with the reference's names (dial_mpc/envs/__init__.py:14-30 and the
+``brax_envs.register_environment`` calls at unitree_go2_env.py:806-808, unitree_h1_env.py:904-906)."""
+from typing import Any, Callable, Dict
+
+from dial_mpc_amd.envs.unitree_go2_env import (
+    UnitreeGo2Env, UnitreeGo2EnvConfig, UnitreeGo2SeqJumpEnv, UnitreeGo2SeqJumpEnvConfig)
+from dial_mpc_amd.envs.unitree_h1_env import UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig
+
+_configs: Dict[str, Any] = {
+    "unitree_h1_walk": UnitreeH1WalkEnvConfig,
+    "unitree_go2_walk": UnitreeGo2EnvConfig,
+    "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnvConfig,
+}
+_envs: Dict[str, Callable] = {
+    "unitree_h1_walk": UnitreeH1WalkEnv,
+    "unitree_go2_walk": UnitreeGo2Env,
+    "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
+}
+# reference envs that are NEXT rows and not built yet
+_NOT_BUILT = ("unitree_h1_push_crate", "unitree_h1_loco", "unitree_go2_crate_climb", "allegro_reorient")
+
+
+def register_config(name: str, config: Any):
+    _configs[name] = config
+
+
+def get_config(name: str) -> Any:
+    if name not in _configs and name in _NOT_BUILT:
+        raise NotImplementedError(f"env {name!r} exists in the reference but has no HIP kernel yet")
+    return _configs[name]
+
+
+def register_environment(name: str, env_class: Callable):
+    """brax_envs.register_environment equivalent."""
+    _envs[name] = env_class
+
+
+def get_environment(env_name: str, **kwargs):
+    """brax_envs.get_environment equivalent (dial_core.py:221).  User-defined JAX envs cannot run on
+    the HIP path: unknown names raise instead of silently falling back to anything on the CPU."""
+    if env_name not in _envs:
+        if env_name in _NOT_BUILT:
+            raise NotImplementedError(f"env {env_name!r} exists in the reference but has no HIP kernel yet")
+        raise KeyError(f"unknown environment {env_name!r}; registered: {sorted(_envs)}")
+    return _envs[env_name](**kwargs)

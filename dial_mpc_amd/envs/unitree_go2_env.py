@@ -1,0 +1,155 @@
+"""Unitree Go2 environments: config dataclasses and task descriptions with the reference's
+constants (dial_mpc/envs/unitree_go2_env.py:25-124 walk/trot, :319-401,559-592 seq_jump).
+
+``reset`` / ``step`` execute in libdialhip.so; the reward formulas are in csrc/rollout_body.h
+(product) and oracle/dial_oracle.c (checker).  Crate-climb is a NEXT row."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Union
+
+import numpy as np
+
+from dial_mpc_amd import _abi
+from dial_mpc_amd.envs.base_env import BaseEnv, BaseEnvConfig, System, load_model
+
+TASK_GO2_WALK = _abi.MACROS["DIAL_TASK_GO2_WALK"]
+TASK_GO2_SEQ_JUMP = _abi.MACROS["DIAL_TASK_GO2_SEQ_JUMP"]
+
+
+@dataclass
+class UnitreeGo2EnvConfig(BaseEnvConfig):
+    kp: Union[float, Any] = 30.0
+    kd: Union[float, Any] = 0.0
+    default_vx: float = 1.0
+    default_vy: float = 0.0
+    default_vyaw: float = 0.0
+    ramp_up_time: float = 2.0
+    gait: str = "trot"
+
+
+class UnitreeGo2Env(BaseEnv):
+    task_kind = TASK_GO2_WALK
+
+    def __init__(self, config: UnitreeGo2EnvConfig):
+        super().__init__(config)
+        self._foot_radius = 0.0175
+        self._gait = config.gait
+        self._gait_phase = {  # unitree_go2_env.py:43-49
+            "stand": np.zeros(4),
+            "walk": np.array([0.0, 0.5, 0.75, 0.25]),
+            "trot": np.array([0.0, 0.5, 0.5, 0.0]),
+            "canter": np.array([0.0, 0.33, 0.33, 0.66]),
+            "gallop": np.array([0.0, 0.05, 0.4, 0.35]),
+        }
+        self._gait_params = {  # ratio, cadence, amplitude (:50-57)
+            "stand": np.array([1.0, 1.0, 0.0]),
+            "walk": np.array([0.75, 1.0, 0.08]),
+            "trot": np.array([0.45, 2, 0.08]),
+            "canter": np.array([0.4, 4, 0.06]),
+            "gallop": np.array([0.3, 3.5, 0.10]),
+        }
+        self._torso_idx = self.sys.mj_model.body_id("base")
+        self._init_q = self.sys.mj_model.keyframe("home").qpos
+        self._default_pose = self._init_q[7:]
+        self.joint_range = np.array(  # sampling range (:66-81)
+            [[-0.5, 0.5], [0.4, 1.4], [-2.3, -0.85],
+             [-0.5, 0.5], [0.4, 1.4], [-2.3, -0.85],
+             [-0.5, 0.5], [0.4, 1.4], [-2.3, -1.3],
+             [-0.5, 0.5], [0.4, 1.4], [-2.3, -1.3]])
+        feet_site = ["FL_foot", "FR_foot", "RL_foot", "RR_foot"]  # :82-87 (note: FL first)
+        self._feet_site_id = np.array([self.sys.mj_model.site_id(f) for f in feet_site])
+        self._init_pos_tar = np.array([0.282, 0.0, 0.3])  # :108
+        self._done_height = 0.18  # :247
+
+    def make_system(self, config: UnitreeGo2EnvConfig) -> System:
+        model = load_model("unitree_go2", "mjx_scene_force.xml")
+        return System(model).tree_replace({"opt.timestep": config.timestep})
+
+    def task_dict(self) -> Dict[str, Any]:
+        d = super().task_dict()
+        cfg = self._config
+        duty, cadence, amp = self._gait_params[self._gait]
+        d.update(
+            torso_x=self._torso_idx - 1, upright_x=0, nfeet=4, feet_site=self._feet_site_id,
+            foot_radius=self._foot_radius, gait_duty=duty, gait_cadence=cadence, gait_amp=amp,
+            gait_phase=self._gait_phase[self._gait],
+            cmd_vel=[cfg.default_vx, cfg.default_vy, 0.0], cmd_ang_vel=[0.0, 0.0, cfg.default_vyaw],
+            ramp_up_time=cfg.ramp_up_time, done_height=self._done_height,
+            init_pos_tar=self._init_pos_tar, n_stage=0, jump_dt=1.0,
+        )
+        return d
+
+
+@dataclass
+class UnitreeGo2SeqJumpEnvConfig(UnitreeGo2EnvConfig):
+    jump_dt: float = 1.0
+    contact_targets: Any = None
+    contact_target_radius: Any = None
+    pose_target_sequence: Any = None
+    yaw_target_sequence: Any = None
+
+
+def _euler_to_quat_deg(v):
+    """brax.math.euler_to_quat (degrees, intrinsic x-y'-z'')."""
+    c1, c2, c3 = np.cos(np.asarray(v) * np.pi / 360)
+    s1, s2, s3 = np.sin(np.asarray(v) * np.pi / 360)
+    return np.array([c1 * c2 * c3 - s1 * s2 * s3, s1 * c2 * c3 + c1 * s2 * s3,
+                     c1 * s2 * c3 - s1 * c2 * s3, c1 * c2 * s3 + s1 * s2 * c3])
+
+
+def _quat_to_3x3(q):
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+class UnitreeGo2SeqJumpEnv(UnitreeGo2Env):
+    task_kind = TASK_GO2_SEQ_JUMP
+
+    def __init__(self, config: UnitreeGo2SeqJumpEnvConfig = None):
+        config = config if config is not None else UnitreeGo2SeqJumpEnvConfig()
+        super().__init__(config)
+        if config.contact_targets is None or config.contact_target_radius is None:
+            (self._contact_targets, self._contact_target_radius, self._pose_target_sequence,
+             self._yaw_target_sequence) = UnitreeGo2SeqJumpEnv.generate_jumping_sequence(
+                np.asarray(config.pose_target_sequence, dtype=np.float64),
+                np.asarray(config.yaw_target_sequence, dtype=np.float64), 0.1)
+        else:
+            self._contact_targets = np.asarray(config.contact_targets, dtype=np.float64)
+            self._contact_target_radius = np.asarray(config.contact_target_radius, dtype=np.float64)
+            self._pose_target_sequence = np.asarray(config.pose_target_sequence, dtype=np.float64)
+            self._yaw_target_sequence = np.asarray(config.yaw_target_sequence, dtype=np.float64)
+        self.joint_range = np.array(  # unitree_go2_env.py:346-361
+            [[-0.5, 0.5], [0.4, 2.0], [-2.3, -1.3],
+             [-0.5, 0.5], [0.4, 2.0], [-2.3, -1.3],
+             [-0.5, 0.5], [0.4, 1.4], [-2.3, -1.3],
+             [-0.5, 0.5], [0.4, 1.4], [-2.3, -1.3]])
+        self._init_pos_tar = np.array([0.0, 0.0, 0.27])  # :369
+        self._done_height = 0.1  # :504
+
+    @staticmethod
+    def generate_jumping_sequence(com_pos, com_heading, foot_place_radius: float):
+        """unitree_go2_env.py:559-592 (foot order FR, FL, RR, RL = contact order)."""
+        com_pos = np.asarray(com_pos, dtype=np.float64)
+        n_steps = com_pos.shape[0]
+        assert n_steps == len(com_heading)
+        contact_target_radius = np.full((n_steps, 4), foot_place_radius)
+        contact_targets = []
+        for i in range(n_steps):
+            contact_target = np.repeat(com_pos[i][None], 4, axis=0)
+            offsets = np.array([[0.2, -0.135, 0.0], [0.2, 0.135, 0.0],
+                                [-0.2, -0.135, 0.0], [-0.2, 0.135, 0.0]])
+            R = _quat_to_3x3(_euler_to_quat_deg(np.array([0.0, 0.0, com_heading[i] * 180 / np.pi])))
+            contact_targets.append(contact_target + offsets @ R.T)
+        return (np.array(contact_targets), contact_target_radius, np.array(com_pos),
+                np.array(com_heading, dtype=np.float64))
+
+    def task_dict(self) -> Dict[str, Any]:
+        d = super().task_dict()
+        S = self._contact_targets.shape[0]
+        d.update(n_stage=S, jump_dt=self._config.jump_dt, contact_targets=self._contact_targets,
+                 contact_radius=self._contact_target_radius, pose_targets=self._pose_target_sequence,
+                 yaw_targets=self._yaw_target_sequence)
+        return d

@@ -1,0 +1,291 @@
+/*
+ * dial_mpc.h -- C ABI of the MI355X-native DIAL-MPC inner loop.
+ *
+ * This header is the single source of truth for
+ *   (1) the plain-old-data structs that describe a compiled robot model, an
+ *       environment task and the planner configuration, and
+ *   (2) the entry points of libdialhip.so (the HIP product path) and of
+ *       liboracle_f32/f64.so (the CPU oracle, test infrastructure only).
+ * dial_mpc_amd/_abi.py parses THIS file to build the ctypes mirrors, so a field
+ * added here is automatically visible from Python.  Keep the struct syntax
+ * simple: one field per line, `int32_t`/`float` only, array extents as DIAL_*
+ * macros or literals.
+ *
+ * Reference interfaces replaced (paths relative to LeCAR-Lab/dial-mpc):
+ *   dial_rollout        <- MBDPI.rollout_us_vmap      dial_mpc/core/dial_core.py:36-42,80-81
+ *   dial_reverse_once   <- MBDPI.reverse_once         dial_mpc/core/dial_core.py:103-145
+ *   dial_shift          <- MBDPI.shift                dial_mpc/core/dial_core.py:160-166
+ *   dial_env_step       <- BaseEnv/<Env>.step         dial_mpc/envs/unitree_go2_env.py:126-261,
+ *                                                     :403-521, dial_mpc/envs/unitree_h1_env.py:181-321
+ *   dial_env_reset      <- <Env>.reset + pipeline_init  dial_mpc/envs/unitree_go2_env.py:101-124
+ *   dial_model          <- brax System / mujoco MjModel built by BaseEnv.make_system
+ *                                                     dial_mpc/envs/base_env.py:15-29
+ *   dial_task           <- <Env>Config dataclasses    dial_mpc/envs/unitree_go2_env.py:25-33,
+ *                                                     dial_mpc/config/base_env_config.py:4-20
+ *   dial_cfg            <- DialConfig                 dial_mpc/core/dial_config.py:4-23
+ *
+ * All device pointers are plain `float*`/`const float*` into HBM owned by the
+ * caller (PyTorch-ROCm tensors via .data_ptr()); `stream` is a hipStream_t passed
+ * as void* so that this header has no HIP dependency.
+ */
+#ifndef DIAL_MPC_H
+#define DIAL_MPC_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- static capacity limits (all robots in the reference fit) --------------- */
+#define DIAL_MAX_BODY 24   /* incl. world body 0 (H1 walk: 21)                   */
+#define DIAL_MAX_JNT 24
+#define DIAL_MAX_Q 32
+#define DIAL_MAX_V 28      /* H1 walk: 25                                        */
+#define DIAL_MAX_U 20      /* H1 walk: 19                                        */
+#define DIAL_MAX_GEOM 8    /* collision geoms only                               */
+#define DIAL_MAX_SITE 8
+#define DIAL_MAX_CON 8     /* static contact list (Go2: 4, H1 walk: 4)           */
+#define DIAL_MAX_LIM 24    /* limited hinge joints                               */
+#define DIAL_MAX_FEET 4
+#define DIAL_MAX_STAGE 12  /* seq-jump stages                                    */
+#define DIAL_MAX_T 36      /* Hsample+1                                          */
+#define DIAL_MAX_NODE 10   /* Hnode+1                                            */
+#define DIAL_INFO_N 48     /* floats of env info in the packed state             */
+
+/* joint types (MuJoCo numbering) */
+#define DIAL_JNT_FREE 0
+#define DIAL_JNT_BALL 1
+#define DIAL_JNT_SLIDE 2
+#define DIAL_JNT_HINGE 3
+
+/* geom types (MuJoCo numbering, subset) */
+#define DIAL_GEOM_PLANE 0
+#define DIAL_GEOM_SPHERE 2
+#define DIAL_GEOM_CAPSULE 3
+
+/* static contact kinds */
+#define DIAL_CON_PLANE_SPHERE 0
+#define DIAL_CON_PLANE_CAPSULE_P 1 /* capsule end  +axis*halflen */
+#define DIAL_CON_PLANE_CAPSULE_N 2 /* capsule end  -axis*halflen */
+
+/* task kinds */
+#define DIAL_TASK_GO2_WALK 0
+#define DIAL_TASK_GO2_SEQ_JUMP 1
+#define DIAL_TASK_H1_WALK 2
+
+/* packed-state info slots (floats; integers are stored as exactly representable floats) */
+#define DIAL_INFO_STEP 0
+#define DIAL_INFO_POS_TAR 1      /* 3 */
+#define DIAL_INFO_VEL_TAR 4      /* 3 */
+#define DIAL_INFO_ANG_VEL_TAR 7  /* 3 */
+#define DIAL_INFO_YAW_TAR 10
+#define DIAL_INFO_LAST_CONTACT 11 /* 4 */
+#define DIAL_INFO_AIR_TIME 15     /* 4 */
+#define DIAL_INFO_STAGE 19
+#define DIAL_INFO_DONE 20
+#define DIAL_INFO_REWARD 21
+#define DIAL_INFO_LAST_CTRL 22    /* DIAL_MAX_U */
+
+/* error codes */
+#define DIAL_OK 0
+#define DIAL_ERR_ARG (-1)
+#define DIAL_ERR_HIP (-2)
+#define DIAL_ERR_UNSUPPORTED (-3)
+
+/* Compiled robot model: what mujoco.MjModel / brax System holds for the hot path.
+ * Produced by dial_mpc_amd/mjcf.py from the MJCF.  Body 0 is the world.          */
+typedef struct dial_model {
+  int32_t nq;
+  int32_t nv;
+  int32_t nu;
+  int32_t nbody;
+  int32_t njnt;
+  int32_t ngeom;
+  int32_t nsite;
+  int32_t ncon;
+  int32_t nlim;
+  int32_t nefc;
+  int32_t iterations;
+  int32_t ls_iterations;
+  int32_t eulerdamp;
+  int32_t cone;
+  float timestep;
+  float gravity[3];
+  float tolerance;
+  float ls_tolerance;
+  float impratio;
+  float meaninertia;
+  int32_t body_parent[DIAL_MAX_BODY];
+  int32_t body_jntadr[DIAL_MAX_BODY];
+  int32_t body_jntnum[DIAL_MAX_BODY];
+  int32_t body_dofadr[DIAL_MAX_BODY];
+  int32_t body_dofnum[DIAL_MAX_BODY];
+  int32_t body_depth[DIAL_MAX_BODY];
+  int32_t body_subtree_end[DIAL_MAX_BODY];
+  int32_t body_rootid[DIAL_MAX_BODY];
+  float body_pos[DIAL_MAX_BODY][3];
+  float body_quat[DIAL_MAX_BODY][4];
+  float body_ipos[DIAL_MAX_BODY][3];
+  float body_iquat[DIAL_MAX_BODY][4];
+  float body_mass[DIAL_MAX_BODY];
+  float body_inertia[DIAL_MAX_BODY][3];
+  float body_invweight0[DIAL_MAX_BODY][2];
+  int32_t jnt_type[DIAL_MAX_JNT];
+  int32_t jnt_qposadr[DIAL_MAX_JNT];
+  int32_t jnt_dofadr[DIAL_MAX_JNT];
+  int32_t jnt_bodyid[DIAL_MAX_JNT];
+  int32_t jnt_limited[DIAL_MAX_JNT];
+  float jnt_pos[DIAL_MAX_JNT][3];
+  float jnt_axis[DIAL_MAX_JNT][3];
+  float jnt_range[DIAL_MAX_JNT][2];
+  float jnt_solref[DIAL_MAX_JNT][2];
+  float jnt_solimp[DIAL_MAX_JNT][5];
+  float jnt_margin[DIAL_MAX_JNT];
+  float qpos0[DIAL_MAX_Q];
+  float key_qpos[DIAL_MAX_Q];
+  int32_t dof_bodyid[DIAL_MAX_V];
+  int32_t dof_jntid[DIAL_MAX_V];
+  int32_t dof_parentid[DIAL_MAX_V];
+  float dof_armature[DIAL_MAX_V];
+  float dof_damping[DIAL_MAX_V];
+  float dof_invweight0[DIAL_MAX_V];
+  int32_t geom_type[DIAL_MAX_GEOM];
+  int32_t geom_bodyid[DIAL_MAX_GEOM];
+  float geom_pos[DIAL_MAX_GEOM][3];
+  float geom_quat[DIAL_MAX_GEOM][4];
+  float geom_size[DIAL_MAX_GEOM][3];
+  int32_t site_bodyid[DIAL_MAX_SITE];
+  float site_pos[DIAL_MAX_SITE][3];
+  float site_quat[DIAL_MAX_SITE][4];
+  int32_t con_kind[DIAL_MAX_CON];
+  int32_t con_geom1[DIAL_MAX_CON];
+  int32_t con_geom2[DIAL_MAX_CON];
+  int32_t con_body1[DIAL_MAX_CON];
+  int32_t con_body2[DIAL_MAX_CON];
+  int32_t con_dim[DIAL_MAX_CON];
+  float con_friction[DIAL_MAX_CON][5];
+  float con_solref[DIAL_MAX_CON][2];
+  float con_solimp[DIAL_MAX_CON][5];
+  float con_margin[DIAL_MAX_CON];
+  int32_t lim_jnt[DIAL_MAX_LIM];
+  int32_t act_dofadr[DIAL_MAX_U];
+  int32_t act_qposadr[DIAL_MAX_U];
+  int32_t act_ctrllimited[DIAL_MAX_U];
+  int32_t act_isposition[DIAL_MAX_U];
+  float act_gear[DIAL_MAX_U];
+  float act_kp[DIAL_MAX_U];
+  float act_ctrlrange[DIAL_MAX_U][2];
+} dial_model;
+
+/* Environment task: <Env>Config + the constants the env classes hard-code.        */
+typedef struct dial_task {
+  int32_t kind;
+  int32_t n_frames;
+  int32_t position_control;
+  int32_t torso_x;
+  int32_t upright_x;
+  int32_t nfeet;
+  int32_t feet_site[DIAL_MAX_FEET];
+  int32_t n_stage;
+  float dt;
+  float action_scale;
+  float kp[DIAL_MAX_U];
+  float kd[DIAL_MAX_U];
+  float joint_range[DIAL_MAX_U][2];
+  float phys_range[DIAL_MAX_U][2];
+  float tau_range[DIAL_MAX_U][2];
+  float foot_radius;
+  float gait_duty;
+  float gait_cadence;
+  float gait_amp;
+  float gait_phase[DIAL_MAX_FEET];
+  float cmd_vel[3];
+  float cmd_ang_vel[3];
+  float ramp_up_time;
+  float done_height;
+  float jump_dt;
+  float contact_targets[DIAL_MAX_STAGE][4][3];
+  float contact_radius[DIAL_MAX_STAGE][4];
+  float pose_targets[DIAL_MAX_STAGE][3];
+  float yaw_targets[DIAL_MAX_STAGE];
+  float init_pos_tar[3];
+} dial_task;
+
+/* Planner configuration: DialConfig + the constant spline matrices
+ * W = node2u(I) [(Hsample+1) x (Hnode+1)] and V = u2node(I) [(Hnode+1) x (Hsample+1)]. */
+typedef struct dial_cfg {
+  int32_t Nsample;
+  int32_t Hsample;
+  int32_t Hnode;
+  float temp_sample;
+  float W[DIAL_MAX_T][DIAL_MAX_NODE];
+  float V[DIAL_MAX_NODE][DIAL_MAX_T];
+} dial_cfg;
+
+/* packed state: [qpos nq | qvel nv | qacc_warmstart nv | info DIAL_INFO_N] floats */
+static inline int dial_state_size(int nq, int nv) { return nq + 2 * nv + DIAL_INFO_N; }
+
+/* =============================== product C ABI (libdialhip.so) ================= */
+typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg); not thread-safe */
+
+/* host pointers; copies model/task/cfg to the device and allocates scratch for
+ * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable. */
+int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task,
+                const dial_cfg* cfg, int device);
+void dial_destroy(dial_ctx* ctx);
+const char* dial_last_error(const dial_ctx* ctx); /* ctx may be NULL: last global error */
+
+/* K3. Semantics of MBDPI.rollout_us_vmap (dial_core.py:80-81): B rollouts of T = Hsample+1
+ * env.steps from the SAME packed state.  us:[B,T,nu]; rewss:[B,T]; qss:[B,T,nq];
+ * qdss:[B,T,nv]; xposs:[B,T,(nbody-1)*3].  qss/qdss/xposs may be NULL.  All device ptrs. */
+int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, float* rewss,
+                 float* qss, float* qdss, float* xposs, void* stream);
+
+/* K1..K4. Semantics of MBDPI.reverse_once (dial_core.py:103-145) for the sample shard
+ * [n_begin, n_begin+n_local) of cfg.Nsample (single GPU: 0, Nsample); the mean trajectory is
+ * always rolled out as an extra sample.  eps:[n_local,Hnode+1,nu] standard-normal draws (the
+ * reference's jax.random.normal, passed as data); noise_scale:[ns] with ns = Hnode+1 or 1.
+ * Outputs: Ybar_out:[Hnode+1,nu], rews:[n_local+1] (last = mean trajectory), qbar:[T,nq],
+ * qdbar:[T,nv], xbar:[T,(nbody-1)*3]; with n_local < Nsample the *_out tensors hold this
+ * shard's partial (un-normalised) sums -- see dial_reverse_finish.                  */
+int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in,
+                      const float* noise_scale, int ns, const float* eps, float* Ybar_out,
+                      float* rews, float* qbar, float* qdbar, float* xbar, void* stream);
+
+/* Multi-GPU split of reverse_once: phase A rolls out this rank's shard and writes
+ * its per-sample mean rewards; the caller all-gathers rews over ranks; phase B forms the global
+ * weights redundantly on every rank and this rank's partial weighted sums, which the caller
+ * all-reduces (sum).  packed_out: [ (Hnode+1)*nu | T*nq | T*nv | T*(nbody-1)*3 ] floats.     */
+int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in,
+                       const float* noise_scale, int ns, const float* eps, int n_local,
+                       int with_mean, float* rews_local, void* stream);
+int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin,
+                      int n_local, int with_mean, float* packed_out, void* stream);
+
+/* K5. MBDPI.shift (dial_core.py:160-166): Y:[Hnode+1,nu] in place. */
+int dial_shift(dial_ctx* ctx, float* Y, void* stream);
+
+/* K6. env.step on the true state (B = 1), state updated in place; xpos_out:[(nbody-1)*3],
+ * xquat_out:[(nbody-1)*4], ctrl_out:[nu] optional (may be NULL).                    */
+int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_out,
+                  float* xquat_out, float* ctrl_out, void* stream);
+
+/* env.reset: state <- (qpos, qvel, zeros) followed by mjx.forward (pipeline_init), info
+ * initialised for the task.  qpos:[nq], qvel:[nv] device pointers.                  */
+int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* state,
+                   float* xpos_out, float* xquat_out, void* stream);
+
+/* timing hook for bench.py: average duration in ms of the last n launches of the rollout
+ * kernel, measured with hipEvents on the launch stream (enable with dial_set_timing).   */
+int dial_set_timing(dial_ctx* ctx, int enable);
+int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches);
+
+/* ABI self-description used by tests: sizeof of the three structs. */
+int dial_abi_sizes(int* model_bytes, int* task_bytes, int* cfg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIAL_MPC_H */
