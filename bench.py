@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the DIAL-MPC inner loop on MI355X.
+
+Workload (BASELINE.json `metric`): unitree_go2_trot, Nsample = 2048 per GPU, Hsample = 16, Hnode = 4.
+One "step" = one annealing iteration `MBDPI.reverse_once` (K1..K4: sample -> spline -> (N+1) x 17
+env.steps -> softmax -> weighted means) over synthetic Go2 states that are already resident in HBM.
+`value` = sample-rollouts/s over all ranks ((N_total + 1) rollouts per step; one rollout = Hsample+1
+env.steps).  Weak scaling: every GPU rolls out 2048 samples, N_total = 2048 * n_gpus (BASELINE config 5 is
+the 8-GPU instance of the same sharding with 8192 samples per GPU).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = rollout_kernel; achieved = ALGORITHMIC HBM bytes (356 B per
+                Go2 env.step = us in + reward,q,qd,x.pos out) x env.steps per launch / average launch
+                duration from hipEvents on the launch stream; peak 8000 GB/s.  The path is VALU/latency
+                bound, so the estimated fp32-VALU fraction is reported next to it.
+  cpu_baseline  the C oracle ("port": a CPU restatement, NOT the JAX reference -- JAX/Brax/MJX are not
+                installable) timed on the host cores of this box on a bounded sample of the same workload.
+  plan_latency_ms  p50/p95 of one control tick (env.step + shift + Ndiffuse x reverse_once) vs the 20 ms tick.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GO2_BYTES_PER_STEP = 356          # SURVEY 8d / BASELINE.md: 48 B in + 308 B out per env.step
+GO2_FLOP_PER_STEP = 6.0e4         # SURVEY 8d estimate (dense MJX formulation)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
+VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(example: str, N: int, H: int, budget_s: float = 12.0):
+    """Time the CPU oracle (kind = "port") on this box's host cores.  Test-infrastructure code is used
+    here ONLY as the reported baseline, never on the timed GPU path."""
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from conftest import seeded_inputs, setup_case
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+    o32.reverse_once(s0, Ybar, sigma, eps)                      # warm-up (thread pool, page faults)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        r = o32.reverse_once(s0, Ybar, sigma, eps)
+        Ybar = r["Ybar"]
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt * cores >= budget_s or reps >= 50:
+            break
+    return {"value": (N + 1) * reps / dt, "unit": "sample-rollouts/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x reverse_once(N={N}, H={H}) fp32 C oracle, OpenMP over samples, "
+                      f"{dt:.2f} s wall; not the JAX reference (not installable)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nsample-per-gpu", type=int, default=2048)
+    ap.add_argument("--hsample", type=int, default=16)
+    ap.add_argument("--example", default="unitree_go2_trot")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import yaml
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
+    from dial_mpc_amd.utils.io_utils import get_example_path
+
+    cfgd = yaml.safe_load(open(get_example_path(args.example + ".yaml")))
+    N_total = args.nsample_per_gpu * world
+    cfgd["Nsample"], cfgd["Hsample"] = N_total, args.hsample
+    dial_config, env_config, env = load_dial_and_env(cfgd)
+    mbdpi = MBDPI(dial_config, env)
+    dev = mbdpi.device
+    T, Hn1, nu = dial_config.Hsample + 1, dial_config.Hnode + 1, mbdpi.nu
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    from dial_mpc_amd.utils.synthetic import perturbed_state
+    states = [env.reset(0).packed]
+    for seed in range(7):
+        q, qd = perturbed_state(env, seed)
+        st, _, _ = mbdpi.ctx.env_reset(torch.as_tensor(q, dtype=torch.float32, device=dev),
+                                       torch.as_tensor(qd, dtype=torch.float32, device=dev))
+        states.append(st)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)                              # same stream on every rank: eps is the global array
+    eps_pool = [torch.randn((N_total, Hn1, nu), generator=gen, device=dev, dtype=torch.float32) for _ in range(4)]
+    sigma = mbdpi.sigma_control.clone()
+    Y = torch.zeros((Hn1, nu), dtype=torch.float32, device=dev)
+
+    def one_step(i, Y):
+        _, Y, info = mbdpi.reverse_once(states[i % len(states)], None, Y, sigma, eps=eps_pool[i % len(eps_pool)])
+        return Y
+
+    for i in range(args.warmup):
+        Y = one_step(i, Y)
+    mbdpi.ctx.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        Y = one_step(i, Y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    kernel_ms, launches = mbdpi.ctx.rollout_ms()
+    mbdpi.ctx.set_timing(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # ---- plan latency: one control tick = env.step + shift + Ndiffuse x reverse_once (dial_core.py:245-264)
+    lat = []
+    state = env.reset(0)
+    Yp = torch.zeros((Hn1, nu), dtype=torch.float32, device=dev)
+    for tick in range(args.ticks + 1):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        state = env.step(state, Yp[0])
+        Yp = mbdpi.shift(Yp)
+        for i in range(dial_config.Ndiffuse):
+            _, Yp, _ = mbdpi.reverse_once(state, None, Yp, sigma * dial_config.traj_diffuse_factor ** i,
+                                          eps=eps_pool[(tick + i) % len(eps_pool)])
+        torch.cuda.synchronize()
+        if tick > 0:
+            lat.append((time.perf_counter() - a) * 1e3)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    B_global = N_total + 1
+    value = B_global * args.steps / elapsed
+    n_local = mbdpi.n_local + 1                     # rollouts per launch on this rank (incl. the mean trajectory)
+    avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    alg_bytes = GO2_BYTES_PER_STEP * n_local * T
+    achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    valu_tflops = GO2_FLOP_PER_STEP * n_local * T / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    out = {
+        "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16", "value": value,
+        "unit": "sample-rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.example} reverse_once: Nsample={args.nsample_per_gpu}/GPU "
+                               f"(N_total={N_total}), Hsample={args.hsample}, Hnode={dial_config.Hnode}, "
+                               f"8 synthetic Go2 states (home + 7 perturbed), eps ~ N(0,1) resident in HBM",
+                   "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel",
+                     "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "path is fp32-VALU/latency bound (170 FLOP/B >> 20 FLOP/B machine balance)",
+                     "valu_tflops_est": valu_tflops, "valu_frac_est": valu_tflops / VALU_PEAK_TFLOPS},
+        "plan_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
+                            "ticks": len(lat), "tick_budget_ms": 20.0,
+                            "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.example, args.nsample_per_gpu, args.hsample)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

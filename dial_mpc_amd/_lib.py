@@ -1,0 +1,222 @@
+"""Loader and thin wrappers of libdialhip.so -- the HIP product path.
+
+There is deliberately NO fallback: if the shared library is missing, or no HIP device is present, the
+calls below raise.  Tensors are PyTorch-ROCm tensors used purely as HBM allocations; the kernels get
+raw device pointers and the current torch stream through the C ABI of include/dial_mpc.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+from dial_mpc_amd import _abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libdialhip.so")
+_SOURCES = ("dial_hip.hip", "rollout_driver.h", "rollout_body.h", "derived.h", "dmath.h", "wave.h")
+_lib = None
+
+
+class DialHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/dial_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in _SOURCES] + [_abi.HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH,
+           os.path.join(_CSRC, "dial_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DialHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is the only compute path; there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    lib.dial_create.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci]
+    lib.dial_destroy.argtypes = [vp]
+    lib.dial_destroy.restype = None
+    lib.dial_last_error.argtypes = [vp]
+    lib.dial_last_error.restype = ctypes.c_char_p
+    lib.dial_rollout.argtypes = [vp, fp, fp, ci, fp, fp, fp, fp, vp]
+    lib.dial_reverse_once.argtypes = [vp, fp, fp, fp, ci, fp, fp, fp, fp, fp, fp, vp]
+    lib.dial_shard_rollout.argtypes = [vp, fp, fp, fp, ci, fp, ci, ci, fp, vp]
+    lib.dial_shard_reduce.argtypes = [vp, fp, ci, ci, ci, ci, fp, vp]
+    lib.dial_shift.argtypes = [vp, fp, vp]
+    lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
+    lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
+    lib.dial_set_timing.argtypes = [vp, ci]
+    lib.dial_get_rollout_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci)]
+    lib.dial_abi_sizes.argtypes = [ctypes.POINTER(ci)] * 3
+    lib.dial_selftest.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    lib.dial_debug_scratch.argtypes = [vp] + [ctypes.POINTER(vp)] * 6
+    lib.dial_lds_bytes.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+EXPORTED = ("dial_create", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
+            "dial_shard_rollout", "dial_shard_reduce", "dial_shift", "dial_env_step", "dial_env_reset",
+            "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
+
+
+def _ptr(t) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32", "need contiguous float32 device tensors"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Context:
+    """One dial_ctx: (device, model, task, cfg).  Not thread-safe (C ABI contract)."""
+
+    def __init__(self, model: "_abi.DialModel", task: "_abi.DialTask", cfg: Optional["_abi.DialCfg"],
+                 device: Optional[int] = None):
+        import torch
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise DialHipError("no HIP device visible to PyTorch: the DIAL-MPC kernels only run on a GPU")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        self.model, self.task, self.cfg = model, task, cfg
+        self.nq, self.nv, self.nu, self.nbody = model.nq, model.nv, model.nu, model.nbody
+        self.nx = (model.nbody - 1) * 3
+        self.state_size = _abi.state_size(model.nq, model.nv)
+        h = ctypes.c_void_p()
+        rc = self.lib.dial_create(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
+                                  ctypes.addressof(cfg) if cfg is not None else None, self.device)
+        if rc != 0:
+            raise DialHipError(f"dial_create failed ({rc}): {self.lib.dial_last_error(None).decode()}")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dial_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise DialHipError(f"{what} failed ({rc}): {self.lib.dial_last_error(self.h).decode()}")
+
+    # ---- K6
+    def env_reset(self, qpos, qvel):
+        import torch
+        state = torch.zeros(self.state_size, dtype=torch.float32, device=self.torch_device)
+        xpos = torch.zeros((self.nbody - 1, 3), dtype=torch.float32, device=self.torch_device)
+        xquat = torch.zeros((self.nbody - 1, 4), dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.dial_env_reset(self.h, _ptr(qpos), _ptr(qvel), _ptr(state), _ptr(xpos), _ptr(xquat),
+                                            _stream()), "dial_env_reset")
+        return state, xpos, xquat
+
+    def env_step(self, state, action):
+        import torch
+        state = state.clone()
+        xpos = torch.zeros((self.nbody - 1, 3), dtype=torch.float32, device=self.torch_device)
+        xquat = torch.zeros((self.nbody - 1, 4), dtype=torch.float32, device=self.torch_device)
+        ctrl = torch.zeros(self.nu, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.dial_env_step(self.h, _ptr(state), _ptr(action), _ptr(xpos), _ptr(xquat), _ptr(ctrl),
+                                           _stream()), "dial_env_step")
+        return state, xpos, xquat, ctrl
+
+    # ---- K3
+    def rollout(self, state, us, want_states: bool = True):
+        import torch
+        B, T = us.shape[0], us.shape[1]
+        assert T == self.cfg.Hsample + 1 and us.shape[2] == self.nu
+        dev = self.torch_device
+        rewss = torch.empty((B, T), dtype=torch.float32, device=dev)
+        qss = torch.empty((B, T, self.nq), dtype=torch.float32, device=dev) if want_states else None
+        qdss = torch.empty((B, T, self.nv), dtype=torch.float32, device=dev) if want_states else None
+        xss = torch.empty((B, T, self.nx), dtype=torch.float32, device=dev) if want_states else None
+        self._check(self.lib.dial_rollout(self.h, _ptr(state), _ptr(us), B, _ptr(rewss), _ptr(qss), _ptr(qdss),
+                                          _ptr(xss), _stream()), "dial_rollout")
+        return rewss, qss, qdss, xss
+
+    # ---- K1..K4
+    def reverse_once(self, state, Ybar, noise_scale, eps, out=None):
+        import torch
+        cfg, dev = self.cfg, self.torch_device
+        N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1
+        assert tuple(eps.shape) == (N, Hn1, self.nu) and tuple(Ybar.shape) == (Hn1, self.nu)
+        ns = int(noise_scale.numel())
+        if out is None:
+            out = dict(Ybar=torch.empty((Hn1, self.nu), dtype=torch.float32, device=dev),
+                       rews=torch.empty(N + 1, dtype=torch.float32, device=dev),
+                       qbar=torch.empty((T, self.nq), dtype=torch.float32, device=dev),
+                       qdbar=torch.empty((T, self.nv), dtype=torch.float32, device=dev),
+                       xbar=torch.empty((T, self.nx), dtype=torch.float32, device=dev))
+        self._check(self.lib.dial_reverse_once(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale), ns, _ptr(eps),
+                                               _ptr(out["Ybar"]), _ptr(out["rews"]), _ptr(out["qbar"]),
+                                               _ptr(out["qdbar"]), _ptr(out["xbar"]), _stream()), "dial_reverse_once")
+        return out
+
+    def shard_rollout(self, state, Ybar, noise_scale, eps_local, n_local: int, with_mean: bool, rews_local):
+        ns = int(noise_scale.numel())
+        self._check(self.lib.dial_shard_rollout(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale), ns,
+                                                _ptr(eps_local) if n_local > 0 else None, n_local, int(with_mean),
+                                                _ptr(rews_local), _stream()), "dial_shard_rollout")
+
+    def shard_reduce(self, rews_all, n_total: int, n_begin: int, n_local: int, include_mean: bool, packed_out):
+        self._check(self.lib.dial_shard_reduce(self.h, _ptr(rews_all), n_total, n_begin, n_local, int(include_mean),
+                                               _ptr(packed_out), _stream()), "dial_shard_reduce")
+
+    def packed_size(self) -> int:
+        T, Hn1 = self.cfg.Hsample + 1, self.cfg.Hnode + 1
+        return Hn1 * self.nu + T * (self.nq + self.nv + self.nx)
+
+    # ---- K5
+    def shift(self, Y):
+        Y = Y.clone()
+        self._check(self.lib.dial_shift(self.h, _ptr(Y), _stream()), "dial_shift")
+        return Y
+
+    # ---- measurement
+    def set_timing(self, enable: bool):
+        self._check(self.lib.dial_set_timing(self.h, int(enable)), "dial_set_timing")
+
+    def rollout_ms(self):
+        tot, n = ctypes.c_double(0), ctypes.c_int(0)
+        self._check(self.lib.dial_get_rollout_ms(self.h, ctypes.byref(tot), ctypes.byref(n)), "dial_get_rollout_ms")
+        return tot.value, n.value
+
+    def debug_scratch(self):
+        """Host copies of the scratch tensors of the last reverse_once (tests only)."""
+        import numpy as np
+        import torch
+        ptrs = [ctypes.c_void_p() for _ in range(6)]
+        self._check(self.lib.dial_debug_scratch(self.h, *[ctypes.byref(p) for p in ptrs]), "dial_debug_scratch")
+        cfg = self.cfg
+        B, T, Hn1 = cfg.Nsample + 1, cfg.Hsample + 1, cfg.Hnode + 1
+        shapes = [(B, Hn1, self.nu), (B, T), (B, T, self.nq), (B, T, self.nv), (B, T, self.nx), (B,)]
+        names = ["Y0s", "rewss", "qss", "qdss", "xss", "weights"]
+        torch.cuda.synchronize()
+        hip = ctypes.CDLL("libamdhip64.so")
+        out = {}
+        for name, p, shp in zip(names, ptrs, shapes):
+            host = np.empty(shp, np.float32)
+            rc = hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), p, ctypes.c_size_t(host.nbytes), ctypes.c_int(2))
+            if rc != 0:
+                raise DialHipError(f"hipMemcpy of scratch {name} failed ({rc})")
+            out[name] = host
+        return out

@@ -1,0 +1,457 @@
+// dial_hip.hip -- gfx950 kernels and the C ABI of libdialhip.so (see include/dial_mpc.h).
+//
+// Kernels
+//   rollout_kernel   K1+K2+K3: one 64-lane workgroup (= one wavefront) per sample; per-sample state in
+//                    LDS, model/task constants through the scalar/vector caches, per-step outputs
+//                    streamed to HBM in the layout of MBDPI.rollout_us_vmap.
+//   weights_kernel   K4a: rew_bar, std, softmax over all N+1 mean rewards (one workgroup, fixed
+//                    reduction order => bit-identical on every GPU of a sharded run).
+//   wsum_*_kernel    K4b: weighted means of Y0s / q / qd / x.pos, two deterministic passes.
+//   shift_kernel     K5, env_step_kernel / env_reset_kernel  K6 (B = 1).
+// There is no CPU fallback: every entry point needs a HIP device and fails with DIAL_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rollout_driver.h"
+
+#define WSUM_CHUNKS 32
+
+// ------------------------------------------------------------------ kernels
+extern "C" __global__ void __launch_bounds__(64)
+rollout_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
+               const dial_derived* __restrict__ dv, const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x;
+  if (n >= B) return;
+  Ws s;
+  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  Wave w;
+  w.lane = threadIdx.x;
+  dial::rollout_sample(w, m, t, dv, cfg, s, io, n);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+env_step_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
+                const dial_derived* __restrict__ dv, float* state, const float* action, float* xpos_out,
+                float* xquat_out, float* ctrl_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Ws s;
+  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  Wave w;
+  w.lane = threadIdx.x;
+  dial::env_step_single(w, m, t, dv, s, state, action, xpos_out, xquat_out, ctrl_out);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+env_reset_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
+                 const dial_derived* __restrict__ dv, const float* qpos, const float* qvel, float* state,
+                 float* xpos_out, float* xquat_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Ws s;
+  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  Wave w;
+  w.lane = threadIdx.x;
+  dial::env_reset_single(w, m, t, dv, s, qpos, qvel, state, xpos_out, xquat_out);
+}
+
+// Deterministic block reduction helpers (256 threads).
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  float r = red[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = red[tid + o] > red[tid] ? red[tid + o] : red[tid];
+    __syncthreads();
+  }
+  float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// K4a (dial_core.py:121-128): rews [B] (last = mean trajectory) -> softmax weights [B].
+// logp0 = (rews - rew_bar) / std(rews) / temp; std is the population std over all B samples.
+extern "C" __global__ void __launch_bounds__(256)
+weights_kernel(const float* __restrict__ rews, int B, float temp, float* __restrict__ weights) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int n = tid; n < B; n += 256) acc += rews[n];
+  const float mean = block_sum256(acc, red) / (float)B;
+  acc = 0.f;
+  for (int n = tid; n < B; n += 256) { float d = rews[n] - mean; acc += d * d; }
+  const float stdv = sqrtf(block_sum256(acc, red) / (float)B);
+  const float rew_bar = rews[B - 1];
+  float mx = -INFINITY;
+  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; mx = l > mx ? l : mx; }
+  mx = block_max256(mx, red);
+  acc = 0.f;
+  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; acc += expf(l - mx); }
+  const float den = block_sum256(acc, red);
+  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; weights[n] = expf(l - mx) / den; }
+}
+
+// K4b (dial_core.py:132-135): out[c] = sum_n w[widx(n)] * X_seg[n][c] over the local samples.
+struct WsumSeg { const float* X; float* out; int C; int c0; };
+struct WsumArgs { WsumSeg seg[4]; int nseg, Ctot, n_rows, w_begin, mean_row, mean_widx; };
+
+extern "C" __global__ void __launch_bounds__(256)
+wsum_partial_kernel(WsumArgs a, const float* __restrict__ weights, float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.Ctot) return;
+  int sg = 0;
+  for (int k = 1; k < a.nseg; k++) if (c >= a.seg[k].c0) sg = k;
+  const float* X = a.seg[sg].X;
+  const int C = a.seg[sg].C, cl = c - a.seg[sg].c0;
+  const int chunk = blockIdx.y, per = (a.n_rows + WSUM_CHUNKS - 1) / WSUM_CHUNKS;
+  const int r0 = chunk * per, r1 = (r0 + per < a.n_rows) ? r0 + per : a.n_rows;
+  float acc = 0.f;
+  for (int r = r0; r < r1; r++) {
+    // rows [0, mean_row) are this shard's noisy samples -> weight index w_begin + r; the mean row (if
+    // present and included) uses mean_widx; a mean row that is not included has mean_widx < 0.
+    int wi = (r == a.mean_row) ? a.mean_widx : a.w_begin + r;
+    if (wi >= 0) acc += weights[wi] * X[(size_t)r * C + cl];
+  }
+  partial[(size_t)chunk * a.Ctot + c] = acc;
+}
+extern "C" __global__ void __launch_bounds__(256)
+wsum_final_kernel(WsumArgs a, const float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.Ctot) return;
+  int sg = 0;
+  for (int k = 1; k < a.nseg; k++) if (c >= a.seg[k].c0) sg = k;
+  float acc = 0.f;
+  for (int ch = 0; ch < WSUM_CHUNKS; ch++) acc += partial[(size_t)ch * a.Ctot + c];
+  if (a.seg[sg].out) a.seg[sg].out[c - a.seg[sg].c0] = acc;
+}
+
+// K5 (dial_core.py:160-166): u = W Y; u = roll(u,-1); u[-1] = 0; Y = V u.  One small workgroup.
+extern "C" __global__ void __launch_bounds__(64)
+shift_kernel(const dial_cfg* __restrict__ cfg, int nu, float* Y) {
+  __shared__ float u[DIAL_MAX_T * DIAL_MAX_U];
+  const int T = cfg->Hsample + 1, Hn1 = cfg->Hnode + 1;
+  for (int it = threadIdx.x; it < T * nu; it += 64) {
+    const int st = it / nu, a = it - st * nu;
+    float acc = 0.f;
+    if (st + 1 < T)
+      for (int k = 0; k < Hn1; k++) acc += cfg->W[st + 1][k] * Y[k * nu + a];
+    u[it] = acc;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < Hn1 * nu; it += 64) {
+    const int k = it / nu, a = it - k * nu;
+    float acc = 0.f;
+    for (int st = 0; st < T; st++) acc += cfg->V[k][st] * u[st * nu + a];
+    Y[it] = acc;
+  }
+}
+
+// wave primitive self-test: out[0] = DPP sum of lane ids, out[1] = shuffle sum, out[2] = max
+extern "C" __global__ void __launch_bounds__(64) selftest_kernel(float* out) {
+  float v = (float)threadIdx.x + 0.5f;
+  float a = dialwave::wave_sum_dpp(v), b = dialwave::wave_sum_shfl(v), c = dialwave::wave_max_shfl(v);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+}
+
+// ------------------------------------------------------------------ host side
+struct dial_ctx {
+  int device = 0;
+  dial_model hm;
+  dial_task ht;
+  dial_cfg hc;
+  dial_derived hd;
+  bool has_cfg = false;
+  dial_model* dmodel = nullptr;
+  dial_task* dtask = nullptr;
+  dial_cfg* dcfg = nullptr;
+  dial_derived* dder = nullptr;
+  int B_cap = 0, T = 0, Hn1 = 0, nx = 0;
+  float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
+  float *weights = nullptr, *partial = nullptr;
+  size_t lds_bytes = 0;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  std::string err;
+};
+
+static std::string g_err;
+
+static int fail(dial_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(ctx, DIAL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+extern "C" {
+
+const char* dial_last_error(const dial_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int dial_abi_sizes(int* a, int* b, int* c) {
+  if (a) *a = (int)sizeof(dial_model);
+  if (b) *b = (int)sizeof(dial_task);
+  if (c) *c = (int)sizeof(dial_cfg);
+  return DIAL_OK;
+}
+
+void dial_destroy(dial_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  void* ptrs[] = {ctx->dmodel, ctx->dtask, ctx->dcfg, ctx->dder, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
+                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  delete ctx;
+}
+
+int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device) {
+  if (!out || !model || !task) return fail(nullptr, DIAL_ERR_ARG, "dial_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, DIAL_ERR_HIP, "dial_create: no HIP device available (the HIP path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
+  if (model->eulerdamp) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: eulerdamp-enabled models are not supported");
+  if (model->cone != 0) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: only pyramidal cones are supported");
+  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_H1_WALK)
+    return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
+  if (model->nefc > 64 || model->nv > DIAL_MAX_V || model->nq + 2 * model->nv + DIAL_INFO_N > 4096)
+    return fail(nullptr, DIAL_ERR_ARG, "dial_create: model exceeds kernel capacities");
+  dial_ctx* ctx = new dial_ctx();
+  ctx->device = device;
+  ctx->hm = *model;
+  ctx->ht = *task;
+  int rc = dial_build_derived(model, &ctx->hd);
+  if (rc != DIAL_OK) { delete ctx; return fail(nullptr, rc, "dial_create: unsupported model topology"); }
+  ctx->lds_bytes = (size_t)ctx->hd.ws_words * sizeof(float);
+  ctx->nx = (model->nbody - 1) * 3;
+  HIP_TRY(ctx, hipSetDevice(device));
+  if (ctx->lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, DIAL_ERR_HIP, "dial_create: LDS workspace too large"); }
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->dmodel, sizeof(dial_model)));
+  HIP_TRY(ctx, hipMalloc(&ctx->dtask, sizeof(dial_task)));
+  HIP_TRY(ctx, hipMalloc(&ctx->dder, sizeof(dial_derived)));
+  HIP_TRY(ctx, hipMemcpy(ctx->dmodel, model, sizeof(dial_model), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->dder, &ctx->hd, sizeof(dial_derived), hipMemcpyHostToDevice));
+  if (cfg) {
+    if (cfg->Hsample + 1 > DIAL_MAX_T || cfg->Hnode + 1 > DIAL_MAX_NODE || cfg->Hnode < 2 || cfg->Nsample < 1) {
+      dial_destroy(ctx);
+      return fail(nullptr, DIAL_ERR_ARG, "dial_create: Hsample/Hnode/Nsample out of range");
+    }
+    ctx->hc = *cfg;
+    ctx->has_cfg = true;
+    ctx->B_cap = cfg->Nsample + 1;
+    ctx->T = cfg->Hsample + 1;
+    ctx->Hn1 = cfg->Hnode + 1;
+    const size_t B = ctx->B_cap, T = ctx->T;
+    HIP_TRY(ctx, hipMalloc(&ctx->dcfg, sizeof(dial_cfg)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dcfg, cfg, sizeof(dial_cfg), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&ctx->Y0s, sizeof(float) * B * ctx->Hn1 * model->nu));
+    HIP_TRY(ctx, hipMalloc(&ctx->rewss, sizeof(float) * B * T));
+    HIP_TRY(ctx, hipMalloc(&ctx->rews, sizeof(float) * B));
+    HIP_TRY(ctx, hipMalloc(&ctx->qss, sizeof(float) * B * T * model->nq));
+    HIP_TRY(ctx, hipMalloc(&ctx->qdss, sizeof(float) * B * T * model->nv));
+    HIP_TRY(ctx, hipMalloc(&ctx->xss, sizeof(float) * B * T * ctx->nx));
+    HIP_TRY(ctx, hipMalloc(&ctx->weights, sizeof(float) * B));
+    const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
+    HIP_TRY(ctx, hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
+  }
+  *out = ctx;
+  return DIAL_OK;
+}
+
+int dial_set_timing(dial_ctx* ctx, int enable) {
+  if (!ctx) return DIAL_ERR_ARG;
+  ctx->timing = enable != 0;
+  ctx->events_used = 0;
+  return DIAL_OK;
+}
+
+int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches) {
+  if (!ctx || !total_ms || !launches) return DIAL_ERR_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i < ctx->events_used; i++) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->events[i].second));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int)ctx->events_used;
+  ctx->events_used = 0;
+  return DIAL_OK;
+}
+
+static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipStream_t st) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) {
+    if (ctx->events_used == ctx->events.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(ctx, hipEventCreate(&a));
+      HIP_TRY(ctx, hipEventCreate(&b));
+      ctx->events.emplace_back(a, b);
+    }
+    e0 = ctx->events[ctx->events_used].first;
+    e1 = ctx->events[ctx->events_used].second;
+    ctx->events_used++;
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+  }
+  hipLaunchKernelGGL(rollout_kernel, dim3(B), dim3(64), ctx->lds_bytes, st, ctx->dmodel, ctx->dtask, ctx->dder,
+                     ctx->dcfg, io, B);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
+  return DIAL_OK;
+}
+
+int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, float* rewss, float* qss, float* qdss,
+                 float* xposs, void* stream) {
+  if (!ctx || !state || !us || !rewss || B < 1) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: bad argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: context was created without a dial_cfg");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dial::RolloutIO io{state, us, nullptr, nullptr, nullptr, 0, 0, ctx->T, ctx->Hn1, nullptr, rewss, nullptr, qss, qdss, xposs};
+  return launch_rollout(ctx, io, B, (hipStream_t)stream);
+}
+
+int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                       const float* eps, int n_local, int with_mean, float* rews_local, void* stream) {
+  if (!ctx || !state || !Ybar_in || !noise_scale || (!eps && n_local > 0) || !rews_local)
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: null argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: context was created without a dial_cfg");
+  if (ns != 1 && ns != ctx->Hn1) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: noise_scale must have 1 or Hnode+1 entries");
+  const int B = n_local + (with_mean ? 1 : 0);
+  if (n_local < 0 || B < 1 || B > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: shard larger than Nsample+1");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
+                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss};
+  return launch_rollout(ctx, io, B, (hipStream_t)stream);
+}
+
+static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_begin, int mean_row, int mean_widx,
+                       float* Yo, float* qo, float* qdo, float* xo, hipStream_t st) {
+  const dial_model& m = ctx->hm;
+  WsumArgs a;
+  const int T = ctx->T;
+  a.nseg = 4;
+  a.seg[0] = {ctx->Y0s, Yo, ctx->Hn1 * m.nu, 0};
+  a.seg[1] = {ctx->qss, qo, T * m.nq, a.seg[0].C};
+  a.seg[2] = {ctx->qdss, qdo, T * m.nv, a.seg[1].c0 + a.seg[1].C};
+  a.seg[3] = {ctx->xss, xo, T * ctx->nx, a.seg[2].c0 + a.seg[2].C};
+  a.Ctot = a.seg[3].c0 + a.seg[3].C;
+  a.n_rows = n_rows; a.w_begin = w_begin; a.mean_row = mean_row; a.mean_widx = mean_widx;
+  const int gx = (a.Ctot + 255) / 256;
+  hipLaunchKernelGGL(wsum_partial_kernel, dim3(gx, WSUM_CHUNKS), dim3(256), 0, st, a, weights, ctx->partial);
+  hipLaunchKernelGGL(wsum_final_kernel, dim3(gx), dim3(256), 0, st, a, (const float*)ctx->partial);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
+}
+
+int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin, int n_local, int with_mean,
+                      float* packed_out, void* stream) {
+  if (!ctx || !rews_all || !packed_out) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: null argument");
+  if (!ctx->has_cfg || n_total + 1 > ctx->B_cap * 64 || n_local + 1 > ctx->B_cap || n_begin < 0 || n_begin + n_local > n_total)
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: bad shard description");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  // global weights need n_total+1 floats; reuse ctx->weights when it fits, else fail loudly
+  if (n_total + 1 > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: create the context with Nsample = global sample count");
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  const dial_model& m = ctx->hm;
+  float* Yo = packed_out;
+  float* qo = Yo + ctx->Hn1 * m.nu;
+  float* qdo = qo + ctx->T * m.nq;
+  float* xo = qdo + ctx->T * m.nv;
+  // local rows: [0,n_local) noisy, row n_local = mean trajectory (always rolled out by dial_shard_rollout
+  // when requested there); it contributes to the partial sums only when with_mean != 0.
+  return launch_wsum(ctx, ctx->weights, n_local + 1, n_begin, n_local, with_mean ? n_total : -1, Yo, qo, qdo, xo, st);
+}
+
+int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                      const float* eps, float* Ybar_out, float* rews, float* qbar, float* qdbar, float* xbar,
+                      void* stream) {
+  if (!ctx || !Ybar_out || !rews) return fail(ctx, DIAL_ERR_ARG, "dial_reverse_once: null argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_reverse_once: context was created without a dial_cfg");
+  const int N = ctx->hc.Nsample;
+  int rc = dial_shard_rollout(ctx, state, Ybar_in, noise_scale, ns, eps, N, 1, rews, stream);
+  if (rc != DIAL_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
+  return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st);
+}
+
+int dial_shift(dial_ctx* ctx, float* Y, void* stream) {
+  if (!ctx || !Y) return fail(ctx, DIAL_ERR_ARG, "dial_shift: null argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_shift: context was created without a dial_cfg");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(shift_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const dial_cfg*)ctx->dcfg, ctx->hm.nu, Y);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
+}
+
+int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_out, float* xquat_out,
+                  float* ctrl_out, void* stream) {
+  if (!ctx || !state || !action) return fail(ctx, DIAL_ERR_ARG, "dial_env_step: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream, ctx->dmodel, ctx->dtask,
+                     ctx->dder, state, action, xpos_out, xquat_out, ctrl_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
+}
+
+int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* state, float* xpos_out,
+                   float* xquat_out, void* stream) {
+  if (!ctx || !state || !qpos || !qvel) return fail(ctx, DIAL_ERR_ARG, "dial_env_reset: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(env_reset_kernel, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream, ctx->dmodel, ctx->dtask,
+                     ctx->dder, qpos, qvel, state, xpos_out, xquat_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
+}
+
+// Internal diagnostics (not part of the public header): wave primitive self-test and the scratch
+// tensors of the last reverse_once, used by the GPU parity tests for stage-wise comparison.
+int dial_selftest(float* out3_host) {
+  float* d = nullptr;
+  if (hipMalloc(&d, 3 * sizeof(float)) != hipSuccess) return DIAL_ERR_HIP;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+  hipError_t e = hipMemcpy(out3_host, d, 3 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
+}
+int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, float** qdss, float** xss, float** weights) {
+  if (!ctx) return DIAL_ERR_ARG;
+  if (Y0s) *Y0s = ctx->Y0s;
+  if (rewss) *rewss = ctx->rewss;
+  if (qss) *qss = ctx->qss;
+  if (qdss) *qdss = ctx->qdss;
+  if (xss) *xss = ctx->xss;
+  if (weights) *weights = ctx->weights;
+  return DIAL_OK;
+}
+int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_bytes : -1; }
+
+}  // extern "C"

@@ -1,0 +1,842 @@
+// rollout_body.h -- one env.step (PD control -> rigid-body physics step -> reward) executed by ONE
+// wavefront on LDS-resident state, written as lane-parallel phases (see wave.h).
+//
+// This is the product restatement of the reference's hot loop
+//     rollout_us -> env.step -> pipeline_step                dial_mpc/core/dial_core.py:36-42
+//     UnitreeGo2Env.step / SeqJumpEnv.step / UnitreeH1WalkEnv.step
+//                                                           dial_mpc/envs/unitree_go2_env.py:126-261,403-521
+//                                                           dial_mpc/envs/unitree_h1_env.py:181-321
+//     BaseEnv.act2joint / act2tau                            dial_mpc/envs/base_env.py:38-66
+// with the third-party physics (brax -> mujoco.mjx.step, not in the reference tree) re-designed for a
+// 64-lane wavefront: every stage below names the MJX function whose result it reproduces.
+//
+// The file compiles for gfx950 (hipcc) and, with -DDIAL_EMU, for the host wave emulator used by the
+// tests (tests/wave_emu).  Model / task / derived tables are read straight from global memory (they
+// are a few KB shared by every wavefront, i.e. L1/K$-resident); all per-sample state lives in LDS.
+#pragma once
+#include "derived.h"
+#include "dmath.h"
+
+#define MJ_MINVAL 1e-15f
+#define MJ_MINIMP 0.0001f
+#define MJ_MAXIMP 0.9999f
+#define DIAL_PI 3.14159265358979323846f
+
+namespace dial {
+
+// ---------------------------------------------------------------- constraint rows (implicit J)
+// Row r < nlim is a joint-limit row (J = lsign * e_dof); the other rows are pyramid edges of contact
+// c = (r - nlim) / 4: J = Jn + f * Jt with f = +-friction (constraint._instantiate_contact).
+struct RowRef { int is_lim, dof, c, tan; float f; };
+DIAL_DEV RowRef row_ref(const dial_model* m, int r) {
+  RowRef rr;
+  rr.is_lim = r < m->nlim;
+  if (rr.is_lim) {
+    rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
+    rr.c = 0; rr.tan = 0; rr.f = 0.f;
+  } else {
+    int e = (r - m->nlim) & 3;
+    rr.c = (r - m->nlim) >> 2;
+    rr.tan = 1 + (e >> 1);
+    float mu = m->con_friction[rr.c][rr.tan - 1];
+    rr.f = (e & 1) ? -mu : mu;
+    rr.dof = 0;
+  }
+  return rr;
+}
+DIAL_DEV float row_dot(const dial_model* m, const Ws& s, int r, const float* v) {
+  RowRef rr = row_ref(m, r);
+  if (rr.is_lim) return s.lsign[r] * v[rr.dof];
+  int nv = m->nv;
+  const float* jn = s.Jc + (rr.c * 3) * nv;
+  const float* jt = s.Jc + (rr.c * 3 + rr.tan) * nv;
+  float acc = 0.f;
+  for (int i = 0; i < nv; i++) acc += (jn[i] + jt[i] * rr.f) * v[i];
+  return acc;
+}
+// (J^T f)_i
+DIAL_DEV float jt_dot(const dial_model* m, const dial_derived* dv, const Ws& s, int i, const float* f) {
+  int nv = m->nv, nl = m->nlim;
+  float acc = 0.f;
+  int lr = dv->dof_limrow[i];
+  if (lr >= 0) acc += s.lsign[lr] * f[lr];
+  for (int c = 0; c < m->ncon; c++) {
+    float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
+    float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+    const float* fc = f + nl + 4 * c;
+    acc += (jn + j1 * mu1) * fc[0];
+    acc += (jn - j1 * mu1) * fc[1];
+    acc += (jn + j2 * mu2) * fc[2];
+    acc += (jn - j2 * mu2) * fc[3];
+  }
+  return acc;
+}
+DIAL_DEV float msym(const Ws& s, int nv, int i, int j) { return i >= j ? s.M[i * nv + j] : s.M[j * nv + i]; }
+
+// ---------------------------------------------------------------- dense Cholesky solve, fused
+// Left-looking Cholesky of the lower triangle of A (n x n, ld = n) into Lo, one phase per column; the
+// forward substitution of `rhs` is fused into the same phases (item i owns L[i][k] and rhs[i]), then n
+// phases of column-oriented back substitution.  On return x = A^-1 rhs0; rhs and ysol are clobbered.
+template <class W>
+DIAL_DEV void chol_solve(W& w, int n, const float* A, float* Lo, float* rhs, float* y, float* x) {
+  for (int k = 0; k < n; k++) {
+    w.items(n - k, [&](int idx) {
+      int i = k + idx;
+      float sik = A[i * n + k], dkk = A[k * n + k];
+      for (int p = 0; p < k; p++) {
+        float lkp = Lo[k * n + p];
+        sik -= Lo[i * n + p] * lkp;
+        dkk -= lkp * lkp;
+      }
+      float lkk = DM_SQRT(dkk);
+      float yk = rhs[k] / lkk;
+      if (i == k) {
+        Lo[k * n + k] = lkk;
+        y[k] = yk;
+      } else {
+        float lik = sik / lkk;
+        Lo[i * n + k] = lik;
+        rhs[i] -= lik * yk;
+      }
+    });
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    w.items(k + 1, [&](int i) {
+      float xk = y[k] / Lo[k * n + k];
+      if (i == k) x[k] = xk;
+      else y[i] -= Lo[k * n + i] * xk;
+    });
+  }
+}
+// triangular solves only (factor already in Lo): x = (L L^T)^-1 rhs
+template <class W>
+DIAL_DEV void chol_resolve(W& w, int n, const float* Lo, float* rhs, float* y, float* x) {
+  for (int k = 0; k < n; k++) {
+    w.items(n - k, [&](int idx) {
+      int i = k + idx;
+      float yk = rhs[k] / Lo[k * n + k];
+      if (i == k) y[k] = yk;
+      else rhs[i] -= Lo[i * n + k] * yk;
+    });
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    w.items(k + 1, [&](int i) {
+      float xk = y[k] / Lo[k * n + k];
+      if (i == k) x[k] = xk;
+      else y[i] -= Lo[k * n + i] * xk;
+    });
+  }
+}
+
+// ---------------------------------------------------------------- constraint._kbi
+DIAL_DEV void kbi(const dial_model* m, const float* solref, const float* solimp, float pos, float& k, float& b,
+                  float& imp) {
+  float timeconst = dm::fmaxf_(solref[0], 2.f * m->timestep), dampratio = solref[1];
+  float dmin = dm::clip(solimp[0], MJ_MINIMP, MJ_MAXIMP), dmax = dm::clip(solimp[1], MJ_MINIMP, MJ_MAXIMP);
+  float width = dm::fmaxf_(MJ_MINVAL, solimp[2]), mid = dm::clip(solimp[3], MJ_MINIMP, MJ_MAXIMP);
+  float power = dm::fmaxf_(1.f, solimp[4]);
+  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  b = 2.f / (dmax * timeconst);
+  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0.f) b = -solref[1] / dmax;
+  float x = dm::absf(pos) / width;
+  float ia = (1.f / DM_POW(mid, power - 1.f)) * DM_POW(x, power);
+  float ib = 1.f - (1.f / DM_POW(1.f - mid, power - 1.f)) * DM_POW(1.f - x, power);
+  float yv = x < mid ? ia : ib;
+  float im = dmin + yv * (dmax - dmin);
+  im = dm::clip(im, dmin, dmax);
+  if (x > 1.f) im = dmax;
+  imp = im;
+}
+
+// ================================================================ mjx.forward
+template <class W>
+DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const Ws& s) {
+  const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom, nsite = m->nsite, nc = m->ncon;
+  const int ne = m->nefc, nl = m->nlim;
+
+  // ---- smooth.kinematics: level-synchronous sweep over the body tree
+  for (int d = 1; d <= dv->nlevel; d++) {
+    const int b0 = dv->lvl_start[d - 1];
+    w.items(dv->lvl_start[d] - b0, [&](int idx) {
+      const int b = dv->lvl_body[b0 + idx], p = m->body_parent[b];
+      float pq[4] = {s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+      float bp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
+      float bq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+      float pos[3], quat[4];
+      dm::rotate(pos, bp, pq);
+      for (int k = 0; k < 3; k++) pos[k] += s.xpos[3 * p + k];
+      dm::quat_mul(quat, pq, bq);
+      for (int ji = m->body_jntadr[b]; ji < m->body_jntadr[b] + m->body_jntnum[b]; ji++) {
+        const int qa = m->jnt_qposadr[ji];
+        float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+        float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+        if (m->jnt_type[ji] == DIAL_JNT_FREE) {
+          for (int k = 0; k < 3; k++) { pos[k] = s.qpos[qa + k]; s.xanchor[3 * ji + k] = pos[k]; }
+          s.xaxis[3 * ji] = 0.f; s.xaxis[3 * ji + 1] = 0.f; s.xaxis[3 * ji + 2] = 1.f;
+          for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
+          dm::normalize4(quat);
+          for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = quat[k];
+        } else {
+          float anchor[3], axis[3];
+          dm::rotate(anchor, jp, quat);
+          for (int k = 0; k < 3; k++) anchor[k] += pos[k];
+          dm::rotate(axis, ja, quat);
+          for (int k = 0; k < 3; k++) { s.xanchor[3 * ji + k] = anchor[k]; s.xaxis[3 * ji + k] = axis[k]; }
+          if (m->jnt_type[ji] == DIAL_JNT_HINGE) {
+            float qloc[4], t3[3];
+            dm::axis_angle_to_quat(qloc, ja, s.qpos[qa] - m->qpos0[qa]);
+            dm::quat_mul(quat, quat, qloc);
+            dm::rotate(t3, jp, quat);
+            for (int k = 0; k < 3; k++) pos[k] = anchor[k] - t3[k];
+          } else {
+            float disp = s.qpos[qa] - m->qpos0[qa];
+            for (int k = 0; k < 3; k++) pos[k] += axis[k] * disp;
+          }
+        }
+      }
+      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = pos[k];
+      for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = quat[k];
+    });
+  }
+  // ---- local_to_global for inertial frames, geoms and sites
+  w.items(nb + ng + nsite, [&](int it) {
+    if (it < nb) {
+      const int b = it;
+      float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      float mat[9], t3[3], qi[4];
+      dm::quat_to_mat(mat, q);
+      for (int k = 0; k < 9; k++) s.xmat[9 * b + k] = mat[k];
+      float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
+      float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+      dm::rotate(t3, ip, q);
+      for (int k = 0; k < 3; k++) s.xipos[3 * b + k] = s.xpos[3 * b + k] + t3[k];
+      dm::quat_mul(qi, q, iq);
+      dm::quat_to_mat(mat, qi);
+      for (int k = 0; k < 9; k++) s.ximat[9 * b + k] = mat[k];
+    } else if (it < nb + ng) {
+      const int g = it - nb, b = m->geom_bodyid[g];
+      float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      float gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]};
+      float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
+      float t3[3], qg[4], mat[9];
+      dm::rotate(t3, gp, q);
+      for (int k = 0; k < 3; k++) s.gpos[3 * g + k] = s.xpos[3 * b + k] + t3[k];
+      dm::quat_mul(qg, q, gq);
+      dm::quat_to_mat(mat, qg);
+      s.gaxis[3 * g] = mat[2]; s.gaxis[3 * g + 1] = mat[5]; s.gaxis[3 * g + 2] = mat[8];
+    } else {
+      const int si = it - nb - ng, b = m->site_bodyid[si];
+      float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      float sp[3] = {m->site_pos[si][0], m->site_pos[si][1], m->site_pos[si][2]}, t3[3];
+      dm::rotate(t3, sp, q);
+      for (int k = 0; k < 3; k++) s.spos[3 * si + k] = s.xpos[3 * b + k] + t3[k];
+    }
+  });
+  // ---- smooth.com_pos: subtree COM of every kinematic-tree root (stored at the root's index)
+  w.items(3 * nb, [&](int it) {
+    const int b = it / 3, k = it - 3 * b;
+    if (b == 0 || m->body_parent[b] != 0) return;
+    float mp = 0.f, ms = 0.f;
+    for (int d = m->body_subtree_end[b] - 1; d >= b; d--) {
+      mp += s.xipos[3 * d + k] * m->body_mass[d];
+      ms += m->body_mass[d];
+    }
+    s.com[3 * b + k] = ms < MJ_MINVAL ? s.xipos[3 * b + k] : mp / ms;
+  });
+  // ---- cinert (per body) and cdof (per joint)
+  w.items(nb + nj, [&](int it) {
+    if (it < nb) {
+      const int b = it;
+      float* ci = s.cinert + 10 * b;
+      if (b == 0) { for (int k = 0; k < 10; k++) ci[k] = 0.f; return; }
+      const float* c = s.com + 3 * m->body_rootid[b];
+      const float* R = s.ximat + 9 * b;
+      float off[3] = {s.xipos[3 * b] - c[0], s.xipos[3 * b + 1] - c[1], s.xipos[3 * b + 2] - c[2]};
+      float mb = m->body_mass[b], oo = dm::dot3(off, off);
+      float in0 = m->body_inertia[b][0], in1 = m->body_inertia[b][1], in2 = m->body_inertia[b][2];
+      const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+      for (int e = 0; e < 6; e++) {
+        int i = ii[e], j = jj[e];
+        float v = R[3 * i] * in0 * R[3 * j] + R[3 * i + 1] * in1 * R[3 * j + 1] + R[3 * i + 2] * in2 * R[3 * j + 2];
+        float hh = (i == j ? oo : 0.f) - off[i] * off[j];
+        ci[e] = v + hh * mb;
+      }
+      ci[6] = off[0] * mb; ci[7] = off[1] * mb; ci[8] = off[2] * mb; ci[9] = mb;
+    } else {
+      const int ji = it - nb, b = m->jnt_bodyid[ji], da = m->jnt_dofadr[ji];
+      const float* c = s.com + 3 * m->body_rootid[b];
+      float off[3] = {c[0] - s.xanchor[3 * ji], c[1] - s.xanchor[3 * ji + 1], c[2] - s.xanchor[3 * ji + 2]};
+      if (m->jnt_type[ji] == DIAL_JNT_FREE) {
+        for (int i = 0; i < 3; i++)
+          for (int k = 0; k < 6; k++) s.cdof[6 * (da + i) + k] = (k == 3 + i) ? 1.f : 0.f;
+        for (int i = 0; i < 3; i++) {
+          float a[3] = {s.xmat[9 * b + i], s.xmat[9 * b + 3 + i], s.xmat[9 * b + 6 + i]}, cr[3];
+          dm::cross3(cr, a, off);
+          for (int k = 0; k < 3; k++) { s.cdof[6 * (da + 3 + i) + k] = a[k]; s.cdof[6 * (da + 3 + i) + 3 + k] = cr[k]; }
+        }
+      } else if (m->jnt_type[ji] == DIAL_JNT_HINGE) {
+        float ax[3] = {s.xaxis[3 * ji], s.xaxis[3 * ji + 1], s.xaxis[3 * ji + 2]}, cr[3];
+        dm::cross3(cr, ax, off);
+        for (int k = 0; k < 3; k++) { s.cdof[6 * da + k] = ax[k]; s.cdof[6 * da + 3 + k] = cr[k]; }
+      } else {
+        for (int k = 0; k < 3; k++) { s.cdof[6 * da + k] = 0.f; s.cdof[6 * da + 3 + k] = s.xaxis[3 * ji + k]; }
+      }
+    }
+  });
+  // ---- smooth.com_vel: cvel[b] = sum over ancestor dofs (root first), no recursion needed
+  w.items(6 * nb, [&](int it) {
+    const int b = it / 6, k = it - 6 * b;
+    float acc = 0.f;
+    unsigned mask = dv->body_ancmask[b];
+    for (int i = 0; i < nv; i++)
+      if ((mask >> i) & 1u) acc += s.cdof[6 * i + k] * s.qvel[i];
+    s.cvel[6 * b + k] = acc;
+  });
+  // ---- cdof_dot (per dof): motion_cross(velocity accumulated BEFORE this joint, cdof)
+  w.items(nv, [&](int i) {
+    const int ji = m->dof_jntid[i], b = m->dof_bodyid[i], p = m->body_parent[b], da = m->jnt_dofadr[ji];
+    float* out = s.cdofdot + 6 * i;
+    if (m->jnt_type[ji] == DIAL_JNT_FREE && i < da + 3) { for (int k = 0; k < 6; k++) out[k] = 0.f; return; }
+    float vs[6];
+    for (int k = 0; k < 6; k++) vs[k] = s.cvel[6 * p + k];
+    const int jend = (m->jnt_type[ji] == DIAL_JNT_FREE) ? da + 3 : da;
+    for (int j = m->body_dofadr[b]; j < jend; j++)
+      for (int k = 0; k < 6; k++) vs[k] += s.cdof[6 * j + k] * s.qvel[j];
+    float cd[6];
+    for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+    dm::motion_cross(out, vs, cd);
+  });
+  // ---- smooth.rne forward part: cacc[b] = [0,-g] + sum over ancestor dofs cdof_dot*qvel
+  w.items(6 * nb, [&](int it) {
+    const int b = it / 6, k = it - 6 * b;
+    float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
+    unsigned mask = dv->body_ancmask[b];
+    for (int i = 0; i < nv; i++)
+      if ((mask >> i) & 1u) acc += s.cdofdot[6 * i + k] * s.qvel[i];
+    s.cacc[6 * b + k] = acc;
+  });
+  // ---- smooth.crb composite inertias (subtree sums) | rne local body forces
+  w.items(11 * nb, [&](int it) {
+    if (it < 10 * nb) {
+      const int b = it / 10, k = it - 10 * b;
+      float acc = 0.f;
+      if (b > 0)
+        for (int d = m->body_subtree_end[b] - 1; d >= b; d--) acc += s.cinert[10 * d + k];
+      s.crb[10 * b + k] = acc;
+    } else {
+      const int b = it - 10 * nb;
+      float ci[10], ca[6], cv[6], f1[6], f2[6], f3[6];
+      for (int k = 0; k < 10; k++) ci[k] = s.cinert[10 * b + k];
+      for (int k = 0; k < 6; k++) { ca[k] = s.cacc[6 * b + k]; cv[k] = s.cvel[6 * b + k]; }
+      dm::inert_mul(f1, ci, ca);
+      dm::inert_mul(f2, ci, cv);
+      dm::motion_cross_force(f3, cv, f2);
+      for (int k = 0; k < 6; k++) s.cfl[6 * b + k] = f1[k] + f3[k];
+    }
+  });
+  // ---- F_i = crb[body_i] * cdof_i | cfrc subtree sums (rne backward part)
+  w.items(nv + 6 * nb, [&](int it) {
+    if (it < nv) {
+      const int i = it, b = m->dof_bodyid[i];
+      float ci[10], cd[6], f[6];
+      for (int k = 0; k < 10; k++) ci[k] = s.crb[10 * b + k];
+      for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+      dm::inert_mul(f, ci, cd);
+      for (int k = 0; k < 6; k++) s.Fd[6 * i + k] = f[k];
+    } else {
+      const int b = (it - nv) / 6, k = (it - nv) - 6 * b;
+      float acc = 0.f;
+      for (int d = m->body_subtree_end[b] - 1; d >= b; d--) acc += s.cfl[6 * d + k];
+      s.cfrc[6 * b + k] = acc;
+    }
+  });
+  // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
+  //      | collision_driver (static contact list)
+  w.items(dv->ntri + nv + nc, [&](int it) {
+    if (it < dv->ntri) {
+      const int i = dv->tri[it] >> 8, j = dv->tri[it] & 0xff;
+      float v = 0.f;
+      if ((dv->dof_ancmask[i] >> j) & 1u) {
+        for (int k = 0; k < 6; k++) v += s.Fd[6 * i + k] * s.cdof[6 * j + k];
+      }
+      if (i == j) v += m->dof_armature[i];
+      s.M[i * nv + j] = v;
+    } else if (it < dv->ntri + nv) {
+      const int i = it - dv->ntri, b = m->dof_bodyid[i];
+      float bias = 0.f;
+      for (int k = 0; k < 6; k++) bias += s.cdof[6 * i + k] * s.cfrc[6 * b + k];
+      float passive = -m->dof_damping[i] * s.qvel[i];
+      float actf = 0.f;
+      const int a = dv->dof_act[i];
+      if (a >= 0) {
+        float c = s.ctrl[a];
+        if (m->act_ctrllimited[a]) c = dm::clip(c, m->act_ctrlrange[a][0], m->act_ctrlrange[a][1]);
+        float force = m->act_isposition[a] ? m->act_kp[a] * (c - s.qpos[m->act_qposadr[a]]) : c;
+        actf = m->act_gear[a] * force;
+      }
+      float qf = passive - bias + actf;
+      s.qfs[i] = qf;
+      s.rhs[i] = qf;
+    } else {
+      const int c = it - dv->ntri - nv, g1 = m->con_geom1[c], g2 = m->con_geom2[c];
+      float n[3] = {s.gaxis[3 * g1], s.gaxis[3 * g1 + 1], s.gaxis[3 * g1 + 2]};
+      float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
+      float radius = m->geom_size[g2][0];
+      float* fr = s.cframe + 9 * c;
+      if (m->con_kind[c] == DIAL_CON_PLANE_SPHERE) {
+        // collision_primitive make_frame(n)
+        float a[3] = {n[0], n[1], n[2]}, nn = DM_SQRT(dm::dot3(a, a));
+        for (int k = 0; k < 3; k++) a[k] /= nn;
+        float bb[3] = {0.f, 0.f, 0.f};
+        if (-0.5f < a[1] && a[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
+        float ab = dm::dot3(a, bb);
+        for (int k = 0; k < 3; k++) bb[k] -= a[k] * ab;
+        nn = DM_SQRT(dm::dot3(bb, bb));
+        for (int k = 0; k < 3; k++) bb[k] /= nn;
+        float cc[3];
+        dm::cross3(cc, a, bb);
+        for (int k = 0; k < 3; k++) { fr[k] = a[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
+      } else {
+        float axis[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]};
+        float na = dm::dot3(n, axis), bb[3];
+        for (int k = 0; k < 3; k++) bb[k] = axis[k] - n[k] * na;
+        float bn = DM_SQRT(dm::dot3(bb, bb));
+        if (bn < 0.5f) {
+          bb[0] = 0.f; bb[1] = 0.f; bb[2] = 0.f;
+          if (-0.5f < n[1] && n[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
+        } else {
+          for (int k = 0; k < 3; k++) bb[k] /= bn;
+        }
+        float cc[3];
+        dm::cross3(cc, n, bb);
+        for (int k = 0; k < 3; k++) { fr[k] = n[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
+        float sgn = m->con_kind[c] == DIAL_CON_PLANE_CAPSULE_P ? 1.f : -1.f, hl = m->geom_size[g2][1];
+        for (int k = 0; k < 3; k++) ctr[k] += sgn * axis[k] * hl;
+      }
+      float diff[3] = {ctr[0] - s.gpos[3 * g1], ctr[1] - s.gpos[3 * g1 + 1], ctr[2] - s.gpos[3 * g1 + 2]};
+      float dist = dm::dot3(diff, n) - radius;
+      s.cdist[c] = dist;
+      for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = ctr[k] - n[k] * (radius + 0.5f * dist);
+    }
+  });
+  // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
+  w.items(nc * nv, [&](int it) {
+    const int c = it / nv, i = it - c * nv;
+    const int b1 = m->con_body1[c], b2 = m->con_body2[c];
+    float cd[6];
+    for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+    float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
+    float diff[3] = {0.f, 0.f, 0.f};
+    if ((dv->body_ancmask[b2] >> i) & 1u) {
+      const float* cm = s.com + 3 * m->body_rootid[b2];
+      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
+      dm::cross3(cr, cd, off);
+      for (int k = 0; k < 3; k++) diff[k] += cd[3 + k] + cr[k];
+    }
+    if ((dv->body_ancmask[b1] >> i) & 1u) {
+      const float* cm = s.com + 3 * m->body_rootid[b1];
+      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
+      dm::cross3(cr, cd, off);
+      for (int k = 0; k < 3; k++) diff[k] -= cd[3 + k] + cr[k];
+    }
+    for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * c + 3 * a, diff);
+  });
+  // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
+  w.items(ne, [&](int r) {
+    if (r < nl) {
+      const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+      float q = s.qpos[qa];
+      float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+      float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+      float sgn = dist_min < dist_max ? 1.f : -1.f;
+      s.lsign[r] = sgn;
+      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+      float k_, b_, imp;
+      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
+      float vel = sgn * s.qvel[da];
+      s.aref[r] = -b_ * vel - k_ * imp * pos;
+      s.D[r] = 1.f / R;
+    } else {
+      const int c = (r - nl) >> 2;
+      s.lsign[r] = 0.f;
+      float pos = s.cdist[c] - m->con_margin[c];
+      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+      float t = m->body_invweight0[m->con_body1[c]][0] + m->body_invweight0[m->con_body2[c]][0];
+      float mu = m->con_friction[c][0];
+      float invweight = t + mu * mu * t;
+      invweight = invweight * 2.f * mu * mu / m->impratio;
+      float k_, b_, imp;
+      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
+      float R = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
+      float vel = row_dot(m, s, r, s.qvel);
+      s.aref[r] = -b_ * vel - k_ * imp * pos;
+      s.D[r] = 1.f / R;
+    }
+  });
+  // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
+  chol_solve(w, nv, s.M, s.L, s.rhs, s.ysol, s.qas);
+  if (ne == 0) {
+    w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
+    return;
+  }
+
+  // ================================================================ solver.solve (Newton)
+  // warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
+  w.items(2 * ne + 2 * nv, [&](int it) {
+    if (it < ne) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
+    else if (it < 2 * ne) s.JarefS[it - ne] = row_dot(m, s, it - ne, s.qas) - s.aref[it - ne];
+    else if (it < 2 * ne + nv) {
+      const int i = it - 2 * ne;
+      float acc = 0.f;
+      for (int j = 0; j < nv; j++) acc += msym(s, nv, i, j) * s.warm[j];
+      s.MaW[i] = acc;
+    } else {
+      const int i = it - 2 * ne - nv;
+      float acc = 0.f;
+      for (int j = 0; j < nv; j++) acc += msym(s, nv, i, j) * s.qas[j];
+      s.MaS[i] = acc;
+    }
+  });
+  float cw = w.sum(ne, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+  float gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
+  float cs = w.sum(ne, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+  float gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
+  const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
+  const bool use_warm = cost_w < cost_s;
+  w.items(ne + nv, [&](int it) {
+    if (it < ne) s.Jaref[it] = use_warm ? s.JarefW[it] : s.JarefS[it];
+    else {
+      const int i = it - ne;
+      s.qacc[i] = use_warm ? s.warm[i] : s.qas[i];
+      s.Ma[i] = use_warm ? s.MaW[i] : s.MaS[i];
+    }
+  });
+  float cost = use_warm ? cost_w : cost_s;
+  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
+  float prev_cost = INFINITY;
+  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+
+  // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
+  auto constraint_grad = [&]() {
+    w.items(ne, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
+    w.items(nv, [&](int i) {
+      float qc = jt_dot(m, dv, s, i, s.frc);
+      s.qfc[i] = qc;
+      float g = s.Ma[i] - s.qfs[i] - qc;
+      s.grad[i] = g;
+      s.rhs[i] = g;
+    });
+  };
+  // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
+  auto newton_dir = [&]() {
+    w.items(dv->ntri, [&](int it) {
+      const int i = dv->tri[it] >> 8, j = dv->tri[it] & 0xff;
+      float acc = 0.f;
+      if (i == j) {
+        int lr = dv->dof_limrow[i];
+        if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
+      }
+      for (int c = 0; c < nc; c++) {
+        const float* jn = s.Jc + (c * 3) * nv;
+        float jni = jn[i], jnj = jn[j];
+        float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
+        float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+        const int r0 = nl + 4 * c;
+        float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
+        float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
+        acc += ((jni + t1i * mu1) * d0) * (jnj + t1j * mu1);
+        acc += ((jni - t1i * mu1) * d1) * (jnj - t1j * mu1);
+        acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
+        acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
+      }
+      s.H[i * nv + j] = s.M[i * nv + j] + acc;
+    });
+    chol_solve(w, nv, s.H, s.L, s.rhs, s.ysol, s.search);  // M's factor in s.L is dead after qacc_smooth
+    w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
+  };
+
+  constraint_grad();
+  newton_dir();
+
+  int niter = 0;
+  for (;;) {
+    if (m->iterations != 1) {
+      float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
+      float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      bool done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+      if (done) break;
+    } else if (niter >= 1) {
+      break;
+    }
+    // ---------------- solver._linesearch
+    w.items(nv + ne, [&](int it) {
+      if (it < nv) {
+        float acc = 0.f;
+        for (int j = 0; j < nv; j++) acc += msym(s, nv, it, j) * s.search[j];
+        s.mv[it] = acc;
+      } else {
+        s.jv[it - nv] = row_dot(m, s, it - nv, s.search);
+      }
+    });
+    float sn2, s1, s2;
+    w.sum3(nv, [&](int i, float& a, float& b, float& c) {
+      float sv = s.search[i];
+      a = sv * sv; b = sv * s.Ma[i] - sv * s.qfs[i]; c = sv * s.mv[i];
+    }, sn2, s1, s2);
+    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
+    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
+    w.items(ne, [&](int r) {
+      float ja = s.Jaref[r], jvr = s.jv[r], dr = s.D[r];
+      s.quad[3 * r] = 0.5f * ja * ja * dr;
+      s.quad[3 * r + 1] = jvr * ja * dr;
+      s.quad[3 * r + 2] = 0.5f * jvr * jvr * dr;
+    });
+    struct LsPoint { float alpha, cost, d0, d1; };
+    auto ls_point = [&](float alpha) {
+      float q0, q1, q2;
+      w.sum3(ne, [&](int r, float& a, float& b, float& c) {
+        if (s.Jaref[r] + alpha * s.jv[r] < 0.f) { a = s.quad[3 * r]; b = s.quad[3 * r + 1]; c = s.quad[3 * r + 2]; }
+      }, q0, q1, q2);
+      q0 += qg0; q1 += qg1; q2 += qg2;
+      LsPoint p;
+      p.alpha = alpha;
+      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+      p.d0 = 2.f * alpha * q2 + q1;
+      p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      return p;
+    };
+    LsPoint p0 = ls_point(0.f);
+    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
+    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    bool swap = true;
+    int ls_iter = 0;
+    for (;;) {
+      bool done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      if (done) break;
+      LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
+      LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
+      LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
+      bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+      if (swap_lo_next) lo = lo_next;
+      bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+      if (swap_lo_mid) lo = mid;
+      bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+      if (swap_hi_next) hi = hi_next;
+      bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+      if (swap_hi_mid) hi = mid;
+      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      ls_iter++;
+    }
+    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    if (improved) {
+      w.items(nv + ne, [&](int it) {
+        if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }
+        else s.Jaref[it - nv] += s.jv[it - nv] * alpha;
+      });
+    }
+    // ---------------- _update_constraint + _update_gradient
+    constraint_grad();
+    float c2 = w.sum(ne, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
+    gauss = 0.5f * g2;
+    prev_cost = cost;
+    cost = 0.5f * c2 + gauss;
+    niter++;
+    // a new Newton direction is only consumed if another iteration will run
+    bool more;
+    if (m->iterations != 1) {
+      float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
+      float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      more = !(niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance);
+    } else {
+      more = false;
+    }
+    if (more) newton_dir();
+  }
+  w.items(nv, [&](int i) { s.warm[i] = s.qacc[i]; });
+}
+
+// ================================================================ forward.euler (eulerdamp disabled)
+template <class W>
+DIAL_DEV void euler(W& w, const dial_model* m, const Ws& s) {
+  const float dt = m->timestep;
+  w.items(m->nv, [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
+  w.items(m->njnt, [&](int ji) {
+    const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+    if (m->jnt_type[ji] == DIAL_JNT_FREE) {
+      for (int k = 0; k < 3; k++) s.qpos[qa + k] += dt * s.qvel[da + k];
+      float v[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
+      float nrm = DM_SQRT(dm::dot3(v, v)), axis[3] = {1.f, 0.f, 0.f}, qr[4], qn[4];
+      if (nrm > 0.f) { axis[0] = v[0] / nrm; axis[1] = v[1] / nrm; axis[2] = v[2] / nrm; }
+      dm::axis_angle_to_quat(qr, axis, dt * nrm);
+      float q0[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+      dm::quat_mul(qn, q0, qr);
+      dm::normalize4(qn);
+      for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = qn[k];
+    } else {
+      s.qpos[qa] += dt * s.qvel[da];
+    }
+  });
+}
+
+// ================================================================ env.step
+DIAL_DEV float foot_step_height(float tt, float footphase, float duty) {
+  const float two_pi = 2.f * DIAL_PI;
+  float x = tt + DIAL_PI - footphase;
+  float angle = x - two_pi * DM_FLOOR(x / two_pi) - DIAL_PI;
+  if (duty < 1.f) angle = angle * 0.5f / (1.f - duty);
+  float clipped = dm::clip(angle, -DIAL_PI / 2.f, DIAL_PI / 2.f);
+  float value = duty < 1.f ? DM_COS(clipped) : 0.f;
+  return dm::absf(value) >= 1e-6f ? dm::absf(value) : 0.f;
+}
+DIAL_DEV float quat_yaw(const float* q) {
+  return DM_ATAN2(-2.f * q[1] * q[2] + 2.f * q[0] * q[3], q[1] * q[1] + q[0] * q[0] - q[3] * q[3] - q[2] * q[2]);
+}
+
+// One env.step from the action in s.act (nu values).  Returns the (wave-uniform) reward.
+template <class W>
+DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s) {
+  const int nu = m->nu;
+  // act2joint / act2tau (base_env.py:38-66)
+  w.items(nu, [&](int a) {
+    float an = (s.act[a] * t->action_scale + 1.0f) / 2.0f;
+    float jt = t->joint_range[a][0] + an * (t->joint_range[a][1] - t->joint_range[a][0]);
+    jt = dm::clip(jt, t->phys_range[a][0], t->phys_range[a][1]);
+    float c;
+    if (t->position_control) c = jt;
+    else {
+      float q_err = jt - s.qpos[7 + a];
+      c = dm::clip(t->kp[a] * q_err - t->kd[a] * s.qvel[6 + a], t->tau_range[a][0], t->tau_range[a][1]);
+    }
+    s.ctrl[a] = c;
+  });
+  for (int f = 0; f < t->n_frames; f++) {  // pipeline_step
+    forward(w, m, dv, s);
+    euler(w, m, s);
+  }
+  // reward / done / info: scalar work, one lane (reads the PRE-integration forward quantities)
+  w.items(1, [&](int) {
+    const float dt = t->dt;
+    const int tb = t->torso_x + 1, ub = t->upright_x + 1;
+    float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+    float rot_u[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+    const float* c = s.com + 3 * m->body_rootid[tb];
+    float off[3] = {s.xpos[3 * tb] - c[0], s.xpos[3 * tb + 1] - c[1], s.xpos[3 * tb + 2] - c[2]};
+    float ang[3] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2]}, cr[3], vel[3];
+    dm::cross3(cr, off, ang);
+    for (int k = 0; k < 3; k++) vel[k] = s.cvel[6 * tb + 3 + k] - cr[k];
+    float* info = s.info;
+    const float step = info[DIAL_INFO_STEP];
+    float up[3] = {0.f, 0.f, 1.f}, vec[3];
+    dm::rotate(vec, up, rot_u);
+    float reward_upright = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
+    float yaw = quat_yaw(rot_t);
+    float reward = 0.f;
+    if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK) {
+      for (int k = 0; k < 3; k++) {
+        float v = t->cmd_vel[k], a = t->cmd_ang_vel[k];
+        info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / t->ramp_up_time, v);
+        info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / t->ramp_up_time, a);
+      }
+      float reward_gaits = 0.f;
+      bool contact[DIAL_MAX_FEET];
+      for (int f = 0; f < t->nfeet; f++) {
+        float z_tar = t->gait_amp * foot_step_height(step * dt * 2.f * DIAL_PI * t->gait_cadence + DIAL_PI,
+                                                     2.f * DIAL_PI * t->gait_phase[f], t->gait_duty);
+        float zs = s.spos[3 * t->feet_site[f] + 2], fz;
+        if (t->kind == DIAL_TASK_GO2_WALK) {
+          float e = (z_tar - zs) / 0.05f;
+          reward_gaits += e * e;
+          fz = zs - t->foot_radius;
+        } else {
+          float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
+          reward_gaits += (z_tar - zf) * (z_tar - zf);
+          fz = zs;
+        }
+        contact[f] = fz < 1e-3f;
+      }
+      reward_gaits = -reward_gaits;
+      float yaw_tar = info[DIAL_INFO_YAW_TAR] + info[DIAL_INFO_ANG_VEL_TAR + 2] * dt * step;
+      float d_yaw = yaw - yaw_tar;
+      float wy = DM_ATAN2(DM_SIN(d_yaw), DM_COS(d_yaw));
+      float reward_yaw = -(wy * wy);
+      float vb[3], ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
+      dm::inv_rotate(vb, vel, rot_t);
+      dm::inv_rotate(ab, angs, rot_t);
+      float e0 = vb[0] - info[DIAL_INFO_VEL_TAR], e1 = vb[1] - info[DIAL_INFO_VEL_TAR + 1];
+      float reward_vel = -(e0 * e0 + e1 * e1);
+      float ea = ab[2] - info[DIAL_INFO_ANG_VEL_TAR + 2];
+      float reward_ang_vel = -(ea * ea);
+      float dh = s.xpos[3 * tb + 2] - info[DIAL_INFO_POS_TAR + 2];
+      float reward_height = -(dh * dh);
+      if (t->kind == DIAL_TASK_GO2_WALK) {
+        reward = reward_gaits * 0.1f + reward_upright * 0.5f + reward_yaw * 0.3f + reward_vel * 1.0f +
+                 reward_ang_vel * 1.0f + reward_height * 1.0f;
+      } else {
+        float reward_energy = 0.f;
+        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / t->tau_range[a][1]; reward_energy += e * e; }
+        reward_energy = -reward_energy;
+        reward = reward_gaits * 5.0f + reward_upright * 0.5f + reward_yaw * 0.1f + reward_vel * 1.0f +
+                 reward_ang_vel * 1.0f + reward_height * 0.5f + reward_energy * 0.01f;
+      }
+      for (int f = 0; f < t->nfeet; f++) {
+        bool filt = contact[f] || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
+        info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
+        info[DIAL_INFO_LAST_CONTACT + f] = contact[f] ? 1.f : 0.f;
+      }
+    } else {  // DIAL_TASK_GO2_SEQ_JUMP
+      const int stage = (int)info[DIAL_INFO_STAGE];
+      float rp = 0.f;
+      for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - t->pose_targets[stage][k]; rp += e * e; }
+      float reward_pos = -rp;
+      float ey = yaw - t->yaw_targets[stage];
+      float reward_yaw = -(ey * ey);
+      float reward_contact = 0.f, penalty_contact = 0.f;
+      for (int i = 0; i < 4; i++) {
+        bool pen = s.cdist[i] <= 0.001f;
+        for (int j = 0; j < t->n_stage; j++) {
+          float dx = s.cpos[3 * i] - t->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - t->contact_targets[j][i][1];
+          bool cond = (dx * dx + dy * dy) <= t->contact_radius[j][i] * t->contact_radius[j][i];
+          float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
+          reward_contact += cond ? val : 0.f;
+          pen = pen && !cond;
+        }
+        penalty_contact += pen ? 1.f : 0.f;
+      }
+      reward = reward_pos * 1.0f + reward_upright * 1.0f + reward_yaw * 0.3f + reward_contact * 0.1f -
+               penalty_contact * 0.1f + 1.0f * 10.0f;
+      for (int a = 0; a < nu; a++) info[DIAL_INFO_LAST_CTRL + a] = s.ctrl[a];
+    }
+    float upv[3];
+    dm::rotate(upv, up, rot_t);
+    bool done = upv[2] < 0.f;
+    for (int a = 0; a < nu; a++) {
+      float q = s.qpos[7 + a];
+      done = done || q < t->joint_range[a][0] || q > t->joint_range[a][1];
+    }
+    done = done || s.xpos[3 * tb + 2] < t->done_height;
+    info[DIAL_INFO_DONE] = done ? 1.f : 0.f;
+    info[DIAL_INFO_STEP] = step + 1.f;
+    if (t->kind == DIAL_TASK_GO2_SEQ_JUMP) {
+      float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / t->jump_dt);
+      info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(t->n_stage - 1));
+    }
+    info[DIAL_INFO_REWARD] = reward;
+  });
+  return s.info[DIAL_INFO_REWARD];
+}
+
+// Initialise the world-body entries of the kinematic arrays (done once per wavefront).
+template <class W>
+DIAL_DEV void init_world(W& w, const Ws& s) {
+  w.items(1, [&](int) {
+    for (int k = 0; k < 3; k++) { s.xpos[k] = 0.f; s.com[k] = 0.f; }
+    s.xquat[0] = 1.f; s.xquat[1] = 0.f; s.xquat[2] = 0.f; s.xquat[3] = 0.f;
+  });
+}
+
+}  // namespace dial

@@ -1,0 +1,144 @@
+// rollout_driver.h -- what one wavefront does for one sample: stage the shared initial state in LDS,
+// build its control nodes (K1) and controls (K2), run T env.steps (K3) and stream the per-step
+// outputs of MBDPI.rollout_us_vmap to HBM.  Shared by the HIP kernels and the host wave emulator.
+//
+// Reference: dial_mpc/core/dial_core.py:106-117 (sampling + node2u), :36-42 (rollout_us).
+#pragma once
+#include "rollout_body.h"
+
+namespace dial {
+
+struct RolloutIO {
+  const float* state;        // packed initial state, shared by all samples
+  const float* us;           // [B,T,nu] controls, or nullptr -> build them from nodes
+  const float* eps;          // [n_noise,Hn1,nu] standard-normal draws (nodes mode)
+  const float* Ybar;         // [Hn1,nu]
+  const float* noise_scale;  // [ns]
+  int ns;
+  int n_noise;               // samples with index >= n_noise roll out the mean trajectory Ybar
+  int T, Hn1;
+  float* Y0s;                // out [B,Hn1,nu] (nodes mode) or nullptr
+  float* rewss;              // out [B,T] or nullptr
+  float* rews;               // out [B] mean over T, or nullptr
+  float* qss;                // out [B,T,nq] or nullptr
+  float* qdss;               // out [B,T,nv] or nullptr
+  float* xss;                // out [B,T,(nbody-1)*3] or nullptr
+};
+
+template <class W>
+DIAL_DEV void load_state(W& w, const dial_model* m, const Ws& s, const float* state) {
+  const int nq = m->nq, nv = m->nv;
+  w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
+    float v = state[i];
+    if (i < nq) s.qpos[i] = v;
+    else if (i < nq + nv) s.qvel[i - nq] = v;
+    else if (i < nq + 2 * nv) s.warm[i - nq - nv] = v;
+    else s.info[i - nq - 2 * nv] = v;
+  });
+}
+template <class W>
+DIAL_DEV void store_state(W& w, const dial_model* m, const Ws& s, float* state) {
+  const int nq = m->nq, nv = m->nv;
+  w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
+    float v;
+    if (i < nq) v = s.qpos[i];
+    else if (i < nq + nv) v = s.qvel[i - nq];
+    else if (i < nq + 2 * nv) v = s.warm[i - nq - nv];
+    else v = s.info[i - nq - 2 * nv];
+    state[i] = v;
+  });
+}
+
+template <class W>
+DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv,
+                             const dial_cfg* cfg, const Ws& s, const RolloutIO& io, int n) {
+  const int nq = m->nq, nv = m->nv, nu = m->nu, nx = (m->nbody - 1) * 3, T = io.T, Hn1 = io.Hn1;
+  init_world(w, s);
+  load_state(w, m, s, io.state);
+  if (!io.us) {
+    // K1: candidate nodes (dial_core.py:110-115)
+    w.items(Hn1 * nu, [&](int it) {
+      const int k = it / nu, a = it - k * nu;
+      float v;
+      if (n < io.n_noise) {
+        float sc = io.noise_scale[io.ns == 1 ? 0 : k];
+        v = io.eps[((size_t)n * Hn1 + k) * nu + a] * sc + io.Ybar[k * nu + a];
+        if (k == 0) v = io.Ybar[a];
+      } else {
+        v = io.Ybar[k * nu + a];
+      }
+      v = dm::clip(v, -1.f, 1.f);
+      s.Y[it] = v;
+      if (io.Y0s) io.Y0s[(size_t)n * Hn1 * nu + it] = v;
+    });
+  }
+  float rsum = 0.f;
+  for (int st = 0; st < T; st++) {
+    // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
+    w.items(nu, [&](int a) {
+      float u;
+      if (io.us) u = io.us[((size_t)n * T + st) * nu + a];
+      else {
+        u = 0.f;
+        for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
+      }
+      s.act[a] = u;
+    });
+    float rew = env_step(w, m, t, dv, s);
+    rsum += rew;
+    const size_t o = (size_t)n * T + st;
+    w.items(nq + nv + nx + 1, [&](int i) {
+      if (i < nq) { if (io.qss) io.qss[o * nq + i] = s.qpos[i]; }
+      else if (i < nq + nv) { if (io.qdss) io.qdss[o * nv + (i - nq)] = s.qvel[i - nq]; }
+      else if (i < nq + nv + nx) { if (io.xss) io.xss[o * nx + (i - nq - nv)] = s.xpos[3 + (i - nq - nv)]; }
+      else { if (io.rewss) io.rewss[o] = rew; }
+    });
+  }
+  if (io.rews) {
+    const float mean = rsum / (float)T;
+    w.items(1, [&](int) { io.rews[n] = mean; });
+  }
+}
+
+// env.step on the true state (B = 1)
+template <class W>
+DIAL_DEV void env_step_single(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s,
+                              float* state, const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
+  init_world(w, s);
+  load_state(w, m, s, state);
+  w.items(m->nu, [&](int a) { s.act[a] = action[a]; });
+  env_step(w, m, t, dv, s);
+  store_state(w, m, s, state);
+  const int nb1 = m->nbody - 1;
+  w.items(nb1 * 7 + m->nu, [&](int i) {
+    if (i < nb1 * 3) { if (xpos_out) xpos_out[i] = s.xpos[3 + i]; }
+    else if (i < nb1 * 7) { if (xquat_out) xquat_out[i - nb1 * 3] = s.xquat[4 + (i - nb1 * 3)]; }
+    else { if (ctrl_out) ctrl_out[i - nb1 * 7] = s.ctrl[i - nb1 * 7]; }
+  });
+}
+
+// env.reset: pipeline_init(q, qd) = mjx.forward with ctrl = 0, then the task's initial info
+template <class W>
+DIAL_DEV void env_reset_single(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s,
+                               const float* qpos, const float* qvel, float* state, float* xpos_out, float* xquat_out) {
+  init_world(w, s);
+  const int nq = m->nq, nv = m->nv;
+  w.items(nq + 2 * nv + DIAL_INFO_N + m->nu, [&](int i) {
+    if (i < nq) s.qpos[i] = qpos[i];
+    else if (i < nq + nv) s.qvel[i - nq] = qvel[i - nq];
+    else if (i < nq + 2 * nv) s.warm[i - nq - nv] = 0.f;
+    else if (i < nq + 2 * nv + DIAL_INFO_N) {
+      const int k = i - nq - 2 * nv;
+      s.info[k] = (k >= DIAL_INFO_POS_TAR && k < DIAL_INFO_POS_TAR + 3) ? t->init_pos_tar[k - DIAL_INFO_POS_TAR] : 0.f;
+    } else s.ctrl[i - nq - 2 * nv - DIAL_INFO_N] = 0.f;
+  });
+  forward(w, m, dv, s);
+  store_state(w, m, s, state);
+  const int nb1 = m->nbody - 1;
+  w.items(nb1 * 7, [&](int i) {
+    if (i < nb1 * 3) { if (xpos_out) xpos_out[i] = s.xpos[3 + i]; }
+    else { if (xquat_out) xquat_out[i - nb1 * 3] = s.xquat[4 + (i - nb1 * 3)]; }
+  });
+}
+
+}  // namespace dial

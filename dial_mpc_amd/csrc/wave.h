@@ -1,0 +1,154 @@
+// wave.h -- the "one wavefront owns one sample" execution model.
+//
+// A rollout is owned by ONE 64-lane wavefront (workgroup = 64 threads).  The kernel body
+// (rollout_body.h) is written as a sequence of *phases*:
+//
+//   w.items(count, [&](int i) { ... });   // work items i = lane, lane+64, ... ; LDS fence after
+//   float s = w.sum(count, [&](int i) { return ...; });   // wave-uniform reduction (count <= 64)
+//
+// Rules the body obeys (checked by the CPU emulation build, see below):
+//   * inside one items() call an item only reads LDS written by EARLIER phases and writes LDS
+//     words no other item of the same call touches;
+//   * variables declared outside the lambdas are wave-uniform (same value in every lane);
+//     lambdas never assign to them;
+//   * all cross-lane traffic goes through LDS or through sum()/sum3().
+//
+// Two implementations of the same interface:
+//   * HIP/gfx950 (default): lane = threadIdx.x; items() ends in a workgroup barrier, which for a
+//     single-wave workgroup is an LDS wait (s_waitcnt lgkmcnt(0)) -- DS operations of one wave
+//     execute in order, so that is all the synchronisation needed; sum() is a DPP butterfly in
+//     registers (no LDS traffic).
+//   * DIAL_EMU (g++ on the host, TEST INFRASTRUCTURE): lanes are executed sequentially.  With
+//     race checking on, every items() phase is executed twice from the same LDS snapshot, in
+//     ascending and in descending item order, and the resulting LDS images must be bit-identical;
+//     any intra-phase read-after-write / write-after-write dependence shows up as a mismatch.
+//     This lets the exact kernel logic be verified against the oracle without a GPU.
+#pragma once
+
+#ifdef DIAL_EMU
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#define DIAL_DEV inline
+#define DIAL_UNROLL
+
+struct Wave {
+  float* lds = nullptr;
+  int lds_words = 0;
+  bool check_races = false;
+  int races = 0;
+  int phase = 0;
+
+  template <class F>
+  void items(int count, F f) {
+    phase++;
+    if (!check_races) {
+      for (int i = 0; i < count; i++) f(i);
+      return;
+    }
+    std::vector<float> snap(lds, lds + lds_words);
+    for (int i = 0; i < count; i++) f(i);
+    std::vector<float> fwd(lds, lds + lds_words);
+    std::memcpy(lds, snap.data(), sizeof(float) * lds_words);
+    for (int i = count - 1; i >= 0; i--) f(i);
+    if (std::memcmp(fwd.data(), lds, sizeof(float) * lds_words) != 0) {
+      if (races < 10) {
+        int w = 0;
+        for (; w < lds_words; w++)
+          if (std::memcmp(&fwd[w], &lds[w], 4) != 0) break;
+        std::fprintf(stderr, "[wave_emu] intra-phase dependence in phase #%d (first differing LDS word %d)\n", phase, w);
+      }
+      races++;
+    }
+  }
+  template <class F>
+  float sum(int count, F f) {
+    float s = 0.f;
+    for (int i = 0; i < count; i++) s += f(i);
+    return s;
+  }
+  // three sums at once; f(i, a, b, c) adds its contribution to a, b, c
+  template <class F>
+  void sum3(int count, F f, float& a, float& b, float& c) {
+    a = b = c = 0.f;
+    for (int i = 0; i < count; i++) {
+      float x = 0.f, y = 0.f, z = 0.f;
+      f(i, x, y, z);
+      a += x; b += y; c += z;
+    }
+  }
+  template <class F>
+  float maxv(int count, F f) {
+    float s = -INFINITY;
+    for (int i = 0; i < count; i++) { float v = f(i); s = v > s ? v : s; }
+    return s;
+  }
+};
+
+#else  // ------------------------------------------------------------------ HIP / gfx950
+#include <hip/hip_runtime.h>
+#define DIAL_DEV __device__ __forceinline__
+
+namespace dialwave {
+// DPP controls (gfx9/CDNA): quad_perm 0x00-0xff, row_shr n 0x110+n, row_mirror 0x140,
+// row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND);
+  return v + __builtin_bit_cast(float, moved);
+}
+// Full-wave sum.  After the six steps lane 63 holds the total; broadcast it as a scalar.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xb1>(v);         // quad_perm [1,0,3,2]
+  v = dpp_add<0x4e>(v);         // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);        // row_half_mirror
+  v = dpp_add<0x140>(v);        // row_mirror  -> every lane of a 16-row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast15 -> rows 1,3 += rows 0,2
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast31 -> rows 2,3 += row 1(=0+1)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float wave_max_shfl(float v) {
+  for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+#ifdef DIAL_NO_DPP
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_shfl(v); }
+#else
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+#endif
+}  // namespace dialwave
+
+struct Wave {
+  int lane;
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+
+  template <class F>
+  __device__ __forceinline__ void items(int count, F f) {
+    for (int i = lane; i < count; i += 64) f(i);
+    sync();
+  }
+  template <class F>
+  __device__ __forceinline__ float sum(int count, F f) {
+    float v = lane < count ? f(lane) : 0.f;
+    return dialwave::wave_sum(v);
+  }
+  template <class F>
+  __device__ __forceinline__ void sum3(int count, F f, float& a, float& b, float& c) {
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (lane < count) f(lane, x, y, z);
+    a = dialwave::wave_sum(x);
+    b = dialwave::wave_sum(y);
+    c = dialwave::wave_sum(z);
+  }
+  template <class F>
+  __device__ __forceinline__ float maxv(int count, F f) {
+    float v = lane < count ? f(lane) : -INFINITY;
+    return dialwave::wave_max_shfl(v);
+  }
+};
+#endif

@@ -2,7 +2,7 @@
 constants (dial_mpc/envs/unitree_go2_env.py:25-124 walk/trot, :319-401,559-592 seq_jump).
 
 ``reset`` / ``step`` execute in libdialhip.so; the reward formulas are in csrc/rollout_body.h
-(product) and oracle/dial_oracle.c (checker).  Crate-climb is a NEXT row."""
+(product); the CPU checker restates them independently.  Crate-climb is a NEXT row."""
 from __future__ import annotations
 
 from dataclasses import dataclass

@@ -1,0 +1,98 @@
+"""ctypes wrapper of the host wave emulator (tests/wave_emu/emu.cpp).  TEST INFRASTRUCTURE ONLY:
+it compiles the kernel body with -DDIAL_EMU so that the exact kernel logic can be compared with the
+oracle (and race-checked) without a GPU.  Nothing under dial_mpc_amd/ loads it."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from dial_mpc_amd import _abi
+
+_HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wave_emu")
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dial_mpc_amd", "csrc")
+_SO = os.path.join(_HERE, "libwave_emu.so")
+
+
+def build():
+    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
+                                               ("wave.h", "dmath.h", "derived.h", "rollout_body.h", "rollout_driver.h")]
+    srcs.append(_abi.HEADER)
+    if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(f) for f in srcs):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fno-strict-aliasing",
+                           "-ffp-contract=off", "-o", _SO, os.path.join(_HERE, "emu.cpp")])
+
+
+class Emu:
+    def __init__(self, model, task, cfg=None):
+        build()
+        self.lib = ctypes.CDLL(_SO)
+        self.model, self.task, self.cfg = model, task, cfg
+        self.nq, self.nv, self.nu, self.nbody = model.nq, model.nv, model.nu, model.nbody
+        self.nx = (model.nbody - 1) * 3
+        self.state_size = _abi.state_size(model.nq, model.nv)
+
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+    @staticmethod
+    def _a(x):
+        return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+    def env_reset(self, qpos, qvel, check_races=True):
+        state = np.zeros(self.state_size, np.float32)
+        xpos = np.zeros((self.nbody - 1, 3), np.float32)
+        xquat = np.zeros((self.nbody - 1, 4), np.float32)
+        rc = self.lib.emu_env_reset(ctypes.byref(self.model), ctypes.byref(self.task), self._p(self._a(qpos)),
+                                    self._p(self._a(qvel)), self._p(state), self._p(xpos), self._p(xquat),
+                                    int(check_races))
+        assert rc == 0, f"emu_env_reset: rc={rc} (races or error)"
+        return state, xpos, xquat
+
+    def env_step(self, state, action, check_races=True):
+        state = self._a(state).copy()
+        xpos = np.zeros((self.nbody - 1, 3), np.float32)
+        xquat = np.zeros((self.nbody - 1, 4), np.float32)
+        ctrl = np.zeros(self.nu, np.float32)
+        rc = self.lib.emu_env_step(ctypes.byref(self.model), ctypes.byref(self.task), self._p(state),
+                                   self._p(self._a(action)), self._p(xpos), self._p(xquat), self._p(ctrl),
+                                   int(check_races))
+        assert rc == 0, f"emu_env_step: rc={rc} (races or error)"
+        return state, xpos, xquat, ctrl
+
+    def rollout(self, state, us, check_races=False):
+        us = self._a(us)
+        B, T = us.shape[:2]
+        rewss = np.zeros((B, T), np.float32)
+        rews = np.zeros(B, np.float32)
+        qss = np.zeros((B, T, self.nq), np.float32)
+        qdss = np.zeros((B, T, self.nv), np.float32)
+        xss = np.zeros((B, T, self.nx), np.float32)
+        rc = self.lib.emu_rollout(ctypes.byref(self.model), ctypes.byref(self.task),
+                                  ctypes.byref(self.cfg) if self.cfg is not None else None,
+                                  self._p(self._a(state)), self._p(us), None, None, None, 0, 0, B, T, 0, None,
+                                  self._p(rewss), self._p(rews), self._p(qss), self._p(qdss), self._p(xss),
+                                  int(check_races))
+        assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
+        return rewss, qss, qdss, xss, rews
+
+    def rollout_nodes(self, state, Ybar, noise_scale, eps, check_races=False):
+        cfg = self.cfg
+        N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1
+        B = N + 1
+        eps, Ybar = self._a(eps), self._a(Ybar)
+        ns = self._a(noise_scale).reshape(-1)
+        Y0s = np.zeros((B, Hn1, self.nu), np.float32)
+        rewss = np.zeros((B, T), np.float32)
+        rews = np.zeros(B, np.float32)
+        qss = np.zeros((B, T, self.nq), np.float32)
+        qdss = np.zeros((B, T, self.nv), np.float32)
+        xss = np.zeros((B, T, self.nx), np.float32)
+        rc = self.lib.emu_rollout(ctypes.byref(self.model), ctypes.byref(self.task), ctypes.byref(cfg),
+                                  self._p(self._a(state)), None, self._p(eps), self._p(Ybar), self._p(ns),
+                                  int(ns.size), N, B, T, Hn1, self._p(Y0s), self._p(rewss), self._p(rews),
+                                  self._p(qss), self._p(qdss), self._p(xss), int(check_races))
+        assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
+        return dict(Y0s=Y0s, rewss=rewss, rews=rews, qss=qss, qdss=qdss, xss=xss)

@@ -1,0 +1,23 @@
+"""The committed fixtures are reproduced by the current oracle (fp64 and fp32) and the wave emulator."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import TOL, setup_case
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,example,N,H", [("go2_trot_N64_H8", "unitree_go2_trot", 64, 8),
+                                              ("go2_seq_jump_N48_H16", "unitree_go2_seq_jump", 48, 16),
+                                              ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16)])
+def test_oracle_reproduces_fixture(name, example, N, H):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    for dt, tol in ((np.float64, 1e-5), (np.float32, 2e-3)):
+        orc = O.Oracle(model, task, cfg, dt)
+        r = orc.reverse_once(g["state"], g["Ybar_in"], g["noise_scale"], g["eps"], full=True)
+        assert np.allclose(r["rewss"], g["rewss"], atol=tol, rtol=tol)
+        assert np.allclose(r["Ybar"], g["Ybar"], atol=max(tol, 1e-4))

@@ -1,0 +1,157 @@
+"""GPU parity gate: libdialhip.so (through the C ABI) vs the fp32 CPU oracle on identical seeded inputs.
+
+Tolerances (fp32, stated in conftest.TOL): rewards 2e-3 (abs+rel), q / x.pos 1e-3, qd 2e-2, softmax
+weights 2e-2 rel, Ybar 2e-3, weighted means 5e-3.  Measured agreement is ~1e-5."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    return np.allclose(a, b, rtol=tol["rtol"], atol=tol["atol"])
+
+
+def _dev(x):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device="cuda")
+
+
+def test_wave_primitives_selftest():
+    from dial_mpc_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_float * 3)()
+    assert lib.dial_selftest(out) == 0
+    assert out[0] == 2048.0 and out[1] == 2048.0 and out[2] == 63.5   # sum_{l<64}(l+0.5), max
+
+
+@pytest.mark.parametrize("example,N,H", CASES)
+def test_env_reset_and_step_match_oracle(example, N, H):
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    ctx = _lib.Context(model, task, cfg)
+    nv = model.nv
+    s_o, xp_o, xq_o = o32.env_reset(env._init_q, np.zeros(nv))
+    s_g, xp_g, xq_g = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(nv)))
+    assert np.allclose(s_g.cpu().numpy(), s_o, atol=2e-4)
+    assert np.allclose(xp_g.cpu().numpy(), xp_o, atol=1e-6) and np.allclose(xq_g.cpu().numpy(), xq_o, atol=1e-6)
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        a = rng.uniform(-0.5, 0.5, model.nu).astype(np.float32)
+        s_o, xp_o, xq_o, c_o = o32.env_step(s_o, a)
+        s_g, xp_g, xq_g, c_g = ctx.env_step(s_g, _dev(a))
+    sg = s_g.cpu().numpy()
+    assert np.allclose(sg[:model.nq], s_o[:model.nq], atol=1e-3)
+    assert np.allclose(c_g.cpu().numpy(), c_o, rtol=1e-3, atol=2e-2)
+    assert sg[model.nq + 2 * nv] == 10.0                              # info.step
+
+
+@pytest.mark.parametrize("example,N,H", CASES)
+def test_rollout_matches_oracle(example, N, H):
+    """dial_rollout == MBDPI.rollout_us_vmap semantics, from the keyframe and from perturbed states."""
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    ctx = _lib.Context(model, task, cfg)
+    rng = np.random.default_rng(4)
+    for seed in (None, 0, 1):
+        q, qd = (env._init_q, np.zeros(model.nv)) if seed is None else perturbed_state(env, seed)
+        s0, _, _ = o32.env_reset(q, qd)
+        us = rng.uniform(-0.8, 0.8, (16, H + 1, model.nu)).astype(np.float32)
+        r_o = o32.rollout(s0, us)
+        r_g = ctx.rollout(_dev(s0), _dev(us))
+        for name, a, b in zip(("rewss", "q", "qd", "x"), r_o, r_g):
+            b = b.cpu().numpy()
+            assert _close(b, a, TOL[name]), (example, seed, name, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("example,N,H", CASES + [("unitree_go2_trot", 256, 16)])
+def test_reverse_once_matches_oracle_stagewise(example, N, H):
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.2)
+    ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+    out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+    sc = ctx.debug_scratch()
+    Y0s_ref = np.clip(np.concatenate([eps * sigma[None, :, None] + Ybar, Ybar[None]], 0), -1, 1)
+    Y0s_ref[:-1, 0] = np.clip(Ybar[0], -1, 1)
+    assert np.array_equal(sc["Y0s"], Y0s_ref.astype(np.float32))       # K1 is exact
+    assert _close(sc["rewss"], ro["rewss"], TOL["rewss"])               # K2 + K3
+    assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=2e-3, atol=1e-3)
+    assert _close(sc["weights"], ro["weights"], TOL["weights"])         # K4a
+    assert abs(sc["weights"].sum() - 1) < 1e-4
+    assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], TOL["Ybar"])   # K4b
+    assert _close(out["qbar"].cpu().numpy(), ro["qbar"], TOL["bar"])
+    assert _close(out["qdbar"].cpu().numpy(), ro["qdbar"], dict(rtol=1e-2, atol=5e-2))
+    assert _close(out["xbar"].cpu().numpy(), ro["xbar"], TOL["bar"])
+
+
+def test_shift_matches_oracle():
+    import oracle as O
+    from dial_mpc_amd import _lib
+    for example, N, H in CASES:
+        dc, env, model, task, cfg = setup_case(example, N, H)
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        ctx = _lib.Context(model, task, cfg)
+        Y = np.random.default_rng(0).uniform(-1, 1, (dc.Hnode + 1, model.nu)).astype(np.float32)
+        assert np.allclose(ctx.shift(_dev(Y)).cpu().numpy(), o32.shift(Y), atol=1e-5)
+
+
+def test_golden_fixture_go2_trot():
+    """Committed fixture (generated by tools/make_golden.py with the fp64 oracle): HIP vs stored outputs."""
+    import os
+    from dial_mpc_amd import _lib
+    path = os.path.join(os.path.dirname(__file__), "golden", "go2_trot_N64_H8.npz")
+    g = np.load(path)
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 64, 8)
+    ctx = _lib.Context(model, task, cfg)
+    out = ctx.reverse_once(_dev(g["state"]), _dev(g["Ybar_in"]), _dev(g["noise_scale"]), _dev(g["eps"]))
+    assert _close(ctx.debug_scratch()["rewss"], g["rewss"], TOL["rewss"])
+    assert _close(out["Ybar"].cpu().numpy(), g["Ybar"], TOL["Ybar"])
+
+
+def test_full_size_properties_go2_n2048_h16():
+    """BASELINE headline size (Go2 N=2048 H=16): size-independent properties instead of an oracle run."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 2048, 16)
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=1, Ybar_scale=0.1)
+    out1 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    sc1 = ctx.debug_scratch()
+    rews1 = out1["rews"].cpu().numpy()
+    # (1) determinism: bit-identical on a second launch
+    out2 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    assert torch.equal(out1["Ybar"], out2["Ybar"]) and np.array_equal(rews1, out2["rews"].cpu().numpy())
+    # (2) weights are a distribution; Ybar is a convex combination of clipped nodes
+    assert abs(sc1["weights"].sum() - 1) < 1e-4 and sc1["weights"].min() >= 0
+    Yb = out1["Ybar"].cpu().numpy()
+    assert np.all(np.abs(Yb) <= 1 + 1e-5)
+    assert np.allclose(Yb, np.einsum("n,nka->ka", sc1["weights"].astype(np.float64), sc1["Y0s"].astype(np.float64)), atol=1e-4)
+    # (3) permutation equivariance: permuting the noise rows permutes the sample rewards, leaves Ybar unchanged
+    perm = np.random.default_rng(0).permutation(2048)
+    out3 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps[perm]))
+    rews3 = out3["rews"].cpu().numpy()
+    assert np.array_equal(rews3[:-1], rews1[:-1][perm]) and rews3[-1] == rews1[-1]
+    assert np.allclose(out3["Ybar"].cpu().numpy(), Yb, atol=1e-4)
+    # (4) the appended mean-trajectory sample equals a plain rollout of node2u(clip(Ybar))
+    W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(dc.Hsample + 1)], np.float32)
+    us = (W @ np.clip(Ybar, -1, 1))[None]
+    rewss_mean = ctx.rollout(s0, _dev(us))[0].cpu().numpy()
+    assert np.allclose(rewss_mean[0], sc1["rewss"][-1], atol=1e-5)
+    # (5) rews are means of rewss; first-step reward is action independent (stale kinematics)
+    assert np.allclose(rews1, sc1["rewss"].mean(1), atol=1e-5)
+    assert np.ptp(sc1["rewss"][:, 0]) < 1e-6
+    assert np.all(np.isfinite(sc1["qss"])) and np.all(np.isfinite(sc1["xss"]))

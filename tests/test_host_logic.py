@@ -1,0 +1,71 @@
+"""Host-side mirror of the reference interface: config loading, registry, control maps, task description."""
+import numpy as np
+import pytest
+import yaml
+
+import dial_mpc_amd.envs as dial_envs
+from dial_mpc_amd import _abi
+from dial_mpc_amd.core.dial_config import DialConfig
+from dial_mpc_amd.examples import deploy_examples, examples
+from dial_mpc_amd.utils.function_utils import get_foot_step, global_to_body_velocity
+from dial_mpc_amd.utils.io_utils import get_example_path, load_dataclass_from_dict
+from conftest import setup_case
+
+
+def test_example_yaml_loads_into_both_dataclasses():
+    d = yaml.safe_load(open(get_example_path("unitree_go2_trot.yaml")))
+    dc = load_dataclass_from_dict(DialConfig, d)
+    assert (dc.Nsample, dc.Hsample, dc.Hnode, dc.Ndiffuse, dc.Ndiffuse_init) == (2048, 16, 4, 2, 10)
+    assert dc.temp_sample == 0.05 and dc.env_name == "unitree_go2_walk"
+    ec = load_dataclass_from_dict(dial_envs.get_config(dc.env_name), d, convert_list_to_array=True)
+    assert ec.default_vx == 0.8 and ec.ramp_up_time == 1.0 and ec.gait == "trot" and ec.kp == 30.0 and ec.kd == 0.0
+    assert not hasattr(ec, "Nsample")                      # keys of the other dataclass are silently ignored
+
+
+def test_registry_names_and_errors():
+    assert "unitree_go2_trot" in examples and "unitree_go2_trot_deploy" in deploy_examples
+    with pytest.raises(NotImplementedError):
+        dial_envs.get_environment("allegro_reorient")
+    with pytest.raises(KeyError):
+        dial_envs.get_environment("my_custom_jax_env")     # user JAX envs cannot run on the HIP path
+
+
+def test_act2joint_and_act2tau_match_reference_formula():
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8)
+    act = np.linspace(-1.2, 1.2, 12)
+    jt = env.act2joint(act)
+    jr, pr = env.joint_range, env.physical_joint_range
+    ref = np.clip(jr[:, 0] + (act + 1) / 2 * (jr[:, 1] - jr[:, 0]), pr[:, 0], pr[:, 1])
+    assert np.allclose(jt, ref, atol=1e-6)
+    ps = type("PS", (), dict(qpos=np.r_[np.zeros(7), env._init_q[7:]], qvel=np.ones(18)))
+    tau = env.act2tau(act, ps)
+    assert np.allclose(tau, 30.0 * (jt - env._init_q[7:]) - 0.0, atol=1e-4)   # Go2: kd = 0, unlimited torque
+
+
+def test_task_description_go2_and_seq_jump():
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8)
+    assert task.kind == _abi.MACROS["DIAL_TASK_GO2_WALK"] and task.n_frames == 1 and task.nfeet == 4
+    assert list(task.feet_site[:4]) == [2, 1, 4, 3]         # FL, FR, RL, RR site ids (env order), body order is FR first
+    assert abs(task.dt - 0.02) < 1e-9 and task.torso_x == 0
+    dc, env, model, task, cfg = setup_case("unitree_go2_seq_jump", 8, 8)
+    assert task.kind == _abi.MACROS["DIAL_TASK_GO2_SEQ_JUMP"] and task.n_stage == 5
+    ct = _abi.as_numpy(task, "contact_targets")
+    assert np.allclose(ct[1, 0], [0.4 + 0.2, -0.135, 0.27]) and np.allclose(ct[1, 3], [0.4 - 0.2, 0.135, 0.27])
+    assert np.allclose(_abi.as_numpy(task, "contact_radius")[:5], 0.1)
+
+
+def test_h1_task_description():
+    dc, env, model, task, cfg = setup_case("unitree_h1_jog", 8, 8)
+    assert task.kind == _abi.MACROS["DIAL_TASK_H1_WALK"] and task.nfeet == 2 and task.torso_x == 11
+    assert np.allclose(_abi.as_numpy(task, "kp")[:5], [200, 200, 200, 200, 60])
+    assert np.allclose(_abi.as_numpy(task, "tau_range")[3], [-300, 300])
+
+
+def test_host_helpers():
+    h = get_foot_step(0.45, 2, 0.08, np.array([0.0, 0.5, 0.5, 0.0]), 0.1)
+    assert np.allclose(h, [0, 0.03323321, 0.03323321, 0], atol=1e-7)
+    from scipy.spatial.transform import Rotation as R
+    q = R.from_euler("XYZ", [0.1, -0.2, 0.7]).as_quat()     # scipy: (x,y,z,w)
+    qw = np.r_[q[3], q[:3]]
+    v = np.array([0.3, -1.0, 2.0])
+    assert np.allclose(global_to_body_velocity(v, qw), R.from_quat(q).inv().apply(v), atol=1e-12)

@@ -1,0 +1,102 @@
+"""world_size-2 gloo test (CPU) of the sample-sharding / collective logic of reverse_once.
+
+The compute backend is a stand-in context (wave emulator for the rollouts + NumPy for the K4 algebra) --
+the production backend is dial_mpc_amd._lib.Context on a GPU; what is under test here is the partition,
+the all-gather layout, the identical-weights property and the all-reduce of the packed partial sums:
+the sharded result must equal the unsharded one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import seeded_inputs, setup_case
+
+
+class FakeCtx:
+    """Implements shard_rollout / shard_reduce / packed_size with the emulator + NumPy on CPU tensors."""
+
+    def __init__(self, model, task, cfg):
+        import emu_lib
+        self.emu = emu_lib.Emu(model, task, cfg)
+        self.cfg = cfg
+        self.torch_device = torch.device("cpu")
+        self.nq, self.nv, self.nu, self.nx = model.nq, model.nv, model.nu, (model.nbody - 1) * 3
+        self.last = None
+
+    def packed_size(self):
+        T, Hn1 = self.cfg.Hsample + 1, self.cfg.Hnode + 1
+        return Hn1 * self.nu + T * (self.nq + self.nv + self.nx)
+
+    def shard_rollout(self, state, Ybar, noise_scale, eps_local, n_local, with_mean, rews_out):
+        import ctypes
+        cfg = self.cfg
+        Hn1, T, B = cfg.Hnode + 1, cfg.Hsample + 1, n_local + 1
+        e = self.emu
+        Y0s = np.zeros((B, Hn1, self.nu), np.float32)
+        rewss = np.zeros((B, T), np.float32)
+        rews = np.zeros(B, np.float32)
+        qss = np.zeros((B, T, self.nq), np.float32)
+        qdss = np.zeros((B, T, self.nv), np.float32)
+        xss = np.zeros((B, T, self.nx), np.float32)
+        ns = noise_scale.numpy().astype(np.float32)
+        rc = e.lib.emu_rollout(ctypes.byref(e.model), ctypes.byref(e.task), ctypes.byref(cfg),
+                               e._p(e._a(state.numpy())), None, e._p(e._a(eps_local.numpy())),
+                               e._p(e._a(Ybar.numpy())), e._p(ns), int(ns.size), n_local, B, T, Hn1, e._p(Y0s),
+                               e._p(rewss), e._p(rews), e._p(qss), e._p(qdss), e._p(xss), 0)
+        assert rc == 0
+        rews_out.copy_(torch.from_numpy(rews))
+        self.last = (Y0s, qss, qdss, xss)
+
+    def shard_reduce(self, rews_all, n_total, n_begin, n_local, include_mean, packed_out):
+        r = rews_all.numpy().astype(np.float32)
+        logp = (r - r[-1]) / r.std() / np.float32(self.cfg.temp_sample)
+        w = np.exp(logp - logp.max())
+        w = (w / w.sum()).astype(np.float32)
+        wl = np.concatenate([w[n_begin:n_begin + n_local], [w[n_total] if include_mean else 0.0]]).astype(np.float32)
+        parts = [np.einsum("n,nc->c", wl, a.reshape(a.shape[0], -1)) for a in self.last]
+        packed_out.copy_(torch.from_numpy(np.concatenate(parts).astype(np.float32)))
+
+
+def _worker(rank, world, port, N, H, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dial_mpc_amd.core.sharding import sharded_reverse_once
+        import oracle as O
+        dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H)
+        ctx = FakeCtx(model, task, cfg)
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
+        eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
+        out = sharded_reverse_once(ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0),
+                                   torch.from_numpy(Ybar), torch.from_numpy(sigma), torch.from_numpy(eps))
+        ret[rank] = [o.numpy().copy() for o in out]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [64, 37])   # 37: ragged last shard
+def test_sharded_reverse_once_equals_unsharded(N):
+    import oracle as O
+    H, world = 8, 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, N, H, ret), nprocs=world, join=True)
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
+    ref = o32.reverse_once(s0, Ybar, sigma, eps)
+    for rank in range(world):
+        Yb, rews, qbar, qdbar, xbar = ret[rank]
+        assert np.allclose(rews, ref["rews"], atol=1e-3)
+        assert np.allclose(Yb, ref["Ybar"], atol=2e-3) and np.allclose(qbar, ref["qbar"], atol=5e-3)
+        assert np.allclose(xbar, ref["xbar"].reshape(xbar.shape), atol=5e-3)
+    for a, b in zip(ret[0], ret[1]):                    # every rank holds bit-identical results
+        assert np.array_equal(a, b)

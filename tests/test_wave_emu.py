@@ -1,0 +1,66 @@
+"""The exact kernel body (csrc/rollout_body.h) compiled for the host wave emulator vs the fp32 oracle.
+
+This is NOT the product path (GPU parity is tests/test_gpu_parity.py); it verifies the lane-parallel
+restructuring of the physics on a machine without a GPU and runs the intra-phase race detector
+(every phase executed in both lane orders from the same LDS snapshot must give identical LDS images)."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle as O
+from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case
+
+
+def _close(a, b, tol):
+    return np.allclose(a, b, rtol=tol["rtol"], atol=tol["atol"])
+
+
+@pytest.mark.parametrize("example,N,H", CASES)
+def test_emulated_kernel_matches_oracle(example, N, H):
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    nv, nu = model.nv, model.nu
+    s_o, xp_o, xq_o = o32.env_reset(env._init_q, np.zeros(nv))
+    s_e, xp_e, xq_e = emu.env_reset(env._init_q, np.zeros(nv), check_races=True)
+    assert np.allclose(s_o, s_e, atol=2e-4) and np.allclose(xp_o, xp_e, atol=1e-6)
+    eps, sigma, Ybar = seeded_inputs(dc, nu, seed=0)
+    ro = o32.reverse_once(s_o, Ybar, sigma, eps, full=True)
+    re = emu.rollout_nodes(s_o, Ybar, sigma, eps, check_races=True)   # asserts: zero races
+    assert _close(re["rewss"], ro["rewss"], TOL["rewss"])
+    assert np.allclose(re["rews"], ro["rews"], rtol=2e-3, atol=1e-3)
+    Y0s_ref = np.clip(np.concatenate([eps * sigma[None, :, None] + Ybar, Ybar[None]], 0), -1, 1)
+    Y0s_ref[:-1, 0] = np.clip(Ybar[0], -1, 1)
+    assert np.array_equal(re["Y0s"], Y0s_ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("example,N,H", CASES[:2])
+def test_emulated_kernel_from_perturbed_states(example, N, H):
+    """BASELINE.md synthetic states: contact-active set differs from the rest pose."""
+    dc, env, model, task, cfg = setup_case(example, 8, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    rng = np.random.default_rng(11)
+    for seed in range(3):
+        q, qd = perturbed_state(env, seed)
+        s_o, _, _ = o32.env_reset(q, qd)
+        us = rng.uniform(-0.8, 0.8, (8, H + 1, model.nu)).astype(np.float32)
+        r_o = o32.rollout(s_o, us)
+        r_e = emu.rollout(s_o, us, check_races=(seed == 0))
+        for name, a, b in zip(("rewss", "q", "qd", "x"), r_o, r_e):
+            assert _close(b, a, TOL[name]), (name, np.abs(a - b).max())
+
+
+def test_emulated_env_step_sequence():
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    s_o, _, _ = o32.env_reset(env._init_q, np.zeros(18))
+    s_e = s_o.copy()
+    rng = np.random.default_rng(2)
+    for k in range(20):
+        a = rng.uniform(-0.5, 0.5, 12).astype(np.float32)
+        s_o, xp_o, xq_o, c_o = o32.env_step(s_o, a)
+        s_e, xp_e, xq_e, c_e = emu.env_step(s_e, a, check_races=(k == 0))
+    assert np.allclose(s_o[:19], s_e[:19], atol=1e-3) and np.allclose(c_o, c_e, atol=1e-2)
+    assert s_o[55] == 20.0 and s_e[55] == 20.0                     # info.step advanced
