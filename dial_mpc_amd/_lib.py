@@ -14,7 +14,7 @@ from typing import Optional
 from dial_mpc_amd import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libdialhip.so")
+LIB_PATH = os.environ.get("DIAL_HIP_LIB", os.path.join(_CSRC, "libdialhip.so"))  # override: profiling builds
 _SOURCES = ("dial_hip.hip", "rollout_driver.h", "rollout_body.h", "derived.h", "dmath.h", "wave.h")
 _lib = None
 

@@ -21,7 +21,7 @@
 #define WSUM_CHUNKS 32
 
 // ------------------------------------------------------------------ kernels
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 3)
 rollout_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
                const dial_derived* __restrict__ dv, const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -183,6 +183,7 @@ struct dial_ctx {
   int B_cap = 0, T = 0, Hn1 = 0, nx = 0;
   float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
   float *weights = nullptr, *partial = nullptr;
+  unsigned long long* prof = nullptr;
   size_t lds_bytes = 0;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -280,6 +281,8 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     HIP_TRY(ctx, hipMalloc(&ctx->weights, sizeof(float) * B));
     const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
     HIP_TRY(ctx, hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
+    HIP_TRY(ctx, hipMalloc(&ctx->prof, sizeof(unsigned long long) * 16));
+    HIP_TRY(ctx, hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 16));
   }
   *out = ctx;
   return DIAL_OK;
@@ -333,7 +336,7 @@ int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, floa
   if (!ctx || !state || !us || !rewss || B < 1) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: bad argument");
   if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: context was created without a dial_cfg");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dial::RolloutIO io{state, us, nullptr, nullptr, nullptr, 0, 0, ctx->T, ctx->Hn1, nullptr, rewss, nullptr, qss, qdss, xposs};
+  dial::RolloutIO io{state, us, nullptr, nullptr, nullptr, 0, 0, ctx->T, ctx->Hn1, nullptr, rewss, nullptr, qss, qdss, xposs, nullptr};
   return launch_rollout(ctx, io, B, (hipStream_t)stream);
 }
 
@@ -347,7 +350,7 @@ int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in, 
   if (n_local < 0 || B < 1 || B > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: shard larger than Nsample+1");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
-                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss};
+                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss, ctx->prof};
   return launch_rollout(ctx, io, B, (hipStream_t)stream);
 }
 
@@ -453,5 +456,10 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
   return DIAL_OK;
 }
 int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_bytes : -1; }
+// DIAL_PROFILE builds: cycle counters of sample 0 of the last rollout launch (16 sections)
+int dial_debug_prof(dial_ctx* ctx, unsigned long long* out16) {
+  if (!ctx || !ctx->prof) return DIAL_ERR_ARG;
+  return hipMemcpy(out16, ctx->prof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost) == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
+}
 
 }  // extern "C"

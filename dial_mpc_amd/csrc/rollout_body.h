@@ -155,6 +155,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom, nsite = m->nsite, nc = m->ncon;
   const int ne = m->nefc, nl = m->nlim;
 
+  DIAL_MARK(w, 15);
   // ---- smooth.kinematics: level-synchronous sweep over the body tree
   for (int d = 1; d <= dv->nlevel; d++) {
     const int b0 = dv->lvl_start[d - 1];
@@ -200,6 +201,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     });
   }
   // ---- local_to_global for inertial frames, geoms and sites
+  DIAL_MARK(w, 0);
   w.items(nb + ng + nsite, [&](int it) {
     if (it < nb) {
       const int b = it;
@@ -421,6 +423,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     }
   });
   // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
+  DIAL_MARK(w, 1);
   w.items(nc * nv, [&](int it) {
     const int c = it / nv, i = it - c * nv;
     const int b1 = m->con_body1[c], b2 = m->con_body2[c];
@@ -476,7 +479,9 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     }
   });
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
+  DIAL_MARK(w, 2);
   chol_solve(w, nv, s.M, s.L, s.rhs, s.ysol, s.qas);
+  DIAL_MARK(w, 3);
   if (ne == 0) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
     return;
@@ -531,6 +536,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   };
   // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
   auto newton_dir = [&]() {
+    DIAL_MARK(w, 14);
     w.items(dv->ntri, [&](int it) {
       const int i = dv->tri[it] >> 8, j = dv->tri[it] & 0xff;
       float acc = 0.f;
@@ -553,12 +559,15 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       }
       s.H[i * nv + j] = s.M[i * nv + j] + acc;
     });
+    DIAL_MARK(w, 5);
     chol_solve(w, nv, s.H, s.L, s.rhs, s.ysol, s.search);  // M's factor in s.L is dead after qacc_smooth
     w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
   };
 
   constraint_grad();
+  DIAL_MARK(w, 4);
   newton_dir();
+  DIAL_MARK(w, 6);
 
   int niter = 0;
   for (;;) {
@@ -571,6 +580,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       break;
     }
     // ---------------- solver._linesearch
+    DIAL_MARK(w, 8);
     w.items(nv + ne, [&](int it) {
       if (it < nv) {
         float acc = 0.f;
@@ -639,6 +649,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       });
     }
     // ---------------- _update_constraint + _update_gradient
+    DIAL_MARK(w, 7);
     constraint_grad();
     float c2 = w.sum(ne, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
     float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
@@ -647,6 +658,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     cost = 0.5f * c2 + gauss;
     niter++;
     // a new Newton direction is only consumed if another iteration will run
+    DIAL_MARK(w, 8);
     bool more;
     if (m->iterations != 1) {
       float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
@@ -656,8 +668,10 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       more = false;
     }
     if (more) newton_dir();
+    DIAL_MARK(w, 6);
   }
   w.items(nv, [&](int i) { s.warm[i] = s.qacc[i]; });
+  DIAL_MARK(w, 8);
 }
 
 // ================================================================ forward.euler (eulerdamp disabled)
@@ -714,9 +728,11 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
     }
     s.ctrl[a] = c;
   });
+  DIAL_MARK(w, 10);
   for (int f = 0; f < t->n_frames; f++) {  // pipeline_step
     forward(w, m, dv, s);
     euler(w, m, s);
+    DIAL_MARK(w, 9);
   }
   // reward / done / info: scalar work, one lane (reads the PRE-integration forward quantities)
   w.items(1, [&](int) {
@@ -827,6 +843,7 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
     }
     info[DIAL_INFO_REWARD] = reward;
   });
+  DIAL_MARK(w, 10);
   return s.info[DIAL_INFO_REWARD];
 }
 

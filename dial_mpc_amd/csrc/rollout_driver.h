@@ -23,6 +23,7 @@ struct RolloutIO {
   float* qss;                // out [B,T,nq] or nullptr
   float* qdss;               // out [B,T,nv] or nullptr
   float* xss;                // out [B,T,(nbody-1)*3] or nullptr
+  unsigned long long* prof;  // DIAL_PROFILE builds: per-section cycle counts of sample 0, else nullptr
 };
 
 template <class W>
@@ -53,6 +54,9 @@ template <class W>
 DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv,
                              const dial_cfg* cfg, const Ws& s, const RolloutIO& io, int n) {
   const int nq = m->nq, nv = m->nv, nu = m->nu, nx = (m->nbody - 1) * 3, T = io.T, Hn1 = io.Hn1;
+#ifdef DIAL_PROFILE
+  w.tprev = __builtin_readcyclecounter();
+#endif
   init_world(w, s);
   load_state(w, m, s, io.state);
   if (!io.us) {
@@ -84,6 +88,7 @@ DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, cons
       }
       s.act[a] = u;
     });
+    DIAL_MARK(w, 11);
     float rew = env_step(w, m, t, dv, s);
     rsum += rew;
     const size_t o = (size_t)n * T + st;
@@ -94,6 +99,10 @@ DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, cons
       else { if (io.rewss) io.rewss[o] = rew; }
     });
   }
+#ifdef DIAL_PROFILE
+  DIAL_MARK(w, 11);
+  if (io.prof && n == 0 && w.lane == 0) for (int k = 0; k < DIAL_NSEC; k++) io.prof[k] = w.acc[k];
+#endif
   if (io.rews) {
     const float mean = rsum / (float)T;
     w.items(1, [&](int) { io.rews[n] = mean; });

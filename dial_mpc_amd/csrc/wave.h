@@ -33,6 +33,7 @@
 #define DIAL_DEV inline
 #define DIAL_UNROLL
 
+#define DIAL_MARK(w, id)
 struct Wave {
   float* lds = nullptr;
   int lds_words = 0;
@@ -123,8 +124,22 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 #endif
 }  // namespace dialwave
 
+#ifdef DIAL_PROFILE
+#define DIAL_NSEC 16
+#define DIAL_MARK(w, id) (w).mark(id)
+#else
+#define DIAL_MARK(w, id)
+#endif
 struct Wave {
   int lane;
+#ifdef DIAL_PROFILE
+  unsigned long long tprev = 0, acc[DIAL_NSEC] = {};
+  __device__ __forceinline__ void mark(int id) {
+    unsigned long long t = __builtin_readcyclecounter();
+    acc[id] += t - tprev;
+    tprev = t;
+  }
+#endif
   __device__ __forceinline__ void sync() { __syncthreads(); }
 
   template <class F>

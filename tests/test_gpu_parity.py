@@ -86,7 +86,7 @@ def test_reverse_once_matches_oracle_stagewise(example, N, H):
     sc = ctx.debug_scratch()
     Y0s_ref = np.clip(np.concatenate([eps * sigma[None, :, None] + Ybar, Ybar[None]], 0), -1, 1)
     Y0s_ref[:-1, 0] = np.clip(Ybar[0], -1, 1)
-    assert np.array_equal(sc["Y0s"], Y0s_ref.astype(np.float32))       # K1 is exact
+    assert np.allclose(sc["Y0s"], Y0s_ref, rtol=0, atol=2.5e-7)          # K1: exact up to one fused multiply-add rounding
     assert _close(sc["rewss"], ro["rewss"], TOL["rewss"])               # K2 + K3
     assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=2e-3, atol=1e-3)
     assert _close(sc["weights"], ro["weights"], TOL["weights"])         # K4a

@@ -30,7 +30,7 @@ int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, co
     w.lds = lds.data();
     w.lds_words = dv.ws_words;
     w.check_races = check_races != 0;
-    dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss};
+    dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr};
     dial::rollout_sample(w, m, t, &dv, cfg, s, io, n);
     races += w.races;
   }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-section cycle breakdown of the rollout kernel (needs the -DDIAL_PROFILE build):
+     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DDIAL_PROFILE -o libdialhip_prof.so dial_hip.hip
+     DIAL_HIP_LIB=.../libdialhip_prof.so python tools/profile_sections.py
+Prints shader-clock cycles accumulated by sample 0 over one rollout for B = 1 and B = N+1."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import seeded_inputs, setup_case  # noqa: E402
+from dial_mpc_amd import _lib  # noqa: E402
+
+NAMES = {0: "kinematics (levels)", 1: "smooth dyn: frames..M,qfs,collision", 2: "Jc + efc rows", 3: "chol(M)+solve",
+         4: "warmstart select + constraint_grad", 5: "H build", 6: "chol(H)+solve", 7: "linesearch", 8: "post-ls update/sums",
+         9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)"}
+
+example = sys.argv[1] if len(sys.argv) > 1 else "unitree_go2_trot"
+dc, env, model, task, cfg = setup_case(example, 2048, 16)
+ctx = _lib.Context(model, task, cfg)
+dev = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device="cuda")  # noqa: E731
+s0, _, _ = ctx.env_reset(dev(env._init_q), dev(np.zeros(model.nv)))
+eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+lib = ctx.lib
+lib.dial_debug_prof.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(dc.Hsample + 1)], np.float32)
+for label, B in (("B=1", 1), ("B=2049", 2049)):
+    if B == 1:
+        us = dev((W @ np.clip(Ybar, -1, 1))[None])
+        ctx.rollout(s0, us)
+        # dial_rollout does not pass the profile buffer; use the shard path with n_local = 0 (mean sample only)
+        rews = torch.zeros(1, device="cuda")
+        ctx.shard_rollout(s0, dev(Ybar), dev(sigma), dev(eps[:1]), 0, True, rews)
+    else:
+        ctx.reverse_once(s0, dev(Ybar), dev(sigma), dev(eps))
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 16)()
+    assert lib.dial_debug_prof(ctx.h, out) == 0
+    tot = sum(out)
+    print(f"--- {example} {label}: total {tot} cycles over {dc.Hsample + 1} steps = {tot / (dc.Hsample + 1):.0f} / step")
+    for k in range(16):
+        if out[k]:
+            print(f"  [{k:2d}] {NAMES.get(k, '?'):42s} {out[k]:10d}  {100.0 * out[k] / tot:5.1f}%  {out[k] / (dc.Hsample + 1):9.0f}/step")
