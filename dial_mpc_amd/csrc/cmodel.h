@@ -1,0 +1,97 @@
+// cmodel.h -- dimension-specialised, compact copies of (dial_model, dial_task, derived tables).
+//
+// The C ABI carries capacity-sized structs (include/dial_mpc.h).  The kernels are instantiated per robot
+// with compile-time dimensions (Go2, H1) so that (a) the constants fit in LDS next to the per-sample state
+// (CModel<Go2> is 5.4 KB instead of 8.9 KB + 3 KB + 2.6 KB), (b) every LDS address is an immediate offset and
+// (c) loops over dofs / rows unroll, which the register-resident linear algebra needs.  A generic
+// instantiation (capacity dimensions, constants read from global memory) serves any other model.
+#pragma once
+#include <stdint.h>
+#include "../../include/dial_mpc.h"
+
+template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_>
+struct Dims {
+  static constexpr bool is_static = STATIC;
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
+  static constexpr int NE = NL_ + 4 * NC_;
+  static constexpr int NTRI = NV_ * (NV_ + 1) / 2;
+};
+using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12>;
+using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19>;
+using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
+                     DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
+
+// Everything one env.step reads that is constant across samples and steps.
+template <class D_>
+struct CModel {
+  using D = D_;
+  // ---- scalars
+  int32_t nq, nv, nu, nbody, njnt, ngeom, nsite, ncon, nlim, nefc;
+  int32_t iterations, ls_iterations, nlevel, ntri;
+  float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
+  // ---- bodies
+  int32_t body_parent[D::NB], body_jntadr[D::NB], body_jntnum[D::NB], body_dofadr[D::NB], body_dofnum[D::NB];
+  int32_t body_subtree_end[D::NB], body_rootid[D::NB];
+  uint32_t body_ancmask[D::NB];
+  float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
+  float body_mass[D::NB], body_inertia[D::NB][3], body_invweight0[D::NB];
+  int32_t lvl_start[D::NB + 1], lvl_body[D::NB];
+  // ---- joints
+  int32_t jnt_type[D::NJ], jnt_qposadr[D::NJ], jnt_dofadr[D::NJ], jnt_bodyid[D::NJ];
+  float jnt_pos[D::NJ][3], jnt_axis[D::NJ][3], jnt_range[D::NJ][2], jnt_solref[D::NJ][2], jnt_solimp[D::NJ][5];
+  float jnt_margin[D::NJ], qpos0[D::NQ];
+  // ---- dofs
+  int32_t dof_bodyid[D::NV], dof_jntid[D::NV], dof_act[D::NV], dof_limrow[D::NV];
+  uint32_t dof_ancmask[D::NV];
+  float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
+  uint16_t tri[D::NTRI + (D::NTRI & 1)];
+  // ---- geoms / sites / contacts / limits / actuators
+  int32_t geom_bodyid[D::NG];
+  float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];
+  int32_t site_bodyid[D::NS];
+  float site_pos[D::NS][3];
+  int32_t con_kind[D::NC], con_geom1[D::NC], con_geom2[D::NC], con_body1[D::NC], con_body2[D::NC];
+  float con_friction[D::NC][5], con_solref[D::NC][2], con_solimp[D::NC][5], con_margin[D::NC];
+  int32_t lim_jnt[D::NL];
+  int32_t act_qposadr[D::NU], act_ctrllimited[D::NU], act_isposition[D::NU];
+  float act_gear[D::NU], act_kp[D::NU], act_ctrlrange[D::NU][2];
+  // ---- task (dial_task; the seq-jump stage tables stay in the global dial_task)
+  int32_t kind, n_frames, position_control, torso_x, upright_x, nfeet, n_stage, feet_site[DIAL_MAX_FEET];
+  float dt, action_scale, foot_radius, gait_duty, gait_cadence, gait_amp, gait_phase[DIAL_MAX_FEET];
+  float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3];
+  float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2];
+};
+
+// ---- runtime / compile-time dimension accessors
+#if defined(__HIPCC__)
+#define CM_HD __host__ __device__ inline
+#else
+#define CM_HD inline
+#endif
+#define CM_DIM(fn, FIELD, field)                                   \
+  template <class M>                                               \
+  CM_HD constexpr int fn(const M* m) {                             \
+    if constexpr (M::D::is_static) return M::D::FIELD;             \
+    else return m->field;                                          \
+  }
+CM_DIM(dim_nq, NQ, nq)
+CM_DIM(dim_nv, NV, nv)
+CM_DIM(dim_nu, NU, nu)
+CM_DIM(dim_nb, NB, nbody)
+CM_DIM(dim_nj, NJ, njnt)
+CM_DIM(dim_ng, NG, ngeom)
+CM_DIM(dim_ns, NS, nsite)
+CM_DIM(dim_nc, NC, ncon)
+CM_DIM(dim_nl, NL, nlim)
+CM_DIM(dim_ne, NE, nefc)
+CM_DIM(dim_ntri, NTRI, ntri)
+#undef CM_DIM
+
+// ---- host: does a model fit a static instantiation exactly?
+template <class D>
+static inline bool dims_match(const dial_model* m) {
+  return m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
+         m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL;
+}
+
+struct dial_derived;  // derived.h

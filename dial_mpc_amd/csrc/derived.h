@@ -1,8 +1,8 @@
-// derived.h -- topology tables derived from dial_model on the host (dial_create) and read by the
-// kernels, plus the per-wavefront LDS workspace layout.  Internal to the library (not ABI).
+// derived.h -- host-side topology tables derived from dial_model, the conversion of the capacity-sized ABI
+// structs into the dimension-specialised CModel<D>, and the per-wavefront LDS workspace layout.
+// Internal to the library (not ABI).
 #pragma once
-#include <stdint.h>
-#include "../../include/dial_mpc.h"
+#include "cmodel.h"
 
 #define DIAL_MAX_TRI ((DIAL_MAX_V * (DIAL_MAX_V + 1)) / 2)
 
@@ -16,50 +16,7 @@ struct dial_derived {
   int32_t dof_limrow[DIAL_MAX_V];          // limit row of dof i, or -1
   int32_t ntri;                            // nv*(nv+1)/2
   uint16_t tri[DIAL_MAX_TRI];              // lower-triangle entries, (i << 8) | j, row-major
-  int32_t ws_words;                        // LDS words per wavefront
 };
-
-
-// ---- per-wavefront LDS workspace (pointers into one float array) -----------------------------
-struct Ws {
-  float *qpos, *qvel, *warm, *info, *ctrl, *act, *Y;
-  float *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *spos, *com;
-  float *cinert, *cdof, *cvel, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd;
-  float *M, *L, *H;
-  float *cdist, *cpos, *cframe, *Jc;
-  float *D, *aref, *lsign, *Jaref, *JarefW, *JarefS, *jv, *frc, *quad;
-  float *qfs, *qas, *qacc, *Ma, *MaW, *MaS, *grad, *search, *mv, *qfc, *rhs, *ysol;
-};
-
-#if defined(__HIPCC__)
-#define WS_HD __host__ __device__ inline
-#else
-#define WS_HD inline
-#endif
-
-// Carve the workspace out of `base`; returns the number of words used.  Used with base = nullptr on
-// the host to size the dynamic LDS allocation.
-WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
-                   int ncon, int nefc, int nnode) {
-  int o = 0;
-#define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
-  WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
-  WS_TAKE(act, nu) WS_TAKE(Y, nnode * nu)
-  WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(xmat, nbody * 9) WS_TAKE(xipos, nbody * 3)
-  WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3) WS_TAKE(xaxis, njnt * 3) WS_TAKE(gpos, ngeom * 3)
-  WS_TAKE(gaxis, ngeom * 3) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
-  WS_TAKE(cinert, nbody * 10) WS_TAKE(cdof, nv * 6) WS_TAKE(cvel, nbody * 6) WS_TAKE(cdofdot, nv * 6)
-  WS_TAKE(cacc, nbody * 6) WS_TAKE(crb, nbody * 10) WS_TAKE(cfl, nbody * 6) WS_TAKE(cfrc, nbody * 6)
-  WS_TAKE(Fd, nv * 6)
-  WS_TAKE(M, nv * nv) WS_TAKE(L, nv * nv) WS_TAKE(H, nv * nv)
-  WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, ncon * 3 * nv)
-  WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc) WS_TAKE(JarefW, nefc)
-  WS_TAKE(JarefS, nefc) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc) WS_TAKE(quad, nefc * 3)
-  WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(MaW, nv) WS_TAKE(MaS, nv)
-  WS_TAKE(grad, nv) WS_TAKE(search, nv) WS_TAKE(mv, nv) WS_TAKE(qfc, nv) WS_TAKE(rhs, nv) WS_TAKE(ysol, nv)
-#undef WS_TAKE
-  return o;
-}
 
 // Host: build the derived tables.  Returns 0 or a negative DIAL_ERR_* code.
 static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
@@ -97,8 +54,125 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
   for (int i = 0; i < m->nv; i++)
     for (int j = 0; j <= i; j++) dv->tri[t++] = (uint16_t)((i << 8) | j);
   dv->ntri = t;
-  Ws s;
-  dv->ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon,
-                          m->nefc, DIAL_MAX_NODE);
   return DIAL_OK;
+}
+
+// Host: capacity-sized ABI structs -> CModel<D>.  The caller has checked dims_match<D>() for static D.
+template <class D>
+static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_task* t, const dial_derived* dv) {
+  CModel<D>& o = *c;
+  for (size_t i = 0; i < sizeof(o); i++) ((char*)c)[i] = 0;
+  o.nq = m->nq; o.nv = m->nv; o.nu = m->nu; o.nbody = m->nbody; o.njnt = m->njnt; o.ngeom = m->ngeom;
+  o.nsite = m->nsite; o.ncon = m->ncon; o.nlim = m->nlim; o.nefc = m->nefc;
+  o.iterations = m->iterations; o.ls_iterations = m->ls_iterations; o.nlevel = dv->nlevel; o.ntri = dv->ntri;
+  o.timestep = m->timestep; o.tolerance = m->tolerance; o.ls_tolerance = m->ls_tolerance;
+  o.impratio = m->impratio; o.meaninertia = m->meaninertia;
+  for (int k = 0; k < 3; k++) o.gravity[k] = m->gravity[k];
+  for (int b = 0; b < m->nbody; b++) {
+    o.body_parent[b] = m->body_parent[b]; o.body_jntadr[b] = m->body_jntadr[b]; o.body_jntnum[b] = m->body_jntnum[b];
+    o.body_dofadr[b] = m->body_dofadr[b]; o.body_dofnum[b] = m->body_dofnum[b];
+    o.body_subtree_end[b] = m->body_subtree_end[b]; o.body_rootid[b] = m->body_rootid[b];
+    o.body_ancmask[b] = dv->body_ancmask[b];
+    for (int k = 0; k < 3; k++) { o.body_pos[b][k] = m->body_pos[b][k]; o.body_ipos[b][k] = m->body_ipos[b][k]; o.body_inertia[b][k] = m->body_inertia[b][k]; }
+    for (int k = 0; k < 4; k++) { o.body_quat[b][k] = m->body_quat[b][k]; o.body_iquat[b][k] = m->body_iquat[b][k]; }
+    o.body_mass[b] = m->body_mass[b]; o.body_invweight0[b] = m->body_invweight0[b][0];
+    o.lvl_body[b] = dv->lvl_body[b];
+  }
+  for (int b = 0; b <= m->nbody && b <= D::NB; b++) o.lvl_start[b] = dv->lvl_start[b < DIAL_MAX_BODY + 1 ? b : DIAL_MAX_BODY];
+  for (int j = 0; j < m->njnt; j++) {
+    o.jnt_type[j] = m->jnt_type[j]; o.jnt_qposadr[j] = m->jnt_qposadr[j]; o.jnt_dofadr[j] = m->jnt_dofadr[j];
+    o.jnt_bodyid[j] = m->jnt_bodyid[j]; o.jnt_margin[j] = m->jnt_margin[j];
+    for (int k = 0; k < 3; k++) { o.jnt_pos[j][k] = m->jnt_pos[j][k]; o.jnt_axis[j][k] = m->jnt_axis[j][k]; }
+    for (int k = 0; k < 2; k++) { o.jnt_range[j][k] = m->jnt_range[j][k]; o.jnt_solref[j][k] = m->jnt_solref[j][k]; }
+    for (int k = 0; k < 5; k++) o.jnt_solimp[j][k] = m->jnt_solimp[j][k];
+  }
+  for (int i = 0; i < m->nq; i++) o.qpos0[i] = m->qpos0[i];
+  for (int i = 0; i < m->nv; i++) {
+    o.dof_bodyid[i] = m->dof_bodyid[i]; o.dof_jntid[i] = m->dof_jntid[i]; o.dof_act[i] = dv->dof_act[i];
+    o.dof_limrow[i] = dv->dof_limrow[i]; o.dof_ancmask[i] = dv->dof_ancmask[i];
+    o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
+  }
+  for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
+  for (int g = 0; g < m->ngeom; g++) {
+    o.geom_bodyid[g] = m->geom_bodyid[g];
+    for (int k = 0; k < 3; k++) { o.geom_pos[g][k] = m->geom_pos[g][k]; o.geom_size[g][k] = m->geom_size[g][k]; }
+    for (int k = 0; k < 4; k++) o.geom_quat[g][k] = m->geom_quat[g][k];
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    o.site_bodyid[s] = m->site_bodyid[s];
+    for (int k = 0; k < 3; k++) o.site_pos[s][k] = m->site_pos[s][k];
+  }
+  for (int cidx = 0; cidx < m->ncon; cidx++) {
+    o.con_kind[cidx] = m->con_kind[cidx]; o.con_geom1[cidx] = m->con_geom1[cidx]; o.con_geom2[cidx] = m->con_geom2[cidx];
+    o.con_body1[cidx] = m->con_body1[cidx]; o.con_body2[cidx] = m->con_body2[cidx]; o.con_margin[cidx] = m->con_margin[cidx];
+    for (int k = 0; k < 5; k++) { o.con_friction[cidx][k] = m->con_friction[cidx][k]; o.con_solimp[cidx][k] = m->con_solimp[cidx][k]; }
+    for (int k = 0; k < 2; k++) o.con_solref[cidx][k] = m->con_solref[cidx][k];
+  }
+  for (int l = 0; l < m->nlim; l++) o.lim_jnt[l] = m->lim_jnt[l];
+  for (int a = 0; a < m->nu; a++) {
+    o.act_qposadr[a] = m->act_qposadr[a]; o.act_ctrllimited[a] = m->act_ctrllimited[a];
+    o.act_isposition[a] = m->act_isposition[a]; o.act_gear[a] = m->act_gear[a]; o.act_kp[a] = m->act_kp[a];
+    o.act_ctrlrange[a][0] = m->act_ctrlrange[a][0]; o.act_ctrlrange[a][1] = m->act_ctrlrange[a][1];
+    o.kp[a] = t->kp[a]; o.kd[a] = t->kd[a];
+    for (int k = 0; k < 2; k++) { o.joint_range[a][k] = t->joint_range[a][k]; o.phys_range[a][k] = t->phys_range[a][k]; o.tau_range[a][k] = t->tau_range[a][k]; }
+  }
+  o.kind = t->kind; o.n_frames = t->n_frames; o.position_control = t->position_control; o.torso_x = t->torso_x;
+  o.upright_x = t->upright_x; o.nfeet = t->nfeet; o.n_stage = t->n_stage;
+  for (int f = 0; f < DIAL_MAX_FEET; f++) { o.feet_site[f] = t->feet_site[f]; o.gait_phase[f] = t->gait_phase[f]; }
+  o.dt = t->dt; o.action_scale = t->action_scale; o.foot_radius = t->foot_radius; o.gait_duty = t->gait_duty;
+  o.gait_cadence = t->gait_cadence; o.gait_amp = t->gait_amp; o.ramp_up_time = t->ramp_up_time;
+  o.done_height = t->done_height; o.jump_dt = t->jump_dt;
+  for (int k = 0; k < 3; k++) { o.cmd_vel[k] = t->cmd_vel[k]; o.cmd_ang_vel[k] = t->cmd_ang_vel[k]; o.init_pos_tar[k] = t->init_pos_tar[k]; }
+}
+
+// ---- per-wavefront LDS workspace (pointers into one float array) -----------------------------
+// Arrays that are dead before the constraint solver starts share their storage with arrays that only live
+// inside the solver ("union" below); symmetric matrices are stored as packed lower triangles.
+struct Ws {
+  float *qpos, *qvel, *warm, *info, *ctrl, *act, *Y;
+  float *xpos, *xquat, *spos, *com, *cvel, *cdof;
+  float *M, *L;
+  float *cdist, *cpos, *cframe, *Jc;
+  float *D, *aref, *lsign, *Jaref, *qfs, *qas, *qacc, *Ma, *rhs;
+  // dynamics temporaries (dead after the contact-Jacobian phase) ...
+  float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd;
+  // ... aliased by solver-only arrays
+  float *H, *JarefW, *JarefS, *jv, *frc, *quad, *MaW, *MaS, *grad, *search, *mv, *qfc, *ysol;
+};
+
+#if defined(__HIPCC__)
+#define WS_HD __host__ __device__ inline
+#else
+#define WS_HD inline
+#endif
+
+WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
+
+// Carve the workspace out of `base`; returns the number of words used (call with base = nullptr to size
+// the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path).
+WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
+                   int ncon, int nefc, int nnode, bool with_L) {
+  int o = 0;
+  const int ntri = (nv * (nv + 1)) / 2;
+#define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
+  WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
+  WS_TAKE(act, nu) WS_TAKE(Y, nnode * nu)
+  WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
+  WS_TAKE(cvel, nbody * 6) WS_TAKE(cdof, nv * 6)
+  WS_TAKE(M, ntri) WS_TAKE(L, with_L ? ntri : 0)
+  WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, ncon * 3 * nv)
+  WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
+  WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
+  const int u0 = o;
+  WS_TAKE(xmat, nbody * 9) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
+  WS_TAKE(xaxis, njnt * 3) WS_TAKE(gpos, ngeom * 3) WS_TAKE(gaxis, ngeom * 3)
+  WS_TAKE(cinert, nbody * 10) WS_TAKE(cdofdot, nv * 6) WS_TAKE(cacc, nbody * 6) WS_TAKE(crb, nbody * 10)
+  WS_TAKE(cfl, nbody * 6) WS_TAKE(cfrc, nbody * 6) WS_TAKE(Fd, nv * 6)
+  const int u1 = o;
+  o = u0;
+  WS_TAKE(H, ntri) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc)
+  WS_TAKE(quad, nefc * 3) WS_TAKE(MaW, nv) WS_TAKE(MaS, nv) WS_TAKE(grad, nv) WS_TAKE(search, nv)
+  WS_TAKE(mv, nv) WS_TAKE(qfc, nv) WS_TAKE(ysol, nv)
+#undef WS_TAKE
+  return o > u1 ? o : u1;
 }

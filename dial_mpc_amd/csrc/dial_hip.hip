@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,41 +22,61 @@
 #define WSUM_CHUNKS 32
 
 // ------------------------------------------------------------------ kernels
-extern "C" __global__ void __launch_bounds__(64, 3)
-rollout_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
-               const dial_derived* __restrict__ dv, const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B) {
+// Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
+template <class D>
+__device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s) {
+  const CModel<D>* m = gm;
+  float* wsbase = smem;
+  if constexpr (D::is_static) {
+    constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspace 16-B aligned
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64) dst[i] = src[i];
+    __syncthreads();
+    m = reinterpret_cast<const CModel<D>*>(smem);
+    wsbase = smem + CMW;
+  }
+  ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
+           dim_ne(m), DIAL_MAX_NODE, dial::kNeedL<D>);
+  return m;
+}
+
+template <class D>
+__global__ void __launch_bounds__(64, 3)
+rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
+               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   if (n >= B) return;
   Ws s;
-  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  const CModel<D>* m = stage_model<D>(gm, smem, s);
   Wave w;
   w.lane = threadIdx.x;
-  dial::rollout_sample(w, m, t, dv, cfg, s, io, n);
+  dial::rollout_sample(w, m, tg, cfg, s, io, n);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-env_step_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
-                const dial_derived* __restrict__ dv, float* state, const float* action, float* xpos_out,
-                float* xquat_out, float* ctrl_out) {
+template <class D>
+__global__ void __launch_bounds__(64)
+env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg, float* state,
+                const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  const CModel<D>* m = stage_model<D>(gm, smem, s);
   Wave w;
   w.lane = threadIdx.x;
-  dial::env_step_single(w, m, t, dv, s, state, action, xpos_out, xquat_out, ctrl_out);
+  dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-env_reset_kernel(const dial_model* __restrict__ m, const dial_task* __restrict__ t,
-                 const dial_derived* __restrict__ dv, const float* qpos, const float* qvel, float* state,
+template <class D>
+__global__ void __launch_bounds__(64)
+env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const float* qvel, float* state,
                  float* xpos_out, float* xquat_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  ws_carve(s, smem, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
+  const CModel<D>* m = stage_model<D>(gm, smem, s);
   Wave w;
   w.lane = threadIdx.x;
-  dial::env_reset_single(w, m, t, dv, s, qpos, qvel, state, xpos_out, xquat_out);
+  dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
 }
 
 // Deterministic block reduction helpers (256 threads).
@@ -176,10 +197,10 @@ struct dial_ctx {
   dial_cfg hc;
   dial_derived hd;
   bool has_cfg = false;
-  dial_model* dmodel = nullptr;
+  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1
+  void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
-  dial_derived* dder = nullptr;
   int B_cap = 0, T = 0, Hn1 = 0, nx = 0;
   float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
   float *weights = nullptr, *partial = nullptr;
@@ -219,7 +240,7 @@ int dial_abi_sizes(int* a, int* b, int* c) {
 void dial_destroy(dial_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  void* ptrs[] = {ctx->dmodel, ctx->dtask, ctx->dcfg, ctx->dder, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
+  void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
                   ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -246,19 +267,37 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
   ctx->ht = *task;
   int rc = dial_build_derived(model, &ctx->hd);
   if (rc != DIAL_OK) { delete ctx; return fail(nullptr, rc, "dial_create: unsupported model topology"); }
-  ctx->lds_bytes = (size_t)ctx->hd.ws_words * sizeof(float);
   ctx->nx = (model->nbody - 1) * 3;
   HIP_TRY(ctx, hipSetDevice(device));
-  if (ctx->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-    if (e != hipSuccess) { delete ctx; return fail(nullptr, DIAL_ERR_HIP, "dial_create: LDS workspace too large"); }
+  {
+    // pick the kernel instantiation and upload its constants
+    auto upload = [&](auto tag) -> int {
+      using D = decltype(tag);
+      CModel<D>* h = new CModel<D>();
+      fill_cmodel(h, model, task, &ctx->hd);
+      Ws s;
+      const int ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
+                                    model->ngeom, model->nsite, model->ncon, model->nefc, DIAL_MAX_NODE,
+                                    dial::kNeedL<D>);
+      const size_t cm_bytes = D::is_static ? ((sizeof(CModel<D>) + 15) / 16) * 16 : 0;
+      ctx->lds_bytes = cm_bytes + (size_t)ws_words * sizeof(float);
+      hipError_t e = hipMalloc(&ctx->dcm, sizeof(CModel<D>));
+      if (e == hipSuccess) e = hipMemcpy(ctx->dcm, h, sizeof(CModel<D>), hipMemcpyHostToDevice);
+      delete h;
+      return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
+    };
+    int urc;
+    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model)) { ctx->inst = 1; urc = upload(DimsGo2{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model)) { ctx->inst = 2; urc = upload(DimsH1{}); }
+    else { ctx->inst = 0; urc = upload(DimsMax{}); }
+    if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
-  HIP_TRY(ctx, hipMalloc(&ctx->dmodel, sizeof(dial_model)));
+  if (ctx->lds_bytes > 64 * 1024) {
+    dial_destroy(ctx);
+    return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds 64 KiB");
+  }
   HIP_TRY(ctx, hipMalloc(&ctx->dtask, sizeof(dial_task)));
-  HIP_TRY(ctx, hipMalloc(&ctx->dder, sizeof(dial_derived)));
-  HIP_TRY(ctx, hipMemcpy(ctx->dmodel, model, sizeof(dial_model), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemcpy(ctx->dder, &ctx->hd, sizeof(dial_derived), hipMemcpyHostToDevice));
   if (cfg) {
     if (cfg->Hsample + 1 > DIAL_MAX_T || cfg->Hnode + 1 > DIAL_MAX_NODE || cfg->Hnode < 2 || cfg->Nsample < 1) {
       dial_destroy(ctx);
@@ -324,8 +363,13 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
     ctx->events_used++;
     HIP_TRY(ctx, hipEventRecord(e0, st));
   }
-  hipLaunchKernelGGL(rollout_kernel, dim3(B), dim3(64), ctx->lds_bytes, st, ctx->dmodel, ctx->dtask, ctx->dder,
-                     ctx->dcfg, io, B);
+#define DIAL_LAUNCH_ROLLOUT(D)                                                                              \
+  hipLaunchKernelGGL(rollout_kernel<D>, dim3(B), dim3(64), ctx->lds_bytes, st, (const CModel<D>*)ctx->dcm, \
+                     (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B)
+  if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2);
+  else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1);
+  else DIAL_LAUNCH_ROLLOUT(DimsMax);
+#undef DIAL_LAUNCH_ROLLOUT
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
   return DIAL_OK;
@@ -419,8 +463,14 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
                   float* ctrl_out, void* stream) {
   if (!ctx || !state || !action) return fail(ctx, DIAL_ERR_ARG, "dial_env_step: null argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream, ctx->dmodel, ctx->dtask,
-                     ctx->dder, state, action, xpos_out, xquat_out, ctrl_out);
+#define DIAL_LAUNCH_STEP(D)                                                                                         \
+  hipLaunchKernelGGL(env_step_kernel<D>, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream,                   \
+                     (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask, state, action, xpos_out, xquat_out, \
+                     ctrl_out)
+  if (ctx->inst == 1) DIAL_LAUNCH_STEP(DimsGo2);
+  else if (ctx->inst == 2) DIAL_LAUNCH_STEP(DimsH1);
+  else DIAL_LAUNCH_STEP(DimsMax);
+#undef DIAL_LAUNCH_STEP
   HIP_TRY(ctx, hipGetLastError());
   return DIAL_OK;
 }
@@ -429,8 +479,13 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
                    float* xquat_out, void* stream) {
   if (!ctx || !state || !qpos || !qvel) return fail(ctx, DIAL_ERR_ARG, "dial_env_reset: null argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(env_reset_kernel, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream, ctx->dmodel, ctx->dtask,
-                     ctx->dder, qpos, qvel, state, xpos_out, xquat_out);
+#define DIAL_LAUNCH_RESET(D)                                                                        \
+  hipLaunchKernelGGL(env_reset_kernel<D>, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream,   \
+                     (const CModel<D>*)ctx->dcm, qpos, qvel, state, xpos_out, xquat_out)
+  if (ctx->inst == 1) DIAL_LAUNCH_RESET(DimsGo2);
+  else if (ctx->inst == 2) DIAL_LAUNCH_RESET(DimsH1);
+  else DIAL_LAUNCH_RESET(DimsMax);
+#undef DIAL_LAUNCH_RESET
   HIP_TRY(ctx, hipGetLastError());
   return DIAL_OK;
 }

@@ -24,19 +24,26 @@
 
 namespace dial {
 
+// Does the instantiation keep a Cholesky factor in LDS (LDS solver path)?  The dimension-specialised
+// instantiations factor in registers instead.
+template <class D>
+inline constexpr bool kNeedL = true;
+
 // ---------------------------------------------------------------- constraint rows (implicit J)
 // Row r < nlim is a joint-limit row (J = lsign * e_dof); the other rows are pyramid edges of contact
 // c = (r - nlim) / 4: J = Jn + f * Jt with f = +-friction (constraint._instantiate_contact).
 struct RowRef { int is_lim, dof, c, tan; float f; };
-DIAL_DEV RowRef row_ref(const dial_model* m, int r) {
+template <class M>
+DIAL_DEV RowRef row_ref(const M* m, int r) {
   RowRef rr;
-  rr.is_lim = r < m->nlim;
+  const int nl = dim_nl(m);
+  rr.is_lim = r < nl;
   if (rr.is_lim) {
     rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
     rr.c = 0; rr.tan = 0; rr.f = 0.f;
   } else {
-    int e = (r - m->nlim) & 3;
-    rr.c = (r - m->nlim) >> 2;
+    int e = (r - nl) & 3;
+    rr.c = (r - nl) >> 2;
     rr.tan = 1 + (e >> 1);
     float mu = m->con_friction[rr.c][rr.tan - 1];
     rr.f = (e & 1) ? -mu : mu;
@@ -44,10 +51,11 @@ DIAL_DEV RowRef row_ref(const dial_model* m, int r) {
   }
   return rr;
 }
-DIAL_DEV float row_dot(const dial_model* m, const Ws& s, int r, const float* v) {
+template <class M>
+DIAL_DEV float row_dot(const M* m, const Ws& s, int r, const float* v) {
   RowRef rr = row_ref(m, r);
   if (rr.is_lim) return s.lsign[r] * v[rr.dof];
-  int nv = m->nv;
+  const int nv = dim_nv(m);
   const float* jn = s.Jc + (rr.c * 3) * nv;
   const float* jt = s.Jc + (rr.c * 3 + rr.tan) * nv;
   float acc = 0.f;
@@ -55,12 +63,13 @@ DIAL_DEV float row_dot(const dial_model* m, const Ws& s, int r, const float* v) 
   return acc;
 }
 // (J^T f)_i
-DIAL_DEV float jt_dot(const dial_model* m, const dial_derived* dv, const Ws& s, int i, const float* f) {
-  int nv = m->nv, nl = m->nlim;
+template <class M>
+DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f) {
+  const int nv = dim_nv(m), nl = dim_nl(m);
   float acc = 0.f;
-  int lr = dv->dof_limrow[i];
+  int lr = m->dof_limrow[i];
   if (lr >= 0) acc += s.lsign[lr] * f[lr];
-  for (int c = 0; c < m->ncon; c++) {
+  for (int c = 0; c < dim_nc(m); c++) {
     float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
     float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
     const float* fc = f + nl + 4 * c;
@@ -71,10 +80,10 @@ DIAL_DEV float jt_dot(const dial_model* m, const dial_derived* dv, const Ws& s, 
   }
   return acc;
 }
-DIAL_DEV float msym(const Ws& s, int nv, int i, int j) { return i >= j ? s.M[i * nv + j] : s.M[j * nv + i]; }
+DIAL_DEV float msym(const Ws& s, int i, int j) { return i >= j ? s.M[tri_idx(i, j)] : s.M[tri_idx(j, i)]; }
 
 // ---------------------------------------------------------------- dense Cholesky solve, fused
-// Left-looking Cholesky of the lower triangle of A (n x n, ld = n) into Lo, one phase per column; the
+// Left-looking Cholesky of the packed lower triangle A (row i at i(i+1)/2) into the packed Lo, one phase per column; the
 // forward substitution of `rhs` is fused into the same phases (item i owns L[i][k] and rhs[i]), then n
 // phases of column-oriented back substitution.  On return x = A^-1 rhs0; rhs and ysol are clobbered.
 template <class W>
@@ -82,54 +91,96 @@ DIAL_DEV void chol_solve(W& w, int n, const float* A, float* Lo, float* rhs, flo
   for (int k = 0; k < n; k++) {
     w.items(n - k, [&](int idx) {
       int i = k + idx;
-      float sik = A[i * n + k], dkk = A[k * n + k];
+      const int ri = tri_idx(i, 0), rk = tri_idx(k, 0);
+      float sik = A[ri + k], dkk = A[rk + k];
       for (int p = 0; p < k; p++) {
-        float lkp = Lo[k * n + p];
-        sik -= Lo[i * n + p] * lkp;
+        float lkp = Lo[rk + p];
+        sik -= Lo[ri + p] * lkp;
         dkk -= lkp * lkp;
       }
       float lkk = DM_SQRT(dkk);
       float yk = rhs[k] / lkk;
       if (i == k) {
-        Lo[k * n + k] = lkk;
+        Lo[rk + k] = lkk;
         y[k] = yk;
       } else {
         float lik = sik / lkk;
-        Lo[i * n + k] = lik;
+        Lo[ri + k] = lik;
         rhs[i] -= lik * yk;
       }
     });
   }
   for (int k = n - 1; k >= 0; k--) {
     w.items(k + 1, [&](int i) {
-      float xk = y[k] / Lo[k * n + k];
+      float xk = y[k] / Lo[tri_idx(k, k)];
       if (i == k) x[k] = xk;
-      else y[i] -= Lo[k * n + i] * xk;
+      else y[i] -= Lo[tri_idx(k, i)] * xk;
     });
   }
 }
-// triangular solves only (factor already in Lo): x = (L L^T)^-1 rhs
-template <class W>
-DIAL_DEV void chol_resolve(W& w, int n, const float* Lo, float* rhs, float* y, float* x) {
-  for (int k = 0; k < n; k++) {
-    w.items(n - k, [&](int idx) {
-      int i = k + idx;
-      float yk = rhs[k] / Lo[k * n + k];
-      if (i == k) y[k] = yk;
-      else rhs[i] -= Lo[i * n + k] * yk;
-    });
+// Register-resident Cholesky solve (dimension-specialised instantiations): lane i owns row i of the
+// matrix in N registers.  Right-looking factorisation: at step k the pivot and the column entries l_jk are
+// broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row; the strictly lower
+// triangle ends up in a[], the reciprocal diagonal in dinv / rinv[].  The forward substitution needs only
+// rows; the backward one needs columns, obtained through one packed-triangle transpose in LDS (scratch).
+// ~N^2 + 8N VALU/readlane instructions and 2 LDS round trips instead of 2N LDS-latency-bound phases.
+template <int N, class W>
+DIAL_DEV void reg_chol_solve(W& w, const float* A, const float* rhs, float* scratch, float* x) {
+  vfloat a[N], c[N];
+  float rinv[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a[j] = w.per_lane([&](int l) { return (l < N && j <= l) ? A[tri_idx(l, j)] : 0.f; });
+  vfloat b = w.per_lane([&](int l) { return l < N ? rhs[l] : 0.f; });
+  vfloat dinv = vsplat(0.f);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float akk = bcast(a[k], k);
+    const float r = fast_rsqrt(akk);
+    rinv[k] = r;
+    vfloat lik = vsel(w.lane_gt(k), a[k] * r, vsplat(0.f));
+    a[k] = lik;
+    dinv = vsel(w.lane_eq(k), vsplat(r), dinv);
+#pragma unroll
+    for (int j = k + 1; j < N; j++) {
+      const float ljk = bcast(lik, j);
+      a[j] = a[j] - lik * ljk;
+    }
   }
-  for (int k = n - 1; k >= 0; k--) {
-    w.items(k + 1, [&](int i) {
-      float xk = y[k] / Lo[k * n + k];
-      if (i == k) x[k] = xk;
-      else y[i] -= Lo[k * n + i] * xk;
-    });
+  // forward substitution L y = b (lane k's b is final once steps p < k are done; a[k] is 0 in lanes <= k)
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float yk = bcast(b, k) * rinv[k];
+    b = b - a[k] * yk;
   }
+  vfloat y = b * dinv;
+  // transpose the strictly lower triangle through LDS: lane i writes row i, reads column i
+  w.items(N, [&](int i) {
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (j < i) scratch[tri_idx(i, j)] = lane_val(a[j], i);
+  });
+#pragma unroll
+  for (int j = 0; j < N; j++) c[j] = w.per_lane([&](int l) { return (l < j && j < N) ? scratch[tri_idx(j, l)] : 0.f; });
+  // backward substitution L^T x = y
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const float xk = bcast(y, k) * rinv[k];
+    y = y - c[k] * xk;
+  }
+  vfloat xv = y * dinv;
+  w.items(N, [&](int i) { x[i] = lane_val(xv, i); });
+}
+
+// x = A^-1 rhs for the packed SPD matrix A (M or H).  rhs is clobbered (LDS path).
+template <class W, class M>
+DIAL_DEV void solve_spd(W& w, const M* m, const Ws& s, const float* A, float* rhs, float* x) {
+  if constexpr (M::D::is_static) reg_chol_solve<M::D::NV>(w, A, rhs, s.L, x);
+  else chol_solve(w, dim_nv(m), A, s.L, rhs, s.ysol, x);
 }
 
 // ---------------------------------------------------------------- constraint._kbi
-DIAL_DEV void kbi(const dial_model* m, const float* solref, const float* solimp, float pos, float& k, float& b,
+template <class M>
+DIAL_DEV void kbi(const M* m, const float* solref, const float* solimp, float pos, float& k, float& b,
                   float& imp) {
   float timeconst = dm::fmaxf_(solref[0], 2.f * m->timestep), dampratio = solref[1];
   float dmin = dm::clip(solimp[0], MJ_MINIMP, MJ_MAXIMP), dmax = dm::clip(solimp[1], MJ_MINIMP, MJ_MAXIMP);
@@ -150,17 +201,17 @@ DIAL_DEV void kbi(const dial_model* m, const float* solref, const float* solimp,
 }
 
 // ================================================================ mjx.forward
-template <class W>
-DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const Ws& s) {
-  const int nb = m->nbody, nv = m->nv, nj = m->njnt, ng = m->ngeom, nsite = m->nsite, nc = m->ncon;
-  const int ne = m->nefc, nl = m->nlim;
+template <class W, class M>
+DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
+  const int nb = dim_nb(m), nv = dim_nv(m), nj = dim_nj(m), ng = dim_ng(m), nsite = dim_ns(m), nc = dim_nc(m);
+  const int ne = dim_ne(m), nl = dim_nl(m), ntri = dim_ntri(m);
 
   DIAL_MARK(w, 15);
   // ---- smooth.kinematics: level-synchronous sweep over the body tree
-  for (int d = 1; d <= dv->nlevel; d++) {
-    const int b0 = dv->lvl_start[d - 1];
-    w.items(dv->lvl_start[d] - b0, [&](int idx) {
-      const int b = dv->lvl_body[b0 + idx], p = m->body_parent[b];
+  for (int d = 1; d <= m->nlevel; d++) {
+    const int b0 = m->lvl_start[d - 1];
+    w.items(m->lvl_start[d] - b0, [&](int idx) {
+      const int b = m->lvl_body[b0 + idx], p = m->body_parent[b];
       float pq[4] = {s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
       float bp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
       float bq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
@@ -290,7 +341,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   w.items(6 * nb, [&](int it) {
     const int b = it / 6, k = it - 6 * b;
     float acc = 0.f;
-    unsigned mask = dv->body_ancmask[b];
+    unsigned mask = m->body_ancmask[b];
     for (int i = 0; i < nv; i++)
       if ((mask >> i) & 1u) acc += s.cdof[6 * i + k] * s.qvel[i];
     s.cvel[6 * b + k] = acc;
@@ -313,7 +364,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   w.items(6 * nb, [&](int it) {
     const int b = it / 6, k = it - 6 * b;
     float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
-    unsigned mask = dv->body_ancmask[b];
+    unsigned mask = m->body_ancmask[b];
     for (int i = 0; i < nv; i++)
       if ((mask >> i) & 1u) acc += s.cdofdot[6 * i + k] * s.qvel[i];
     s.cacc[6 * b + k] = acc;
@@ -355,22 +406,22 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   });
   // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
   //      | collision_driver (static contact list)
-  w.items(dv->ntri + nv + nc, [&](int it) {
-    if (it < dv->ntri) {
-      const int i = dv->tri[it] >> 8, j = dv->tri[it] & 0xff;
+  w.items(ntri + nv + nc, [&](int it) {
+    if (it < ntri) {
+      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
       float v = 0.f;
-      if ((dv->dof_ancmask[i] >> j) & 1u) {
+      if ((m->dof_ancmask[i] >> j) & 1u) {
         for (int k = 0; k < 6; k++) v += s.Fd[6 * i + k] * s.cdof[6 * j + k];
       }
       if (i == j) v += m->dof_armature[i];
-      s.M[i * nv + j] = v;
-    } else if (it < dv->ntri + nv) {
-      const int i = it - dv->ntri, b = m->dof_bodyid[i];
+      s.M[it] = v;
+    } else if (it < ntri + nv) {
+      const int i = it - ntri, b = m->dof_bodyid[i];
       float bias = 0.f;
       for (int k = 0; k < 6; k++) bias += s.cdof[6 * i + k] * s.cfrc[6 * b + k];
       float passive = -m->dof_damping[i] * s.qvel[i];
       float actf = 0.f;
-      const int a = dv->dof_act[i];
+      const int a = m->dof_act[i];
       if (a >= 0) {
         float c = s.ctrl[a];
         if (m->act_ctrllimited[a]) c = dm::clip(c, m->act_ctrlrange[a][0], m->act_ctrlrange[a][1]);
@@ -381,7 +432,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       s.qfs[i] = qf;
       s.rhs[i] = qf;
     } else {
-      const int c = it - dv->ntri - nv, g1 = m->con_geom1[c], g2 = m->con_geom2[c];
+      const int c = it - ntri - nv, g1 = m->con_geom1[c], g2 = m->con_geom2[c];
       float n[3] = {s.gaxis[3 * g1], s.gaxis[3 * g1 + 1], s.gaxis[3 * g1 + 2]};
       float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
       float radius = m->geom_size[g2][0];
@@ -431,13 +482,13 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
     float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
     float diff[3] = {0.f, 0.f, 0.f};
-    if ((dv->body_ancmask[b2] >> i) & 1u) {
+    if ((m->body_ancmask[b2] >> i) & 1u) {
       const float* cm = s.com + 3 * m->body_rootid[b2];
       float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
       dm::cross3(cr, cd, off);
       for (int k = 0; k < 3; k++) diff[k] += cd[3 + k] + cr[k];
     }
-    if ((dv->body_ancmask[b1] >> i) & 1u) {
+    if ((m->body_ancmask[b1] >> i) & 1u) {
       const float* cm = s.com + 3 * m->body_rootid[b1];
       float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
       dm::cross3(cr, cd, off);
@@ -466,7 +517,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
       s.lsign[r] = 0.f;
       float pos = s.cdist[c] - m->con_margin[c];
       if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
-      float t = m->body_invweight0[m->con_body1[c]][0] + m->body_invweight0[m->con_body2[c]][0];
+      float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
       float mu = m->con_friction[c][0];
       float invweight = t + mu * mu * t;
       invweight = invweight * 2.f * mu * mu / m->impratio;
@@ -480,7 +531,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   });
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
-  chol_solve(w, nv, s.M, s.L, s.rhs, s.ysol, s.qas);
+  solve_spd(w, m, s, s.M, s.rhs, s.qas);
   DIAL_MARK(w, 3);
   if (ne == 0) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
@@ -495,12 +546,12 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     else if (it < 2 * ne + nv) {
       const int i = it - 2 * ne;
       float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, nv, i, j) * s.warm[j];
+      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.warm[j];
       s.MaW[i] = acc;
     } else {
       const int i = it - 2 * ne - nv;
       float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, nv, i, j) * s.qas[j];
+      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.qas[j];
       s.MaS[i] = acc;
     }
   });
@@ -527,7 +578,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   auto constraint_grad = [&]() {
     w.items(ne, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
     w.items(nv, [&](int i) {
-      float qc = jt_dot(m, dv, s, i, s.frc);
+      float qc = jt_dot(m, s, i, s.frc);
       s.qfc[i] = qc;
       float g = s.Ma[i] - s.qfs[i] - qc;
       s.grad[i] = g;
@@ -537,11 +588,11 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
   // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
   auto newton_dir = [&]() {
     DIAL_MARK(w, 14);
-    w.items(dv->ntri, [&](int it) {
-      const int i = dv->tri[it] >> 8, j = dv->tri[it] & 0xff;
+    w.items(ntri, [&](int it) {
+      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
       float acc = 0.f;
       if (i == j) {
-        int lr = dv->dof_limrow[i];
+        int lr = m->dof_limrow[i];
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
       }
       for (int c = 0; c < nc; c++) {
@@ -557,10 +608,10 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
         acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
         acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
       }
-      s.H[i * nv + j] = s.M[i * nv + j] + acc;
+      s.H[it] = s.M[it] + acc;
     });
     DIAL_MARK(w, 5);
-    chol_solve(w, nv, s.H, s.L, s.rhs, s.ysol, s.search);  // M's factor in s.L is dead after qacc_smooth
+    solve_spd(w, m, s, s.H, s.rhs, s.search);
     w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
   };
 
@@ -584,7 +635,7 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
     w.items(nv + ne, [&](int it) {
       if (it < nv) {
         float acc = 0.f;
-        for (int j = 0; j < nv; j++) acc += msym(s, nv, it, j) * s.search[j];
+        for (int j = 0; j < nv; j++) acc += msym(s, it, j) * s.search[j];
         s.mv[it] = acc;
       } else {
         s.jv[it - nv] = row_dot(m, s, it - nv, s.search);
@@ -675,11 +726,11 @@ DIAL_DEV void forward(W& w, const dial_model* m, const dial_derived* dv, const W
 }
 
 // ================================================================ forward.euler (eulerdamp disabled)
-template <class W>
-DIAL_DEV void euler(W& w, const dial_model* m, const Ws& s) {
+template <class W, class M>
+DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
   const float dt = m->timestep;
-  w.items(m->nv, [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
-  w.items(m->njnt, [&](int ji) {
+  w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
+  w.items(dim_nj(m), [&](int ji) {
     const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
     if (m->jnt_type[ji] == DIAL_JNT_FREE) {
       for (int k = 0; k < 3; k++) s.qpos[qa + k] += dt * s.qvel[da + k];
@@ -712,32 +763,32 @@ DIAL_DEV float quat_yaw(const float* q) {
 }
 
 // One env.step from the action in s.act (nu values).  Returns the (wave-uniform) reward.
-template <class W>
-DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s) {
-  const int nu = m->nu;
+template <class W, class M>
+DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
+  const int nu = dim_nu(m);
   // act2joint / act2tau (base_env.py:38-66)
   w.items(nu, [&](int a) {
-    float an = (s.act[a] * t->action_scale + 1.0f) / 2.0f;
-    float jt = t->joint_range[a][0] + an * (t->joint_range[a][1] - t->joint_range[a][0]);
-    jt = dm::clip(jt, t->phys_range[a][0], t->phys_range[a][1]);
+    float an = (s.act[a] * m->action_scale + 1.0f) / 2.0f;
+    float jt = m->joint_range[a][0] + an * (m->joint_range[a][1] - m->joint_range[a][0]);
+    jt = dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
     float c;
-    if (t->position_control) c = jt;
+    if (m->position_control) c = jt;
     else {
       float q_err = jt - s.qpos[7 + a];
-      c = dm::clip(t->kp[a] * q_err - t->kd[a] * s.qvel[6 + a], t->tau_range[a][0], t->tau_range[a][1]);
+      c = dm::clip(m->kp[a] * q_err - m->kd[a] * s.qvel[6 + a], m->tau_range[a][0], m->tau_range[a][1]);
     }
     s.ctrl[a] = c;
   });
   DIAL_MARK(w, 10);
-  for (int f = 0; f < t->n_frames; f++) {  // pipeline_step
-    forward(w, m, dv, s);
+  for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
+    forward(w, m, s);
     euler(w, m, s);
     DIAL_MARK(w, 9);
   }
   // reward / done / info: scalar work, one lane (reads the PRE-integration forward quantities)
   w.items(1, [&](int) {
-    const float dt = t->dt;
-    const int tb = t->torso_x + 1, ub = t->upright_x + 1;
+    const float dt = m->dt;
+    const int tb = m->torso_x + 1, ub = m->upright_x + 1;
     float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
     float rot_u[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
     const float* c = s.com + 3 * m->body_rootid[tb];
@@ -752,22 +803,22 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
     float reward_upright = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
     float yaw = quat_yaw(rot_t);
     float reward = 0.f;
-    if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK) {
+    if (m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK) {
       for (int k = 0; k < 3; k++) {
-        float v = t->cmd_vel[k], a = t->cmd_ang_vel[k];
-        info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / t->ramp_up_time, v);
-        info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / t->ramp_up_time, a);
+        float v = m->cmd_vel[k], a = m->cmd_ang_vel[k];
+        info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
+        info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
       }
       float reward_gaits = 0.f;
       bool contact[DIAL_MAX_FEET];
-      for (int f = 0; f < t->nfeet; f++) {
-        float z_tar = t->gait_amp * foot_step_height(step * dt * 2.f * DIAL_PI * t->gait_cadence + DIAL_PI,
-                                                     2.f * DIAL_PI * t->gait_phase[f], t->gait_duty);
-        float zs = s.spos[3 * t->feet_site[f] + 2], fz;
-        if (t->kind == DIAL_TASK_GO2_WALK) {
+      for (int f = 0; f < m->nfeet; f++) {
+        float z_tar = m->gait_amp * foot_step_height(step * dt * 2.f * DIAL_PI * m->gait_cadence + DIAL_PI,
+                                                     2.f * DIAL_PI * m->gait_phase[f], m->gait_duty);
+        float zs = s.spos[3 * m->feet_site[f] + 2], fz;
+        if (m->kind == DIAL_TASK_GO2_WALK) {
           float e = (z_tar - zs) / 0.05f;
           reward_gaits += e * e;
-          fz = zs - t->foot_radius;
+          fz = zs - m->foot_radius;
         } else {
           float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
           reward_gaits += (z_tar - zf) * (z_tar - zf);
@@ -789,17 +840,17 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
       float reward_ang_vel = -(ea * ea);
       float dh = s.xpos[3 * tb + 2] - info[DIAL_INFO_POS_TAR + 2];
       float reward_height = -(dh * dh);
-      if (t->kind == DIAL_TASK_GO2_WALK) {
+      if (m->kind == DIAL_TASK_GO2_WALK) {
         reward = reward_gaits * 0.1f + reward_upright * 0.5f + reward_yaw * 0.3f + reward_vel * 1.0f +
                  reward_ang_vel * 1.0f + reward_height * 1.0f;
       } else {
         float reward_energy = 0.f;
-        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / t->tau_range[a][1]; reward_energy += e * e; }
+        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
         reward_energy = -reward_energy;
         reward = reward_gaits * 5.0f + reward_upright * 0.5f + reward_yaw * 0.1f + reward_vel * 1.0f +
                  reward_ang_vel * 1.0f + reward_height * 0.5f + reward_energy * 0.01f;
       }
-      for (int f = 0; f < t->nfeet; f++) {
+      for (int f = 0; f < m->nfeet; f++) {
         bool filt = contact[f] || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
         info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
         info[DIAL_INFO_LAST_CONTACT + f] = contact[f] ? 1.f : 0.f;
@@ -807,16 +858,16 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
     } else {  // DIAL_TASK_GO2_SEQ_JUMP
       const int stage = (int)info[DIAL_INFO_STAGE];
       float rp = 0.f;
-      for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - t->pose_targets[stage][k]; rp += e * e; }
+      for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - tg->pose_targets[stage][k]; rp += e * e; }
       float reward_pos = -rp;
-      float ey = yaw - t->yaw_targets[stage];
+      float ey = yaw - tg->yaw_targets[stage];
       float reward_yaw = -(ey * ey);
       float reward_contact = 0.f, penalty_contact = 0.f;
       for (int i = 0; i < 4; i++) {
         bool pen = s.cdist[i] <= 0.001f;
-        for (int j = 0; j < t->n_stage; j++) {
-          float dx = s.cpos[3 * i] - t->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - t->contact_targets[j][i][1];
-          bool cond = (dx * dx + dy * dy) <= t->contact_radius[j][i] * t->contact_radius[j][i];
+        for (int j = 0; j < m->n_stage; j++) {
+          float dx = s.cpos[3 * i] - tg->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - tg->contact_targets[j][i][1];
+          bool cond = (dx * dx + dy * dy) <= tg->contact_radius[j][i] * tg->contact_radius[j][i];
           float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
           reward_contact += cond ? val : 0.f;
           pen = pen && !cond;
@@ -832,14 +883,14 @@ DIAL_DEV float env_step(W& w, const dial_model* m, const dial_task* t, const dia
     bool done = upv[2] < 0.f;
     for (int a = 0; a < nu; a++) {
       float q = s.qpos[7 + a];
-      done = done || q < t->joint_range[a][0] || q > t->joint_range[a][1];
+      done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
     }
-    done = done || s.xpos[3 * tb + 2] < t->done_height;
+    done = done || s.xpos[3 * tb + 2] < m->done_height;
     info[DIAL_INFO_DONE] = done ? 1.f : 0.f;
     info[DIAL_INFO_STEP] = step + 1.f;
-    if (t->kind == DIAL_TASK_GO2_SEQ_JUMP) {
-      float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / t->jump_dt);
-      info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(t->n_stage - 1));
+    if (m->kind == DIAL_TASK_GO2_SEQ_JUMP) {
+      float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / m->jump_dt);
+      info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(m->n_stage - 1));
     }
     info[DIAL_INFO_REWARD] = reward;
   });

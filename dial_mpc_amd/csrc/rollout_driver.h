@@ -26,9 +26,9 @@ struct RolloutIO {
   unsigned long long* prof;  // DIAL_PROFILE builds: per-section cycle counts of sample 0, else nullptr
 };
 
-template <class W>
-DIAL_DEV void load_state(W& w, const dial_model* m, const Ws& s, const float* state) {
-  const int nq = m->nq, nv = m->nv;
+template <class W, class M>
+DIAL_DEV void load_state(W& w, const M* m, const Ws& s, const float* state) {
+  const int nq = dim_nq(m), nv = dim_nv(m);
   w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
     float v = state[i];
     if (i < nq) s.qpos[i] = v;
@@ -37,9 +37,9 @@ DIAL_DEV void load_state(W& w, const dial_model* m, const Ws& s, const float* st
     else s.info[i - nq - 2 * nv] = v;
   });
 }
-template <class W>
-DIAL_DEV void store_state(W& w, const dial_model* m, const Ws& s, float* state) {
-  const int nq = m->nq, nv = m->nv;
+template <class W, class M>
+DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
+  const int nq = dim_nq(m), nv = dim_nv(m);
   w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
     float v;
     if (i < nq) v = s.qpos[i];
@@ -50,10 +50,10 @@ DIAL_DEV void store_state(W& w, const dial_model* m, const Ws& s, float* state) 
   });
 }
 
-template <class W>
-DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv,
-                             const dial_cfg* cfg, const Ws& s, const RolloutIO& io, int n) {
-  const int nq = m->nq, nv = m->nv, nu = m->nu, nx = (m->nbody - 1) * 3, T = io.T, Hn1 = io.Hn1;
+template <class W, class M>
+DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_cfg* cfg, const Ws& s,
+                             const RolloutIO& io, int n) {
+  const int nq = dim_nq(m), nv = dim_nv(m), nu = dim_nu(m), nx = (dim_nb(m) - 1) * 3, T = io.T, Hn1 = io.Hn1;
 #ifdef DIAL_PROFILE
   w.tprev = __builtin_readcyclecounter();
 #endif
@@ -89,7 +89,7 @@ DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, cons
       s.act[a] = u;
     });
     DIAL_MARK(w, 11);
-    float rew = env_step(w, m, t, dv, s);
+    float rew = env_step(w, m, tg, s);
     rsum += rew;
     const size_t o = (size_t)n * T + st;
     w.items(nq + nv + nx + 1, [&](int i) {
@@ -110,16 +110,16 @@ DIAL_DEV void rollout_sample(W& w, const dial_model* m, const dial_task* t, cons
 }
 
 // env.step on the true state (B = 1)
-template <class W>
-DIAL_DEV void env_step_single(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s,
-                              float* state, const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
+template <class W, class M>
+DIAL_DEV void env_step_single(W& w, const M* m, const dial_task* tg, const Ws& s, float* state,
+                              const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
   init_world(w, s);
   load_state(w, m, s, state);
-  w.items(m->nu, [&](int a) { s.act[a] = action[a]; });
-  env_step(w, m, t, dv, s);
+  w.items(dim_nu(m), [&](int a) { s.act[a] = action[a]; });
+  env_step(w, m, tg, s);
   store_state(w, m, s, state);
-  const int nb1 = m->nbody - 1;
-  w.items(nb1 * 7 + m->nu, [&](int i) {
+  const int nb1 = dim_nb(m) - 1;
+  w.items(nb1 * 7 + dim_nu(m), [&](int i) {
     if (i < nb1 * 3) { if (xpos_out) xpos_out[i] = s.xpos[3 + i]; }
     else if (i < nb1 * 7) { if (xquat_out) xquat_out[i - nb1 * 3] = s.xquat[4 + (i - nb1 * 3)]; }
     else { if (ctrl_out) ctrl_out[i - nb1 * 7] = s.ctrl[i - nb1 * 7]; }
@@ -127,23 +127,23 @@ DIAL_DEV void env_step_single(W& w, const dial_model* m, const dial_task* t, con
 }
 
 // env.reset: pipeline_init(q, qd) = mjx.forward with ctrl = 0, then the task's initial info
-template <class W>
-DIAL_DEV void env_reset_single(W& w, const dial_model* m, const dial_task* t, const dial_derived* dv, const Ws& s,
-                               const float* qpos, const float* qvel, float* state, float* xpos_out, float* xquat_out) {
+template <class W, class M>
+DIAL_DEV void env_reset_single(W& w, const M* m, const Ws& s, const float* qpos, const float* qvel, float* state,
+                               float* xpos_out, float* xquat_out) {
   init_world(w, s);
-  const int nq = m->nq, nv = m->nv;
-  w.items(nq + 2 * nv + DIAL_INFO_N + m->nu, [&](int i) {
+  const int nq = dim_nq(m), nv = dim_nv(m);
+  w.items(nq + 2 * nv + DIAL_INFO_N + dim_nu(m), [&](int i) {
     if (i < nq) s.qpos[i] = qpos[i];
     else if (i < nq + nv) s.qvel[i - nq] = qvel[i - nq];
     else if (i < nq + 2 * nv) s.warm[i - nq - nv] = 0.f;
     else if (i < nq + 2 * nv + DIAL_INFO_N) {
       const int k = i - nq - 2 * nv;
-      s.info[k] = (k >= DIAL_INFO_POS_TAR && k < DIAL_INFO_POS_TAR + 3) ? t->init_pos_tar[k - DIAL_INFO_POS_TAR] : 0.f;
+      s.info[k] = (k >= DIAL_INFO_POS_TAR && k < DIAL_INFO_POS_TAR + 3) ? m->init_pos_tar[k - DIAL_INFO_POS_TAR] : 0.f;
     } else s.ctrl[i - nq - 2 * nv - DIAL_INFO_N] = 0.f;
   });
-  forward(w, m, dv, s);
+  forward(w, m, s);
   store_state(w, m, s, state);
-  const int nb1 = m->nbody - 1;
+  const int nb1 = dim_nb(m) - 1;
   w.items(nb1 * 7, [&](int i) {
     if (i < nb1 * 3) { if (xpos_out) xpos_out[i] = s.xpos[3 + i]; }
     else { if (xquat_out) xquat_out[i - nb1 * 3] = s.xquat[4 + (i - nb1 * 3)]; }

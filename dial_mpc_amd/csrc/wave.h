@@ -33,6 +33,25 @@
 #define DIAL_DEV inline
 #define DIAL_UNROLL
 
+
+// ---- SPMD register values for the register-resident sections (rows-in-lanes linear algebra).
+// On the GPU a `vfloat` is one VGPR (a float per lane) and bcast() is v_readlane; in the emulator it is
+// an explicit 64-wide vector and every operator works lane-wise, so the same source runs in lock step.
+struct vbool { bool x[64]; };
+struct vfloat {
+  float x[64];
+};
+inline vfloat vsplat(float v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v; return r; }
+inline vfloat operator+(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] + b.x[l]; return r; }
+inline vfloat operator-(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] - b.x[l]; return r; }
+inline vfloat operator*(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b.x[l]; return r; }
+inline vfloat operator*(const vfloat& a, float b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b; return r; }
+inline vfloat vsel(const vbool& c, const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = c.x[l] ? a.x[l] : b.x[l]; return r; }
+inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
+inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
+inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+
 #define DIAL_MARK(w, id)
 struct Wave {
   float* lds = nullptr;
@@ -85,6 +104,13 @@ struct Wave {
     for (int i = 0; i < count; i++) { float v = f(i); s = v > s ? v : s; }
     return s;
   }
+  // SPMD helpers: value computed per lane; lane-index predicates
+  template <class F>
+  vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
+  vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
+  vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
+  // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
+  void fence() {}
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -123,6 +149,19 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_shfl(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 #endif
 }  // namespace dialwave
+
+
+// ---- SPMD register values (see the emulator section): one VGPR per vfloat, v_readlane broadcasts.
+using vfloat = float;
+using vbool = bool;
+__device__ __forceinline__ vfloat vsplat(float v) { return v; }
+__device__ __forceinline__ vfloat vsel(vbool c, vfloat a, vfloat b) { return c ? a : b; }
+__device__ __forceinline__ float bcast(vfloat v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float lane_val(vfloat v, int) { return v; }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 #ifdef DIAL_PROFILE
 #define DIAL_NSEC 16
@@ -165,5 +204,10 @@ struct Wave {
     float v = lane < count ? f(lane) : -INFINITY;
     return dialwave::wave_max_shfl(v);
   }
+  template <class F>
+  __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
+  __device__ __forceinline__ vbool lane_gt(int k) const { return lane > k; }
+  __device__ __forceinline__ vbool lane_eq(int k) const { return lane == k; }
+  __device__ __forceinline__ void fence() { __syncthreads(); }
 };
 #endif

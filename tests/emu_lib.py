@@ -15,8 +15,7 @@ _SO = os.path.join(_HERE, "libwave_emu.so")
 
 
 def build():
-    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                               ("wave.h", "dmath.h", "derived.h", "rollout_body.h", "rollout_driver.h")]
+    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     srcs.append(_abi.HEADER)
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(f) for f in srcs):
         return
@@ -25,8 +24,11 @@ def build():
 
 
 class Emu:
-    def __init__(self, model, task, cfg=None):
+    def __init__(self, model, task, cfg=None, path=0):
+        """path 0: dimension-specialised instantiation when the model matches one (like the HIP library);
+        path 1: force the generic instantiation."""
         build()
+        self.path = int(path)
         self.lib = ctypes.CDLL(_SO)
         self.model, self.task, self.cfg = model, task, cfg
         self.nq, self.nv, self.nu, self.nbody = model.nq, model.nv, model.nu, model.nbody
@@ -47,7 +49,7 @@ class Emu:
         xquat = np.zeros((self.nbody - 1, 4), np.float32)
         rc = self.lib.emu_env_reset(ctypes.byref(self.model), ctypes.byref(self.task), self._p(self._a(qpos)),
                                     self._p(self._a(qvel)), self._p(state), self._p(xpos), self._p(xquat),
-                                    int(check_races))
+                                    int(check_races), self.path)
         assert rc == 0, f"emu_env_reset: rc={rc} (races or error)"
         return state, xpos, xquat
 
@@ -58,7 +60,7 @@ class Emu:
         ctrl = np.zeros(self.nu, np.float32)
         rc = self.lib.emu_env_step(ctypes.byref(self.model), ctypes.byref(self.task), self._p(state),
                                    self._p(self._a(action)), self._p(xpos), self._p(xquat), self._p(ctrl),
-                                   int(check_races))
+                                   int(check_races), self.path)
         assert rc == 0, f"emu_env_step: rc={rc} (races or error)"
         return state, xpos, xquat, ctrl
 
@@ -74,7 +76,7 @@ class Emu:
                                   ctypes.byref(self.cfg) if self.cfg is not None else None,
                                   self._p(self._a(state)), self._p(us), None, None, None, 0, 0, B, T, 0, None,
                                   self._p(rewss), self._p(rews), self._p(qss), self._p(qdss), self._p(xss),
-                                  int(check_races))
+                                  int(check_races), self.path)
         assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
         return rewss, qss, qdss, xss, rews
 
@@ -93,6 +95,12 @@ class Emu:
         rc = self.lib.emu_rollout(ctypes.byref(self.model), ctypes.byref(self.task), ctypes.byref(cfg),
                                   self._p(self._a(state)), None, self._p(eps), self._p(Ybar), self._p(ns),
                                   int(ns.size), N, B, T, Hn1, self._p(Y0s), self._p(rewss), self._p(rews),
-                                  self._p(qss), self._p(qdss), self._p(xss), int(check_races))
+                                  self._p(qss), self._p(qdss), self._p(xss), int(check_races), self.path)
         assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
         return dict(Y0s=Y0s, rewss=rewss, rews=rews, qss=qss, qdss=qdss, xss=xss)
+
+    def sizes(self):
+        """(which instantiation: 0 generic / 1 Go2 / 2 H1, sizeof(CModel), workspace words)."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        k = self.lib.emu_sizes(ctypes.byref(self.model), ctypes.byref(a), ctypes.byref(b))
+        return k, a.value, b.value

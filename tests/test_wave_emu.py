@@ -15,11 +15,13 @@ def _close(a, b, tol):
     return np.allclose(a, b, rtol=tol["rtol"], atol=tol["atol"])
 
 
+@pytest.mark.parametrize("path", [0, 1], ids=["specialised", "generic"])
 @pytest.mark.parametrize("example,N,H", CASES)
-def test_emulated_kernel_matches_oracle(example, N, H):
+def test_emulated_kernel_matches_oracle(example, N, H, path):
     dc, env, model, task, cfg = setup_case(example, N, H)
     o32 = O.Oracle(model, task, cfg, np.float32)
-    emu = emu_lib.Emu(model, task, cfg)
+    emu = emu_lib.Emu(model, task, cfg, path=path)
+    assert path == 1 or emu.sizes()[0] == (2 if "h1" in example else 1)
     nv, nu = model.nv, model.nu
     s_o, xp_o, xq_o = o32.env_reset(env._init_q, np.zeros(nv))
     s_e, xp_e, xq_e = emu.env_reset(env._init_q, np.zeros(nv), check_races=True)

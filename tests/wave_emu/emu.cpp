@@ -4,70 +4,127 @@
 // check_races != 0, every phase is executed in both item orders from the same LDS snapshot to expose
 // intra-phase dependences (see wave.h).  This lets `pytest -m "not gpu"` compare the exact kernel
 // logic with the oracle on a machine without a GPU.  It is never loaded by dial_mpc_amd/.
+//
+// `path`: 0 = pick the dimension-specialised instantiation when the model matches one (what the HIP
+// library does), 1 = force the generic (capacity-dimension) instantiation.
 #define DIAL_EMU 1
 #include "../../dial_mpc_amd/csrc/rollout_driver.h"
 
 #include <vector>
+
+namespace {
+
+template <class D>
+struct Runner {
+  CModel<D> cm;
+  int ws_words;
+  Runner(const dial_model* m, const dial_task* t, const dial_derived* dv) {
+    fill_cmodel(&cm, m, t, dv);
+    Ws s;
+    ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
+                        DIAL_MAX_NODE, dial::kNeedL<D>);
+  }
+  void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
+    lds.assign(ws_words, 0.f);
+    ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
+             DIAL_MAX_NODE, dial::kNeedL<D>);
+    w.lds = lds.data();
+    w.lds_words = ws_words;
+    w.check_races = check_races != 0;
+  }
+};
+
+template <class D>
+int run_rollout(const dial_model* m, const dial_task* t, const dial_derived* dv, const dial_cfg* cfg,
+                const dial::RolloutIO& io, int B, int check_races) {
+  Runner<D> r(m, t, dv);
+  int races = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : races)
+  for (int n = 0; n < B; n++) {
+    std::vector<float> lds;
+    Ws s;
+    Wave w;
+    r.setup(lds, s, w, check_races);
+    dial::rollout_sample(w, &r.cm, t, cfg, s, io, n);
+    races += w.races;
+  }
+  return races;
+}
+template <class D>
+int run_env_step(const dial_model* m, const dial_task* t, const dial_derived* dv, float* state, const float* action,
+                 float* xpos, float* xquat, float* ctrl, int check_races) {
+  Runner<D> r(m, t, dv);
+  std::vector<float> lds;
+  Ws s;
+  Wave w;
+  r.setup(lds, s, w, check_races);
+  dial::env_step_single(w, &r.cm, t, s, state, action, xpos, xquat, ctrl);
+  return w.races;
+}
+template <class D>
+int run_env_reset(const dial_model* m, const dial_task* t, const dial_derived* dv, const float* qpos,
+                  const float* qvel, float* state, float* xpos, float* xquat, int check_races) {
+  Runner<D> r(m, t, dv);
+  std::vector<float> lds;
+  Ws s;
+  Wave w;
+  r.setup(lds, s, w, check_races);
+  dial::env_reset_single(w, &r.cm, s, qpos, qvel, state, xpos, xquat);
+  return w.races;
+}
+
+#define DISPATCH(path, m, CALL)                                        \
+  if ((path) == 0 && dims_match<DimsGo2>(m)) return CALL(DimsGo2);     \
+  if ((path) == 0 && dims_match<DimsH1>(m)) return CALL(DimsH1);       \
+  return CALL(DimsMax);
+
+}  // namespace
 
 extern "C" {
 
 int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, const float* state, const float* us,
                 const float* eps, const float* Ybar, const float* noise_scale, int ns, int n_noise, int B, int T,
                 int Hn1, float* Y0s, float* rewss, float* rews, float* qss, float* qdss, float* xss,
-                int check_races) {
+                int check_races, int path) {
   dial_derived dv;
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
   if (m->eulerdamp) return DIAL_ERR_UNSUPPORTED;
-  int races = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : races)
-  for (int n = 0; n < B; n++) {
-    std::vector<float> lds(dv.ws_words, 0.f);
-    Ws s;
-    ws_carve(s, lds.data(), m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-             DIAL_MAX_NODE);
-    Wave w;
-    w.lds = lds.data();
-    w.lds_words = dv.ws_words;
-    w.check_races = check_races != 0;
-    dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr};
-    dial::rollout_sample(w, m, t, &dv, cfg, s, io, n);
-    races += w.races;
-  }
-  return races;
+  dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr};
+#define CALL(D) run_rollout<D>(m, t, &dv, cfg, io, B, check_races)
+  DISPATCH(path, m, CALL)
+#undef CALL
 }
 
 int emu_env_step(const dial_model* m, const dial_task* t, float* state, const float* action, float* xpos,
-                 float* xquat, float* ctrl, int check_races) {
+                 float* xquat, float* ctrl, int check_races, int path) {
   dial_derived dv;
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
-  std::vector<float> lds(dv.ws_words, 0.f);
-  Ws s;
-  ws_carve(s, lds.data(), m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
-  Wave w;
-  w.lds = lds.data(); w.lds_words = dv.ws_words; w.check_races = check_races != 0;
-  dial::env_step_single(w, m, t, &dv, s, state, action, xpos, xquat, ctrl);
-  return w.races;
+#define CALL(D) run_env_step<D>(m, t, &dv, state, action, xpos, xquat, ctrl, check_races)
+  DISPATCH(path, m, CALL)
+#undef CALL
 }
 
 int emu_env_reset(const dial_model* m, const dial_task* t, const float* qpos, const float* qvel, float* state,
-                  float* xpos, float* xquat, int check_races) {
+                  float* xpos, float* xquat, int check_races, int path) {
   dial_derived dv;
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
-  std::vector<float> lds(dv.ws_words, 0.f);
-  Ws s;
-  ws_carve(s, lds.data(), m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc, DIAL_MAX_NODE);
-  Wave w;
-  w.lds = lds.data(); w.lds_words = dv.ws_words; w.check_races = check_races != 0;
-  dial::env_reset_single(w, m, t, &dv, s, qpos, qvel, state, xpos, xquat);
-  return w.races;
+#define CALL(D) run_env_reset<D>(m, t, &dv, qpos, qvel, state, xpos, xquat, check_races)
+  DISPATCH(path, m, CALL)
+#undef CALL
 }
 
-int emu_ws_words(const dial_model* m) {
+int emu_sizes(const dial_model* m, int* cmodel_bytes, int* ws_words) {
   dial_derived dv;
   if (dial_build_derived(m, &dv)) return -1;
-  return dv.ws_words;
+  dial_task t{};
+  if (dims_match<DimsGo2>(m)) { Runner<DimsGo2> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 1; }
+  if (dims_match<DimsH1>(m)) { Runner<DimsH1> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 2; }
+  Runner<DimsMax> r(m, &t, &dv);
+  *cmodel_bytes = (int)sizeof(r.cm);
+  *ws_words = r.ws_words;
+  return 0;
 }
 }
