@@ -129,7 +129,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
 // Arrays that are dead before the constraint solver starts share their storage with arrays that only live
 // inside the solver ("union" below); symmetric matrices are stored as packed lower triangles.
 struct Ws {
-  float *qpos, *qvel, *warm, *info, *ctrl, *act, *Y;
+  float *qpos, *qvel, *warm, *info, *ctrl, *act, *Y, *ztar, *rpart;
   float *xpos, *xquat, *spos, *com, *cvel, *cdof;
   float *M, *L;
   float *cdist, *cpos, *cframe, *Jc;
@@ -156,7 +156,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   const int ntri = (nv * (nv + 1)) / 2;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
-  WS_TAKE(act, nu) WS_TAKE(Y, nnode * nu)
+  WS_TAKE(act, nu) WS_TAKE(Y, nnode * nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 8)
   WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
   WS_TAKE(cvel, nbody * 6) WS_TAKE(cdof, nv * 6)
   WS_TAKE(M, ntri) WS_TAKE(L, with_L ? ntri : 0)

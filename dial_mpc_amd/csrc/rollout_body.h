@@ -191,8 +191,14 @@ DIAL_DEV void kbi(const M* m, const float* solref, const float* solimp, float po
   if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0.f) b = -solref[1] / dmax;
   float x = dm::absf(pos) / width;
-  float ia = (1.f / DM_POW(mid, power - 1.f)) * DM_POW(x, power);
-  float ib = 1.f - (1.f / DM_POW(1.f - mid, power - 1.f)) * DM_POW(1.f - x, power);
+  float ia, ib;
+  if (power == 2.f) {          // MuJoCo's default solimp power: x^2 / mid, no transcendental needed
+    ia = (1.f / mid) * (x * x);
+    ib = 1.f - (1.f / (1.f - mid)) * ((1.f - x) * (1.f - x));
+  } else {
+    ia = (1.f / DM_POW(mid, power - 1.f)) * DM_POW(x, power);
+    ib = 1.f - (1.f / DM_POW(1.f - mid, power - 1.f)) * DM_POW(1.f - x, power);
+  }
   float yv = x < mid ? ia : ib;
   float im = dmin + yv * (dmax - dmin);
   im = dm::clip(im, dmin, dmax);
@@ -615,21 +621,30 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
   };
 
-  constraint_grad();
-  DIAL_MARK(w, 4);
-  newton_dir();
-  DIAL_MARK(w, 6);
-
+  // Newton iterations.  Each stage appears once in the instruction stream (the kernel is instruction-cache
+  // sensitive): [forces + gradient] -> convergence test -> [H, Cholesky, search] -> [line search].
   int niter = 0;
   for (;;) {
+    constraint_grad();
+    if (niter > 0) {
+      float c2 = w.sum(ne, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+      float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
+      gauss = 0.5f * g2;
+      prev_cost = cost;
+      cost = 0.5f * c2 + gauss;
+    }
+    DIAL_MARK(w, 4);
+    bool done;
     if (m->iterations != 1) {
       float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
       float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
-      bool done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
-      if (done) break;
-    } else if (niter >= 1) {
-      break;
+      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+    } else {
+      done = niter >= 1;
     }
+    if (done) break;
+    newton_dir();
+    DIAL_MARK(w, 6);
     // ---------------- solver._linesearch
     DIAL_MARK(w, 8);
     w.items(nv + ne, [&](int it) {
@@ -649,18 +664,16 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    w.items(ne, [&](int r) {
-      float ja = s.Jaref[r], jvr = s.jv[r], dr = s.D[r];
-      s.quad[3 * r] = 0.5f * ja * ja * dr;
-      s.quad[3 * r + 1] = jvr * ja * dr;
-      s.quad[3 * r + 2] = 0.5f * jvr * jvr * dr;
-    });
+    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r)
+    const vfloat vJa = w.per_lane([&](int l) { return l < ne ? s.Jaref[l] : 0.f; });
+    const vfloat vjv = w.per_lane([&](int l) { return l < ne ? s.jv[l] : 0.f; });
+    const vfloat vD = w.per_lane([&](int l) { return l < ne ? s.D[l] : 0.f; });
+    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
+    const vfloat vzero = vsplat(0.f);
     struct LsPoint { float alpha, cost, d0, d1; };
     auto ls_point = [&](float alpha) {
-      float q0, q1, q2;
-      w.sum3(ne, [&](int r, float& a, float& b, float& c) {
-        if (s.Jaref[r] + alpha * s.jv[r] < 0.f) { a = s.quad[3 * r]; b = s.quad[3 * r + 1]; c = s.quad[3 * r + 2]; }
-      }, q0, q1, q2);
+      const vbool act = vlt0(vJa + vjv * alpha);
+      float q0 = w.vsum(vsel(act, vq0, vzero)), q1 = w.vsum(vsel(act, vq1, vzero)), q2 = w.vsum(vsel(act, vq2, vzero));
       q0 += qg0; q1 += qg1; q2 += qg2;
       LsPoint p;
       p.alpha = alpha;
@@ -699,27 +712,8 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         else s.Jaref[it - nv] += s.jv[it - nv] * alpha;
       });
     }
-    // ---------------- _update_constraint + _update_gradient
-    DIAL_MARK(w, 7);
-    constraint_grad();
-    float c2 = w.sum(ne, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-    float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
-    gauss = 0.5f * g2;
-    prev_cost = cost;
-    cost = 0.5f * c2 + gauss;
     niter++;
-    // a new Newton direction is only consumed if another iteration will run
-    DIAL_MARK(w, 8);
-    bool more;
-    if (m->iterations != 1) {
-      float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
-      float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
-      more = !(niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance);
-    } else {
-      more = false;
-    }
-    if (more) newton_dir();
-    DIAL_MARK(w, 6);
+    DIAL_MARK(w, 7);
   }
   w.items(nv, [&](int i) { s.warm[i] = s.qacc[i]; });
   DIAL_MARK(w, 8);
@@ -763,21 +757,35 @@ DIAL_DEV float quat_yaw(const float* q) {
 }
 
 // One env.step from the action in s.act (nu values).  Returns the (wave-uniform) reward.
+// The scalar reward terms are independent of each other, so they are spread over lanes (one term per
+// lane) and summed by one lane in the reference's order afterwards: the critical path is the longest term
+// (atan2 / sin / cos), not their sum.
 template <class W, class M>
 DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   const int nu = dim_nu(m);
-  // act2joint / act2tau (base_env.py:38-66)
-  w.items(nu, [&](int a) {
-    float an = (s.act[a] * m->action_scale + 1.0f) / 2.0f;
-    float jt = m->joint_range[a][0] + an * (m->joint_range[a][1] - m->joint_range[a][0]);
-    jt = dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
-    float c;
-    if (m->position_control) c = jt;
-    else {
-      float q_err = jt - s.qpos[7 + a];
-      c = dm::clip(m->kp[a] * q_err - m->kd[a] * s.qvel[6 + a], m->tau_range[a][0], m->tau_range[a][1]);
+  const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK;
+  // act2joint / act2tau (base_env.py:38-66) | desired foot heights from the gait clock (get_foot_step)
+  w.items(nu + DIAL_MAX_FEET, [&](int it) {
+    if (it < nu) {
+      const int a = it;
+      float an = (s.act[a] * m->action_scale + 1.0f) / 2.0f;
+      float jt = m->joint_range[a][0] + an * (m->joint_range[a][1] - m->joint_range[a][0]);
+      jt = dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
+      float c;
+      if (m->position_control) c = jt;
+      else {
+        float q_err = jt - s.qpos[7 + a];
+        c = dm::clip(m->kp[a] * q_err - m->kd[a] * s.qvel[6 + a], m->tau_range[a][0], m->tau_range[a][1]);
+      }
+      s.ctrl[a] = c;
+    } else {
+      const int f = it - nu;
+      if (walk && f < m->nfeet) {
+        const float step = s.info[DIAL_INFO_STEP];
+        s.ztar[f] = m->gait_amp * foot_step_height(step * m->dt * 2.f * DIAL_PI * m->gait_cadence + DIAL_PI,
+                                                   2.f * DIAL_PI * m->gait_phase[f], m->gait_duty);
+      }
     }
-    s.ctrl[a] = c;
   });
   DIAL_MARK(w, 10);
   for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
@@ -785,108 +793,148 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     euler(w, m, s);
     DIAL_MARK(w, 9);
   }
-  // reward / done / info: scalar work, one lane (reads the PRE-integration forward quantities)
-  w.items(1, [&](int) {
+  // ---- reward terms, one per lane (all read the PRE-integration forward quantities)
+  //   rpart: 0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty
+  //          5 height            6 energy    7 done
+  w.items(8, [&](int it) {
     const float dt = m->dt;
     const int tb = m->torso_x + 1, ub = m->upright_x + 1;
-    float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
-    float rot_u[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
-    const float* c = s.com + 3 * m->body_rootid[tb];
-    float off[3] = {s.xpos[3 * tb] - c[0], s.xpos[3 * tb + 1] - c[1], s.xpos[3 * tb + 2] - c[2]};
-    float ang[3] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2]}, cr[3], vel[3];
-    dm::cross3(cr, off, ang);
-    for (int k = 0; k < 3; k++) vel[k] = s.cvel[6 * tb + 3 + k] - cr[k];
     float* info = s.info;
     const float step = info[DIAL_INFO_STEP];
-    float up[3] = {0.f, 0.f, 1.f}, vec[3];
-    dm::rotate(vec, up, rot_u);
-    float reward_upright = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
-    float yaw = quat_yaw(rot_t);
-    float reward = 0.f;
-    if (m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK) {
+    float out = 0.f;
+    if (it == 0) {
+      if (walk) {
+        float reward_gaits = 0.f;
+        for (int f = 0; f < m->nfeet; f++) {
+          const float z_tar = s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
+          float fz;
+          if (m->kind == DIAL_TASK_GO2_WALK) {
+            float e = (z_tar - zs) / 0.05f;
+            reward_gaits += e * e;
+            fz = zs - m->foot_radius;
+          } else {
+            float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
+            reward_gaits += (z_tar - zf) * (z_tar - zf);
+            fz = zs;
+          }
+          const bool contact = fz < 1e-3f;
+          const bool filt = contact || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
+          info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
+          info[DIAL_INFO_LAST_CONTACT + f] = contact ? 1.f : 0.f;
+        }
+        out = -reward_gaits;
+      } else {
+        const int stage = (int)info[DIAL_INFO_STAGE];
+        float reward_contact = 0.f, penalty_contact = 0.f;
+        for (int i = 0; i < 4; i++) {
+          bool pen = s.cdist[i] <= 0.001f;
+          for (int j = 0; j < m->n_stage; j++) {
+            float dx = s.cpos[3 * i] - tg->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - tg->contact_targets[j][i][1];
+            bool cond = (dx * dx + dy * dy) <= tg->contact_radius[j][i] * tg->contact_radius[j][i];
+            float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
+            reward_contact += cond ? val : 0.f;
+            pen = pen && !cond;
+          }
+          penalty_contact += pen ? 1.f : 0.f;
+        }
+        out = reward_contact;
+        s.rpart[4] = penalty_contact;
+      }
+    } else if (it == 1) {
+      float rot_u[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+      float up[3] = {0.f, 0.f, 1.f}, vec[3];
+      dm::rotate(vec, up, rot_u);
+      out = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
+    } else if (it == 2) {
+      float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+      const float yaw = quat_yaw(rot_t);
+      if (walk) {
+        const float a2 = m->cmd_ang_vel[2];
+        const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+        const float d_yaw = yaw - (info[DIAL_INFO_YAW_TAR] + avt * dt * step);
+        const float wy = DM_ATAN2(DM_SIN(d_yaw), DM_COS(d_yaw));
+        out = -(wy * wy);
+      } else {
+        const float ey = yaw - tg->yaw_targets[(int)info[DIAL_INFO_STAGE]];
+        out = -(ey * ey);
+      }
+    } else if (it == 3 || it == 4) {
+      if (walk) {
+        float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+        const float* c = s.com + 3 * m->body_rootid[tb];
+        float off[3] = {s.xpos[3 * tb] - c[0], s.xpos[3 * tb + 1] - c[1], s.xpos[3 * tb + 2] - c[2]};
+        float ang[3] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2]};
+        if (it == 3) {
+          float cr[3], vel[3], vb[3];
+          dm::cross3(cr, off, ang);
+          for (int k = 0; k < 3; k++) vel[k] = s.cvel[6 * tb + 3 + k] - cr[k];
+          dm::inv_rotate(vb, vel, rot_t);
+          float vt[2];
+          for (int k = 0; k < 2; k++) { const float v = m->cmd_vel[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+          const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
+          out = -(e0 * e0 + e1 * e1);
+        } else {
+          float ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
+          dm::inv_rotate(ab, angs, rot_t);
+          const float a2 = m->cmd_ang_vel[2];
+          const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+          out = -(ea * ea);
+        }
+      } else if (it == 3) {
+        const int stage = (int)info[DIAL_INFO_STAGE];
+        float rp = 0.f;
+        for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - tg->pose_targets[stage][k]; rp += e * e; }
+        out = -rp;
+      } else {
+        return;  // seq-jump: rpart[4] (penalty) is written by item 0
+      }
+    } else if (it == 5) {
+      const float dh = s.xpos[3 * tb + 2] - info[DIAL_INFO_POS_TAR + 2];
+      out = -(dh * dh);
+    } else if (it == 6) {
+      float reward_energy = 0.f;
+      if (m->kind == DIAL_TASK_H1_WALK)
+        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
+      out = -reward_energy;
+    } else {
+      float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+      float up[3] = {0.f, 0.f, 1.f}, upv[3];
+      dm::rotate(upv, up, rot_t);
+      bool done = upv[2] < 0.f;
+      for (int a = 0; a < nu; a++) {
+        float q = s.qpos[7 + a];
+        done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
+      }
+      done = done || s.xpos[3 * tb + 2] < m->done_height;
+      out = done ? 1.f : 0.f;
+    }
+    s.rpart[it] = out;
+  });
+  // ---- total in the reference's summation order + info update (one lane; last_ctrl by nu lanes)
+  w.items(1 + nu, [&](int it) {
+    float* info = s.info;
+    if (it > 0) {
+      if (!walk) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
+      return;
+    }
+    const float dt = m->dt, step = info[DIAL_INFO_STEP];
+    const float* r = s.rpart;
+    float reward;
+    if (m->kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239
+      reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;
+    } else if (m->kind == DIAL_TASK_H1_WALK) {    // unitree_h1_env.py:286-298
+      reward = r[0] * 5.0f + r[1] * 0.5f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f;
+    } else {                                      // unitree_go2_env.py:485-496
+      reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
+    }
+    if (walk) {
       for (int k = 0; k < 3; k++) {
-        float v = m->cmd_vel[k], a = m->cmd_ang_vel[k];
+        const float v = m->cmd_vel[k], a = m->cmd_ang_vel[k];
         info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
         info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
       }
-      float reward_gaits = 0.f;
-      bool contact[DIAL_MAX_FEET];
-      for (int f = 0; f < m->nfeet; f++) {
-        float z_tar = m->gait_amp * foot_step_height(step * dt * 2.f * DIAL_PI * m->gait_cadence + DIAL_PI,
-                                                     2.f * DIAL_PI * m->gait_phase[f], m->gait_duty);
-        float zs = s.spos[3 * m->feet_site[f] + 2], fz;
-        if (m->kind == DIAL_TASK_GO2_WALK) {
-          float e = (z_tar - zs) / 0.05f;
-          reward_gaits += e * e;
-          fz = zs - m->foot_radius;
-        } else {
-          float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
-          reward_gaits += (z_tar - zf) * (z_tar - zf);
-          fz = zs;
-        }
-        contact[f] = fz < 1e-3f;
-      }
-      reward_gaits = -reward_gaits;
-      float yaw_tar = info[DIAL_INFO_YAW_TAR] + info[DIAL_INFO_ANG_VEL_TAR + 2] * dt * step;
-      float d_yaw = yaw - yaw_tar;
-      float wy = DM_ATAN2(DM_SIN(d_yaw), DM_COS(d_yaw));
-      float reward_yaw = -(wy * wy);
-      float vb[3], ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
-      dm::inv_rotate(vb, vel, rot_t);
-      dm::inv_rotate(ab, angs, rot_t);
-      float e0 = vb[0] - info[DIAL_INFO_VEL_TAR], e1 = vb[1] - info[DIAL_INFO_VEL_TAR + 1];
-      float reward_vel = -(e0 * e0 + e1 * e1);
-      float ea = ab[2] - info[DIAL_INFO_ANG_VEL_TAR + 2];
-      float reward_ang_vel = -(ea * ea);
-      float dh = s.xpos[3 * tb + 2] - info[DIAL_INFO_POS_TAR + 2];
-      float reward_height = -(dh * dh);
-      if (m->kind == DIAL_TASK_GO2_WALK) {
-        reward = reward_gaits * 0.1f + reward_upright * 0.5f + reward_yaw * 0.3f + reward_vel * 1.0f +
-                 reward_ang_vel * 1.0f + reward_height * 1.0f;
-      } else {
-        float reward_energy = 0.f;
-        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
-        reward_energy = -reward_energy;
-        reward = reward_gaits * 5.0f + reward_upright * 0.5f + reward_yaw * 0.1f + reward_vel * 1.0f +
-                 reward_ang_vel * 1.0f + reward_height * 0.5f + reward_energy * 0.01f;
-      }
-      for (int f = 0; f < m->nfeet; f++) {
-        bool filt = contact[f] || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
-        info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
-        info[DIAL_INFO_LAST_CONTACT + f] = contact[f] ? 1.f : 0.f;
-      }
-    } else {  // DIAL_TASK_GO2_SEQ_JUMP
-      const int stage = (int)info[DIAL_INFO_STAGE];
-      float rp = 0.f;
-      for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - tg->pose_targets[stage][k]; rp += e * e; }
-      float reward_pos = -rp;
-      float ey = yaw - tg->yaw_targets[stage];
-      float reward_yaw = -(ey * ey);
-      float reward_contact = 0.f, penalty_contact = 0.f;
-      for (int i = 0; i < 4; i++) {
-        bool pen = s.cdist[i] <= 0.001f;
-        for (int j = 0; j < m->n_stage; j++) {
-          float dx = s.cpos[3 * i] - tg->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - tg->contact_targets[j][i][1];
-          bool cond = (dx * dx + dy * dy) <= tg->contact_radius[j][i] * tg->contact_radius[j][i];
-          float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
-          reward_contact += cond ? val : 0.f;
-          pen = pen && !cond;
-        }
-        penalty_contact += pen ? 1.f : 0.f;
-      }
-      reward = reward_pos * 1.0f + reward_upright * 1.0f + reward_yaw * 0.3f + reward_contact * 0.1f -
-               penalty_contact * 0.1f + 1.0f * 10.0f;
-      for (int a = 0; a < nu; a++) info[DIAL_INFO_LAST_CTRL + a] = s.ctrl[a];
     }
-    float upv[3];
-    dm::rotate(upv, up, rot_t);
-    bool done = upv[2] < 0.f;
-    for (int a = 0; a < nu; a++) {
-      float q = s.qpos[7 + a];
-      done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
-    }
-    done = done || s.xpos[3 * tb + 2] < m->done_height;
-    info[DIAL_INFO_DONE] = done ? 1.f : 0.f;
+    info[DIAL_INFO_DONE] = r[7];
     info[DIAL_INFO_STEP] = step + 1.f;
     if (m->kind == DIAL_TASK_GO2_SEQ_JUMP) {
       float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / m->jump_dt);

@@ -47,6 +47,7 @@ inline vfloat operator-(const vfloat& a, const vfloat& b) { vfloat r; for (int l
 inline vfloat operator*(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b.x[l]; return r; }
 inline vfloat operator*(const vfloat& a, float b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b; return r; }
 inline vfloat vsel(const vbool& c, const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = c.x[l] ? a.x[l] : b.x[l]; return r; }
+inline vbool vlt0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] < 0.f; return r; }
 inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
 inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
@@ -111,6 +112,8 @@ struct Wave {
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
   void fence() {}
+  // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
+  float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -156,6 +159,7 @@ using vfloat = float;
 using vbool = bool;
 __device__ __forceinline__ vfloat vsplat(float v) { return v; }
 __device__ __forceinline__ vfloat vsel(vbool c, vfloat a, vfloat b) { return c ? a : b; }
+__device__ __forceinline__ vbool vlt0(vfloat a) { return a < 0.f; }
 __device__ __forceinline__ float bcast(vfloat v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -179,7 +183,19 @@ struct Wave {
     tprev = t;
   }
 #endif
-  __device__ __forceinline__ void sync() { __syncthreads(); }
+  // Phase boundary.  DS (LDS) instructions of ONE wave execute in order, so a later ds_read observes an
+  // earlier ds_write of any lane of the same wave without waiting for the write to retire: all that is
+  // needed is that the compiler does not move LDS accesses across the boundary (wavefront-scope fence +
+  // scheduling barrier).  -DDIAL_BLOCK_SYNC restores the conservative workgroup barrier.
+  __device__ __forceinline__ void sync() {
+#ifdef DIAL_BLOCK_SYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  }
 
   template <class F>
   __device__ __forceinline__ void items(int count, F f) {
@@ -208,6 +224,7 @@ struct Wave {
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
   __device__ __forceinline__ vbool lane_gt(int k) const { return lane > k; }
   __device__ __forceinline__ vbool lane_eq(int k) const { return lane == k; }
-  __device__ __forceinline__ void fence() { __syncthreads(); }
+  __device__ __forceinline__ void fence() { sync(); }
+  __device__ __forceinline__ float vsum(vfloat v) { return dialwave::wave_sum(v); }
 };
 #endif
