@@ -15,6 +15,7 @@ struct Dims {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr int NE = NL_ + 4 * NC_;
   static constexpr int NTRI = NV_ * (NV_ + 1) / 2;
+  static constexpr int NANC = 12;   // max dofs on a root-to-body path (Go2: 9, H1: 11)
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19>;
@@ -33,6 +34,9 @@ struct CModel {
   int32_t body_parent[D::NB], body_jntadr[D::NB], body_jntnum[D::NB], body_dofadr[D::NB], body_dofnum[D::NB];
   int32_t body_subtree_end[D::NB], body_rootid[D::NB];
   uint32_t body_ancmask[D::NB];
+  int32_t body_nanc[D::NB];              // number of ancestor-or-own dofs of body b ...
+  uint8_t body_anc[D::NB][D::NANC];      // ... and their indices, root first
+  int32_t body_flags[D::NB];             // bit 0: body_quat is identity, bit 1: all joint anchors at the body origin
   float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
   float body_mass[D::NB], body_inertia[D::NB][3], body_invweight0[D::NB];
   int32_t lvl_start[D::NB + 1], lvl_body[D::NB];

@@ -21,6 +21,11 @@ struct dial_derived {
 // Host: build the derived tables.  Returns 0 or a negative DIAL_ERR_* code.
 static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
   if (m->nv > 32 || m->nbody > DIAL_MAX_BODY || m->nv > DIAL_MAX_V) return DIAL_ERR_ARG;
+  for (int b = 0; b < m->nbody; b++) {   // root-to-body dof paths must fit the ancestor lists (NANC = 12)
+    int depth_dofs = 0;
+    for (int bb = b; bb > 0; bb = m->body_parent[bb]) depth_dofs += m->body_dofnum[bb];
+    if (depth_dofs > 12) return DIAL_ERR_UNSUPPORTED;
+  }
   int nlevel = 0;
   for (int b = 1; b < m->nbody; b++) nlevel = m->body_depth[b] > nlevel ? m->body_depth[b] : nlevel;
   dv->nlevel = nlevel;
@@ -73,6 +78,19 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.body_dofadr[b] = m->body_dofadr[b]; o.body_dofnum[b] = m->body_dofnum[b];
     o.body_subtree_end[b] = m->body_subtree_end[b]; o.body_rootid[b] = m->body_rootid[b];
     o.body_ancmask[b] = dv->body_ancmask[b];
+    {
+      int na = 0;
+      for (int i = 0; i < m->nv && na < D::NANC; i++)
+        if ((dv->body_ancmask[b] >> i) & 1u) o.body_anc[b][na++] = (uint8_t)i;
+      o.body_nanc[b] = na;
+      int flags = 0;
+      if (m->body_quat[b][0] == 1.f && m->body_quat[b][1] == 0.f && m->body_quat[b][2] == 0.f && m->body_quat[b][3] == 0.f) flags |= 1;
+      bool origin = true;
+      for (int ji = m->body_jntadr[b]; ji >= 0 && ji < m->body_jntadr[b] + m->body_jntnum[b]; ji++)
+        origin = origin && m->jnt_pos[ji][0] == 0.f && m->jnt_pos[ji][1] == 0.f && m->jnt_pos[ji][2] == 0.f;
+      if (origin) flags |= 2;
+      o.body_flags[b] = flags;
+    }
     for (int k = 0; k < 3; k++) { o.body_pos[b][k] = m->body_pos[b][k]; o.body_ipos[b][k] = m->body_ipos[b][k]; o.body_inertia[b][k] = m->body_inertia[b][k]; }
     for (int k = 0; k < 4; k++) { o.body_quat[b][k] = m->body_quat[b][k]; o.body_iquat[b][k] = m->body_iquat[b][k]; }
     o.body_mass[b] = m->body_mass[b]; o.body_invweight0[b] = m->body_invweight0[b][0];

@@ -320,8 +320,8 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     HIP_TRY(ctx, hipMalloc(&ctx->weights, sizeof(float) * B));
     const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
     HIP_TRY(ctx, hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
-    HIP_TRY(ctx, hipMalloc(&ctx->prof, sizeof(unsigned long long) * 16));
-    HIP_TRY(ctx, hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 16));
+    HIP_TRY(ctx, hipMalloc(&ctx->prof, sizeof(unsigned long long) * 32));
+    HIP_TRY(ctx, hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 32));
   }
   *out = ctx;
   return DIAL_OK;
@@ -512,9 +512,9 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
 }
 int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_bytes : -1; }
 // DIAL_PROFILE builds: cycle counters of sample 0 of the last rollout launch (16 sections)
-int dial_debug_prof(dial_ctx* ctx, unsigned long long* out16) {
+int dial_debug_prof(dial_ctx* ctx, unsigned long long* out16 /* 32 entries */) {
   if (!ctx || !ctx->prof) return DIAL_ERR_ARG;
-  return hipMemcpy(out16, ctx->prof, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost) == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
+  return hipMemcpy(out16, ctx->prof, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost) == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
 }
 
 }  // extern "C"

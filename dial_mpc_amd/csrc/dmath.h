@@ -12,6 +12,7 @@
 #define DM_POW(x, y) std::pow(x, y)
 #define DM_FLOOR(x) std::floor(x)
 #define DM_EXP(x) std::exp(x)
+#define DM_RINT(x) std::nearbyint(x)
 #else
 #define DM_SQRT(x) sqrtf(x)
 #define DM_SIN(x) sinf(x)
@@ -20,6 +21,7 @@
 #define DM_POW(x, y) powf(x, y)
 #define DM_FLOOR(x) floorf(x)
 #define DM_EXP(x) expf(x)
+#define DM_RINT(x) rintf(x)
 #endif
 
 namespace dm {
@@ -65,8 +67,19 @@ DIAL_DEV void normalize4(float* q) {
   float n = DM_SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (n > 0.f) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
 }
+// sin / cos of a joint half-angle.  On the GPU: the native v_sin_f32 / v_cos_f32 (argument in revolutions,
+// abs error ~1e-6 on |x| <= pi); joint angles are bounded by the joint ranges so no range reduction is needed.
+DIAL_DEV void fast_sincos(float x, float& s, float& c) {
+#ifdef DIAL_EMU
+  s = std::sin(x); c = std::cos(x);
+#else
+  const float r = x * 0.15915494309189535f;
+  s = __builtin_amdgcn_sinf(r); c = __builtin_amdgcn_cosf(r);
+#endif
+}
 DIAL_DEV void axis_angle_to_quat(float* q, const float* axis, float angle) {
-  float s = DM_SIN(angle * 0.5f), c = DM_COS(angle * 0.5f);
+  float s, c;
+  fast_sincos(angle * 0.5f, s, c);
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 DIAL_DEV void inert_mul(float* o, const float* I, const float* v) {

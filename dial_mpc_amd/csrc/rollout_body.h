@@ -206,6 +206,10 @@ DIAL_DEV void kbi(const M* m, const float* solref, const float* solimp, float po
   imp = im;
 }
 
+}  // namespace dial
+#include "solver_reg.h"
+namespace dial {
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
@@ -222,9 +226,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float bp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
       float bq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
       float pos[3], quat[4];
+      const int bflags = m->body_flags[b];
       dm::rotate(pos, bp, pq);
       for (int k = 0; k < 3; k++) pos[k] += s.xpos[3 * p + k];
-      dm::quat_mul(quat, pq, bq);
+      if (bflags & 1) { quat[0] = pq[0]; quat[1] = pq[1]; quat[2] = pq[2]; quat[3] = pq[3]; }   // identity body_quat
+      else dm::quat_mul(quat, pq, bq);
       for (int ji = m->body_jntadr[b]; ji < m->body_jntadr[b] + m->body_jntnum[b]; ji++) {
         const int qa = m->jnt_qposadr[ji];
         float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
@@ -237,16 +243,22 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
           for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = quat[k];
         } else {
           float anchor[3], axis[3];
-          dm::rotate(anchor, jp, quat);
-          for (int k = 0; k < 3; k++) anchor[k] += pos[k];
+          const bool at_origin = (bflags & 2) != 0;   // joint anchor at the body origin: anchor = pos, no offset
+          if (at_origin) { anchor[0] = pos[0]; anchor[1] = pos[1]; anchor[2] = pos[2]; }
+          else {
+            dm::rotate(anchor, jp, quat);
+            for (int k = 0; k < 3; k++) anchor[k] += pos[k];
+          }
           dm::rotate(axis, ja, quat);
           for (int k = 0; k < 3; k++) { s.xanchor[3 * ji + k] = anchor[k]; s.xaxis[3 * ji + k] = axis[k]; }
           if (m->jnt_type[ji] == DIAL_JNT_HINGE) {
             float qloc[4], t3[3];
             dm::axis_angle_to_quat(qloc, ja, s.qpos[qa] - m->qpos0[qa]);
             dm::quat_mul(quat, quat, qloc);
-            dm::rotate(t3, jp, quat);
-            for (int k = 0; k < 3; k++) pos[k] = anchor[k] - t3[k];
+            if (!at_origin) {
+              dm::rotate(t3, jp, quat);
+              for (int k = 0; k < 3; k++) pos[k] = anchor[k] - t3[k];
+            }
           } else {
             float disp = s.qpos[qa] - m->qpos0[qa];
             for (int k = 0; k < 3; k++) pos[k] += axis[k] * disp;
@@ -292,6 +304,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       for (int k = 0; k < 3; k++) s.spos[3 * si + k] = s.xpos[3 * b + k] + t3[k];
     }
   });
+  DIAL_MARK(w, 16);
   // ---- smooth.com_pos: subtree COM of every kinematic-tree root (stored at the root's index)
   w.items(3 * nb, [&](int it) {
     const int b = it / 3, k = it - 3 * b;
@@ -303,6 +316,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
     s.com[3 * b + k] = ms < MJ_MINVAL ? s.xipos[3 * b + k] : mp / ms;
   });
+  DIAL_MARK(w, 17);
   // ---- cinert (per body) and cdof (per joint)
   w.items(nb + nj, [&](int it) {
     if (it < nb) {
@@ -343,15 +357,19 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       }
     }
   });
+  DIAL_MARK(w, 18);
   // ---- smooth.com_vel: cvel[b] = sum over ancestor dofs (root first), no recursion needed
   w.items(6 * nb, [&](int it) {
     const int b = it / 6, k = it - 6 * b;
     float acc = 0.f;
-    unsigned mask = m->body_ancmask[b];
-    for (int i = 0; i < nv; i++)
-      if ((mask >> i) & 1u) acc += s.cdof[6 * i + k] * s.qvel[i];
+    const int na = m->body_nanc[b];
+    for (int a = 0; a < na; a++) {
+      const int i = m->body_anc[b][a];
+      acc += s.cdof[6 * i + k] * s.qvel[i];
+    }
     s.cvel[6 * b + k] = acc;
   });
+  DIAL_MARK(w, 19);
   // ---- cdof_dot (per dof): motion_cross(velocity accumulated BEFORE this joint, cdof)
   w.items(nv, [&](int i) {
     const int ji = m->dof_jntid[i], b = m->dof_bodyid[i], p = m->body_parent[b], da = m->jnt_dofadr[ji];
@@ -366,15 +384,19 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
     dm::motion_cross(out, vs, cd);
   });
+  DIAL_MARK(w, 20);
   // ---- smooth.rne forward part: cacc[b] = [0,-g] + sum over ancestor dofs cdof_dot*qvel
   w.items(6 * nb, [&](int it) {
     const int b = it / 6, k = it - 6 * b;
     float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
-    unsigned mask = m->body_ancmask[b];
-    for (int i = 0; i < nv; i++)
-      if ((mask >> i) & 1u) acc += s.cdofdot[6 * i + k] * s.qvel[i];
+    const int na = m->body_nanc[b];
+    for (int a = 0; a < na; a++) {
+      const int i = m->body_anc[b][a];
+      acc += s.cdofdot[6 * i + k] * s.qvel[i];
+    }
     s.cacc[6 * b + k] = acc;
   });
+  DIAL_MARK(w, 21);
   // ---- smooth.crb composite inertias (subtree sums) | rne local body forces
   w.items(11 * nb, [&](int it) {
     if (it < 10 * nb) {
@@ -394,6 +416,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       for (int k = 0; k < 6; k++) s.cfl[6 * b + k] = f1[k] + f3[k];
     }
   });
+  DIAL_MARK(w, 22);
   // ---- F_i = crb[body_i] * cdof_i | cfrc subtree sums (rne backward part)
   w.items(nv + 6 * nb, [&](int it) {
     if (it < nv) {
@@ -410,6 +433,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.cfrc[6 * b + k] = acc;
     }
   });
+  DIAL_MARK(w, 23);
   // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
   //      | collision_driver (static contact list)
   w.items(ntri + nv + nc, [&](int it) {
@@ -541,6 +565,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   DIAL_MARK(w, 3);
   if (ne == 0) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
+    return;
+  }
+  if constexpr (M::D::is_static) {
+    solver_reg(w, m, s);   // register-resident Newton solver (solver_reg.h)
     return;
   }
 
@@ -852,7 +880,8 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         const float a2 = m->cmd_ang_vel[2];
         const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
         const float d_yaw = yaw - (info[DIAL_INFO_YAW_TAR] + avt * dt * step);
-        const float wy = DM_ATAN2(DM_SIN(d_yaw), DM_COS(d_yaw));
+        // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
+        const float wy = d_yaw - 6.283185307179586f * DM_RINT(d_yaw * 0.15915494309189535f);
         out = -(wy * wy);
       } else {
         const float ey = yaw - tg->yaw_targets[(int)info[DIAL_INFO_STAGE]];

@@ -1,0 +1,253 @@
+// solver_reg.h -- register-resident Newton solver (solver.solve of MJX) for the dimension-specialised
+// instantiations.
+//
+// Lane roles inside the wavefront that owns the sample:
+//   lanes [0, NV)            dof i  -- and the joint-limit row of dof i, if it has one ("row slot")
+//   lanes [32, 32 + 4*NC)    pyramid edge e of contact c (lane 32 + 4c + e)     ("row slot")
+// Persistent registers:
+//   R[NV]   dof lane i: row i of M          contact lane: the constraint row J_r = Jn + f*Jt
+//   per dof lane: qfs, qas, qacc, Ma, grad, search, mv     per row slot: D, aref, lsign, Jaref, jv
+// One sweep  acc += R[j] * readlane(v, j), j < NV  yields M v in the dof lanes AND J v in the contact lanes;
+// J^T f needs 4*NC readlanes; reductions are DPP butterflies.  LDS is used only to build H = M + J^T D J
+// (lane per matrix entry) and for the packed transpose inside the Cholesky solve.
+//
+// Semantics are those of rollout_body.h's LDS solver (same iterates: warm-start choice, MJX line search
+// with <= ls_iterations bracket refinements, skipped final factorisation); the wave emulator runs both
+// against the oracle.
+#pragma once
+// (included from rollout_body.h after msym / tri_idx / kbi are defined)
+
+namespace dial {
+
+// Cholesky solve with the right-hand side / solution in registers (lane i <-> entry i).  See
+// reg_chol_solve in rollout_body.h for the algorithm.
+template <int N, class W>
+DIAL_DEV vfloat reg_chol_solve_v(W& w, const float* A, vfloat b, float* scratch) {
+  vfloat a[N], c[N];
+  float rinv[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a[j] = w.per_lane([&](int l) { return (l < N && j <= l) ? A[tri_idx(l, j)] : 0.f; });
+  vfloat dinv = vsplat(0.f);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float akk = bcast(a[k], k);
+    const float r = fast_rsqrt(akk);
+    rinv[k] = r;
+    vfloat lik = vsel(w.lane_gt(k), a[k] * r, vsplat(0.f));
+    a[k] = lik;
+    dinv = vsel(w.lane_eq(k), vsplat(r), dinv);
+#pragma unroll
+    for (int j = k + 1; j < N; j++) {
+      const float ljk = bcast(lik, j);
+      a[j] = a[j] - lik * ljk;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float yk = bcast(b, k) * rinv[k];
+    b = b - a[k] * yk;
+  }
+  vfloat y = b * dinv;
+  w.items(N, [&](int i) {
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (j < i) scratch[tri_idx(i, j)] = lane_val(a[j], i);
+  });
+#pragma unroll
+  for (int j = 0; j < N; j++) c[j] = w.per_lane([&](int l) { return (l < j && j < N) ? scratch[tri_idx(j, l)] : 0.f; });
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const float xk = bcast(y, k) * rinv[k];
+    y = y - c[k] * xk;
+  }
+  return y * dinv;
+}
+
+template <class W, class M>
+DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
+  constexpr int NV = M::D::NV, NC = M::D::NC, NL = M::D::NL, NTRI = M::D::NTRI;
+  constexpr int C0 = 32;
+  static_assert(NV <= 32 && 4 * NC <= 32, "lane layout needs nv <= 32 and 4*ncon <= 32");
+  const vbool isdof = w.lane_lt(NV);
+  const vfloat vzero = vsplat(0.f);
+
+  // ---- row-slot index of every lane (limit row of the dof, or contact edge row), -1 = none
+  auto row_of = [&](int l) -> int {
+    if (l < NV) return m->dof_limrow[l];
+    if (l >= C0 && l < C0 + 4 * NC) return NL + (l - C0);
+    return -1;
+  };
+  // ---- persistent registers
+  vfloat R[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++)
+    R[j] = w.per_lane([&](int l) {
+      if (l < NV) return msym(s, l, j);
+      if (l >= C0 && l < C0 + 4 * NC) {
+        const int c = (l - C0) >> 2, e = (l - C0) & 3, tan = 1 + (e >> 1);
+        const float mu = m->con_friction[c][tan - 1];
+        return s.Jc[(c * 3) * NV + j] + s.Jc[(c * 3 + tan) * NV + j] * ((e & 1) ? -mu : mu);
+      }
+      return 0.f;
+    });
+  const vfloat vD = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.D[r] : 0.f; });
+  const vfloat varef = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.aref[r] : 0.f; });
+  const vfloat vls = w.per_lane([&](int l) { int r = l < NV ? m->dof_limrow[l] : -1; return r >= 0 ? s.lsign[r] : 0.f; });
+  const vfloat vqfs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] : 0.f; });
+  const vfloat vqas = w.per_lane([&](int l) { return l < NV ? s.qas[l] : 0.f; });
+  const vfloat vwarm = w.per_lane([&](int l) { return l < NV ? s.warm[l] : 0.f; });
+
+  // acc[dof lane i] = (M v)_i, acc[contact lane r] = (J v)_r
+  auto dotR = [&](const vfloat& v) {
+    vfloat acc = vzero;
+#pragma unroll
+    for (int j = 0; j < NV; j++) acc = acc + R[j] * bcast(v, j);
+    return acc;
+  };
+  // row-slot product J_r . v: limit rows are +-e_dof, contact rows come out of the sweep
+  auto row_prod = [&](const vfloat& v, const vfloat& sweep) { return vsel(isdof, vls * v, sweep); };
+  auto row_cost = [&](const vfloat& ja) { return w.vsum(vsel(vlt0(ja), vD * ja * ja, vzero)); };
+
+  // ---- warm-start selection (solver.solve): cost at qacc_warmstart vs cost at qacc_smooth
+  const vfloat pW = dotR(vwarm), pS = dotR(vqas);
+  const vfloat jaW = row_prod(vwarm, pW) - varef, jaS = row_prod(vqas, pS) - varef;
+  const vfloat maW = vsel(isdof, pW, vzero), maS = vsel(isdof, pS, vzero);
+  const float cw = row_cost(jaW), gw = w.vsum((maW - vqfs) * (vwarm - vqas));
+  const float cs = row_cost(jaS), gs = w.vsum((maS - vqfs) * (vqas - vqas));
+  const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
+  const bool use_warm = cost_w < cost_s;
+  vfloat vqacc = use_warm ? vwarm : vqas;
+  vfloat vMa = use_warm ? maW : maS;
+  vfloat vJa = use_warm ? jaW : jaS;
+  float cost = use_warm ? cost_w : cost_s;
+  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
+  float prev_cost = INFINITY;
+  const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
+
+  int niter = 0;
+  for (;;) {
+    // ---- _update_constraint: forces; _update_gradient: grad = Ma - qfrc_smooth - J^T f
+    const vbool act = vlt0(vJa);
+    const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
+    vfloat qfc = vls * vf;  // limit row of the own dof
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const float f0 = bcast(vf, C0 + 4 * c), f1 = bcast(vf, C0 + 4 * c + 1);
+      const float f2 = bcast(vf, C0 + 4 * c + 2), f3 = bcast(vf, C0 + 4 * c + 3);
+      const float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+      // column i of the contact's three frame rows, re-read from LDS (keeping them resident costs 3*NC VGPRs)
+      const vfloat cn = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c) * NV + l] : 0.f; });
+      const vfloat c1 = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c + 1) * NV + l] : 0.f; });
+      const vfloat c2 = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c + 2) * NV + l] : 0.f; });
+      qfc = qfc + cn * ((f0 + f1) + (f2 + f3)) + c1 * (mu1 * (f0 - f1)) + c2 * (mu2 * (f2 - f3));
+    }
+    const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
+    if (niter > 0) {
+      const float c2 = row_cost(vJa), g2 = w.vsum((vMa - vqfs) * (vqacc - vqas));
+      gauss = 0.5f * g2;
+      prev_cost = cost;
+      cost = 0.5f * c2 + gauss;
+    }
+    DIAL_MARK(w, 4);
+    bool done;
+    if (m->iterations != 1) {
+      const float gn = w.vsum(vgrad * vgrad);
+      const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+    } else {
+      done = niter >= 1;
+    }
+    if (done) break;
+
+    // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
+    const vfloat vwgt = vsel(act, vD, vzero);
+    w.items(64, [&](int l) { const int r = row_of(l); if (r >= 0) s.frc[r] = lane_val(vwgt, l); });
+    w.items(NTRI, [&](int it) {
+      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
+      float acc = 0.f;
+      if (i == j) {
+        const int lr = m->dof_limrow[i];
+        if (lr >= 0) acc += s.frc[lr];
+      }
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const float* jn = s.Jc + (c * 3) * NV;
+        const float jni = jn[i], jnj = jn[j];
+        const float t1i = jn[NV + i], t1j = jn[NV + j], t2i = jn[2 * NV + i], t2j = jn[2 * NV + j];
+        const float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+        const float* d = s.frc + NL + 4 * c;
+        acc += ((jni + t1i * mu1) * d[0]) * (jnj + t1j * mu1);
+        acc += ((jni - t1i * mu1) * d[1]) * (jnj - t1j * mu1);
+        acc += ((jni + t2i * mu2) * d[2]) * (jnj + t2j * mu2);
+        acc += ((jni - t2i * mu2) * d[3]) * (jnj - t2j * mu2);
+      }
+      s.H[it] = s.M[it] + acc;
+    });
+    DIAL_MARK(w, 5);
+    const vfloat vsearch = vzero - reg_chol_solve_v<NV>(w, s.H, vgrad, s.L);
+    DIAL_MARK(w, 6);
+
+    // ---- solver._linesearch
+    const vfloat pv = dotR(vsearch);
+    const vfloat vmv = vsel(isdof, pv, vzero);
+    const vfloat vjv = row_prod(vsearch, pv);
+    const float sn2 = w.vsum(vsearch * vsearch);
+    const float s1 = w.vsum(vsearch * vMa - vsearch * vqfs);
+    const float s2 = w.vsum(vsearch * vmv);
+    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
+    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
+    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
+    struct LsPoint { float alpha, cost, d0, d1; };
+    auto ls_point = [&](float alpha) {
+      const vbool on = vlt0(vJa + vjv * alpha);
+      float q0 = w.vsum(vsel(on, vq0, vzero)), q1 = w.vsum(vsel(on, vq1, vzero)), q2 = w.vsum(vsel(on, vq2, vzero));
+      q0 += qg0; q1 += qg1; q2 += qg2;
+      LsPoint p;
+      p.alpha = alpha;
+      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+      p.d0 = 2.f * alpha * q2 + q1;
+      p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      return p;
+    };
+    LsPoint p0 = ls_point(0.f);
+    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
+    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    bool swap = true;
+    int ls_iter = 0;
+    for (;;) {
+      const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      if (ls_done) break;
+      LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
+      LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
+      LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
+      const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+      if (swap_lo_next) lo = lo_next;
+      const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+      if (swap_lo_mid) lo = mid;
+      const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+      if (swap_hi_next) hi = hi_next;
+      const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+      if (swap_hi_mid) hi = mid;
+      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      ls_iter++;
+    }
+    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    if (improved) {
+      vqacc = vqacc + vsearch * alpha;
+      vMa = vMa + vmv * alpha;
+      vJa = vJa + vjv * alpha;
+    }
+    niter++;
+    DIAL_MARK(w, 7);
+  }
+  w.items(NV, [&](int i) {
+    const float q = lane_val(vqacc, i);
+    s.qacc[i] = q;
+    s.warm[i] = q;
+  });
+  DIAL_MARK(w, 8);
+}
+
+}  // namespace dial

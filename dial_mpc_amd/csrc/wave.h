@@ -110,6 +110,7 @@ struct Wave {
   vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
+  vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
   // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
   void fence() {}
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
@@ -168,7 +169,7 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_r
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 #ifdef DIAL_PROFILE
-#define DIAL_NSEC 16
+#define DIAL_NSEC 32
 #define DIAL_MARK(w, id) (w).mark(id)
 #else
 #define DIAL_MARK(w, id)
@@ -224,6 +225,7 @@ struct Wave {
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
   __device__ __forceinline__ vbool lane_gt(int k) const { return lane > k; }
   __device__ __forceinline__ vbool lane_eq(int k) const { return lane == k; }
+  __device__ __forceinline__ vbool lane_lt(int k) const { return lane < k; }
   __device__ __forceinline__ void fence() { sync(); }
   __device__ __forceinline__ float vsum(vfloat v) { return dialwave::wave_sum(v); }
 };

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import seeded_inputs, setup_case  # noqa: E402
 from dial_mpc_amd import _lib  # noqa: E402
 
-NAMES = {0: "kinematics (levels)", 1: "smooth dyn: frames..M,qfs,collision", 2: "Jc + efc rows", 3: "chol(M)+solve",
+NAMES = {0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies, geoms, sites)", 17: "subtree COM", 18: "cinert + cdof", 19: "cvel", 20: "cdof_dot", 21: "cacc", 22: "crb + local forces", 23: "F_i + cfrc", 2: "Jc + efc rows", 3: "chol(M)+solve",
          4: "warmstart select + constraint_grad", 5: "H build", 6: "chol(H)+solve", 7: "linesearch", 8: "post-ls update/sums",
          9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)"}
 
@@ -39,10 +39,10 @@ for label, B in (("B=1", 1), ("B=2049", 2049)):
     else:
         ctx.reverse_once(s0, dev(Ybar), dev(sigma), dev(eps))
     torch.cuda.synchronize()
-    out = (ctypes.c_ulonglong * 16)()
+    out = (ctypes.c_ulonglong * 32)()
     assert lib.dial_debug_prof(ctx.h, out) == 0
     tot = sum(out)
     print(f"--- {example} {label}: total {tot} cycles over {dc.Hsample + 1} steps = {tot / (dc.Hsample + 1):.0f} / step")
-    for k in range(16):
+    for k in range(32):
         if out[k]:
             print(f"  [{k:2d}] {NAMES.get(k, '?'):42s} {out[k]:10d}  {100.0 * out[k] / tot:5.1f}%  {out[k] / (dc.Hsample + 1):9.0f}/step")
