@@ -197,12 +197,30 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
+    // Line-search layout: lane (g, l) = (lane >> 4, lane & 15) owns rows l and l + 16 for quantity g
+    // (g = 0: 0.5 D Jaref^2, g = 1: D jv Jaref, g = 2: 0.5 D jv^2), so ONE 16-lane DPP reduction per trial
+    // point yields all three sums.  Re-layout through LDS (rows are indexed by r there).
+    w.items(64, [&](int l) {
+      const int r = row_of(l);
+      if (r >= 0) { s.Jaref[r] = lane_val(vJa, l); s.jv[r] = lane_val(vjv, l); }
+    });
+    constexpr int NE = M::D::NE, RPL = (NE + 15) / 16;   // rows per line-search lane (Go2: 2, H1: 3)
+    const vbool g0 = w.lane_lt(16), g01 = w.lane_lt(32);
+    vfloat lJa[RPL], ljv[RPL], lQ[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      lJa[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.Jaref[r] : 0.f; });
+      ljv[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.jv[r] : 0.f; });
+      const vfloat lD = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.D[r] : 0.f; });
+      lQ[q] = vsel(g0, (lJa[q] * 0.5f) * lJa[q] * lD, vsel(g01, ljv[q] * lJa[q] * lD, (ljv[q] * 0.5f) * ljv[q] * lD));
+    }
     struct LsPoint { float alpha, cost, d0, d1; };
     auto ls_point = [&](float alpha) {
-      const vbool on = vlt0(vJa + vjv * alpha);
-      float q0 = w.vsum(vsel(on, vq0, vzero)), q1 = w.vsum(vsel(on, vq1, vzero)), q2 = w.vsum(vsel(on, vq2, vzero));
-      q0 += qg0; q1 += qg1; q2 += qg2;
+      vfloat contrib = vzero;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) contrib = contrib + vsel(vlt0(lJa[q] + ljv[q] * alpha), lQ[q], vzero);
+      const vfloat red = w.row16_sum(contrib);
+      const float q0 = bcast(red, 0) + qg0, q1 = bcast(red, 16) + qg1, q2 = bcast(red, 32) + qg2;
       LsPoint p;
       p.alpha = alpha;
       p.cost = alpha * alpha * q2 + alpha * q1 + q0;
@@ -240,6 +258,10 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       vJa = vJa + vjv * alpha;
     }
     niter++;
+#ifdef DIAL_PROFILE
+    w.acc[30] += ls_iter;
+    w.acc[31] += 1;
+#endif
     DIAL_MARK(w, 7);
   }
   w.items(NV, [&](int i) {

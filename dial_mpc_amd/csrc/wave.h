@@ -113,6 +113,16 @@ struct Wave {
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
   // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
   void fence() {}
+  // sum within each aligned group of 16 lanes, result replicated in every lane of the group
+  vfloat row16_sum(const vfloat& v) {
+    vfloat r;
+    for (int g = 0; g < 4; g++) {
+      float t = 0.f;
+      for (int l = 0; l < 16; l++) t += v.x[16 * g + l];
+      for (int l = 0; l < 16; l++) r.x[16 * g + l] = t;
+    }
+    return r;
+  }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
   float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
 };
@@ -228,5 +238,12 @@ struct Wave {
   __device__ __forceinline__ vbool lane_lt(int k) const { return lane < k; }
   __device__ __forceinline__ void fence() { sync(); }
   __device__ __forceinline__ float vsum(vfloat v) { return dialwave::wave_sum(v); }
+  __device__ __forceinline__ vfloat row16_sum(vfloat v) {
+    v = dialwave::dpp_add<0xb1>(v);    // quad_perm [1,0,3,2]
+    v = dialwave::dpp_add<0x4e>(v);    // quad_perm [2,3,0,1]
+    v = dialwave::dpp_add<0x141>(v);   // row_half_mirror
+    v = dialwave::dpp_add<0x140>(v);   // row_mirror
+    return v;
+  }
 };
 #endif
