@@ -164,11 +164,22 @@ def main():
     value = B_global * args.steps / elapsed
     n_local = mbdpi.n_local + 1                     # rollouts per launch on this rank (incl. the mean trajectory)
     avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
-    alg_bytes = GO2_BYTES_PER_STEP * n_local * T
+    # ALGORITHMIC bytes per env.step: us in + reward, q, qd, x.pos out, fp32
+    bytes_per_step = 4 * (nu + 1 + mbdpi.ctx.nq + mbdpi.ctx.nv + mbdpi.ctx.nx)
+    assert args.example != "unitree_go2_trot" or bytes_per_step == GO2_BYTES_PER_STEP
+    flop_per_step = GO2_FLOP_PER_STEP if mbdpi.ctx.nv == 18 else 1.1e5          # SURVEY 8d estimates
+    alg_bytes = bytes_per_step * n_local * T
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    valu_tflops = GO2_FLOP_PER_STEP * n_local * T / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    valu_tflops = flop_per_step * n_local * T / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_rollout_kernel.json")
+    if os.path.exists(pmc_path) and args.example == "unitree_go2_trot" and args.nsample_per_gpu == 2048 and world == 1:
+        pmc = json.load(open(pmc_path))
+        traffic = pmc["hbm_bytes_per_launch"]
+        traffic_src = pmc["source"]
     out = {
-        "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16", "value": value,
+        "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"
+        else f"sample-rollouts/sec (N x H env.steps), {args.example}", "value": value,
         "unit": "sample-rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -177,7 +188,8 @@ def main():
                                f"8 synthetic Go2 states (home + 7 perturbed), eps ~ N(0,1) resident in HBM",
                    "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "rollout_kernel",
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "path is fp32-VALU/latency bound (170 FLOP/B >> 20 FLOP/B machine balance)",

@@ -174,23 +174,37 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   const int ntri = (nv * (nv + 1)) / 2;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
-  WS_TAKE(act, nu) WS_TAKE(Y, nnode * nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 8)
+  WS_TAKE(act, nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 8)
   WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
   WS_TAKE(cvel, nbody * 6) WS_TAKE(cdof, nv * 6)
-  WS_TAKE(M, ntri) WS_TAKE(L, with_L ? ntri : 0)
+  WS_TAKE(M, ntri)
   WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, ncon * 3 * nv)
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   const int u0 = o;
+  // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, nbody * 9) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
-  WS_TAKE(xaxis, njnt * 3) WS_TAKE(gpos, ngeom * 3) WS_TAKE(gaxis, ngeom * 3)
-  WS_TAKE(cinert, nbody * 10) WS_TAKE(cdofdot, nv * 6) WS_TAKE(cacc, nbody * 6) WS_TAKE(crb, nbody * 10)
-  WS_TAKE(cfl, nbody * 6) WS_TAKE(cfrc, nbody * 6) WS_TAKE(Fd, nv * 6)
+  WS_TAKE(xaxis, njnt * 3)
+  const int a1_end = o;
+  o = u0;   // ... so the velocity-dependent temporaries written after that phase reuse it
+  WS_TAKE(cdofdot, nv * 6) WS_TAKE(cacc, nbody * 6) WS_TAKE(cfl, nbody * 6) WS_TAKE(cfrc, nbody * 6)
+  o = o > a1_end ? o : a1_end;
+  WS_TAKE(gpos, ngeom * 3) WS_TAKE(gaxis, ngeom * 3)
+  const int ci0 = o;
+  WS_TAKE(cinert, nbody * 10)
+  const int ci1 = o;
+  o = ci0;  // F_i = crb * cdof is written after the last read of cinert
+  WS_TAKE(Fd, nv * 6)
+  o = o > ci1 ? o : ci1;
+  WS_TAKE(crb, nbody * 10)
   const int u1 = o;
   o = u0;
   WS_TAKE(H, ntri) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc)
   WS_TAKE(quad, nefc * 3) WS_TAKE(MaW, nv) WS_TAKE(MaS, nv) WS_TAKE(grad, nv) WS_TAKE(search, nv)
   WS_TAKE(mv, nv) WS_TAKE(qfc, nv) WS_TAKE(ysol, nv)
+  WS_TAKE(L, with_L ? ntri : 0)   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead
+  o = o > u1 ? o : u1;
+  WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE
-  return o > u1 ? o : u1;
+  return o;
 }

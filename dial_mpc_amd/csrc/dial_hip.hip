@@ -23,35 +23,41 @@
 
 // ------------------------------------------------------------------ kernels
 // Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
-template <class D>
-__device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s) {
+// WPB wavefronts (= samples) per workgroup share ONE staged copy of the constants; each wavefront has
+// its own workspace.  WPB is chosen per robot so that N+1 = 2049 wavefronts are co-resident (>= 9 per CU):
+// Go2 1 (13 KB/wave), H1 2 (7.7 KB constants + 2 x 10.9 KB), generic 1.  This is the only workgroup-level barrier of the kernel (phase boundaries are
+// wavefront-scope fences, wave.h).
+template <class D, int WPB = 1>
+__device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
+                                                        int ws_words) {
   const CModel<D>* m = gm;
   float* wsbase = smem;
   if constexpr (D::is_static) {
     constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspace 16-B aligned
     const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
     __syncthreads();
     m = reinterpret_cast<const CModel<D>*>(smem);
     wsbase = smem + CMW;
   }
+  if constexpr (WPB > 1) wsbase += (threadIdx.x >> 6) * ws_words;   // WPB == 1: LDS addresses stay immediates
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), DIAL_MAX_NODE, dial::kNeedL<D>);
+           dim_ne(m), nnode, dial::kNeedL<D>);
   return m;
 }
 
-template <class D>
-__global__ void __launch_bounds__(64, 3)
+template <class D, int WPB>
+__global__ void __launch_bounds__(64 * WPB, 3)
 rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
-               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B) {
+               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x;
-  if (n >= B) return;
   Ws s;
-  const CModel<D>* m = stage_model<D>(gm, smem, s);
+  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words);
+  const int n = WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x;
+  if (n >= B) return;
   Wave w;
-  w.lane = threadIdx.x;
+  w.lane = threadIdx.x & 63;
   dial::rollout_sample(w, m, tg, cfg, s, io, n);
 }
 
@@ -61,7 +67,7 @@ env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
                 const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  const CModel<D>* m = stage_model<D>(gm, smem, s);
+  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
   Wave w;
   w.lane = threadIdx.x;
   dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
@@ -73,7 +79,7 @@ env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const floa
                  float* xpos_out, float* xquat_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  const CModel<D>* m = stage_model<D>(gm, smem, s);
+  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
   Wave w;
   w.lane = threadIdx.x;
   dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
@@ -205,7 +211,9 @@ struct dial_ctx {
   float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
   float *weights = nullptr, *partial = nullptr;
   unsigned long long* prof = nullptr;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0;        // env_step / env_reset kernels (one wavefront, no node array)
+  size_t lds_rollout = 0;      // rollout kernel: constants + DIAL_WPB workspaces
+  int ws_words = 0, cm_bytes = 0, wpb = 1;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -276,23 +284,26 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
       CModel<D>* h = new CModel<D>();
       fill_cmodel(h, model, task, &ctx->hd);
       Ws s;
-      const int ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
-                                    model->ngeom, model->nsite, model->ncon, model->nefc, DIAL_MAX_NODE,
-                                    dial::kNeedL<D>);
-      const size_t cm_bytes = D::is_static ? ((sizeof(CModel<D>) + 15) / 16) * 16 : 0;
-      ctx->lds_bytes = cm_bytes + (size_t)ws_words * sizeof(float);
+      const int nnode = cfg ? cfg->Hnode + 1 : 0;
+      const int ws0 = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
+                               model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>);
+      ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
+                               model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>);
+      ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
+      ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
+      ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
       hipError_t e = hipMalloc(&ctx->dcm, sizeof(CModel<D>));
       if (e == hipSuccess) e = hipMemcpy(ctx->dcm, h, sizeof(CModel<D>), hipMemcpyHostToDevice);
       delete h;
       return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
     };
     int urc;
-    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model)) { ctx->inst = 1; urc = upload(DimsGo2{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model)) { ctx->inst = 2; urc = upload(DimsH1{}); }
-    else { ctx->inst = 0; urc = upload(DimsMax{}); }
+    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model)) { ctx->inst = 2; ctx->wpb = 2; urc = upload(DimsH1{}); }
+    else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
-  if (ctx->lds_bytes > 64 * 1024) {
+  if (ctx->lds_rollout > 64 * 1024) {
     dial_destroy(ctx);
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds 64 KiB");
   }
@@ -363,12 +374,13 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
     ctx->events_used++;
     HIP_TRY(ctx, hipEventRecord(e0, st));
   }
-#define DIAL_LAUNCH_ROLLOUT(D)                                                                              \
-  hipLaunchKernelGGL(rollout_kernel<D>, dim3(B), dim3(64), ctx->lds_bytes, st, (const CModel<D>*)ctx->dcm, \
-                     (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B)
-  if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2);
-  else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1);
-  else DIAL_LAUNCH_ROLLOUT(DimsMax);
+#define DIAL_LAUNCH_ROLLOUT(D, WPB)                                                                         \
+  hipLaunchKernelGGL((rollout_kernel<D, WPB>), dim3((B + WPB - 1) / WPB), dim3(64 * WPB), ctx->lds_rollout, \
+                     st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
+                     (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words)
+  if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
+  else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 2);
+  else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
@@ -510,7 +522,7 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
   if (weights) *weights = ctx->weights;
   return DIAL_OK;
 }
-int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_bytes : -1; }
+int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_rollout : -1; }
 // DIAL_PROFILE builds: cycle counters of sample 0 of the last rollout launch (16 sections)
 int dial_debug_prof(dial_ctx* ctx, unsigned long long* out16 /* 32 entries */) {
   if (!ctx || !ctx->prof) return DIAL_ERR_ARG;
