@@ -16,6 +16,8 @@ struct Dims {
   static constexpr int NE = NL_ + 4 * NC_;
   static constexpr int NTRI = NV_ * (NV_ + 1) / 2;
   static constexpr int NANC = 12;   // max dofs on a root-to-body path (Go2: 9, H1: 11)
+  static constexpr int NCHAIN = 8;  // max root-to-leaf chains (Go2: 4 legs, H1: 2 legs + 2 arms)
+  static constexpr int CHAINLEN = 8;  // max bodies on a chain (Go2: 4, H1: 6)
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19>;
@@ -40,6 +42,9 @@ struct CModel {
   float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
   float body_mass[D::NB], body_inertia[D::NB][3], body_invweight0[D::NB];
   int32_t lvl_start[D::NB + 1], lvl_body[D::NB];
+  // root-to-leaf chains: prefix sums along a chain give every ancestor sum (cvel, cacc) in one sweep
+  int32_t nchain, chain_len[D::NCHAIN];
+  uint8_t chain_body[D::NCHAIN][D::CHAINLEN];
   // ---- joints
   int32_t jnt_type[D::NJ], jnt_qposadr[D::NJ], jnt_dofadr[D::NJ], jnt_bodyid[D::NJ];
   float jnt_pos[D::NJ][3], jnt_axis[D::NJ][3], jnt_range[D::NJ][2], jnt_solref[D::NJ][2], jnt_solimp[D::NJ][5];

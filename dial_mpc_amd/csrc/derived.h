@@ -97,6 +97,22 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.lvl_body[b] = dv->lvl_body[b];
   }
   for (int b = 0; b <= m->nbody && b <= D::NB; b++) o.lvl_start[b] = dv->lvl_start[b < DIAL_MAX_BODY + 1 ? b : DIAL_MAX_BODY];
+  {  // chains: one per leaf body, listed root first; models that exceed the table sizes get nchain = 0
+    int nch = 0;
+    bool ok = true;
+    for (int b = 1; b < m->nbody && ok; b++) {
+      bool leaf = true;
+      for (int c2 = b + 1; c2 < m->nbody; c2++) leaf = leaf && m->body_parent[c2] != b;
+      if (!leaf) continue;
+      int path[64], len = 0;
+      for (int bb = b; bb > 0 && len < 64; bb = m->body_parent[bb]) path[len++] = bb;
+      if (nch >= D::NCHAIN || len > D::CHAINLEN) { ok = false; break; }
+      o.chain_len[nch] = len;
+      for (int q = 0; q < len; q++) o.chain_body[nch][q] = (uint8_t)path[len - 1 - q];
+      nch++;
+    }
+    o.nchain = ok ? nch : 0;
+  }
   for (int j = 0; j < m->njnt; j++) {
     o.jnt_type[j] = m->jnt_type[j]; o.jnt_qposadr[j] = m->jnt_qposadr[j]; o.jnt_dofadr[j] = m->jnt_dofadr[j];
     o.jnt_bodyid[j] = m->jnt_bodyid[j]; o.jnt_margin[j] = m->jnt_margin[j];

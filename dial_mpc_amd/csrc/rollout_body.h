@@ -359,16 +359,31 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   });
   DIAL_MARK(w, 18);
   // ---- smooth.com_vel: cvel[b] = sum over ancestor dofs (root first), no recursion needed
-  w.items(6 * nb, [&](int it) {
-    const int b = it / 6, k = it - 6 * b;
-    float acc = 0.f;
-    const int na = m->body_nanc[b];
-    for (int a = 0; a < na; a++) {
-      const int i = m->body_anc[b][a];
-      acc += s.cdof[6 * i + k] * s.qvel[i];
-    }
-    s.cvel[6 * b + k] = acc;
-  });
+  if (m->nchain > 0) {
+    // prefix sums down every root-to-leaf chain: item = (chain, component); bodies shared by several chains
+    // are written by each of them with the same value
+    w.items(6 * m->nchain, [&](int it) {
+      const int c = it / 6, k = it - 6 * c;
+      float acc = 0.f;
+      if (c == 0) s.cvel[k] = 0.f;   // world body
+      for (int q = 0; q < m->chain_len[c]; q++) {
+        const int b = m->chain_body[c][q];
+        for (int i = m->body_dofadr[b]; i < m->body_dofadr[b] + m->body_dofnum[b]; i++) acc += s.cdof[6 * i + k] * s.qvel[i];
+        s.cvel[6 * b + k] = acc;
+      }
+    });
+  } else {
+    w.items(6 * nb, [&](int it) {
+      const int b = it / 6, k = it - 6 * b;
+      float acc = 0.f;
+      const int na = m->body_nanc[b];
+      for (int a = 0; a < na; a++) {
+        const int i = m->body_anc[b][a];
+        acc += s.cdof[6 * i + k] * s.qvel[i];
+      }
+      s.cvel[6 * b + k] = acc;
+    });
+  }
   DIAL_MARK(w, 19);
   // ---- cdof_dot (per dof): motion_cross(velocity accumulated BEFORE this joint, cdof)
   w.items(nv, [&](int i) {
@@ -386,16 +401,29 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   });
   DIAL_MARK(w, 20);
   // ---- smooth.rne forward part: cacc[b] = [0,-g] + sum over ancestor dofs cdof_dot*qvel
-  w.items(6 * nb, [&](int it) {
-    const int b = it / 6, k = it - 6 * b;
-    float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
-    const int na = m->body_nanc[b];
-    for (int a = 0; a < na; a++) {
-      const int i = m->body_anc[b][a];
-      acc += s.cdofdot[6 * i + k] * s.qvel[i];
-    }
-    s.cacc[6 * b + k] = acc;
-  });
+  if (m->nchain > 0) {
+    w.items(6 * m->nchain, [&](int it) {
+      const int c = it / 6, k = it - 6 * c;
+      float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
+      if (c == 0) s.cacc[k] = acc;   // world body
+      for (int q = 0; q < m->chain_len[c]; q++) {
+        const int b = m->chain_body[c][q];
+        for (int i = m->body_dofadr[b]; i < m->body_dofadr[b] + m->body_dofnum[b]; i++) acc += s.cdofdot[6 * i + k] * s.qvel[i];
+        s.cacc[6 * b + k] = acc;
+      }
+    });
+  } else {
+    w.items(6 * nb, [&](int it) {
+      const int b = it / 6, k = it - 6 * b;
+      float acc = k >= 3 ? -m->gravity[k - 3] : 0.f;
+      const int na = m->body_nanc[b];
+      for (int a = 0; a < na; a++) {
+        const int i = m->body_anc[b][a];
+        acc += s.cdofdot[6 * i + k] * s.qvel[i];
+      }
+      s.cacc[6 * b + k] = acc;
+    });
+  }
   DIAL_MARK(w, 21);
   // ---- smooth.crb composite inertias (subtree sums) | rne local body forces
   w.items(11 * nb, [&](int it) {
@@ -788,7 +816,9 @@ DIAL_DEV float quat_yaw(const float* q) {
 // The scalar reward terms are independent of each other, so they are spread over lanes (one term per
 // lane) and summed by one lane in the reference's order afterwards: the critical path is the longest term
 // (atan2 / sin / cos), not their sum.
-template <class W, class M>
+// FULL_INFO = false (rollouts): the write-only info fields (done, feet_air_time, last_contact) are not
+// maintained -- nothing reads them inside a rollout (done never terminates one).
+template <bool FULL_INFO, class W, class M>
 DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   const int nu = dim_nu(m);
   const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK;
@@ -824,7 +854,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   // ---- reward terms, one per lane (all read the PRE-integration forward quantities)
   //   rpart: 0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty
   //          5 height            6 energy    7 done
-  w.items(8, [&](int it) {
+  w.items(FULL_INFO ? 8 : 7, [&](int it) {
     const float dt = m->dt;
     const int tb = m->torso_x + 1, ub = m->upright_x + 1;
     float* info = s.info;
@@ -845,10 +875,12 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
             reward_gaits += (z_tar - zf) * (z_tar - zf);
             fz = zs;
           }
-          const bool contact = fz < 1e-3f;
-          const bool filt = contact || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
-          info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
-          info[DIAL_INFO_LAST_CONTACT + f] = contact ? 1.f : 0.f;
+          if (FULL_INFO) {
+            const bool contact = fz < 1e-3f;
+            const bool filt = contact || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
+            info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
+            info[DIAL_INFO_LAST_CONTACT + f] = contact ? 1.f : 0.f;
+          }
         }
         out = -reward_gaits;
       } else {
@@ -963,7 +995,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
       }
     }
-    info[DIAL_INFO_DONE] = r[7];
+    if (FULL_INFO) info[DIAL_INFO_DONE] = r[7];
     info[DIAL_INFO_STEP] = step + 1.f;
     if (m->kind == DIAL_TASK_GO2_SEQ_JUMP) {
       float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / m->jump_dt);

@@ -89,7 +89,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       s.act[a] = u;
     });
     DIAL_MARK(w, 11);
-    float rew = env_step(w, m, tg, s);
+    float rew = env_step<false>(w, m, tg, s);
     rsum += rew;
     const size_t o = (size_t)n * T + st;
     w.items(nq + nv + nx + 1, [&](int i) {
@@ -116,7 +116,7 @@ DIAL_DEV void env_step_single(W& w, const M* m, const dial_task* tg, const Ws& s
   init_world(w, s);
   load_state(w, m, s, state);
   w.items(dim_nu(m), [&](int a) { s.act[a] = action[a]; });
-  env_step(w, m, tg, s);
+  env_step<true>(w, m, tg, s);
   store_state(w, m, s, state);
   const int nb1 = dim_nb(m) - 1;
   w.items(nb1 * 7 + dim_nu(m), [&](int i) {
