@@ -19,7 +19,7 @@
 
 #include "rollout_driver.h"
 
-#define WSUM_CHUNKS 32
+#define WSUM_CHUNKS 64
 
 // ------------------------------------------------------------------ kernels
 // Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
@@ -85,52 +85,51 @@ env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const floa
   dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
 }
 
-// Deterministic block reduction helpers (256 threads).
-__device__ __forceinline__ float block_sum256(float v, float* red) {
+// Deterministic block reductions (1024 threads = 16 wavefronts): DPP butterfly inside each wavefront, then a
+// fixed-order sum of the 16 partials.  The order never depends on timing => bit-identical on every rank.
+#define WK_THREADS 1024
+__device__ __forceinline__ float block_sum(float v, float* red) {
   const int tid = threadIdx.x;
-  red[tid] = v;
+  float ws = dialwave::wave_sum_dpp(v);
+  if ((tid & 63) == 0) red[tid >> 6] = ws;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
-  float r = red[0];
+  float r = 0.f;
+#pragma unroll
+  for (int k = 0; k < WK_THREADS / 64; k++) r += red[k];
   __syncthreads();
   return r;
 }
-__device__ __forceinline__ float block_max256(float v, float* red) {
+__device__ __forceinline__ float block_max(float v, float* red) {
   const int tid = threadIdx.x;
-  red[tid] = v;
+  float wm = dialwave::wave_max_shfl(v);
+  if ((tid & 63) == 0) red[tid >> 6] = wm;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] = red[tid + o] > red[tid] ? red[tid + o] : red[tid];
-    __syncthreads();
-  }
-  float r = red[0];
+  float r = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < WK_THREADS / 64; k++) r = red[k] > r ? red[k] : r;
   __syncthreads();
   return r;
 }
 
 // K4a (dial_core.py:121-128): rews [B] (last = mean trajectory) -> softmax weights [B].
 // logp0 = (rews - rew_bar) / std(rews) / temp; std is the population std over all B samples.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(WK_THREADS)
 weights_kernel(const float* __restrict__ rews, int B, float temp, float* __restrict__ weights) {
-  __shared__ float red[256];
+  __shared__ float red[WK_THREADS / 64];
   const int tid = threadIdx.x;
-  float acc = 0.f;
-  for (int n = tid; n < B; n += 256) acc += rews[n];
-  const float mean = block_sum256(acc, red) / (float)B;
+  float acc = 0.f, mxr = -INFINITY;
+  for (int n = tid; n < B; n += WK_THREADS) { float r = rews[n]; acc += r; mxr = r > mxr ? r : mxr; }
+  const float mean = block_sum(acc, red) / (float)B;
+  const float rmax = block_max(mxr, red);
   acc = 0.f;
-  for (int n = tid; n < B; n += 256) { float d = rews[n] - mean; acc += d * d; }
-  const float stdv = sqrtf(block_sum256(acc, red) / (float)B);
+  for (int n = tid; n < B; n += WK_THREADS) { float d = rews[n] - mean; acc += d * d; }
+  const float stdv = sqrtf(block_sum(acc, red) / (float)B);
   const float rew_bar = rews[B - 1];
-  float mx = -INFINITY;
-  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; mx = l > mx ? l : mx; }
-  mx = block_max256(mx, red);
+  const float mx = (rmax - rew_bar) / stdv / temp;   // max of logp0: the map r -> logp0 is increasing
   acc = 0.f;
-  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; acc += expf(l - mx); }
-  const float den = block_sum256(acc, red);
-  for (int n = tid; n < B; n += 256) { float l = (rews[n] - rew_bar) / stdv / temp; weights[n] = expf(l - mx) / den; }
+  for (int n = tid; n < B; n += WK_THREADS) { float l = (rews[n] - rew_bar) / stdv / temp; acc += expf(l - mx); }
+  const float den = block_sum(acc, red);
+  for (int n = tid; n < B; n += WK_THREADS) { float l = (rews[n] - rew_bar) / stdv / temp; weights[n] = expf(l - mx) / den; }
 }
 
 // K4b (dial_core.py:132-135): out[c] = sum_n w[widx(n)] * X_seg[n][c] over the local samples.
@@ -148,6 +147,7 @@ wsum_partial_kernel(WsumArgs a, const float* __restrict__ weights, float* __rest
   const int chunk = blockIdx.y, per = (a.n_rows + WSUM_CHUNKS - 1) / WSUM_CHUNKS;
   const int r0 = chunk * per, r1 = (r0 + per < a.n_rows) ? r0 + per : a.n_rows;
   float acc = 0.f;
+#pragma unroll 8
   for (int r = r0; r < r1; r++) {
     // rows [0, mean_row) are this shard's noisy samples -> weight index w_begin + r; the mean row (if
     // present and included) uses mean_widx; a mean row that is not included has mean_widx < 0.
@@ -438,7 +438,7 @@ int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_b
   hipStream_t st = (hipStream_t)stream;
   // global weights need n_total+1 floats; reuse ctx->weights when it fits, else fail loudly
   if (n_total + 1 > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: create the context with Nsample = global sample count");
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
   const dial_model& m = ctx->hm;
   float* Yo = packed_out;
   float* qo = Yo + ctx->Hn1 * m.nu;
@@ -458,7 +458,7 @@ int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, c
   int rc = dial_shard_rollout(ctx, state, Ybar_in, noise_scale, ns, eps, N, 1, rews, stream);
   if (rc != DIAL_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(256), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
   return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st);
 }
 
