@@ -9,8 +9,36 @@
 #include <stdint.h>
 #include "../../include/dial_mpc.h"
 
-template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_>
+// ---- compile-time dof-tree topology of a robot (enables branch-induced sparsity in the factorisations)
+struct TopoDense {
+  static constexpr bool dense = true;
+  static constexpr bool anc(int, int) { return true; }
+};
+template <int N>
+struct ParentTable { int8_t p[N]; };
+template <int N>
+constexpr bool topo_anc(const ParentTable<N>& t, int i, int j) {   // is dof j an ancestor-or-self of dof i ?
+  while (i >= 0) {
+    if (i == j) return true;
+    i = t.p[i];
+  }
+  return false;
+}
+struct TopoGo2 {   // free base (0..5) + 4 legs of 3 hinges hanging off dof 5
+  static constexpr bool dense = false;
+  static constexpr ParentTable<18> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 5, 9, 10, 5, 12, 13, 5, 15, 16}};
+  static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
+};
+struct TopoH1 {    // free pelvis, 2 legs of 5, torso (dof 16), 2 arms of 4 hanging off the torso
+  static constexpr bool dense = false;
+  static constexpr ParentTable<25> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5, 16, 17, 18, 19, 16, 21, 22, 23}};
+  static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
+};
+
+template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
+          class Topo_ = TopoDense>
 struct Dims {
+  using Topo = Topo_;
   static constexpr bool is_static = STATIC;
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr int NE = NL_ + 4 * NC_;
@@ -19,10 +47,23 @@ struct Dims {
   static constexpr int NCHAIN = 8;  // max root-to-leaf chains (Go2: 4 legs, H1: 2 legs + 2 arms)
   static constexpr int CHAINLEN = 8;  // max bodies on a chain (Go2: 4, H1: 6)
 };
-using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12>;
-using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19>;
+using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2>;
+using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+#include <type_traits>
+template <int B, int E, class F>
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 // Everything one env.step reads that is constant across samples and steps.
 template <class D_>
@@ -51,7 +92,8 @@ struct CModel {
   float jnt_margin[D::NJ], qpos0[D::NQ];
   // ---- dofs
   int32_t dof_bodyid[D::NV], dof_jntid[D::NV], dof_act[D::NV], dof_limrow[D::NV];
-  uint32_t dof_ancmask[D::NV];
+  uint32_t dof_ancmask[D::NV];           // bit j: dof j is an ancestor-or-self of dof i
+  uint32_t dof_descmask[D::NV];          // bit j: dof j is a descendant-or-self of dof i
   float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
   uint16_t tri[D::NTRI + (D::NTRI & 1)];
   // ---- geoms / sites / contacts / limits / actuators
@@ -99,8 +141,12 @@ CM_DIM(dim_ntri, NTRI, ntri)
 // ---- host: does a model fit a static instantiation exactly?
 template <class D>
 static inline bool dims_match(const dial_model* m) {
-  return m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
-         m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL;
+  bool ok = m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
+            m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL;
+  if constexpr (!D::Topo::dense) {   // the sparse factorisations are specialised to the dof tree as well
+    for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
+  }
+  return ok;
 }
 
 struct dial_derived;  // derived.h

@@ -55,10 +55,15 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
     dv->dof_act[m->act_dofadr[a]] = a;
   }
   for (int l = 0; l < m->nlim; l++) dv->dof_limrow[m->jnt_dofadr[m->lim_jnt[l]]] = l;
+  // lower-triangle entries that can be non-zero: M[i][j] and (for world-only contacts) H[i][j] vanish unless
+  // dof j is an ancestor of dof i (branch-induced sparsity)
   int t = 0;
   for (int i = 0; i < m->nv; i++)
-    for (int j = 0; j <= i; j++) dv->tri[t++] = (uint16_t)((i << 8) | j);
+    for (int j = 0; j <= i; j++)
+      if ((dv->dof_ancmask[i] >> j) & 1u) dv->tri[t++] = (uint16_t)((i << 8) | j);
   dv->ntri = t;
+  for (int c = 0; c < m->ncon; c++)
+    if (m->con_body1[c] != 0) return DIAL_ERR_UNSUPPORTED;   // body-body contacts would fill H between branches
   return DIAL_OK;
 }
 
@@ -124,6 +129,8 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   for (int i = 0; i < m->nv; i++) {
     o.dof_bodyid[i] = m->dof_bodyid[i]; o.dof_jntid[i] = m->dof_jntid[i]; o.dof_act[i] = dv->dof_act[i];
     o.dof_limrow[i] = dv->dof_limrow[i]; o.dof_ancmask[i] = dv->dof_ancmask[i];
+    o.dof_descmask[i] = 0;
+    for (int j = 0; j < m->nv; j++) if ((dv->dof_ancmask[j] >> i) & 1u) o.dof_descmask[i] |= (1u << j);
     o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
   }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];

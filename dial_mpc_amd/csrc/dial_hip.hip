@@ -58,6 +58,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   if (n >= B) return;
   Wave w;
   w.lane = threadIdx.x & 63;
+  w.lane_r = w.lane;
   dial::rollout_sample(w, m, tg, cfg, s, io, n);
 }
 
@@ -70,6 +71,7 @@ env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
   Wave w;
   w.lane = threadIdx.x;
+  w.lane_r = w.lane;
   dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
 }
 
@@ -82,6 +84,7 @@ env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const floa
   const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
   Wave w;
   w.lane = threadIdx.x;
+  w.lane_r = w.lane;
   dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
 }
 

@@ -118,64 +118,10 @@ DIAL_DEV void chol_solve(W& w, int n, const float* A, float* Lo, float* rhs, flo
     });
   }
 }
-// Register-resident Cholesky solve (dimension-specialised instantiations): lane i owns row i of the
-// matrix in N registers.  Right-looking factorisation: at step k the pivot and the column entries l_jk are
-// broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row; the strictly lower
-// triangle ends up in a[], the reciprocal diagonal in dinv / rinv[].  The forward substitution needs only
-// rows; the backward one needs columns, obtained through one packed-triangle transpose in LDS (scratch).
-// ~N^2 + 8N VALU/readlane instructions and 2 LDS round trips instead of 2N LDS-latency-bound phases.
-template <int N, class W>
-DIAL_DEV void reg_chol_solve(W& w, const float* A, const float* rhs, float* scratch, float* x) {
-  vfloat a[N], c[N];
-  float rinv[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) a[j] = w.per_lane([&](int l) { return (l < N && j <= l) ? A[tri_idx(l, j)] : 0.f; });
-  vfloat b = w.per_lane([&](int l) { return l < N ? rhs[l] : 0.f; });
-  vfloat dinv = vsplat(0.f);
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const float akk = bcast(a[k], k);
-    const float r = fast_rsqrt(akk);
-    rinv[k] = r;
-    vfloat lik = vsel(w.lane_gt(k), a[k] * r, vsplat(0.f));
-    a[k] = lik;
-    dinv = vsel(w.lane_eq(k), vsplat(r), dinv);
-#pragma unroll
-    for (int j = k + 1; j < N; j++) {
-      const float ljk = bcast(lik, j);
-      a[j] = a[j] - lik * ljk;
-    }
-  }
-  // forward substitution L y = b (lane k's b is final once steps p < k are done; a[k] is 0 in lanes <= k)
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const float yk = bcast(b, k) * rinv[k];
-    b = b - a[k] * yk;
-  }
-  vfloat y = b * dinv;
-  // transpose the strictly lower triangle through LDS: lane i writes row i, reads column i
-  w.items(N, [&](int i) {
-#pragma unroll
-    for (int j = 0; j < N; j++)
-      if (j < i) scratch[tri_idx(i, j)] = lane_val(a[j], i);
-  });
-#pragma unroll
-  for (int j = 0; j < N; j++) c[j] = w.per_lane([&](int l) { return (l < j && j < N) ? scratch[tri_idx(j, l)] : 0.f; });
-  // backward substitution L^T x = y
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const float xk = bcast(y, k) * rinv[k];
-    y = y - c[k] * xk;
-  }
-  vfloat xv = y * dinv;
-  w.items(N, [&](int i) { x[i] = lane_val(xv, i); });
-}
-
 // x = A^-1 rhs for the packed SPD matrix A (M or H).  rhs is clobbered (LDS path).
 template <class W, class M>
 DIAL_DEV void solve_spd(W& w, const M* m, const Ws& s, const float* A, float* rhs, float* x) {
-  if constexpr (M::D::is_static) reg_chol_solve<M::D::NV>(w, A, rhs, s.L, x);
-  else chol_solve(w, dim_nv(m), A, s.L, rhs, s.ysol, x);
+  chol_solve(w, dim_nv(m), A, s.L, rhs, s.ysol, x);
 }
 
 // ---------------------------------------------------------------- constraint._kbi
@@ -214,7 +160,7 @@ namespace dial {
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   const int nb = dim_nb(m), nv = dim_nv(m), nj = dim_nj(m), ng = dim_ng(m), nsite = dim_ns(m), nc = dim_nc(m);
-  const int ne = dim_ne(m), nl = dim_nl(m), ntri = dim_ntri(m);
+  const int ne = dim_ne(m), nl = dim_nl(m), ntri = m->ntri;   // ntri: structurally non-zero entries of M / H
 
   DIAL_MARK(w, 15);
   // ---- smooth.kinematics: level-synchronous sweep over the body tree
@@ -462,6 +408,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
   });
   DIAL_MARK(w, 23);
+  if constexpr (!M::D::is_static) w.items((nv * (nv + 1)) / 2, [&](int e) { s.M[e] = 0.f; });
   // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
   //      | collision_driver (static contact list)
   w.items(ntri + nv + nc, [&](int it) {
@@ -472,7 +419,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         for (int k = 0; k < 6; k++) v += s.Fd[6 * i + k] * s.cdof[6 * j + k];
       }
       if (i == j) v += m->dof_armature[i];
-      s.M[it] = v;
+      s.M[tri_idx(i, j)] = v;
     } else if (it < ntri + nv) {
       const int i = it - ntri, b = m->dof_bodyid[i];
       float bias = 0.f;
@@ -589,7 +536,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   });
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
-  solve_spd(w, m, s, s.M, s.rhs, s.qas);
+  if constexpr (M::D::is_static) {
+    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.L);
+    w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
+  } else {
+    solve_spd(w, m, s, s.M, s.rhs, s.qas);
+  }
   DIAL_MARK(w, 3);
   if (ne == 0) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
@@ -649,6 +601,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   };
   // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
   auto newton_dir = [&]() {
+    w.items((nv * (nv + 1)) / 2, [&](int e) { s.H[e] = 0.f; });   // generic path only (see solver_reg.h for the other)
     DIAL_MARK(w, 14);
     w.items(ntri, [&](int it) {
       const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
@@ -670,7 +623,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
         acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
       }
-      s.H[it] = s.M[it] + acc;
+      s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
     });
     DIAL_MARK(w, 5);
     solve_spd(w, m, s, s.H, s.rhs, s.search);

@@ -111,6 +111,9 @@ struct Wave {
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
+  void begin_region() {}
+  // reverse the first n lanes: result[l] = v[n-1-l] for l < n (0 elsewhere)
+  vfloat lane_reverse(const vfloat& v, int n) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = l < n ? v.x[n - 1 - l] : 0.f; return r; }
   // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
   void fence() {}
   // sum within each aligned group of 16 lanes, result replicated in every lane of the group
@@ -233,9 +236,20 @@ struct Wave {
   }
   template <class F>
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
-  __device__ __forceinline__ vbool lane_gt(int k) const { return lane > k; }
-  __device__ __forceinline__ vbool lane_eq(int k) const { return lane == k; }
-  __device__ __forceinline__ vbool lane_lt(int k) const { return lane < k; }
+  // Lane-index predicates compare against `lane_r`, a copy of the lane id that begin_region() launders
+  // through an empty asm.  The comparisons are loop invariants of the T-step rollout loop; left alone, LICM
+  // hoists dozens of them out of it as 64-bit SGPR masks that live for the whole kernel and get spilled,
+  // while the v_readlane broadcasts of the register-resident linear algebra starve for scalar registers.
+  // Refreshing lane_r once per region (one solve, one line search) keeps the masks short-lived.
+  int lane_r;
+  __device__ __forceinline__ void begin_region() { int l = lane; asm volatile("" : "+v"(l)); lane_r = l; }
+  __device__ __forceinline__ vbool lane_gt(int k) const { return lane_r > k; }
+  __device__ __forceinline__ vbool lane_eq(int k) const { return lane_r == k; }
+  __device__ __forceinline__ vbool lane_lt(int k) const { return lane_r < k; }
+  __device__ __forceinline__ vfloat lane_reverse(vfloat v, int n) {
+    const float r = __shfl(v, n - 1 - lane, 64);   // ds_bpermute_b32
+    return lane < n ? r : 0.f;
+  }
   __device__ __forceinline__ void fence() { sync(); }
   __device__ __forceinline__ float vsum(vfloat v) { return dialwave::wave_sum(v); }
   __device__ __forceinline__ vfloat row16_sum(vfloat v) {
