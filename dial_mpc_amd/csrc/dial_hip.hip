@@ -59,6 +59,11 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   Wave w;
   w.lane = threadIdx.x & 63;
   w.lane_r = w.lane;
+#ifdef DIAL_PROFILE
+  w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
+  if (w.lane < 32) w.acc[w.lane] = 0;
+  __syncthreads();
+#endif
   dial::rollout_sample(w, m, tg, cfg, s, io, n);
 }
 
@@ -295,6 +300,9 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
       ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
+#ifdef DIAL_PROFILE
+      ctx->lds_rollout += 16 + (size_t)ctx->wpb * 32 * sizeof(unsigned long long);
+#endif
       hipError_t e = hipMalloc(&ctx->dcm, sizeof(CModel<D>));
       if (e == hipSuccess) e = hipMemcpy(ctx->dcm, h, sizeof(CModel<D>), hipMemcpyHostToDevice);
       delete h;

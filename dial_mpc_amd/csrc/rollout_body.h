@@ -27,7 +27,7 @@ namespace dial {
 // Does the instantiation keep a Cholesky factor in LDS (LDS solver path)?  The dimension-specialised
 // instantiations factor in registers instead.
 template <class D>
-inline constexpr bool kNeedL = true;
+inline constexpr bool kNeedL = !D::is_static;
 
 // ---------------------------------------------------------------- constraint rows (implicit J)
 // Row r < nlim is a joint-limit row (J = lsign * e_dof); the other rows are pyramid edges of contact

@@ -26,14 +26,15 @@ namespace dial {
 // j is an ancestor of dof k, which is known at compile time (D::Topo) -- the (k', j') update is simply not
 // emitted otherwise (Go2: 99 of 153 pairs, H1: 169 of 300).  Per step k': pivot and column entries are
 // broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row.  The forward
-// substitution needs rows only; the backward one needs columns, obtained through one packed-triangle
-// transpose in LDS (scratch).  Right-hand side and solution are lane-reversed with one ds_bpermute each.
+// substitution is column oriented (broadcast y_k, update rows), the backward one row oriented (one DPP wave
+// reduction per k), so only rows of L' are ever needed.  Right-hand side and solution are lane-reversed with
+// one ds_bpermute each.
 template <class D, class W, class M>
 DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch) {
   constexpr int N = D::NV;
   using Topo = typename D::Topo;
   w.begin_region();
-  vfloat a[N], c[N];
+  vfloat a[N];
   // the lane's dof is i = N-1-l; its descendant / ancestor bit masks decide which entries can be non-zero
   const auto own_i = [&](int l) { return N - 1 - l; };
   struct Masks { unsigned desc, anc; };
@@ -73,27 +74,17 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
     b = b - a[kp] * yk;
   });
   vfloat y = b * dinv;
-  // transpose the strictly lower triangle of L' through LDS: lane l writes row l, reads column l
-  w.items(N, [&](int l) {
-    const unsigned desc = masks_of(l).desc;
-    static_for<0, N>([&](auto JP) {
-      constexpr int jp = JP, j = N - 1 - jp;
-      if (jp < l && ((desc >> j) & 1u)) scratch[tri_idx(l, jp)] = lane_val(a[jp], l);
-    });
-  });
-  static_for<0, N>([&](auto JP) {
-    constexpr int jp = JP, j = N - 1 - jp;
-    c[jp] = w.per_lane([&](int l) {      // column l of L': rows j' > l, orig j < orig i, non-zero iff j anc of i
-      if (l >= jp) return 0.f;
-      return ((masks_of(l).anc >> j) & 1u) ? scratch[tri_idx(jp, l)] : 0.f;
-    });
-  });
+  // backward substitution L'^T x = y, row oriented: x_k = (y_k - sum_{l>k} l_lk x_l) / l_kk.  Lane l owns l_lk
+  // (register k) and x_l, so the sum is one wave reduction per k -- no transposed copy of L' is needed
+  // (that costs an LDS round trip and N more registers).
+  vfloat x = vsplat(0.f);
   static_for<0, N>([&](auto KQ) {
     constexpr int kp = N - 1 - KQ;
-    const float xk = bcast(y * dinv, kp);
-    y = y - c[kp] * xk;
+    const float sk = w.vsum(a[kp] * x);        // a[kp] is 0 in lanes <= kp, x is 0 in lanes not yet solved
+    x = vsel(w.lane_eq(kp), (y - vsplat(sk)) * dinv, x);
   });
-  return w.lane_reverse(y * dinv, N);
+  (void)scratch;
+  return w.lane_reverse(x, N);
 }
 
 template <class W, class M>
@@ -294,8 +285,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     }
     niter++;
 #ifdef DIAL_PROFILE
-    w.acc[30] += ls_iter;
-    w.acc[31] += 1;
+    if (w.lane == 0 && w.acc) { w.acc[30] += ls_iter; w.acc[31] += 1; }
 #endif
     DIAL_MARK(w, 7);
   }

@@ -190,10 +190,13 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 struct Wave {
   int lane;
 #ifdef DIAL_PROFILE
-  unsigned long long tprev = 0, acc[DIAL_NSEC] = {};
+  // accumulators live in LDS (written by lane 0) so that the profiling build does not eat the scalar
+  // registers the measured code is short of
+  unsigned long long tprev = 0;
+  unsigned long long* acc = nullptr;
   __device__ __forceinline__ void mark(int id) {
     unsigned long long t = __builtin_readcyclecounter();
-    acc[id] += t - tprev;
+    if (lane == 0 && acc) acc[id] += t - tprev;
     tprev = t;
   }
 #endif
