@@ -213,3 +213,33 @@ def test_python_surface_end_to_end():
     assert float(state.pipeline_state.q[2]) > 0.2, (z0, float(state.pipeline_state.q[2]))
     us = mbdpi.node2u_vmap(Y0)
     assert us.shape == (17, 12) and env.act2joint(us[0]).shape == (12,)
+
+
+def test_async_planner_protocol_end_to_end():
+    """SURVEY 8f NEXT 1: MBDPublisher against a fake plant over the reference's six shm segments."""
+    import uuid
+    import yaml
+    from dial_mpc_amd.core.dial_core import load_dial_and_env
+    from dial_mpc_amd.deploy.dial_plan import FakePlant, MBDPublisher
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    cfgd = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
+    cfgd["Nsample"], cfgd["Ndiffuse_init"] = 256, 3
+    dial_config, env_config, env = load_dial_and_env(cfgd)
+    prefix = "t" + uuid.uuid4().hex[:8] + "_"
+    plant = FakePlant(env, dial_config, shm_prefix=prefix)
+    try:
+        pub = MBDPublisher(env, env_config, dial_config, shm_prefix=prefix)
+        assert pub.plan_time_shared[0] < 0
+        for tick in range(6):
+            pub.main_loop(max_ticks=1)
+            assert abs(pub.plan_time_shared[0] - plant.t) < 1e-6
+            tau = plant._seg["tau_shm"][1]
+            acts = plant._seg["acts_shm"][1]
+            assert np.all(np.isfinite(tau)) and np.all(np.isfinite(acts)) and np.abs(tau).max() > 0
+            jr = env.physical_joint_range
+            assert np.all(acts >= jr[:, 0] - 1e-5) and np.all(acts <= jr[:, 1] + 1e-5)
+            plant.step_with_action(pub.Y[0])       # plant advances one control period with the first node
+        assert int(plant.state.info["step"]) == 6 and float(plant.state.pipeline_state.q[2]) > 0.15
+        pub.close()
+    finally:
+        plant.close()

@@ -69,3 +69,21 @@ def test_host_helpers():
     qw = np.r_[q[3], q[:3]]
     v = np.array([0.3, -1.0, 2.0])
     assert np.allclose(global_to_body_velocity(v, qw), R.from_quat(q).inv().apply(v), atol=1e-12)
+
+
+def test_async_planner_shift_matrix_matches_fitpack():
+    """dial_plan.py:136-139: plan shift = spline re-evaluated at step_nodes + shift_time (extrapolating)."""
+    from scipy.interpolate import InterpolatedUnivariateSpline as IUS
+    from dial_mpc_amd.core import spline
+    nodes = np.linspace(0, 0.32, 5)
+    Y = np.random.default_rng(0).uniform(-1, 1, (5, 3))
+    for st in (0.0, 0.0193, 0.02, 0.041):
+        A = spline.interp_matrix(nodes, nodes + st)
+        ref = np.stack([IUS(nodes, Y[:, a], k=2)(nodes + st) for a in range(3)], 1)
+        assert np.allclose(A @ Y, ref, atol=1e-12)
+
+
+def test_deploy_example_loads():
+    d = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
+    dc = load_dataclass_from_dict(DialConfig, d)
+    assert dc.Ndiffuse == 1 and dc.env_name == "unitree_go2_walk"
