@@ -243,3 +243,53 @@ def test_async_planner_protocol_end_to_end():
         pub.close()
     finally:
         plant.close()
+
+
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16)])
+def test_full_size_properties_other_configs(example, N, H):
+    """BASELINE configs 2 and 3 at full size: size-independent properties (no oracle run at this size)."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=2, Ybar_scale=0.1)
+    out1 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    sc = ctx.debug_scratch()
+    out2 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    assert torch.equal(out1["Ybar"], out2["Ybar"]) and torch.equal(out1["rews"], out2["rews"])      # deterministic
+    assert abs(sc["weights"].sum() - 1) < 1e-4 and sc["weights"].min() >= 0
+    rews = out1["rews"].cpu().numpy()
+    assert np.all(np.isfinite(rews)) and np.allclose(rews, sc["rewss"].mean(1), atol=2e-5)
+    perm = np.random.default_rng(1).permutation(N)
+    out3 = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps[perm]))
+    assert np.array_equal(out3["rews"].cpu().numpy()[:-1], rews[:-1][perm])                            # equivariance
+    assert np.allclose(out3["Ybar"].cpu().numpy(), out1["Ybar"].cpu().numpy(), atol=1e-4)
+    assert np.ptp(sc["rewss"][:, 0]) < 1e-5                       # first reward is action independent (SURVEY C.2)
+    # a random subset of the samples agrees with the oracle rollout of exactly those controls
+    import oracle as O
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(H + 1)], np.float32)
+    idx = np.random.default_rng(2).choice(N, 12, replace=False)
+    us = np.einsum("tk,bka->bta", W, sc["Y0s"][idx])
+    s0_host = s0.cpu().numpy()
+    r_o = o32.rollout(s0_host, us)[0]
+    assert np.allclose(sc["rewss"][idx], r_o, **TOL["rewss"])
+
+
+def test_edge_cases_small_and_async_schedule():
+    """Nsample = 1; scalar (async-driver) noise scale; saturating mean plan (clip before the spline only)."""
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 1, 8)
+    ctx = _lib.Context(model, task, cfg)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
+    eps, sigma, _ = seeded_inputs(dc, 12, seed=0)
+    Ybar = np.full((dc.Hnode + 1, 12), 1.7, np.float32)           # outside [-1, 1]: clipped, incl. the mean sample
+    for ns in (sigma, np.array([0.5], np.float32)):
+        ro = o32.reverse_once(s0, Ybar, ns, eps, full=True)
+        out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(ns), _dev(eps))
+        assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=2e-3, atol=1e-3)
+        assert np.allclose(out["Ybar"].cpu().numpy(), ro["Ybar"], atol=2e-3)
+        assert np.abs(out["Ybar"].cpu().numpy()).max() <= 1 + 1e-6
