@@ -58,6 +58,7 @@ def load():
     lib.dial_reverse_once.argtypes = [vp, fp, fp, fp, ci, fp, fp, fp, fp, fp, fp, vp]
     lib.dial_shard_rollout.argtypes = [vp, fp, fp, fp, ci, fp, ci, ci, fp, vp]
     lib.dial_shard_reduce.argtypes = [vp, fp, ci, ci, ci, ci, fp, vp]
+    lib.dial_shard_ybar.argtypes = [vp, fp, ci, fp, fp, fp, ci, fp, vp]
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
@@ -72,7 +73,7 @@ def load():
 
 
 EXPORTED = ("dial_create", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
-            "dial_shard_rollout", "dial_shard_reduce", "dial_shift", "dial_env_step", "dial_env_reset",
+            "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_shift", "dial_env_step", "dial_env_reset",
             "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
@@ -183,6 +184,11 @@ class Context:
     def shard_reduce(self, rews_all, n_total: int, n_begin: int, n_local: int, include_mean: bool, packed_out):
         self._check(self.lib.dial_shard_reduce(self.h, _ptr(rews_all), n_total, n_begin, n_local, int(include_mean),
                                                _ptr(packed_out), _stream()), "dial_shard_reduce")
+
+    def shard_ybar(self, rews_all, n_total: int, eps_all, Ybar, noise_scale, Ybar_out):
+        ns = int(noise_scale.numel())
+        self._check(self.lib.dial_shard_ybar(self.h, _ptr(rews_all), n_total, _ptr(eps_all), _ptr(Ybar), _ptr(noise_scale),
+                                             ns, _ptr(Ybar_out), _stream()), "dial_shard_ybar")
 
     def packed_size(self) -> int:
         T, Hn1 = self.cfg.Hsample + 1, self.cfg.Hnode + 1

@@ -111,7 +111,9 @@ class MBDPI:
                           dtype=torch.float32)
         return gen, eps
 
-    def reverse_once(self, state, rng, Ybar_i, noise_scale, eps=None):
+    def reverse_once(self, state, rng, Ybar_i, noise_scale, eps=None, want_bars: bool = True):
+        """want_bars=False skips qbar/qdbar/xbar (None in info); in a sharded run this also drops the
+        all-reduce, leaving one collective per annealing iteration (core/sharding.py)."""
         import torch
         packed = _packed(state)
         if eps is None:
@@ -124,16 +126,16 @@ class MBDPI:
             Ybar, rews = out["Ybar"], out["rews"]
             qbar, qdbar, xbar = out["qbar"], out["qdbar"], out["xbar"]
         else:
-            Ybar, rews, qbar, qdbar, xbar = self._reverse_once_sharded(packed, Ybar_i, noise_scale, eps)
-        info = {"rews": rews, "qbar": qbar, "qdbar": qdbar, "xbar": xbar.reshape(T, nb1, 3),
+            Ybar, rews, qbar, qdbar, xbar = self._reverse_once_sharded(packed, Ybar_i, noise_scale, eps, want_bars)
+        info = {"rews": rews, "qbar": qbar, "qdbar": qdbar, "xbar": xbar.reshape(T, nb1, 3) if xbar is not None else None,
                 "new_noise_scale": noise_scale}
         return rng, Ybar, info
 
-    def _reverse_once_sharded(self, packed, Ybar_i, noise_scale, eps):
+    def _reverse_once_sharded(self, packed, Ybar_i, noise_scale, eps, want_bars=True):
         import torch.distributed as dist
         from dial_mpc_amd.core.sharding import sharded_reverse_once
         return sharded_reverse_once(self.ctx, dist, self.rank, self.world, self.args.Nsample,
-                                    self.args.Hsample + 1, self.args.Hnode + 1, packed, Ybar_i, noise_scale, eps)
+                                    self.args.Hsample + 1, self.args.Hnode + 1, packed, Ybar_i, noise_scale, eps, want_bars)
 
     # ---- receding-horizon shift (dial_core.py:160-172)
     def shift(self, Y):

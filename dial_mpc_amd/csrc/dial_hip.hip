@@ -175,6 +175,35 @@ wsum_final_kernel(WsumArgs a, const float* __restrict__ partial) {
   if (a.seg[sg].out) a.seg[sg].out[c - a.seg[sg].c0] = acc;
 }
 
+// Weighted mean of ALL candidate nodes, regenerated from the noise (dial_core.py:110-115,132): two passes with
+// a fixed reduction order.  partial: [YB_CHUNKS, C], C = (Hnode+1)*nu.
+#define YB_CHUNKS 128
+extern "C" __global__ void __launch_bounds__(64)
+ybar_partial_kernel(const float* __restrict__ weights, const float* __restrict__ eps, const float* __restrict__ Ybar,
+                    const float* __restrict__ noise_scale, int ns, int n_total, int C, int nu,
+                    float* __restrict__ partial) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const int k = c / nu, chunk = blockIdx.y, per = (n_total + 1 + YB_CHUNKS - 1) / YB_CHUNKS;
+  const int r0 = chunk * per, r1 = (r0 + per < n_total + 1) ? r0 + per : n_total + 1;
+  const float yb = Ybar[c], sc = noise_scale[ns == 1 ? 0 : k], y0 = Ybar[c - k * nu];
+  float acc = 0.f;
+  for (int n = r0; n < r1; n++) {
+    float v = n < n_total ? (k == 0 ? y0 : eps[(size_t)n * C + c] * sc + yb) : yb;
+    v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+    acc += weights[n] * v;
+  }
+  partial[(size_t)chunk * C + c] = acc;
+}
+extern "C" __global__ void __launch_bounds__(64)
+ybar_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int ch = 0; ch < YB_CHUNKS; ch++) acc += partial[(size_t)ch * C + c];
+  out[c] = acc;
+}
+
 // K5 (dial_core.py:160-166): u = W Y; u = roll(u,-1); u[-1] = 0; Y = V u.  One small workgroup.
 extern "C" __global__ void __launch_bounds__(64)
 shift_kernel(const dial_cfg* __restrict__ cfg, int nu, float* Y) {
@@ -458,6 +487,25 @@ int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_b
   // local rows: [0,n_local) noisy, row n_local = mean trajectory (always rolled out by dial_shard_rollout
   // when requested there); it contributes to the partial sums only when with_mean != 0.
   return launch_wsum(ctx, ctx->weights, n_local + 1, n_begin, n_local, with_mean ? n_total : -1, Yo, qo, qdo, xo, st);
+}
+
+int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, const float* Ybar_in,
+                    const float* noise_scale, int ns, float* Ybar_out, void* stream) {
+  if (!ctx || !rews_all || !eps_all || !Ybar_in || !noise_scale || !Ybar_out)
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: null argument");
+  if (!ctx->has_cfg || n_total + 1 > ctx->B_cap || n_total < 1 || (ns != 1 && ns != ctx->Hn1))
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: bad arguments (create the context with Nsample = global sample count)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int C = ctx->Hn1 * ctx->hm.nu;
+  if ((size_t)YB_CHUNKS * C > (size_t)WSUM_CHUNKS * ((size_t)C + ctx->T * (ctx->hm.nq + ctx->hm.nv + ctx->nx)))
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: scratch too small");
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  hipLaunchKernelGGL(ybar_partial_kernel, dim3((C + 63) / 64, YB_CHUNKS), dim3(64), 0, st, (const float*)ctx->weights,
+                     eps_all, Ybar_in, noise_scale, ns, n_total, C, ctx->hm.nu, ctx->partial);
+  hipLaunchKernelGGL(ybar_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)ctx->partial, C, Ybar_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
 }
 
 int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,

@@ -263,6 +263,12 @@ int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in,
                        int with_mean, float* rews_local, void* stream);
 int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin,
                       int n_local, int with_mean, float* packed_out, void* stream);
+/* Single-collective variant (SURVEY 8e option (a)): after the all-gather of the rewards every rank forms the
+ * COMPLETE weighted mean action locally -- the candidate nodes of all n_total samples are regenerated from
+ * the full noise array eps_all:[n_total,Hnode+1,nu] (every rank holds it), so no all-reduce is needed.
+ * Ybar_out:[Hnode+1,nu] is bit-identical on all ranks.                                               */
+int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all,
+                    const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out, void* stream);
 
 /* K5. MBDPI.shift (dial_core.py:160-166): Y:[Hnode+1,nu] in place. */
 int dial_shift(dial_ctx* ctx, float* Y, void* stream);

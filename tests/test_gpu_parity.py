@@ -183,6 +183,11 @@ def test_sharded_path_on_one_rank_matches_unsharded():
         torch.cuda.synchronize()
         assert torch.equal(rews, ref["rews"]) and torch.equal(Yb, ref["Ybar"])
         assert torch.equal(qbar, ref["qbar"]) and torch.equal(xbar, ref["xbar"])
+        # single-collective variant: the mean action is rebuilt locally from the full noise array
+        Yb1, rews1, qb1, _, _ = sharded_reverse_once(ctx, dist, 0, 1, 256, 17, dc.Hnode + 1, s0, _dev(Ybar),
+                                                     _dev(sigma), _dev(eps), want_bars=False)
+        assert qb1 is None and torch.equal(rews1, ref["rews"])
+        assert torch.allclose(Yb1, ref["Ybar"], rtol=0, atol=1e-5)
     finally:
         if created:
             dist.destroy_process_group()

@@ -51,6 +51,17 @@ class FakeCtx:
         rews_out.copy_(torch.from_numpy(rews))
         self.last = (Y0s, qss, qdss, xss)
 
+    def shard_ybar(self, rews_all, n_total, eps_all, Ybar, noise_scale, Ybar_out):
+        r = rews_all.numpy().astype(np.float32)
+        logp = (r - r[-1]) / r.std() / np.float32(self.cfg.temp_sample)
+        w = np.exp(logp - logp.max())
+        w = (w / w.sum()).astype(np.float32)
+        ns, Yb = noise_scale.numpy(), Ybar.numpy()
+        Y0s = eps_all.numpy() * (ns[None, :, None] if ns.size > 1 else ns[0]) + Yb
+        Y0s[:, 0] = Yb[0]
+        Y0s = np.clip(np.concatenate([Y0s, Yb[None]], 0), -1, 1)
+        Ybar_out.copy_(torch.from_numpy(np.einsum("n,nka->ka", w, Y0s).astype(np.float32)))
+
     def shard_reduce(self, rews_all, n_total, n_begin, n_local, include_mean, packed_out):
         r = rews_all.numpy().astype(np.float32)
         logp = (r - r[-1]) / r.std() / np.float32(self.cfg.temp_sample)
@@ -75,7 +86,11 @@ def _worker(rank, world, port, N, H, ret):
         eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
         out = sharded_reverse_once(ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0),
                                    torch.from_numpy(Ybar), torch.from_numpy(sigma), torch.from_numpy(eps))
-        ret[rank] = [o.numpy().copy() for o in out]
+        one = sharded_reverse_once(ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0),
+                                   torch.from_numpy(Ybar), torch.from_numpy(sigma), torch.from_numpy(eps),
+                                   want_bars=False)     # single-collective variant
+        assert one[2] is None and one[3] is None and one[4] is None
+        ret[rank] = [o.numpy().copy() for o in out] + [one[0].numpy().copy()]
     finally:
         dist.destroy_process_group()
 
@@ -94,7 +109,8 @@ def test_sharded_reverse_once_equals_unsharded(N):
     eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
     ref = o32.reverse_once(s0, Ybar, sigma, eps)
     for rank in range(world):
-        Yb, rews, qbar, qdbar, xbar = ret[rank]
+        Yb, rews, qbar, qdbar, xbar, Yb_single = ret[rank]
+        assert np.allclose(Yb_single, ref["Ybar"], atol=2e-3) and np.allclose(Yb_single, Yb, atol=1e-5)
         assert np.allclose(rews, ref["rews"], atol=1e-3)
         assert np.allclose(Yb, ref["Ybar"], atol=2e-3) and np.allclose(qbar, ref["qbar"], atol=5e-3)
         assert np.allclose(xbar, ref["xbar"].reshape(xbar.shape), atol=5e-3)
