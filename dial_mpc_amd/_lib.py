@@ -59,6 +59,10 @@ def load():
     lib.dial_shard_rollout.argtypes = [vp, fp, fp, fp, ci, fp, ci, ci, fp, vp]
     lib.dial_shard_reduce.argtypes = [vp, fp, ci, ci, ci, ci, fp, vp]
     lib.dial_shard_ybar.argtypes = [vp, fp, ci, fp, fp, fp, ci, fp, vp]
+    u64, u32 = ctypes.c_uint64, ctypes.c_uint32
+    lib.dial_reverse_once_rng.argtypes = [vp, fp, fp, fp, ci, u64, u32, fp, fp, fp, fp, fp, vp]
+    lib.dial_shard_rollout_rng.argtypes = [vp, fp, fp, fp, ci, u64, u32, ci, ci, ci, fp, vp]
+    lib.dial_rng_fill.argtypes = [vp, u64, u32, ci, ci, fp, vp]
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
@@ -73,7 +77,8 @@ def load():
 
 
 EXPORTED = ("dial_create", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
-            "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_shift", "dial_env_step", "dial_env_reset",
+            "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
+            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shift", "dial_env_step", "dial_env_reset",
             "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
@@ -174,6 +179,35 @@ class Context:
                                                _ptr(out["Ybar"]), _ptr(out["rews"]), _ptr(out["qbar"]),
                                                _ptr(out["qdbar"]), _ptr(out["xbar"]), _stream()), "dial_reverse_once")
         return out
+
+    def reverse_once_rng(self, state, Ybar, noise_scale, seed: int, counter: int, out=None):
+        """reverse_once with the noise generated inside the rollout kernel (Philox keyed by seed / counter)."""
+        import torch
+        cfg, dev = self.cfg, self.torch_device
+        N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1
+        if out is None:
+            out = dict(Ybar=torch.empty((Hn1, self.nu), dtype=torch.float32, device=dev),
+                       rews=torch.empty(N + 1, dtype=torch.float32, device=dev),
+                       qbar=torch.empty((T, self.nq), dtype=torch.float32, device=dev),
+                       qdbar=torch.empty((T, self.nv), dtype=torch.float32, device=dev),
+                       xbar=torch.empty((T, self.nx), dtype=torch.float32, device=dev))
+        self._check(self.lib.dial_reverse_once_rng(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale),
+                                                   int(noise_scale.numel()), int(seed), int(counter), _ptr(out["Ybar"]),
+                                                   _ptr(out["rews"]), _ptr(out["qbar"]), _ptr(out["qdbar"]),
+                                                   _ptr(out["xbar"]), _stream()), "dial_reverse_once_rng")
+        return out
+
+    def rng_fill(self, seed: int, counter: int, n_begin: int, n_count: int):
+        import torch
+        eps = torch.empty((n_count, self.cfg.Hnode + 1, self.nu), dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.dial_rng_fill(self.h, int(seed), int(counter), n_begin, n_count, _ptr(eps), _stream()),
+                    "dial_rng_fill")
+        return eps
+
+    def shard_rollout_rng(self, state, Ybar, noise_scale, seed, counter, n_begin, n_local, with_mean, rews_local):
+        self._check(self.lib.dial_shard_rollout_rng(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale),
+                                                    int(noise_scale.numel()), int(seed), int(counter), n_begin, n_local,
+                                                    int(with_mean), _ptr(rews_local), _stream()), "dial_shard_rollout_rng")
 
     def shard_rollout(self, state, Ybar, noise_scale, eps_local, n_local: int, with_mean: bool, rews_local):
         ns = int(noise_scale.numel())

@@ -38,8 +38,12 @@ def softmax_update(weights, Y0s, sigma, mu_0t):
 
 
 class MBDPI:
-    def __init__(self, args: DialConfig, env, device: Optional[int] = None):
+    def __init__(self, args: DialConfig, env, device: Optional[int] = None, kernel_rng: bool = False):
+        """kernel_rng=True: the noise is generated inside the rollout kernel (Philox keyed by args.seed and a call
+        counter) instead of by torch.randn -- the production setting; parity runs pass `eps` explicitly."""
         import torch
+        self.kernel_rng = bool(kernel_rng)
+        self._rng_counter = 0
         self.args = args
         self.env = env
         self.nu = env.action_size
@@ -116,6 +120,18 @@ class MBDPI:
         all-reduce, leaving one collective per annealing iteration (core/sharding.py)."""
         import torch
         packed = _packed(state)
+        if eps is None and self.kernel_rng and self.world == 1:
+            import torch
+            Yb = torch.as_tensor(Ybar_i, dtype=torch.float32, device=self.device).contiguous()
+            nsc = torch.as_tensor(noise_scale, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+            out = self.ctx.reverse_once_rng(packed, Yb, nsc, int(self.args.seed), self._rng_counter)
+            self._rng_counter += 1
+            T, nb1 = self.args.Hsample + 1, self.ctx.nbody - 1
+            return rng, out["Ybar"], {"rews": out["rews"], "qbar": out["qbar"], "qdbar": out["qdbar"],
+                                      "xbar": out["xbar"].reshape(T, nb1, 3), "new_noise_scale": nsc}
+        if eps is None and self.kernel_rng:
+            eps = self.ctx.rng_fill(int(self.args.seed), self._rng_counter, 0, self.args.Nsample)   # sharded: full array
+            self._rng_counter += 1
         if eps is None:
             rng, eps = self.sample_eps(rng)
         Ybar_i = torch.as_tensor(Ybar_i, dtype=torch.float32, device=self.device).contiguous()
@@ -223,7 +239,7 @@ def main():
                                                   torch.arange(n_diffuse, device=mbdpi.device))[:, None]
         info = None
         for i in range(n_diffuse):                          # lax.scan(reverse_scan) :262-264
-            rng, Y0, info = mbdpi.reverse_once(state, rng, Y0, factors[i])
+            rng, Y0, info = mbdpi.reverse_once(state, rng, Y0, factors[i], want_bars=(i == n_diffuse - 1))
         torch.cuda.synchronize()
         plan_ms.append((time.time() - t0) * 1e3)
         rews_plan.append(float(info["rews"][-1]))

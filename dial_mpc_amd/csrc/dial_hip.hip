@@ -204,6 +204,19 @@ ybar_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ 
   out[c] = acc;
 }
 
+// Materialise the in-kernel noise: eps_out[n - n_begin, :] for samples n_begin .. n_begin + n_count
+extern "C" __global__ void __launch_bounds__(256)
+rng_fill_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t iter, int n_begin, int n_count, int C, float* eps_out) {
+  const int nq = (C + 3) / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)n_count * nq) return;
+  const int n = (int)(t / nq), q = (int)(t - (long long)n * nq);
+  float z[4];
+  dial::normal_quad((uint32_t)(n_begin + n), (uint32_t)q, iter, seed_lo, seed_hi, z);
+  for (int e = 0; e < 4; e++)
+    if (4 * q + e < C) eps_out[(size_t)n * C + 4 * q + e] = z[e];
+}
+
 // K5 (dial_core.py:160-166): u = W Y; u = roll(u,-1); u[-1] = 0; Y = V u.  One small workgroup.
 extern "C" __global__ void __launch_bounds__(64)
 shift_kernel(const dial_cfg* __restrict__ cfg, int nu, float* Y) {
@@ -432,22 +445,51 @@ int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, floa
   if (!ctx || !state || !us || !rewss || B < 1) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: bad argument");
   if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_rollout: context was created without a dial_cfg");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dial::RolloutIO io{state, us, nullptr, nullptr, nullptr, 0, 0, ctx->T, ctx->Hn1, nullptr, rewss, nullptr, qss, qdss, xposs, nullptr};
+  dial::RolloutIO io{state, us, nullptr, nullptr, nullptr, 0, 0, ctx->T, ctx->Hn1, nullptr, rewss, nullptr, qss, qdss, xposs, nullptr, 0, 0u, 0u, 0u, 0};
+  return launch_rollout(ctx, io, B, (hipStream_t)stream);
+}
+
+static int shard_rollout_impl(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale,
+                              int ns, const float* eps, int use_rng, uint64_t seed, uint32_t counter, int n_begin,
+                              int n_local, int with_mean, float* rews_local, void* stream, const char* who) {
+  if (!ctx || !state || !Ybar_in || !noise_scale || (!eps && !use_rng && n_local > 0) || !rews_local)
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": context was created without a dial_cfg");
+  if (ns != 1 && ns != ctx->Hn1) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": noise_scale must have 1 or Hnode+1 entries");
+  const int B = n_local + (with_mean ? 1 : 0);
+  if (n_local < 0 || B < 1 || B > ctx->B_cap || n_begin < 0) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": shard larger than Nsample+1");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
+                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss, ctx->prof,
+                     use_rng, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter, n_begin};
   return launch_rollout(ctx, io, B, (hipStream_t)stream);
 }
 
 int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
                        const float* eps, int n_local, int with_mean, float* rews_local, void* stream) {
-  if (!ctx || !state || !Ybar_in || !noise_scale || (!eps && n_local > 0) || !rews_local)
-    return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: null argument");
-  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: context was created without a dial_cfg");
-  if (ns != 1 && ns != ctx->Hn1) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: noise_scale must have 1 or Hnode+1 entries");
-  const int B = n_local + (with_mean ? 1 : 0);
-  if (n_local < 0 || B < 1 || B > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_rollout: shard larger than Nsample+1");
+  return shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, eps, 0, 0, 0, 0, n_local, with_mean, rews_local,
+                            stream, "dial_shard_rollout");
+}
+
+int dial_shard_rollout_rng(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                           uint64_t seed, uint32_t counter, int n_begin, int n_local, int with_mean,
+                           float* rews_local, void* stream) {
+  return shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, nullptr, 1, seed, counter, n_begin, n_local,
+                            with_mean, rews_local, stream, "dial_shard_rollout_rng");
+}
+
+int dial_rng_fill(dial_ctx* ctx, uint64_t seed, uint32_t counter, int n_begin, int n_count, float* eps_out,
+                  void* stream) {
+  if (!ctx || !eps_out || n_count < 0 || n_begin < 0) return fail(ctx, DIAL_ERR_ARG, "dial_rng_fill: bad argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_rng_fill: context was created without a dial_cfg");
+  if (n_count == 0) return DIAL_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
-                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss, ctx->prof};
-  return launch_rollout(ctx, io, B, (hipStream_t)stream);
+  const int C = ctx->Hn1 * ctx->hm.nu, nq = (C + 3) / 4;
+  const long long total = (long long)n_count * nq;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter, n_begin, n_count, C, eps_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
 }
 
 static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_begin, int mean_row, int mean_widx,
@@ -508,17 +550,31 @@ int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const flo
   return DIAL_OK;
 }
 
-int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
-                      const float* eps, float* Ybar_out, float* rews, float* qbar, float* qdbar, float* xbar,
-                      void* stream) {
-  if (!ctx || !Ybar_out || !rews) return fail(ctx, DIAL_ERR_ARG, "dial_reverse_once: null argument");
-  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, "dial_reverse_once: context was created without a dial_cfg");
+static int reverse_once_impl(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                             const float* eps, int use_rng, uint64_t seed, uint32_t counter, float* Ybar_out,
+                             float* rews, float* qbar, float* qdbar, float* xbar, void* stream, const char* who) {
+  if (!ctx || !Ybar_out || !rews) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
+  if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": context was created without a dial_cfg");
   const int N = ctx->hc.Nsample;
-  int rc = dial_shard_rollout(ctx, state, Ybar_in, noise_scale, ns, eps, N, 1, rews, stream);
+  int rc = shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, eps, use_rng, seed, counter, 0, N, 1, rews, stream, who);
   if (rc != DIAL_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
   return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st);
+}
+
+int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                      const float* eps, float* Ybar_out, float* rews, float* qbar, float* qdbar, float* xbar,
+                      void* stream) {
+  return reverse_once_impl(ctx, state, Ybar_in, noise_scale, ns, eps, 0, 0, 0, Ybar_out, rews, qbar, qdbar, xbar, stream,
+                           "dial_reverse_once");
+}
+
+int dial_reverse_once_rng(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,
+                          uint64_t seed, uint32_t counter, float* Ybar_out, float* rews, float* qbar, float* qdbar,
+                          float* xbar, void* stream) {
+  return reverse_once_impl(ctx, state, Ybar_in, noise_scale, ns, nullptr, 1, seed, counter, Ybar_out, rews, qbar, qdbar,
+                           xbar, stream, "dial_reverse_once_rng");
 }
 
 int dial_shift(dial_ctx* ctx, float* Y, void* stream) {

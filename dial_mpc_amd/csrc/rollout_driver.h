@@ -5,6 +5,7 @@
 // Reference: dial_mpc/core/dial_core.py:106-117 (sampling + node2u), :36-42 (rollout_us).
 #pragma once
 #include "rollout_body.h"
+#include "philox.h"
 
 namespace dial {
 
@@ -24,6 +25,10 @@ struct RolloutIO {
   float* qdss;               // out [B,T,nv] or nullptr
   float* xss;                // out [B,T,(nbody-1)*3] or nullptr
   unsigned long long* prof;  // DIAL_PROFILE builds: per-section cycle counts of sample 0, else nullptr
+  // in-kernel noise (eps == nullptr && use_rng): Philox keyed by seed, counter = (n_offset + n, quad, rng_iter)
+  int use_rng;
+  uint32_t seed_lo, seed_hi, rng_iter;
+  int n_offset;              // global index of this launch's sample 0 (sample shards)
 };
 
 template <class W, class M>
@@ -66,7 +71,15 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       float v;
       if (n < io.n_noise) {
         float sc = io.noise_scale[io.ns == 1 ? 0 : k];
-        v = io.eps[((size_t)n * Hn1 + k) * nu + a] * sc + io.Ybar[k * nu + a];
+        float e;
+        if (io.use_rng) {
+          float z[4];
+          normal_quad((uint32_t)(io.n_offset + n), (uint32_t)(it >> 2), io.rng_iter, io.seed_lo, io.seed_hi, z);
+          e = z[it & 3];
+        } else {
+          e = io.eps[((size_t)n * Hn1 + k) * nu + a];
+        }
+        v = e * sc + io.Ybar[k * nu + a];
         if (k == 0) v = io.Ybar[a];
       } else {
         v = io.Ybar[k * nu + a];

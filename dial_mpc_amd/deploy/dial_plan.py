@@ -104,7 +104,8 @@ class MBDPublisher:
         info = None
         for i in range(n_diffuse):      # async schedule: traj_diffuse_factor**i, shape (1,) (dial_plan.py:207-209)
             self.rng, self.Y, info = self.mbdpi.reverse_once(state, self.rng, self.Y,
-                                                             np.array([cfg.traj_diffuse_factor ** i], np.float32))
+                                                             np.array([cfg.traj_diffuse_factor ** i], np.float32),
+                                                             want_bars=(i == n_diffuse - 1))
         return info
 
     def main_loop(self, max_ticks: Optional[int] = None, sleep_when_idle: float = 0.0):

@@ -270,6 +270,20 @@ int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_b
 int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all,
                     const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out, void* stream);
 
+/* In-kernel noise (production path): the standard-normal draws are generated inside the
+ * rollout kernel by Philox4x32-10 + Box-Muller keyed by (seed, counter = annealing-iteration index, global
+ * sample index, element) -- no eps tensor crosses HBM and any rank can regenerate any sample's noise.
+ * dial_rng_fill materialises exactly that noise (eps_out:[n_count,Hnode+1,nu], samples n_begin..) so that a run
+ * can be replayed through dial_reverse_once / the oracle for parity.                                   */
+int dial_reverse_once_rng(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale,
+                          int ns, uint64_t seed, uint32_t counter, float* Ybar_out, float* rews, float* qbar,
+                          float* qdbar, float* xbar, void* stream);
+int dial_shard_rollout_rng(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale,
+                           int ns, uint64_t seed, uint32_t counter, int n_begin, int n_local, int with_mean,
+                           float* rews_local, void* stream);
+int dial_rng_fill(dial_ctx* ctx, uint64_t seed, uint32_t counter, int n_begin, int n_count, float* eps_out,
+                  void* stream);
+
 /* K5. MBDPI.shift (dial_core.py:160-166): Y:[Hnode+1,nu] in place. */
 int dial_shift(dial_ctx* ctx, float* Y, void* stream);
 

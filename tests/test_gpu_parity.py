@@ -298,3 +298,31 @@ def test_edge_cases_small_and_async_schedule():
         assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=2e-3, atol=1e-3)
         assert np.allclose(out["Ybar"].cpu().numpy(), ro["Ybar"], atol=2e-3)
         assert np.abs(out["Ybar"].cpu().numpy()).max() <= 1 + 1e-6
+
+
+def test_in_kernel_rng_replays_exactly_and_is_standard_normal():
+    """dial_reverse_once_rng (Philox in the K1 prologue) == dial_reverse_once fed with dial_rng_fill's noise, bit for
+    bit; the generated noise is N(0,1), independent across samples / iterations, reproducible, shard-consistent."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 2048, 16)
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    _, sigma, Ybar = seeded_inputs(dc, 12, seed=5, Ybar_scale=0.1)
+    seed, counter = 0x1234_5678_9ABC, 7
+    out_rng = ctx.reverse_once_rng(s0, _dev(Ybar), _dev(sigma), seed, counter)
+    out_rng = {k: v.clone() for k, v in out_rng.items()}
+    eps = ctx.rng_fill(seed, counter, 0, 2048)
+    out_eps = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), eps)
+    for k in ("Ybar", "rews", "qbar", "xbar"):
+        assert torch.equal(out_rng[k], out_eps[k]), k
+    e = eps.cpu().numpy().astype(np.float64)
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01 and abs((e ** 3).mean()) < 0.03 and abs((e ** 4).mean() - 3) < 0.1
+    assert np.abs(np.corrcoef(e[:1024].reshape(-1), e[1024:].reshape(-1))[0, 1]) < 0.01
+    e2 = ctx.rng_fill(seed, counter + 1, 0, 2048).cpu().numpy()
+    assert np.abs(np.corrcoef(e.reshape(-1), e2.reshape(-1))[0, 1]) < 0.01          # new iteration, new noise
+    assert torch.equal(ctx.rng_fill(seed, counter, 512, 256), eps[512:768])           # any rank regenerates any shard
+    # sharded launch with the global sample offset reproduces the fused run
+    rews = torch.zeros(257, device="cuda")
+    ctx.shard_rollout_rng(s0, _dev(Ybar), _dev(sigma), seed, counter, 1024, 256, True, rews)
+    assert torch.equal(rews[:256], out_rng["rews"][1024:1280]) and torch.equal(rews[256], out_rng["rews"][2048])

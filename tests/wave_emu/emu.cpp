@@ -90,7 +90,7 @@ int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, co
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
   if (m->eulerdamp) return DIAL_ERR_UNSUPPORTED;
-  dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr};
+  dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr, 0, 0u, 0u, 0u, 0};
 #define CALL(D) run_rollout<D>(m, t, &dv, cfg, io, B, check_races)
   DISPATCH(path, m, CALL)
 #undef CALL
