@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nsample-per-gpu", type=int, default=2048)
-    ap.add_argument("--hsample", type=int, default=16)
+    ap.add_argument("--hsample", type=int, default=None, help="default: the example's own Hsample (Go2 trot: 16)")
     ap.add_argument("--example", default="unitree_go2_trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
@@ -95,6 +95,8 @@ def main():
 
     cfgd = yaml.safe_load(open(get_example_path(args.example + ".yaml")))
     N_total = args.nsample_per_gpu * world
+    if args.hsample is None:
+        args.hsample = int(cfgd["Hsample"])
     cfgd["Nsample"], cfgd["Hsample"] = N_total, args.hsample
     dial_config, env_config, env = load_dial_and_env(cfgd)
     mbdpi = MBDPI(dial_config, env)
@@ -185,7 +187,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.example} reverse_once: Nsample={args.nsample_per_gpu}/GPU "
                                f"(N_total={N_total}), Hsample={args.hsample}, Hnode={dial_config.Hnode}, "
-                               f"8 synthetic Go2 states (home + 7 perturbed), eps ~ N(0,1) resident in HBM",
+                               f"8 synthetic robot states (home + 7 perturbed), eps ~ N(0,1) resident in HBM",
                    "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -34,6 +34,11 @@ struct TopoH1 {    // free pelvis, 2 legs of 5, torso (dof 16), 2 arms of 4 hang
   static constexpr ParentTable<25> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5, 16, 17, 18, 19, 16, 21, 22, 23}};
   static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
 };
+struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms are welded to the torso
+  static constexpr bool dense = false;
+  static constexpr ParentTable<17> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5}};
+  static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
+};
 
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
           class Topo_ = TopoDense>
@@ -49,6 +54,7 @@ struct Dims {
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1>;
+using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -100,7 +106,7 @@ struct CModel {
   int32_t geom_bodyid[D::NG];
   float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];
   int32_t site_bodyid[D::NS];
-  float site_pos[D::NS][3];
+  float site_pos[D::NS][3], site_quat[D::NS][4];
   int32_t con_kind[D::NC], con_geom1[D::NC], con_geom2[D::NC], con_body1[D::NC], con_body2[D::NC];
   float con_friction[D::NC][5], con_solref[D::NC][2], con_solimp[D::NC][5], con_margin[D::NC];
   int32_t lim_jnt[D::NL];

@@ -142,6 +142,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   for (int s = 0; s < m->nsite; s++) {
     o.site_bodyid[s] = m->site_bodyid[s];
     for (int k = 0; k < 3; k++) o.site_pos[s][k] = m->site_pos[s][k];
+    for (int k = 0; k < 4; k++) o.site_quat[s][k] = m->site_quat[s][k];
   }
   for (int cidx = 0; cidx < m->ncon; cidx++) {
     o.con_kind[cidx] = m->con_kind[cidx]; o.con_geom1[cidx] = m->con_geom1[cidx]; o.con_geom2[cidx] = m->con_geom2[cidx];
@@ -197,7 +198,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   const int ntri = (nv * (nv + 1)) / 2;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
-  WS_TAKE(act, nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 8)
+  WS_TAKE(act, nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 10)
   WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
   WS_TAKE(cvel, nbody * 6) WS_TAKE(cdof, nv * 6)
   WS_TAKE(M, ntri)

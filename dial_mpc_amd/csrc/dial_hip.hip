@@ -253,7 +253,7 @@ struct dial_ctx {
   dial_cfg hc;
   dial_derived hd;
   bool has_cfg = false;
-  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1
+  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1, 3 H1 loco
   void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
@@ -315,7 +315,7 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
   if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
   if (model->eulerdamp) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: eulerdamp-enabled models are not supported");
   if (model->cone != 0) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: only pyramidal cones are supported");
-  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_H1_WALK)
+  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_H1_LOCO)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
   if (model->nefc > 64 || model->nv > DIAL_MAX_V || model->nq + 2 * model->nv + DIAL_INFO_N > 4096)
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: model exceeds kernel capacities");
@@ -353,6 +353,7 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     int urc;
     if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
     else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model)) { ctx->inst = 2; ctx->wpb = 2; urc = upload(DimsH1{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
@@ -433,6 +434,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
                      (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words)
   if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 2);
+  else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
   HIP_TRY(ctx, hipGetLastError());
@@ -596,6 +598,7 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
                      ctrl_out)
   if (ctx->inst == 1) DIAL_LAUNCH_STEP(DimsGo2);
   else if (ctx->inst == 2) DIAL_LAUNCH_STEP(DimsH1);
+  else if (ctx->inst == 3) DIAL_LAUNCH_STEP(DimsH1Loco);
   else DIAL_LAUNCH_STEP(DimsMax);
 #undef DIAL_LAUNCH_STEP
   HIP_TRY(ctx, hipGetLastError());
@@ -611,6 +614,7 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
                      (const CModel<D>*)ctx->dcm, qpos, qvel, state, xpos_out, xquat_out)
   if (ctx->inst == 1) DIAL_LAUNCH_RESET(DimsGo2);
   else if (ctx->inst == 2) DIAL_LAUNCH_RESET(DimsH1);
+  else if (ctx->inst == 3) DIAL_LAUNCH_RESET(DimsH1Loco);
   else DIAL_LAUNCH_RESET(DimsMax);
 #undef DIAL_LAUNCH_RESET
   HIP_TRY(ctx, hipGetLastError());

@@ -774,7 +774,7 @@ DIAL_DEV float quat_yaw(const float* q) {
 template <bool FULL_INFO, class W, class M>
 DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   const int nu = dim_nu(m);
-  const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK;
+  const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO;
   // act2joint / act2tau (base_env.py:38-66) | desired foot heights from the gait clock (get_foot_step)
   w.items(nu + DIAL_MAX_FEET, [&](int it) {
     if (it < nu) {
@@ -823,8 +823,12 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
             float e = (z_tar - zs) / 0.05f;
             reward_gaits += e * e;
             fz = zs - m->foot_radius;
-          } else {
+          } else if (m->kind == DIAL_TASK_H1_WALK) {
             float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
+            reward_gaits += (z_tar - zf) * (z_tar - zf);
+            fz = zs;
+          } else {  // H1 loco: four contacts per foot (unitree_h1_env.py:746-752)
+            float zf = dm::fminf_(dm::fminf_(s.cdist[4 * f], s.cdist[4 * f + 1]), dm::fminf_(s.cdist[4 * f + 2], s.cdist[4 * f + 3]));
             reward_gaits += (z_tar - zf) * (z_tar - zf);
             fz = zs;
           }
@@ -890,9 +894,19 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         } else {
           float ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
           dm::inv_rotate(ab, angs, rot_t);
-          const float a2 = m->cmd_ang_vel[2];
-          const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
-          out = -(ea * ea);
+          if (m->kind == DIAL_TASK_H1_LOCO) {   // all three components (unitree_h1_env.py:797)
+            float e3 = 0.f;
+            for (int k = 0; k < 3; k++) {
+              const float a = m->cmd_ang_vel[k];
+              const float e = ab[k] - dm::fminf_(a * step * dt / m->ramp_up_time, a);
+              e3 += e * e;
+            }
+            out = -e3;
+          } else {
+            const float a2 = m->cmd_ang_vel[2];
+            const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+            out = -(ea * ea);
+          }
         }
       } else if (it == 3) {
         const int stage = (int)info[DIAL_INFO_STAGE];
@@ -909,7 +923,23 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       float reward_energy = 0.f;
       if (m->kind == DIAL_TASK_H1_WALK)
         for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
-      out = -reward_energy;
+      if (m->kind == DIAL_TASK_H1_LOCO) {   // energy uses the post-step qvel; foot-level term shares this lane
+        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1] * s.qvel[6 + a] / 160.0f; reward_energy += e * e; }
+        float lvl = 0.f;
+        for (int f = 0; f < 2; f++) {
+          const int si = m->feet_site[f], sb = m->site_bodyid[si];
+          float bq[4] = {s.xquat[4 * sb], s.xquat[4 * sb + 1], s.xquat[4 * sb + 2], s.xquat[4 * sb + 3]};
+          float sq[4] = {m->site_quat[si][0], m->site_quat[si][1], m->site_quat[si][2], m->site_quat[si][3]};
+          float q[4], mat[9];
+          dm::quat_mul(q, bq, sq);
+          dm::quat_to_mat(mat, q);
+          lvl += (mat[2] - 0.f) * (mat[2] - 0.f) + (mat[5] - 0.f) * (mat[5] - 0.f) + (mat[8] - 1.f) * (mat[8] - 1.f);
+        }
+        out = -reward_energy;
+        s.rpart[8] = -lvl;                                 // foot-level term (slot 8)
+      } else {
+        out = -reward_energy;
+      }
     } else {
       float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
       float up[3] = {0.f, 0.f, 1.f}, upv[3];
@@ -938,6 +968,9 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;
     } else if (m->kind == DIAL_TASK_H1_WALK) {    // unitree_h1_env.py:286-298
       reward = r[0] * 5.0f + r[1] * 0.5f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f;
+    } else if (m->kind == DIAL_TASK_H1_LOCO) {    // unitree_h1_env.py:812-827
+      reward = r[0] * 10.0f + r[1] * 0.5f + r[2] * 0.5f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f +
+               r[8] * 0.02f + r[6] * 0.01f;
     } else {                                      // unitree_go2_env.py:485-496
       reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
     }

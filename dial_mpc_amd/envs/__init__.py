@@ -4,20 +4,25 @@ from typing import Any, Callable, Dict
 
 from dial_mpc_amd.envs.unitree_go2_env import (
     UnitreeGo2Env, UnitreeGo2EnvConfig, UnitreeGo2SeqJumpEnv, UnitreeGo2SeqJumpEnvConfig)
-from dial_mpc_amd.envs.unitree_h1_env import UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig
+from dial_mpc_amd.envs.unitree_h1_env import (
+    UnitreeH1LocoEnv, UnitreeH1LocoEnvConfig, UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig)
 
 _configs: Dict[str, Any] = {
     "unitree_h1_walk": UnitreeH1WalkEnvConfig,
+    "unitree_h1_loco": UnitreeH1LocoEnvConfig,
     "unitree_go2_walk": UnitreeGo2EnvConfig,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnvConfig,
 }
 _envs: Dict[str, Callable] = {
     "unitree_h1_walk": UnitreeH1WalkEnv,
+    # the reference ships the config and the example but never registers this env with brax
+    # (unitree_h1_env.py:904-906 registers walk and push_crate only); registered here so the example runs
+    "unitree_h1_loco": UnitreeH1LocoEnv,
     "unitree_go2_walk": UnitreeGo2Env,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
 }
 # reference envs that are NEXT rows and not built yet
-_NOT_BUILT = ("unitree_h1_push_crate", "unitree_h1_loco", "unitree_go2_crate_climb", "allegro_reorient")
+_NOT_BUILT = ("unitree_h1_push_crate", "unitree_go2_crate_climb", "allegro_reorient")
 
 
 def register_config(name: str, config: Any):

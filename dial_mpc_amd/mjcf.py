@@ -154,7 +154,59 @@ def _frame_quat(attrs: Dict[str, str], angle_scale: float) -> np.ndarray:
 
 
 # ------------------------------------------------------------------ the compiler
-def compile_mjcf(path: str) -> Dict[str, Any]:
+def _read_stl(path: str, scale: np.ndarray) -> np.ndarray:
+    """Binary STL -> (ntri, 3, 3) float64 triangle vertices (float32 on disk)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    ntri = int(np.frombuffer(raw, dtype="<u4", count=1, offset=80)[0])
+    if len(raw) < 84 + 50 * ntri:
+        raise ValueError(f"{path}: not a binary STL")
+    rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]),
+                        count=ntri, offset=84)
+    return rec["v"].astype(np.float64) * scale
+
+
+def _polyhedron_mass_props(tris: np.ndarray):
+    """Volume, centre of mass and inertia tensor about the COM (unit density) of a closed,
+    outward-oriented triangle surface, by signed tetrahedra against the origin."""
+    a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+    det = np.einsum("ij,ij->i", a, np.cross(b, c))
+    vol = det.sum() / 6.0
+    com = ((a + b + c) * det[:, None]).sum(0) / (24.0 * vol)
+    # second moments  int x_i x_j dV  of each tetrahedron (0,a,b,c):  det/120 * (sum_pq v_p v_q^T + sum_p v_p v_p^T)
+    S = a + b + c
+    C = (np.einsum("ti,tj->ij", S * det[:, None], S)
+         + np.einsum("ti,tj->ij", a * det[:, None], a)
+         + np.einsum("ti,tj->ij", b * det[:, None], b)
+         + np.einsum("ti,tj->ij", c * det[:, None], c)) / 120.0
+    C -= vol * np.outer(com, com)  # shift to the COM
+    inertia = np.trace(C) * np.eye(3) - C
+    return vol, com, inertia
+
+
+def _mesh_mass_props(path: str, scale: np.ndarray, mode: str = "convex"):
+    """Mass properties MuJoCo infers from a mesh geom at unit density.  ``convex`` integrates over the
+    convex hull of the vertices (the mesh/inertia default of current MuJoCo releases), ``exact`` over
+    the mesh surface itself (needs a watertight, consistently oriented mesh)."""
+    tris = _read_stl(path, scale)
+    if mode == "convex":
+        from scipy.spatial import ConvexHull
+        pts = np.unique(tris.reshape(-1, 3), axis=0)
+        hull = ConvexHull(pts, qhull_options="Qt")
+        t = pts[hull.simplices]
+        # orient every facet outward (away from an interior point)
+        inside = pts[hull.vertices].mean(0)
+        nrm = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+        flip = np.einsum("ij,ij->i", nrm, t[:, 0] - inside) < 0
+        t[flip] = t[flip][:, ::-1]
+        tris = t
+    elif mode != "exact":
+        raise ValueError(f"unknown mesh inertia mode {mode!r}")
+    return _polyhedron_mass_props(tris)
+
+
+
+def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
     root = _load_tree(path)
     comp = {}
     for c in root.findall("compiler"):
@@ -175,6 +227,18 @@ def compile_mjcf(path: str) -> Dict[str, Any]:
 
     dfl = _Defaults()
     dfl.load(root)
+
+    meshes: Dict[str, Dict[str, Any]] = {}
+    meshdir = os.path.join(os.path.dirname(os.path.abspath(path)), comp.get("meshdir", ""))
+    for asset in root.findall("asset"):
+        for me in asset.findall("mesh"):
+            f = me.attrib.get("file")
+            if f is None:
+                continue
+            name = me.attrib.get("name", os.path.splitext(os.path.basename(f))[0])
+            meshes[name] = dict(file=os.path.join(meshdir, f),
+                                scale=_floats(me.attrib["scale"]) if "scale" in me.attrib else np.ones(3),
+                                inertia=me.attrib.get("inertia", mesh_inertia))
 
     bodies: List[Dict[str, Any]] = [dict(name="world", parent=0, pos=np.zeros(3),
                                          quat=np.array([1.0, 0, 0, 0]), ipos=np.zeros(3),
@@ -226,7 +290,10 @@ def compile_mjcf(path: str) -> Dict[str, Any]:
                           quat=quat, friction=fr, solref=solref, solimp=solimp,
                           margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)),
                           priority=int(a.get("priority", 0)), solmix=float(a.get("solmix", 1)),
-                          has_mass=("mass" in a and float(a["mass"]) > 0)))
+                          has_mass=("mass" in a and float(a["mass"]) > 0),
+                          mesh=a.get("mesh"), density=float(a.get("density", 1000.0)),
+                          mass=float(a["mass"]) if "mass" in a else None,
+                          group=int(a.get("group", 0))))
 
     def walk(elem: ET.Element, parent_id: int, childclass: Optional[str], depth: int):
         for e in elem:
@@ -314,10 +381,40 @@ def compile_mjcf(path: str) -> Dict[str, Any]:
     joints.sort(key=lambda j: j["body"])
     geoms_all = sorted(geoms, key=lambda g: g["body"])
     sites.sort(key=lambda s: s["body"])
-    for b in bodies[1:]:
-        if not b.get("has_inertial", False):
-            raise NotImplementedError(
-                f"body {b['name']!r} has no <inertial>; inertia-from-geom is not supported")
+    for bi, b in enumerate(bodies[1:], start=1):
+        if b.get("has_inertial", False):
+            continue
+        # compiler inertiafromgeom="auto": a body without <inertial> takes the mass properties of its
+        # geoms (inertiagrouprange 0..5, i.e. visual geoms count).  Mesh geoms only.
+        mass, mcom, parts = 0.0, np.zeros(3), []
+        for g in geoms_all:
+            if g["body"] != bi or not (0 <= g["group"] <= 5):
+                continue
+            if g["type"] != _GEOM_TYPES["mesh"] or g["mesh"] not in meshes:
+                raise NotImplementedError(
+                    f"body {b['name']!r}: inertia-from-geom is only implemented for mesh geoms")
+            me = meshes[g["mesh"]]
+            vol, com, I = _mesh_mass_props(me["file"], me["scale"], me["inertia"])
+            gm = g["mass"] if g["mass"] is not None else g["density"] * vol
+            if gm <= 0:
+                continue
+            R = quat_to_mat(g["quat"])
+            parts.append((gm, g["pos"] + R @ com, R @ (I * (gm / vol)) @ R.T))
+            mass += gm
+            mcom += gm * parts[-1][1]
+        if mass <= 0:
+            raise NotImplementedError(f"body {b['name']!r} has no <inertial> and no massive geoms")
+        mcom /= mass
+        Ib = np.zeros((3, 3))
+        for gm, c, I in parts:
+            d = c - mcom
+            Ib += I + gm * (d @ d * np.eye(3) - np.outer(d, d))
+        w, v = np.linalg.eigh(Ib)
+        order = np.argsort(-w)
+        w, v = w[order], v[:, order]
+        if np.linalg.det(v) < 0:
+            v[:, 2] *= -1
+        b.update(has_inertial=True, ipos=mcom, mass=mass, inertia=w, iquat=_mat_to_quat(v))
 
     # ---- qpos / dof addressing
     nq = nv = 0
@@ -402,9 +499,7 @@ def compile_mjcf(path: str) -> Dict[str, Any]:
                 continue
             if (min(b1, b2), max(b1, b2)) in excludes:
                 continue
-            if g1["type"] > g2["type"]:
-                g1, g2, = g2, g1
-            pairs.append((cgeoms.index(g1), cgeoms.index(g2)))
+            pairs.append((k, i) if g1["type"] > g2["type"] else (i, k))
     # MJX groups contacts by collision function, then condim; within a group geom-pair order.
     def pair_key(p):
         g1, g2 = cgeoms[p[0]], cgeoms[p[1]]

@@ -16,7 +16,8 @@
  *   dial_reverse_once   <- MBDPI.reverse_once         dial_mpc/core/dial_core.py:103-145
  *   dial_shift          <- MBDPI.shift                dial_mpc/core/dial_core.py:160-166
  *   dial_env_step       <- BaseEnv/<Env>.step         dial_mpc/envs/unitree_go2_env.py:126-261,
- *                                                     :403-521, dial_mpc/envs/unitree_h1_env.py:181-321
+ *                                                     :403-521, dial_mpc/envs/unitree_h1_env.py:181-321,
+ *                                                     :696-858 (H1 loco)
  *   dial_env_reset      <- <Env>.reset + pipeline_init  dial_mpc/envs/unitree_go2_env.py:101-124
  *   dial_model          <- brax System / mujoco MjModel built by BaseEnv.make_system
  *                                                     dial_mpc/envs/base_env.py:15-29
@@ -74,6 +75,7 @@ extern "C" {
 #define DIAL_TASK_GO2_WALK 0
 #define DIAL_TASK_GO2_SEQ_JUMP 1
 #define DIAL_TASK_H1_WALK 2
+#define DIAL_TASK_H1_LOCO 3
 
 /* packed-state info slots (floats; integers are stored as exactly representable floats) */
 #define DIAL_INFO_STEP 0

@@ -5,7 +5,7 @@
  *   planner   : dial_mpc/core/dial_core.py:36-48,103-145,160-166   (reverse_once, rollout_us, shift)
  *   control   : dial_mpc/envs/base_env.py:38-66                     (act2joint, act2tau)
  *   env.step  : dial_mpc/envs/unitree_go2_env.py:126-261 (walk), :403-521 (seq_jump),
- *               dial_mpc/envs/unitree_h1_env.py:181-321 (H1 walk)
+ *               dial_mpc/envs/unitree_h1_env.py:181-321 (H1 walk), :696-858 (H1 loco)
  *   helpers   : dial_mpc/utils/function_utils.py:7-43               (inv_rotate, get_foot_step)
  *   x / xd    : dial_mpc/deploy/dial_plan.py:45-61                  (the reference's own copy of
  *               brax.mjx.pipeline's derivation of x, xd from mjx.Data)
@@ -811,7 +811,7 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
   rotate(vec, up, d->xquat[ub]);
   real reward_upright = -((vec[0] - 0) * (vec[0] - 0) + (vec[1] - 0) * (vec[1] - 0) + (vec[2] - 1) * (vec[2] - 1));
   real yaw = quat_yaw(rot_t);
-  if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK) {
+  if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK || t->kind == DIAL_TASK_H1_LOCO) {
     /* unitree_go2_env.py:142-162 / unitree_h1_env.py:196-217: target ramp uses the PRE-increment step */
     for (int k = 0; k < 3; k++) {
       real v = t->cmd_vel[k], a = t->cmd_ang_vel[k];
@@ -828,10 +828,16 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
         z_feet[f] = zs;                                           /* unitree_go2_env.py:166 */
         reward_gaits += ((z_tar[f] - z_feet[f]) / (real)0.05) * ((z_tar[f] - z_feet[f]) / (real)0.05);
         fz = zs - (real)t->foot_radius;                           /* :178 */
-      } else {
+      } else if (t->kind == DIAL_TASK_H1_WALK) {
         z_feet[f] = r_min(d->con_dist[2 * f], d->con_dist[2 * f + 1]); /* unitree_h1_env.py:230-235 */
         reward_gaits += (z_tar[f] - z_feet[f]) * (z_tar[f] - z_feet[f]);
         fz = zs;                                                  /* :240 */
+      } else { /* H1 loco: two capsules (= four contacts) per foot, unitree_h1_env.py:746-752 */
+        real z4 = d->con_dist[4 * f];
+        for (int q = 1; q < 4; q++) z4 = r_min(z4, d->con_dist[4 * f + q]);
+        z_feet[f] = z4;
+        reward_gaits += (z_tar[f] - z_feet[f]) * (z_tar[f] - z_feet[f]);
+        fz = zs;
       }
       contact[f] = fz < (real)1e-3;
     }
@@ -851,6 +857,27 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
     if (t->kind == DIAL_TASK_GO2_WALK) { /* unitree_go2_env.py:227-239 */
       reward = reward_gaits * (real)0.1 + reward_upright * (real)0.5 + reward_yaw * (real)0.3 +
                reward_vel * (real)1.0 + reward_ang_vel * (real)1.0 + reward_height * (real)1.0;
+    } else if (t->kind == DIAL_TASK_H1_LOCO) { /* unitree_h1_env.py:795-827 */
+      real e3 = 0;
+      for (int k = 0; k < 3; k++) { real e = ab[k] - info[DIAL_INFO_ANG_VEL_TAR + k]; e3 += e * e; }
+      real reward_ang3 = -e3;
+      real reward_foot_level = 0;
+      for (int f = 0; f < 2; f++) { /* site_xmat @ [0,0,1] = third column of the site frame */
+        int sb = m->site_bodyid[t->feet_site[f]];
+        real sq[4] = {m->site_quat[t->feet_site[f]][0], m->site_quat[t->feet_site[f]][1], m->site_quat[t->feet_site[f]][2], m->site_quat[t->feet_site[f]][3]};
+        real q[4], mat[9];
+        quat_mul(q, d->xquat[sb], sq);
+        quat_to_mat(mat, q);
+        real v[3] = {mat[2], mat[5], mat[8]};
+        reward_foot_level += (v[0] - 0) * (v[0] - 0) + (v[1] - 0) * (v[1] - 0) + (v[2] - 1) * (v[2] - 1);
+      }
+      reward_foot_level = -reward_foot_level;
+      real reward_energy = 0;
+      for (int a = 0; a < m->nu; a++) { real e = ctrl[a] / (real)t->tau_range[a][1] * d->qvel[6 + a] / (real)160.0; reward_energy += e * e; }
+      reward_energy = -reward_energy;
+      reward = reward_gaits * (real)10.0 + reward_upright * (real)0.5 + reward_yaw * (real)0.5 +
+               reward_vel * (real)1.0 + reward_ang3 * (real)1.0 + reward_height * (real)0.5 +
+               reward_foot_level * (real)0.02 + reward_energy * (real)0.01;
     } else { /* unitree_h1_env.py:282-298 */
       real reward_energy = 0;
       for (int a = 0; a < m->nu; a++) { real e = ctrl[a] / (real)t->tau_range[a][1]; reward_energy += e * e; }

@@ -63,4 +63,5 @@ def seeded_inputs(dc, nu, seed=0, Ybar_scale=0.0):
 from dial_mpc_amd.utils.synthetic import perturbed_state  # noqa: E402,F401
 
 
-CASES = [("unitree_go2_trot", 64, 8), ("unitree_go2_seq_jump", 48, 16), ("unitree_h1_jog", 32, 16)]
+CASES = [("unitree_go2_trot", 64, 8), ("unitree_go2_seq_jump", 48, 16), ("unitree_h1_jog", 32, 16),
+         ("unitree_h1_loco", 32, 20)]

@@ -12,7 +12,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.mark.parametrize("name,example,N,H", [("go2_trot_N64_H8", "unitree_go2_trot", 64, 8),
                                               ("go2_seq_jump_N48_H16", "unitree_go2_seq_jump", 48, 16),
-                                              ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16)])
+                                              ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16),
+                            ("h1_loco_N32_H20", "unitree_h1_loco", 32, 20)])
 def test_oracle_reproduces_fixture(name, example, N, H):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     dc, env, model, task, cfg = setup_case(example, N, H)

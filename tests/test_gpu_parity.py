@@ -109,13 +109,17 @@ def test_shift_matches_oracle():
         assert np.allclose(ctx.shift(_dev(Y)).cpu().numpy(), o32.shift(Y), atol=1e-5)
 
 
-def test_golden_fixture_go2_trot():
-    """Committed fixture (generated by tools/make_golden.py with the fp64 oracle): HIP vs stored outputs."""
+@pytest.mark.parametrize("name,example,N,H", [("go2_trot_N64_H8", "unitree_go2_trot", 64, 8),
+                                              ("go2_seq_jump_N48_H16", "unitree_go2_seq_jump", 48, 16),
+                                              ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16),
+                                              ("h1_loco_N32_H20", "unitree_h1_loco", 32, 20)])
+def test_golden_fixtures(name, example, N, H):
+    """Committed fixtures (generated by tools/make_golden.py with the fp64 oracle): HIP vs stored outputs."""
     import os
     from dial_mpc_amd import _lib
-    path = os.path.join(os.path.dirname(__file__), "golden", "go2_trot_N64_H8.npz")
+    path = os.path.join(os.path.dirname(__file__), "golden", name + ".npz")
     g = np.load(path)
-    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 64, 8)
+    dc, env, model, task, cfg = setup_case(example, N, H)
     ctx = _lib.Context(model, task, cfg)
     out = ctx.reverse_once(_dev(g["state"]), _dev(g["Ybar_in"]), _dev(g["noise_scale"]), _dev(g["eps"]))
     assert _close(ctx.debug_scratch()["rewss"], g["rewss"], TOL["rewss"])
@@ -250,7 +254,8 @@ def test_async_planner_protocol_end_to_end():
         plant.close()
 
 
-@pytest.mark.parametrize("example,N,H", [("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16)])
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16),
+                                         ("unitree_h1_loco", 2048, 20)])
 def test_full_size_properties_other_configs(example, N, H):
     """BASELINE configs 2 and 3 at full size: size-independent properties (no oracle run at this size)."""
     import torch

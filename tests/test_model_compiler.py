@@ -59,3 +59,40 @@ def test_shipped_json_matches_fresh_compile(robot, xml):
     for k, v in fresh.items():
         if isinstance(v, np.ndarray):
             assert np.allclose(v, np.asarray(shipped[k], dtype=v.dtype), rtol=0, atol=0, equal_nan=True), k
+
+
+def _write_stl(path, tris):
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", len(tris)))
+        for t in tris:
+            f.write(struct.pack("<12fH", 0, 0, 0, *np.asarray(t, np.float32).ravel(), 0))
+
+
+def test_mesh_mass_properties_of_a_box(tmp_path):
+    """Inertia-from-geom for mesh geoms (H1 loco arm links): hull and exact integrals of an offset box."""
+    lo, hi = np.array([0.1, -0.2, 0.3]), np.array([0.5, 0.4, 0.6])
+    c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = [c[[q[0], q[1], q[2]]] for q in quads] + [c[[q[0], q[2], q[3]]] for q in quads]
+    p = str(tmp_path / "box.stl")
+    _write_stl(p, tris)
+    ext = hi - lo
+    I_ref = np.prod(ext) / 12.0 * np.diag([ext[1] ** 2 + ext[2] ** 2, ext[0] ** 2 + ext[2] ** 2, ext[0] ** 2 + ext[1] ** 2])
+    for mode in ("convex", "exact"):
+        vol, com, I = mjcf._mesh_mass_props(p, np.ones(3), mode)
+        assert abs(vol - np.prod(ext)) < 1e-7
+        np.testing.assert_allclose(com, (lo + hi) / 2, atol=1e-6)
+        np.testing.assert_allclose(I, I_ref, atol=1e-7)
+
+
+def test_h1_loco_model_dimensions_and_welded_arms():
+    from dial_mpc_amd.envs.base_env import load_model
+    m = load_model("unitree_h1", "mjx_scene_h1_loco.xml")
+    assert (m["nq"], m["nv"], m["nu"], m["nbody"], m["ncon"], m["nlim"], m["nefc"]) == (18, 17, 11, 21, 8, 11, 43)
+    assert (m["iterations"], m["ls_iterations"]) == (1, 1)
+    assert abs(m["body_mass"][12] - 24.457) < 1e-9            # torso with the arm masses folded in
+    arms = np.asarray(m["body_mass"][13:21])
+    assert np.all(arms > 0.3) and np.all(arms < 2.0)           # hull-inferred masses of the welded arm links
+    np.testing.assert_allclose(arms[:4], arms[4:], rtol=2e-3)  # left/right symmetry of the meshes
+    assert list(m["dof_damping"][6:]) == [2.0] * 11

@@ -21,7 +21,7 @@ def test_emulated_kernel_matches_oracle(example, N, H, path):
     dc, env, model, task, cfg = setup_case(example, N, H)
     o32 = O.Oracle(model, task, cfg, np.float32)
     emu = emu_lib.Emu(model, task, cfg, path=path)
-    assert path == 1 or emu.sizes()[0] == (2 if "h1" in example else 1)
+    assert path == 1 or emu.sizes()[0] == {"unitree_h1_jog": 2, "unitree_h1_loco": 3}.get(example, 1)
     nv, nu = model.nv, model.nu
     s_o, xp_o, xq_o = o32.env_reset(env._init_q, np.zeros(nv))
     s_e, xp_e, xq_e = emu.env_reset(env._init_q, np.zeros(nv), check_races=True)

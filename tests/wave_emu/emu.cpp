@@ -76,6 +76,7 @@ int run_env_reset(const dial_model* m, const dial_task* t, const dial_derived* d
 #define DISPATCH(path, m, CALL)                                        \
   if ((path) == 0 && dims_match<DimsGo2>(m)) return CALL(DimsGo2);     \
   if ((path) == 0 && dims_match<DimsH1>(m)) return CALL(DimsH1);       \
+  if ((path) == 0 && dims_match<DimsH1Loco>(m)) return CALL(DimsH1Loco); \
   return CALL(DimsMax);
 
 }  // namespace
@@ -122,6 +123,7 @@ int emu_sizes(const dial_model* m, int* cmodel_bytes, int* ws_words) {
   dial_task t{};
   if (dims_match<DimsGo2>(m)) { Runner<DimsGo2> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 1; }
   if (dims_match<DimsH1>(m)) { Runner<DimsH1> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 2; }
+  if (dims_match<DimsH1Loco>(m)) { Runner<DimsH1Loco> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 3; }
   Runner<DimsMax> r(m, &t, &dv);
   *cmodel_bytes = (int)sizeof(r.cm);
   *ws_words = r.ws_words;
