@@ -31,8 +31,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-hip-fp32-correctly-rounded-divide-sqrt: fp32 divide / sqrt via v_rcp / v_sqrt sequences (<= 2.5 ulp)
     # instead of the IEEE fix-up chains; well inside the fp32 parity tolerance.
+    # device only: -freciprocal-math (a/b -> a * v_rcp(b), no frexp/ldexp range scaling) and -fapprox-func
+    # (native v_sqrt / v_rsq / v_exp / v_log without denormal fix-ups); finite-math is NOT assumed (+-inf
+    # control ranges are compared against).  -fno-slp-vectorize: the SLP pass packs pairs of scalar fp32 ops
+    # into v_pk_* and pays for it in v_mov shuffles -- measured 5-6% slower on this issue-bound kernel.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-o", LIB_PATH,
+           "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+           "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
+           "-Xarch_device", "-fno-slp-vectorize", "-o", LIB_PATH,
            os.path.join(_CSRC, "dial_hip.hip")]
     if verbose:
         print(" ".join(cmd))
