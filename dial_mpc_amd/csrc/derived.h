@@ -191,7 +191,8 @@ struct Ws {
 WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 
 // Carve the workspace out of `base`; returns the number of words used (call with base = nullptr to size
-// the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path).
+// the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path); otherwise
+// L is the nv x stride transpose scratch of the register solver (solver_reg.h).
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
                    int ncon, int nefc, int nnode, bool with_L) {
   int o = 0;
@@ -223,10 +224,12 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(crb, nbody * 10)
   const int u1 = o;
   o = u0;
-  WS_TAKE(H, ntri) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc)
-  WS_TAKE(quad, nefc * 3) WS_TAKE(MaW, nv) WS_TAKE(MaS, nv) WS_TAKE(grad, nv) WS_TAKE(search, nv)
-  WS_TAKE(mv, nv) WS_TAKE(qfc, nv) WS_TAKE(ysol, nv)
-  WS_TAKE(L, with_L ? ntri : 0)   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead
+  WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc)
+  const int ls = with_L ? 1 : 0;   // the rest is LDS-solver state; the register solver keeps it in VGPRs
+  WS_TAKE(JarefW, ls * nefc) WS_TAKE(JarefS, ls * nefc) WS_TAKE(quad, ls * nefc * 3) WS_TAKE(MaW, ls * nv)
+  WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv) WS_TAKE(qfc, ls * nv)
+  WS_TAKE(ysol, ls * nv)
+  WS_TAKE(L, with_L ? ntri : nv * ((nv + 3) & ~3))   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE

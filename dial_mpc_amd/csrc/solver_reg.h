@@ -19,19 +19,24 @@
 
 namespace dial {
 
-// Register-resident sparse Cholesky solve, x = A^-1 b with b / x in registers (lane i <-> dof i).
+// Register-resident sparse L D L^T solve, x = A^-1 b with b / x in registers (lane i <-> dof i).
 //
 // Layout: lane l owns row l of the REVERSED matrix A' = P A P^T (P = order reversal), i.e. dof N-1-l.
 // Eliminating the dofs leaves-first (MuJoCo's L^T D L order) produces no fill-in: L'[j'][k'] != 0 only if dof
 // j is an ancestor of dof k, which is known at compile time (D::Topo) -- the (k', j') update is simply not
 // emitted otherwise (Go2: 99 of 153 pairs, H1: 169 of 300).  Per step k': pivot and column entries are
-// broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row.  The forward
-// substitution is column oriented (broadcast y_k, update rows), the backward one row oriented (one DPP wave
-// reduction per k), so only rows of L' are ever needed.  Right-hand side and solution are lane-reversed with
-// one ds_bpermute each.
+// broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row.  Both substitutions
+// are column oriented (broadcast one entry, one FMA per lane, unit diagonals so no per-step scaling): the
+// forward one runs on the rows of L' that the factorisation leaves in registers, the backward one on the
+// rows of L'^T, which are fetched from an LDS copy of the factor (N ds_writes, N/4 ds_read_b128 per lane;
+// `scratch` needs N * kCholStride<N> floats).  A row-oriented backward pass needs no transpose but costs one
+// full DPP wave reduction per unknown -- 3x the issue slots.  Right-hand side and solution are lane-reversed
+// with one ds_bpermute each.
+template <int N> constexpr int kCholStride = (N + 3) & ~3;
+
 template <class D, class W, class M>
 DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch) {
-  constexpr int N = D::NV;
+  constexpr int N = D::NV, S = kCholStride<N>;
   using Topo = typename D::Topo;
   w.begin_region();
   vfloat a[N];
@@ -54,36 +59,46 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   vfloat dinv = vsplat(0.f);
   static_for<0, N>([&](auto KP) {
     constexpr int kp = KP, k = N - 1 - kp;
-    const float akk = bcast(a[kp], kp);
-    const float r = fast_rsqrt(akk);
-    vfloat lik = vsel(w.lane_gt(kp), a[kp] * r, vsplat(0.f));
+    const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
+    const float rinv = fast_rcp(bcast(col, kp));
+    const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
     a[kp] = lik;
-    dinv = vsel(w.lane_eq(kp), vsplat(r), dinv);
+    dinv = vsel(w.lane_eq(kp), vsplat(rinv), dinv);
     static_for<kp + 1, N>([&](auto JP) {
       constexpr int jp = JP, j = N - 1 - jp;
       if constexpr (Topo::anc(k, j)) {       // l'_{j'k'} != 0 only when dof j is an ancestor of dof k
-        const float ljk = bcast(lik, jp);
-        a[jp] = a[jp] - lik * ljk;
+        const float ajk = bcast(col, jp);
+        a[jp] = a[jp] - lik * ajk;
       }
     });
   });
-  // forward substitution L' y = b
+  // LDS copy of the factor: scratch[k' * S + l] = L'[l][k'], so lane i finds row i of L'^T contiguously
+  w.items(N, [&](int l) {
+    static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[kp * S + l] = lane_val(a[kp], l); });
+  });
+  // forward substitution L' z = b (unit diagonal)
   static_for<0, N>([&](auto KP) {
     constexpr int kp = KP;
-    const float yk = bcast(b * dinv, kp);   // 1/l_kk lives in dinv (no N uniform scalars kept in SGPRs)
-    b = b - a[kp] * yk;
+    b = b - a[kp] * bcast(b, kp);
   });
-  vfloat y = b * dinv;
-  // backward substitution L'^T x = y, row oriented: x_k = (y_k - sum_{l>k} l_lk x_l) / l_kk.  Lane l owns l_lk
-  // (register k) and x_l, so the sum is one wave reduction per k -- no transposed copy of L' is needed
-  // (that costs an LDS round trip and N more registers).
-  vfloat x = vsplat(0.f);
-  static_for<0, N>([&](auto KQ) {
-    constexpr int kp = N - 1 - KQ;
-    const float sk = w.vsum(a[kp] * x);        // a[kp] is 0 in lanes <= kp, x is 0 in lanes not yet solved
-    x = vsel(w.lane_eq(kp), (y - vsplat(sk)) * dinv, x);
+  vfloat x = b * dinv;
+  // backward substitution L'^T x = D^-1 z with u[j] = L'^T[i][j] = L'[j][i] in lane i (0 unless j > i);
+  // the rows are streamed in chunks of four columns, one chunk ahead of its use (8 live registers)
+  constexpr int NQ = S / 4;
+  vfloat u[2][4];
+  const auto fetch = [&](auto Q, vfloat* dst) {
+    constexpr int q = Q;
+    w.per_lane4([&](int l) { return scratch + (l < N ? l : 0) * S + 4 * q; }, dst[0], dst[1], dst[2], dst[3]);
+  };
+  fetch(std::integral_constant<int, NQ - 1>{}, u[(NQ - 1) & 1]);
+  static_for<0, NQ>([&](auto QQ) {
+    constexpr int q = NQ - 1 - QQ;
+    if constexpr (q > 0) fetch(std::integral_constant<int, q - 1>{}, u[(q - 1) & 1]);
+    static_for<0, 4>([&](auto E) {
+      constexpr int kp = 4 * q + 3 - E;
+      if constexpr (kp < N) x = x - u[q & 1][kp & 3] * bcast(x, kp);
+    });
   });
-  (void)scratch;
   return w.lane_reverse(x, N);
 }
 

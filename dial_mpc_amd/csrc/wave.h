@@ -108,6 +108,11 @@ struct Wave {
   // SPMD helpers: value computed per lane; lane-index predicates
   template <class F>
   vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
+  // four consecutive floats from a per-lane, 16-byte aligned address (one ds_read_b128 on the GPU)
+  template <class F>
+  void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
+    for (int l = 0; l < 64; l++) { const float* p = f(l); a.x[l] = p[0]; b.x[l] = p[1]; c.x[l] = p[2]; d.x[l] = p[3]; }
+  }
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
@@ -239,6 +244,11 @@ struct Wave {
   }
   template <class F>
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
+  template <class F>
+  __device__ __forceinline__ void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
+    const float4 t = *reinterpret_cast<const float4*>(f(lane));
+    a = t.x; b = t.y; c = t.z; d = t.w;
+  }
   // Lane-index predicates compare against `lane_r`, a copy of the lane id that begin_region() launders
   // through an empty asm.  The comparisons are loop invariants of the T-step rollout loop; left alone, LICM
   // hoists dozens of them out of it as 64-bit SGPR masks that live for the whole kernel and get spilled,
