@@ -40,21 +40,30 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
   static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
 };
 
+// SQUARE: M / H live in LDS as full nv x S squares (S = nv rounded up to 4: every row is ds_read_b128-able and no
+// index arithmetic or sparsity masks are needed when rows are fetched into registers), the contact Jacobian as
+// dof-major pyramid rows (J^T[i][4c + e]) and H is assembled from a contact-sparse work list (NHI = its capacity).
+// Costs LDS, so it is opt-in per robot.
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
-          class Topo_ = TopoDense>
+          class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2>
 struct Dims {
   using Topo = Topo_;
   static constexpr bool is_static = STATIC;
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr int NE = NL_ + 4 * NC_;
+  static constexpr bool square = SQUARE_;
+  static constexpr int NHI = NHI_;            // capacity of the H work list (square layout)
+  static constexpr int S = (NV_ + 3) & ~3;    // row stride of the square matrices
+  static constexpr int T = 4 * NC_;           // row stride of the dof-major pyramid Jacobian
+  static constexpr int NLP = (NL_ + 3) & ~3;  // contact rows start here in the 16-byte aligned row-weight array
   static constexpr int NTRI = NV_ * (NV_ + 1) / 2;
   static constexpr int NANC = 12;   // max dofs on a root-to-body path (Go2: 9, H1: 11)
   static constexpr int NCHAIN = 8;  // max root-to-leaf chains (Go2: 4 legs, H1: 2 legs + 2 arms)
   static constexpr int CHAINLEN = 8;  // max bodies on a chain (Go2: 4, H1: 6)
 };
-using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2>;
+using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1>;
-using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco>;
+using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 144>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -62,9 +71,11 @@ using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, D
 #include <type_traits>
 template <int B, int E, class F>
 #if defined(__HIPCC__)
-__host__ __device__
+__host__ __device__ __forceinline__
+#else
+inline
 #endif
-inline void static_for(F&& f) {
+void static_for(F&& f) {
   if constexpr (B < E) {
     f(std::integral_constant<int, B>{});
     static_for<B + 1, E>(f);
@@ -102,6 +113,10 @@ struct CModel {
   uint32_t dof_descmask[D::NV];          // bit j: dof j is a descendant-or-self of dof i
   float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
   uint16_t tri[D::NTRI + (D::NTRI & 1)];
+  // H work list (square layout): see dial_derived::hitem
+  int32_t nhitem;
+  uint8_t hpass_n[8];
+  uint32_t hitem[D::NHI];
   // ---- geoms / sites / contacts / limits / actuators
   int32_t geom_bodyid[D::NG];
   float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];

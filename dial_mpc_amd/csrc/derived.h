@@ -5,6 +5,7 @@
 #include "cmodel.h"
 
 #define DIAL_MAX_TRI ((DIAL_MAX_V * (DIAL_MAX_V + 1)) / 2)
+#define DIAL_MAX_HITEM 512
 
 struct dial_derived {
   int32_t nlevel;                          // max body depth
@@ -16,6 +17,14 @@ struct dial_derived {
   int32_t dof_limrow[DIAL_MAX_V];          // limit row of dof i, or -1
   int32_t ntri;                            // nv*(nv+1)/2
   uint16_t tri[DIAL_MAX_TRI];              // lower-triangle entries, (i << 8) | j, row-major
+  // H = M + J^T D J work list: one item per (matrix entry, chunk of <= 4 contacts that touch it).  An entry hit
+  // by more contacts than the chunk size is split over P = 2 or 4 adjacent lanes whose partial sums are combined
+  // with quad DPP adds.  Packed as  i | j<<5 | pcode<<10 (P = 1,2,4) | writer<<12 | limdiag<<13 | n<<14 |
+  // c0<<17 | c1<<20 | c2<<23 | c3<<26.  Groups are ordered P = 4, 2, 1 (so they never straddle a quad) and the
+  // P = 1 items by decreasing n; hpass_n[p] = max n among items 64p .. 64p+63.
+  int32_t nhitem;
+  uint8_t hpass_n[8];
+  uint32_t hitem[DIAL_MAX_HITEM];
 };
 
 // Host: build the derived tables.  Returns 0 or a negative DIAL_ERR_* code.
@@ -64,7 +73,57 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
   dv->ntri = t;
   for (int c = 0; c < m->ncon; c++)
     if (m->con_body1[c] != 0) return DIAL_ERR_UNSUPPORTED;   // body-body contacts would fill H between branches
+  // ---- H work list.  Contact c (world vs body2) touches dof i iff i moves body2; j is an ancestor of i, so
+  // entry (i, j) is touched by exactly the contacts that touch i.
+  dv->nhitem = 0;
+  for (int p = 0; p < 8; p++) dv->hpass_n[p] = 0;
+  if (m->ncon <= 8) {
+    int chunk = 4;
+    for (int i = 0; i < m->nv; i++) {
+      int n = 0;
+      for (int c = 0; c < m->ncon; c++) n += (dv->body_ancmask[m->con_body2[c]] >> i) & 1u;
+      if (n > 0 && n < chunk) chunk = n;
+    }
+    int nh = 0;
+    bool fits = true;
+    // stage 0: groups of 4 lanes, stage 1: groups of 2, stages 2..6: single-lane items with n = 4, 3, 2, 1, 0
+    for (int stage = 0; stage < 7 && fits; stage++) {
+      for (int e = 0; e < t && fits; e++) {
+        const int i = dv->tri[e] >> 8, j = dv->tri[e] & 0xff;
+        int cl[8], n = 0;
+        for (int c = 0; c < m->ncon; c++)
+          if ((dv->body_ancmask[m->con_body2[c]] >> i) & 1u) cl[n++] = c;
+        const int parts = n == 0 ? 1 : (n + chunk - 1) / chunk;
+        if (parts > 4) { fits = false; break; }
+        const int P = parts == 1 ? 1 : (parts == 2 ? 2 : 4);
+        const int want = P == 4 ? 0 : (P == 2 ? 1 : 2 + (4 - n));
+        if (want != stage) continue;
+        for (int q = 0; q < P; q++) {
+          if (nh >= DIAL_MAX_HITEM) { fits = false; break; }
+          uint32_t h = (uint32_t)i | ((uint32_t)j << 5) | ((uint32_t)(P == 1 ? 0 : (P == 2 ? 1 : 2)) << 10);
+          if (q == 0) {
+            h |= 1u << 12;
+            if (i == j && dv->dof_limrow[i] >= 0) h |= 1u << 13;
+          }
+          int nq = 0;
+          for (int k = q * chunk; k < n && k < (q + 1) * chunk; k++) h |= (uint32_t)cl[k] << (17 + 3 * nq++);
+          h |= (uint32_t)nq << 14;
+          if (nq > dv->hpass_n[nh >> 6]) dv->hpass_n[nh >> 6] = (uint8_t)nq;
+          dv->hitem[nh++] = h;
+        }
+      }
+    }
+    if (nh > 8 * 64) fits = false;
+    dv->nhitem = fits ? nh : 0;
+  }
   return DIAL_OK;
+}
+
+// Host: does the derived H work list fit the instantiation's capacity (square layout only)?
+template <class D>
+static inline bool derived_fits(const dial_derived* dv) {
+  if constexpr (D::square) return dv->nhitem > 0 && dv->nhitem <= D::NHI;
+  else return true;
 }
 
 // Host: capacity-sized ABI structs -> CModel<D>.  The caller has checked dims_match<D>() for static D.
@@ -134,6 +193,11 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
   }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
+  if constexpr (D::square) {
+    o.nhitem = dv->nhitem <= D::NHI ? dv->nhitem : 0;
+    for (int p = 0; p < 8; p++) o.hpass_n[p] = dv->hpass_n[p];
+    for (int e = 0; e < o.nhitem; e++) o.hitem[e] = dv->hitem[e];
+  }
   for (int g = 0; g < m->ngeom; g++) {
     o.geom_bodyid[g] = m->geom_bodyid[g];
     for (int k = 0; k < 3; k++) { o.geom_pos[g][k] = m->geom_pos[g][k]; o.geom_size[g][k] = m->geom_size[g][k]; }
@@ -193,17 +257,21 @@ WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 // Carve the workspace out of `base`; returns the number of words used (call with base = nullptr to size
 // the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path); otherwise
 // L is the nv x stride transpose scratch of the register solver (solver_reg.h).
+// `square`: the register solver's square layout (Dims::square): M and H are nv x S squares, Jc holds the dof-major
+// pyramid rows J^T[i][4c + e], the transpose scratch L aliases H, frc is padded so that the contact weights start
+// 16-byte aligned.
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
-                   int ncon, int nefc, int nnode, bool with_L) {
+                   int ncon, int nefc, int nnode, bool with_L, bool square = false) {
   int o = 0;
-  const int ntri = (nv * (nv + 1)) / 2;
+  const int ntri = square ? nv * ((nv + 3) & ~3) : (nv * (nv + 1)) / 2;
+  const int njc = square ? nv * 4 * ncon : ncon * 3 * nv;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
   WS_TAKE(act, nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 10)
   WS_TAKE(xpos, nbody * 3) WS_TAKE(xquat, nbody * 4) WS_TAKE(spos, nsite * 3) WS_TAKE(com, nbody * 3)
   WS_TAKE(cvel, nbody * 6) WS_TAKE(cdof, nv * 6)
   WS_TAKE(M, ntri)
-  WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, ncon * 3 * nv)
+  WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, njc)
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   const int u0 = o;
@@ -224,12 +292,12 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(crb, nbody * 10)
   const int u1 = o;
   o = u0;
-  WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc)
+  WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4)
   const int ls = with_L ? 1 : 0;   // the rest is LDS-solver state; the register solver keeps it in VGPRs
   WS_TAKE(JarefW, ls * nefc) WS_TAKE(JarefS, ls * nefc) WS_TAKE(quad, ls * nefc * 3) WS_TAKE(MaW, ls * nv)
   WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv) WS_TAKE(qfc, ls * nv)
   WS_TAKE(ysol, ls * nv)
-  WS_TAKE(L, with_L ? ntri : nv * ((nv + 3) & ~3))   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead
+  WS_TAKE(L, with_L ? ntri : (square ? 0 : nv * ((nv + 3) & ~3)))   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead   // (square: the callers pass H as scratch -- the factor is written after H has been read into registers)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE

@@ -43,7 +43,7 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   }
   if constexpr (WPB > 1) wsbase += (threadIdx.x >> 6) * ws_words;   // WPB == 1: LDS addresses stay immediates
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), nnode, dial::kNeedL<D>);
+           dim_ne(m), nnode, dial::kNeedL<D>, D::square);
   return m;
 }
 
@@ -336,9 +336,9 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
       Ws s;
       const int nnode = cfg ? cfg->Hnode + 1 : 0;
       const int ws0 = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
-                               model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>);
+                               model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>, D::square);
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
-                               model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>);
+                               model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square);
       ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
@@ -351,9 +351,9 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
       return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
     };
     int urc;
-    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model)) { ctx->inst = 2; ctx->wpb = 2; urc = upload(DimsH1{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
+    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd)) { ctx->inst = 2; ctx->wpb = 2; urc = upload(DimsH1{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }

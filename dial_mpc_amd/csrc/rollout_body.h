@@ -419,7 +419,8 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         for (int k = 0; k < 6; k++) v += s.Fd[6 * i + k] * s.cdof[6 * j + k];
       }
       if (i == j) v += m->dof_armature[i];
-      s.M[tri_idx(i, j)] = v;
+      if constexpr (M::D::square) { s.M[i * M::D::S + j] = v; s.M[j * M::D::S + i] = v; }
+      else s.M[tri_idx(i, j)] = v;
     } else if (it < ntri + nv) {
       const int i = it - ntri, b = m->dof_bodyid[i];
       float bias = 0.f;
@@ -499,7 +500,14 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       dm::cross3(cr, cd, off);
       for (int k = 0; k < 3; k++) diff[k] -= cd[3 + k] + cr[k];
     }
-    for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * c + 3 * a, diff);
+    if constexpr (M::D::square) {   // dof-major pyramid rows J^T[i][4c + e] = Jn +- mu * Jt (one 16-byte store)
+      const float jn = dm::dot3(s.cframe + 9 * c, diff), t1 = dm::dot3(s.cframe + 9 * c + 3, diff) * m->con_friction[c][0];
+      const float t2 = dm::dot3(s.cframe + 9 * c + 6, diff) * m->con_friction[c][1];
+      float* jt = s.Jc + i * M::D::T + 4 * c;
+      jt[0] = jn + t1; jt[1] = jn - t1; jt[2] = jn + t2; jt[3] = jn - t2;
+    } else {
+      for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * c + 3 * a, diff);
+    }
   });
   // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
   w.items(ne, [&](int r) {
@@ -529,7 +537,13 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float k_, b_, imp;
       kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
       float R = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
-      float vel = row_dot(m, s, r, s.qvel);
+      float vel;
+      if constexpr (M::D::square) {
+        vel = 0.f;
+        for (int i = 0; i < M::D::NV; i++) vel += s.Jc[i * M::D::T + (r - nl)] * s.qvel[i];
+      } else {
+        vel = row_dot(m, s, r, s.qvel);
+      }
       s.aref[r] = -b_ * vel - k_ * imp * pos;
       s.D[r] = 1.f / R;
     }
@@ -537,7 +551,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   if constexpr (M::D::is_static) {
-    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.L);
+    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), M::D::square ? s.H : s.L);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
     solve_spd(w, m, s, s.M, s.rhs, s.qas);
@@ -1000,6 +1014,12 @@ DIAL_DEV void init_world(W& w, const Ws& s) {
     for (int k = 0; k < 3; k++) { s.xpos[k] = 0.f; s.com[k] = 0.f; }
     s.xquat[0] = 1.f; s.xquat[1] = 0.f; s.xquat[2] = 0.f; s.xquat[3] = 0.f;
   });
+}
+// Square layout: the structurally zero entries of M are written once per kernel; the sparse writers never touch them.
+template <class W, class M>
+DIAL_DEV void init_square(W& w, const M* m, const Ws& s) {
+  (void)m;
+  if constexpr (M::D::square) w.items(M::D::NV * M::D::S, [&](int e) { s.M[e] = 0.f; });
 }
 
 }  // namespace dial

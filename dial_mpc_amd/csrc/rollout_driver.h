@@ -63,6 +63,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   w.tprev = __builtin_readcyclecounter();
 #endif
   init_world(w, s);
+  init_square(w, m, s);
   load_state(w, m, s, io.state);
   if (!io.us) {
     // K1: candidate nodes (dial_core.py:110-115)
@@ -127,6 +128,7 @@ template <class W, class M>
 DIAL_DEV void env_step_single(W& w, const M* m, const dial_task* tg, const Ws& s, float* state,
                               const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
   init_world(w, s);
+  init_square(w, m, s);
   load_state(w, m, s, state);
   w.items(dim_nu(m), [&](int a) { s.act[a] = action[a]; });
   env_step<true>(w, m, tg, s);
@@ -144,6 +146,7 @@ template <class W, class M>
 DIAL_DEV void env_reset_single(W& w, const M* m, const Ws& s, const float* qpos, const float* qvel, float* state,
                                float* xpos_out, float* xquat_out) {
   init_world(w, s);
+  init_square(w, m, s);
   const int nq = dim_nq(m), nv = dim_nv(m);
   w.items(nq + 2 * nv + DIAL_INFO_N + dim_nu(m), [&](int i) {
     if (i < nq) s.qpos[i] = qpos[i];

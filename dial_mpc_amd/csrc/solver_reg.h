@@ -48,13 +48,28 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
     if (l < N) { k.desc = m->dof_descmask[own_i(l)]; k.anc = m->dof_ancmask[own_i(l)]; }
     return k;
   };
-  static_for<0, N>([&](auto JP) {
-    constexpr int jp = JP, j = N - 1 - jp;   // column j' of A' = orig dof j (>= orig i for the lower triangle of A')
-    a[jp] = w.per_lane([&](int l) {
-      if (l >= N || jp > l) return 0.f;
-      return ((masks_of(l).desc >> j) & 1u) ? A[tri_idx(j, own_i(l))] : 0.f;   // A[j][i] != 0 <=> j descends from i
+  if constexpr (D::square) {
+    // A is a full symmetric square with exact zeros off the sparsity pattern: lane l fetches row N-1-l with
+    // S/4 ds_read_b128.  Entries above the diagonal of A' (and everything in lanes >= N) are never used: a
+    // column is masked when it is finalised, broadcasts only read lanes k' <= l < N.
+    static_for<0, S / 4>([&](auto Q) {
+      constexpr int q = Q;
+      vfloat t[4];
+      w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+      static_for<0, 4>([&](auto E) {
+        constexpr int j = 4 * q + E;
+        if constexpr (j < N) a[N - 1 - j] = t[E];
+      });
     });
-  });
+  } else {
+    static_for<0, N>([&](auto JP) {
+      constexpr int jp = JP, j = N - 1 - jp;   // column j' of A' = orig dof j (>= orig i for the lower triangle of A')
+      a[jp] = w.per_lane([&](int l) {
+        if (l >= N || jp > l) return 0.f;
+        return ((masks_of(l).desc >> j) & 1u) ? A[tri_idx(j, own_i(l))] : 0.f;   // A[j][i] != 0 <=> j descends from i
+      });
+    });
+  }
   vfloat b = w.lane_reverse(bvec, N);
   vfloat dinv = vsplat(0.f);
   static_for<0, N>([&](auto KP) {
@@ -72,9 +87,12 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
       }
     });
   });
-  // LDS copy of the factor: scratch[k' * S + l] = L'[l][k'], so lane i finds row i of L'^T contiguously
+  // LDS copy of the factor in ORIGINAL dof order: scratch[k * S + i] = L'[i'][k'] (i = N-1-i', k = N-1-k'), so the
+  // lane of dof k finds row k' of L'^T contiguously.  Stored this way the non-zeros fall on the sparsity pattern
+  // of A (i an ancestor of k) and everything else is written as an exact 0 -- which is what lets the square
+  // layout reuse the storage of H for it: the next assembly of H only rewrites the pattern.
   w.items(N, [&](int l) {
-    static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[kp * S + l] = lane_val(a[kp], l); });
+    static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
   });
   // forward substitution L' z = b (unit diagonal)
   static_for<0, N>([&](auto KP) {
@@ -82,21 +100,22 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
     b = b - a[kp] * bcast(b, kp);
   });
   vfloat x = b * dinv;
-  // backward substitution L'^T x = D^-1 z with u[j] = L'^T[i][j] = L'[j][i] in lane i (0 unless j > i);
-  // the rows are streamed in chunks of four columns, one chunk ahead of its use (8 live registers)
+  // backward substitution L'^T x = D^-1 z: lane i' needs u[j'] = L'[j'][i'] = scratch[i * S + j] (0 unless j' > i');
+  // the row is streamed in chunks of four columns j = 4q .. 4q+3 (j' = N-1-j descending, the order of use), one
+  // chunk ahead of its use (8 live registers)
   constexpr int NQ = S / 4;
   vfloat u[2][4];
   const auto fetch = [&](auto Q, vfloat* dst) {
     constexpr int q = Q;
-    w.per_lane4([&](int l) { return scratch + (l < N ? l : 0) * S + 4 * q; }, dst[0], dst[1], dst[2], dst[3]);
+    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, dst[0], dst[1], dst[2], dst[3]);
   };
-  fetch(std::integral_constant<int, NQ - 1>{}, u[(NQ - 1) & 1]);
+  fetch(std::integral_constant<int, 0>{}, u[0]);
   static_for<0, NQ>([&](auto QQ) {
-    constexpr int q = NQ - 1 - QQ;
-    if constexpr (q > 0) fetch(std::integral_constant<int, q - 1>{}, u[(q - 1) & 1]);
+    constexpr int q = QQ;
+    if constexpr (q + 1 < NQ) fetch(std::integral_constant<int, q + 1>{}, u[(q + 1) & 1]);
     static_for<0, 4>([&](auto E) {
-      constexpr int kp = 4 * q + 3 - E;
-      if constexpr (kp < N) x = x - u[q & 1][kp & 3] * bcast(x, kp);
+      constexpr int j = 4 * q + E;
+      if constexpr (j < N) x = x - u[q & 1][E] * bcast(x, N - 1 - j);
     });
   });
   return w.lane_reverse(x, N);
@@ -119,17 +138,32 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   };
   // ---- persistent registers
   vfloat R[NV];
+  if constexpr (M::D::square) {
+    // one strided fetch per register: dof lane i walks row i of the square M (stride 1), contact lane r walks
+    // column r of the dof-major pyramid Jacobian (stride T); idle lanes re-read a word that holds 0 (lsign of a contact row)
+    constexpr int S = M::D::S, T = M::D::T;
 #pragma unroll
-  for (int j = 0; j < NV; j++)
-    R[j] = w.per_lane([&](int l) {
-      if (l < NV) return (((m->dof_ancmask[l] | m->dof_descmask[l]) >> j) & 1u) ? msym(s, l, j) : 0.f;
-      if (l >= C0 && l < C0 + 4 * NC) {
-        const int c = (l - C0) >> 2, e = (l - C0) & 3, tan = 1 + (e >> 1);
-        const float mu = m->con_friction[c][tan - 1];
-        return s.Jc[(c * 3) * NV + j] + s.Jc[(c * 3 + tan) * NV + j] * ((e & 1) ? -mu : mu);
-      }
-      return 0.f;
-    });
+    for (int j = 0; j < NV; j++)
+      R[j] = w.per_lane([&](int l) {
+        // (offsets from one base pointer rather than a select of pointers: keeps the accesses in the LDS address space)
+        const int ojc = (int)(s.Jc - s.M), ozero = (int)(s.lsign - s.M) + NL;   // lsign of a contact row is 0
+        const int off = l < NV ? l * S : ((l >= C0 && l < C0 + 4 * NC) ? ojc + (l - C0) : ozero);
+        const int stride = l < NV ? 1 : ((l >= C0 && l < C0 + 4 * NC) ? T : 0);
+        return s.M[off + j * stride];
+      });
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      R[j] = w.per_lane([&](int l) {
+        if (l < NV) return (((m->dof_ancmask[l] | m->dof_descmask[l]) >> j) & 1u) ? msym(s, l, j) : 0.f;
+        if (l >= C0 && l < C0 + 4 * NC) {
+          const int c = (l - C0) >> 2, e = (l - C0) & 3, tan = 1 + (e >> 1);
+          const float mu = m->con_friction[c][tan - 1];
+          return s.Jc[(c * 3) * NV + j] + s.Jc[(c * 3 + tan) * NV + j] * ((e & 1) ? -mu : mu);
+        }
+        return 0.f;
+      });
+  }
   const vfloat vD = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.D[r] : 0.f; });
   const vfloat varef = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.aref[r] : 0.f; });
   const vfloat vls = w.per_lane([&](int l) { int r = l < NV ? m->dof_limrow[l] : -1; return r >= 0 ? s.lsign[r] : 0.f; });
@@ -170,6 +204,15 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     const vbool act = vlt0(vJa);
     const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
     vfloat qfc = vls * vf;  // limit row of the own dof
+    if constexpr (M::D::square) {
+      static_for<0, NC>([&](auto Cc) {
+        constexpr int c = Cc;
+        vfloat jr[4];
+        w.per_lane4([&](int l) { return s.Jc + (l < NV ? l : 0) * M::D::T + 4 * c; }, jr[0], jr[1], jr[2], jr[3]);
+        qfc = qfc + ((jr[0] * bcast(vf, C0 + 4 * c) + jr[1] * bcast(vf, C0 + 4 * c + 1)) +
+                     (jr[2] * bcast(vf, C0 + 4 * c + 2) + jr[3] * bcast(vf, C0 + 4 * c + 3)));
+      });
+    } else
 #pragma unroll
     for (int c = 0; c < NC; c++) {
       const float f0 = bcast(vf, C0 + 4 * c), f1 = bcast(vf, C0 + 4 * c + 1);
@@ -201,6 +244,51 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
 
     // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
     const vfloat vwgt = vsel(act, vD, vzero);
+    if constexpr (M::D::square) {
+      // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC)
+      constexpr int S = M::D::S, T = M::D::T, NLP = M::D::NLP;
+      w.items(64, [&](int l) {
+        const int r = row_of(l);
+        if (r >= 0) s.frc[r < NL ? r : NLP + (r - NL)] = lane_val(vwgt, l);
+      });
+      static_for<0, (M::D::NHI + 63) / 64>([&](auto PASS) {
+        constexpr int pass = PASS;
+        const int nmax = m->hpass_n[pass];
+        const vfloat part = w.per_lane([&](int l) {
+          const int it = pass * 64 + l;
+          if (it >= m->nhitem) return 0.f;
+          const uint32_t h = m->hitem[it];
+          const int i = h & 31u, j = (h >> 5) & 31u, n = (h >> 14) & 7u;
+          float acc = 0.f;
+          static_for<0, 4>([&](auto Qq) {
+            constexpr int q = Qq;
+            if (q < nmax && q < n) {
+              const int c = (h >> (17 + 3 * q)) & 7u;
+              const int oi = i * T + 4 * c, oj = j * T + 4 * c, od = NLP + 4 * c;
+              acc += ((s.Jc[oi] * s.frc[od]) * s.Jc[oj] + (s.Jc[oi + 1] * s.frc[od + 1]) * s.Jc[oj + 1]) +
+                     ((s.Jc[oi + 2] * s.frc[od + 2]) * s.Jc[oj + 2] + (s.Jc[oi + 3] * s.frc[od + 3]) * s.Jc[oj + 3]);
+            }
+          });
+          return acc;
+        });
+        const vfloat pair = part + w.quad_xor1(part);
+        const vfloat quad = pair + w.quad_xor2(pair);
+        w.items(64, [&](int l) {
+          const int it = pass * 64 + l;
+          if (it >= m->nhitem) return;
+          const uint32_t h = m->hitem[it];
+          if (!((h >> 12) & 1u)) return;
+          const int i = h & 31u, j = (h >> 5) & 31u, pc = (h >> 10) & 3u;
+          // (values first, then select: a select between the captured registers' addresses would pin them,
+          //  the closure and with it the whole workspace descriptor to scratch memory)
+          const float t1 = lane_val(part, l), t2 = lane_val(pair, l), t4 = lane_val(quad, l);
+          float v = s.M[i * S + j] + (pc == 0 ? t1 : (pc == 1 ? t2 : t4));
+          if ((h >> 13) & 1u) v += s.frc[m->dof_limrow[i]];
+          s.H[i * S + j] = v;
+          s.H[j * S + i] = v;
+        });
+      });
+    } else {
     w.items(64, [&](int l) { const int r = row_of(l); if (r >= 0) s.frc[r] = lane_val(vwgt, l); });
     w.items(m->ntri, [&](int it) {   // structurally non-zero entries only
       const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
@@ -223,8 +311,9 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       }
       s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
     });
+    }
     DIAL_MARK(w, 5);
-    const vfloat vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, s.L);
+    const vfloat vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, M::D::square ? s.H : s.L);
     DIAL_MARK(w, 6);
 
     // ---- solver._linesearch

@@ -108,6 +108,9 @@ struct Wave {
   // SPMD helpers: value computed per lane; lane-index predicates
   template <class F>
   vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
+  // value of the lane whose index differs in bit 0 / bit 1 (neighbours inside a quad; DPP quad_perm on the GPU)
+  vfloat quad_xor1(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 1]; return r; }
+  vfloat quad_xor2(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 2]; return r; }
   // four consecutive floats from a per-lane, 16-byte aligned address (one ds_read_b128 on the GPU)
   template <class F>
   void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
@@ -244,6 +247,12 @@ struct Wave {
   }
   template <class F>
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
+  __device__ __forceinline__ vfloat quad_xor1(vfloat v) {   // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
+  }
+  __device__ __forceinline__ vfloat quad_xor2(vfloat v) {   // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+  }
   template <class F>
   __device__ __forceinline__ void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
     const float4 t = *reinterpret_cast<const float4*>(f(lane));

@@ -22,12 +22,12 @@ struct Runner {
     fill_cmodel(&cm, m, t, dv);
     Ws s;
     ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-                        DIAL_MAX_NODE, dial::kNeedL<D>);
+                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square);
   }
   void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
     lds.assign(ws_words, 0.f);
     ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
-             DIAL_MAX_NODE, dial::kNeedL<D>);
+             DIAL_MAX_NODE, dial::kNeedL<D>, D::square);
     w.lds = lds.data();
     w.lds_words = ws_words;
     w.check_races = check_races != 0;
