@@ -35,10 +35,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # (native v_sqrt / v_rsq / v_exp / v_log without denormal fix-ups); finite-math is NOT assumed (+-inf
     # control ranges are compared against).  -fno-slp-vectorize: the SLP pass packs pairs of scalar fp32 ops
     # into v_pk_* and pays for it in v_mov shuffles -- measured 5-6% slower on this issue-bound kernel.
+    # -fno-honor-nans: min / max / clip become single v_min / v_max instead of compare + select chains.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-hip-fp32-correctly-rounded-divide-sqrt",
            "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
-           "-Xarch_device", "-fno-slp-vectorize", "-o", LIB_PATH,
+           "-Xarch_device", "-fno-slp-vectorize", "-Xarch_device", "-fno-honor-nans", "-o", LIB_PATH,
            os.path.join(_CSRC, "dial_hip.hip")]
     if verbose:
         print(" ".join(cmd))

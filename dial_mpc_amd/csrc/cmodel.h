@@ -63,7 +63,7 @@ struct Dims {
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1>;
-using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 144>;
+using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 192>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -113,10 +113,13 @@ struct CModel {
   uint32_t dof_descmask[D::NV];          // bit j: dof j is a descendant-or-self of dof i
   float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
   uint16_t tri[D::NTRI + (D::NTRI & 1)];
-  // H work list (square layout): see dial_derived::hitem
+  // H work list (square layout), derived from dial_derived::hitem and padded with no-op items to whole passes:
+  //   hrec[it][0] = i*T | (j*T) << 10 | c0 << 20 | c1 << 23 | c2 << 26 | c3 << 29      (word offsets into J^T)
+  //   hrec[it][1] = i*S+j | (j*S+i) << 10 | limit-row weight index << 20 (NE+3: a zero word) | pcode << 26 |
+  //                 writer << 28 | n << 29
   int32_t nhitem;
   uint8_t hpass_n[8];
-  uint32_t hitem[D::NHI];
+  uint32_t hrec[D::NHI][2];
   // ---- geoms / sites / contacts / limits / actuators
   int32_t geom_bodyid[D::NG];
   float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];

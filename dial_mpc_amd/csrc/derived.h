@@ -194,9 +194,23 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
   if constexpr (D::square) {
+    static_assert(D::NHI % 64 == 0 && D::NV * D::T < 1024 && D::NV * D::S < 1024 && D::NE + 4 < 64, "hrec field widths");
     o.nhitem = dv->nhitem <= D::NHI ? dv->nhitem : 0;
     for (int p = 0; p < 8; p++) o.hpass_n[p] = dv->hpass_n[p];
-    for (int e = 0; e < o.nhitem; e++) o.hitem[e] = dv->hitem[e];
+    for (int e = 0; e < D::NHI; e++) {
+      uint32_t w0 = 0, w1 = (uint32_t)(D::NLP + 4 * D::NC) << 20;   // no-op item: reads valid words, writes nothing
+      if (e < o.nhitem) {
+        const uint32_t h = dv->hitem[e];
+        const uint32_t i = h & 31u, j = (h >> 5) & 31u, pc = (h >> 10) & 3u, wr = (h >> 12) & 1u, ld = (h >> 13) & 1u;
+        const uint32_t n = (h >> 14) & 7u;
+        w0 = (i * D::T) | ((j * D::T) << 10);
+        for (uint32_t q = 0; q < 4; q++) w0 |= ((h >> (17 + 3 * q)) & 7u) << (20 + 3 * q);
+        const uint32_t lim = ld ? (uint32_t)dv->dof_limrow[i] : (uint32_t)(D::NLP + 4 * D::NC);
+        w1 = (i * D::S + j) | ((j * D::S + i) << 10) | (lim << 20) | (pc << 26) | (wr << 28) | (n << 29);
+      }
+      o.hrec[e][0] = w0;
+      o.hrec[e][1] = w1;
+    }
   }
   for (int g = 0; g < m->ngeom; g++) {
     o.geom_bodyid[g] = m->geom_bodyid[g];

@@ -34,6 +34,17 @@ namespace dial {
 // with one ds_bpermute each.
 template <int N> constexpr int kCholStride = (N + 3) & ~3;
 
+// compile-time list of the reversed column indices j' > k' whose dof is an ancestor of dof k = N-1-k'
+template <class Topo, int N, int KP>
+struct AncList {
+  int jp[N > 0 ? N : 1] = {};
+  int n = 0;
+  constexpr AncList() {
+    for (int q = KP + 1; q < N; q++)
+      if (Topo::anc(N - 1 - KP, N - 1 - q)) jp[n++] = q;
+  }
+};
+
 template <class D, class W, class M>
 DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch) {
   constexpr int N = D::NV, S = kCholStride<N>;
@@ -79,12 +90,16 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
     const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
     a[kp] = lik;
     dinv = vsel(w.lane_eq(kp), vsplat(rinv), dinv);
-    static_for<kp + 1, N>([&](auto JP) {
-      constexpr int jp = JP, j = N - 1 - jp;
-      if constexpr (Topo::anc(k, j)) {       // l'_{j'k'} != 0 only when dof j is an ancestor of dof k
-        const float ajk = bcast(col, jp);
-        a[jp] = a[jp] - lik * ajk;
-      }
+    b = b - lik * bcast(b, kp);   // forward substitution L' z = b fused in: its broadcast/FMA chain fills the
+                                  // hazard slots of the column updates below (and vice versa)
+    // l'_{j'k'} != 0 only when dof j is an ancestor of dof k.  The broadcasts run two updates ahead of the FMAs
+    // that consume them, so that the v_readlane -> VALU scalar-operand hazard is covered by useful work
+    constexpr AncList<Topo, N, kp> L{};
+    float sb[3] = {0.f, 0.f, 0.f};
+    static_for<0, L.n + 2>([&](auto IDX) {
+      constexpr int idx = IDX;
+      if constexpr (idx < L.n) sb[idx % 3] = bcast(col, L.jp[idx]);
+      if constexpr (idx >= 2) { constexpr int jp = L.jp[idx - 2]; a[jp] = a[jp] - lik * sb[(idx - 2) % 3]; }
     });
   });
   // LDS copy of the factor in ORIGINAL dof order: scratch[k * S + i] = L'[i'][k'] (i = N-1-i', k = N-1-k'), so the
@@ -93,11 +108,6 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   // layout reuse the storage of H for it: the next assembly of H only rewrites the pattern.
   w.items(N, [&](int l) {
     static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
-  });
-  // forward substitution L' z = b (unit diagonal)
-  static_for<0, N>([&](auto KP) {
-    constexpr int kp = KP;
-    b = b - a[kp] * bcast(b, kp);
   });
   vfloat x = b * dinv;
   // backward substitution L'^T x = D^-1 z: lane i' needs u[j'] = L'[j'][i'] = scratch[i * S + j] (0 unless j' > i');
@@ -172,10 +182,14 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   const vfloat vwarm = w.per_lane([&](int l) { return l < NV ? s.warm[l] : 0.f; });
 
   // acc[dof lane i] = (M v)_i, acc[contact lane r] = (J v)_r
-  auto dotR = [&](const vfloat& v) {
+  auto dotR = [&](const vfloat& v) {   // broadcasts run two FMAs ahead (readlane -> scalar-operand hazard)
     vfloat acc = vzero;
-#pragma unroll
-    for (int j = 0; j < NV; j++) acc = acc + R[j] * bcast(v, j);
+    float sb[3] = {0.f, 0.f, 0.f};
+    static_for<0, NV + 2>([&](auto IDX) {
+      constexpr int idx = IDX;
+      if constexpr (idx < NV) sb[idx % 3] = bcast(v, idx);
+      if constexpr (idx >= 2) acc = acc + R[idx - 2] * sb[(idx - 2) % 3];
+    });
     return acc;
   };
   // row-slot product J_r . v: limit rows are +-e_dof, contact rows come out of the sweep
@@ -245,47 +259,55 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
     const vfloat vwgt = vsel(act, vD, vzero);
     if constexpr (M::D::square) {
-      // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC)
-      constexpr int S = M::D::S, T = M::D::T, NLP = M::D::NLP;
+      // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC), then a zero word
+      constexpr int S = M::D::S, T = M::D::T, NLP = M::D::NLP, NP = M::D::NHI / 64;
+      (void)S;
       w.items(64, [&](int l) {
         const int r = row_of(l);
         if (r >= 0) s.frc[r < NL ? r : NLP + (r - NL)] = lane_val(vwgt, l);
+        if (l == 63) s.frc[NLP + 4 * NC] = 0.f;
       });
-      static_for<0, (M::D::NHI + 63) / 64>([&](auto PASS) {
+      // Every lane accumulates its item of every pass (branch-free records: the LDS latencies of the passes
+      // overlap), partial sums of split entries are combined inside quads, then one phase writes the entries.
+      vfloat tot[NP];
+      static_for<0, NP>([&](auto PASS) {
         constexpr int pass = PASS;
         const int nmax = m->hpass_n[pass];
         const vfloat part = w.per_lane([&](int l) {
-          const int it = pass * 64 + l;
-          if (it >= m->nhitem) return 0.f;
-          const uint32_t h = m->hitem[it];
-          const int i = h & 31u, j = (h >> 5) & 31u, n = (h >> 14) & 7u;
+          const uint32_t w0 = m->hrec[pass * 64 + l][0], n = m->hrec[pass * 64 + l][1] >> 29;
+          const int bi = w0 & 1023u, bj = (w0 >> 10) & 1023u;
           float acc = 0.f;
           static_for<0, 4>([&](auto Qq) {
             constexpr int q = Qq;
-            if (q < nmax && q < n) {
-              const int c = (h >> (17 + 3 * q)) & 7u;
-              const int oi = i * T + 4 * c, oj = j * T + 4 * c, od = NLP + 4 * c;
-              acc += ((s.Jc[oi] * s.frc[od]) * s.Jc[oj] + (s.Jc[oi + 1] * s.frc[od + 1]) * s.Jc[oj + 1]) +
-                     ((s.Jc[oi + 2] * s.frc[od + 2]) * s.Jc[oj + 2] + (s.Jc[oi + 3] * s.frc[od + 3]) * s.Jc[oj + 3]);
+            if (q < nmax) {
+              const int c4 = ((w0 >> (20 + 3 * q)) & 7u) * 4;
+              const int oi = bi + c4, oj = bj + c4, od = NLP + c4;
+              const float t = ((s.Jc[oi] * s.frc[od]) * s.Jc[oj] + (s.Jc[oi + 1] * s.frc[od + 1]) * s.Jc[oj + 1]) +
+                              ((s.Jc[oi + 2] * s.frc[od + 2]) * s.Jc[oj + 2] + (s.Jc[oi + 3] * s.frc[od + 3]) * s.Jc[oj + 3]);
+              acc += q < (int)n ? t : 0.f;
             }
           });
           return acc;
         });
         const vfloat pair = part + w.quad_xor1(part);
         const vfloat quad = pair + w.quad_xor2(pair);
-        w.items(64, [&](int l) {
-          const int it = pass * 64 + l;
-          if (it >= m->nhitem) return;
-          const uint32_t h = m->hitem[it];
-          if (!((h >> 12) & 1u)) return;
-          const int i = h & 31u, j = (h >> 5) & 31u, pc = (h >> 10) & 3u;
-          // (values first, then select: a select between the captured registers' addresses would pin them,
-          //  the closure and with it the whole workspace descriptor to scratch memory)
+        // group total by group size (values first, then select: a select between the captured registers'
+        // addresses would pin them, the closure and with it the whole workspace descriptor to scratch memory)
+        tot[pass] = w.per_lane([&](int l) {
           const float t1 = lane_val(part, l), t2 = lane_val(pair, l), t4 = lane_val(quad, l);
-          float v = s.M[i * S + j] + (pc == 0 ? t1 : (pc == 1 ? t2 : t4));
-          if ((h >> 13) & 1u) v += s.frc[m->dof_limrow[i]];
-          s.H[i * S + j] = v;
-          s.H[j * S + i] = v;
+          const uint32_t pc = (m->hrec[pass * 64 + l][1] >> 26) & 3u;
+          return pc == 0 ? t1 : (pc == 1 ? t2 : t4);
+        });
+      });
+      w.items(64, [&](int l) {
+        static_for<0, NP>([&](auto PASS) {
+          constexpr int pass = PASS;
+          const uint32_t w1 = m->hrec[pass * 64 + l][1];
+          const float v = (s.M[w1 & 1023u] + lane_val(tot[pass], l)) + s.frc[(w1 >> 20) & 63u];
+          if ((w1 >> 28) & 1u) {
+            s.H[w1 & 1023u] = v;
+            s.H[(w1 >> 10) & 1023u] = v;
+          }
         });
       });
     } else {
