@@ -269,32 +269,38 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       });
       // Every lane accumulates its item of every pass (branch-free records: the LDS latencies of the passes
       // overlap), partial sums of split entries are combined inside quads, then one phase writes the entries.
-      vfloat tot[NP];
+      vfloat part[NP], tot[NP];
+      static_for<0, 4>([&](auto Qq) {
+        constexpr int q = Qq;
+        bool any = false;
+        static_for<0, NP>([&](auto PASS) { any = any || q < m->hpass_n[PASS]; });
+        if (any) {   // wave-uniform: round q of the contact lists (Go2: one round)
+          // issue every 16-byte fetch of the round before the first use
+          vfloat ji[NP][4], jj[NP][4], dd[NP][4];
+          static_for<0, NP>([&](auto PASS) {
+            constexpr int pass = PASS;
+            const auto c4 = [&](int l) { return (int)((m->hrec[pass * 64 + l][0] >> (20 + 3 * q)) & 7u) * 4; };
+            w.per_lane4([&](int l) { return s.Jc + (m->hrec[pass * 64 + l][0] & 1023u) + c4(l); }, ji[pass][0], ji[pass][1], ji[pass][2], ji[pass][3]);
+            w.per_lane4([&](int l) { return s.Jc + ((m->hrec[pass * 64 + l][0] >> 10) & 1023u) + c4(l); }, jj[pass][0], jj[pass][1], jj[pass][2], jj[pass][3]);
+            w.per_lane4([&](int l) { return s.frc + NLP + c4(l); }, dd[pass][0], dd[pass][1], dd[pass][2], dd[pass][3]);
+          });
+          static_for<0, NP>([&](auto PASS) {
+            constexpr int pass = PASS;
+            const vfloat t = ((ji[pass][0] * dd[pass][0]) * jj[pass][0] + (ji[pass][1] * dd[pass][1]) * jj[pass][1]) +
+                             ((ji[pass][2] * dd[pass][2]) * jj[pass][2] + (ji[pass][3] * dd[pass][3]) * jj[pass][3]);
+            const vfloat tq = w.per_lane([&](int l) { return q < (int)(m->hrec[pass * 64 + l][1] >> 29) ? lane_val(t, l) : 0.f; });
+            if constexpr (q == 0) part[pass] = tq; else part[pass] = part[pass] + tq;
+          });
+        }
+      });
       static_for<0, NP>([&](auto PASS) {
         constexpr int pass = PASS;
-        const int nmax = m->hpass_n[pass];
-        const vfloat part = w.per_lane([&](int l) {
-          const uint32_t w0 = m->hrec[pass * 64 + l][0], n = m->hrec[pass * 64 + l][1] >> 29;
-          const int bi = w0 & 1023u, bj = (w0 >> 10) & 1023u;
-          float acc = 0.f;
-          static_for<0, 4>([&](auto Qq) {
-            constexpr int q = Qq;
-            if (q < nmax) {
-              const int c4 = ((w0 >> (20 + 3 * q)) & 7u) * 4;
-              const int oi = bi + c4, oj = bj + c4, od = NLP + c4;
-              const float t = ((s.Jc[oi] * s.frc[od]) * s.Jc[oj] + (s.Jc[oi + 1] * s.frc[od + 1]) * s.Jc[oj + 1]) +
-                              ((s.Jc[oi + 2] * s.frc[od + 2]) * s.Jc[oj + 2] + (s.Jc[oi + 3] * s.frc[od + 3]) * s.Jc[oj + 3]);
-              acc += q < (int)n ? t : 0.f;
-            }
-          });
-          return acc;
-        });
-        const vfloat pair = part + w.quad_xor1(part);
+        const vfloat pair = part[pass] + w.quad_xor1(part[pass]);
         const vfloat quad = pair + w.quad_xor2(pair);
         // group total by group size (values first, then select: a select between the captured registers'
         // addresses would pin them, the closure and with it the whole workspace descriptor to scratch memory)
         tot[pass] = w.per_lane([&](int l) {
-          const float t1 = lane_val(part, l), t2 = lane_val(pair, l), t4 = lane_val(quad, l);
+          const float t1 = lane_val(part[pass], l), t2 = lane_val(pair, l), t4 = lane_val(quad, l);
           const uint32_t pc = (m->hrec[pass * 64 + l][1] >> 26) & 3u;
           return pc == 0 ? t1 : (pc == 1 ? t2 : t4);
         });
