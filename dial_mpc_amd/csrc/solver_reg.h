@@ -355,35 +355,52 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    // Line-search layout: lane (g, l) = (lane >> 4, lane & 15) owns rows l and l + 16 for quantity g
-    // (g = 0: 0.5 D Jaref^2, g = 1: D jv Jaref, g = 2: 0.5 D jv^2), so ONE 16-lane DPP reduction per trial
-    // point yields all three sums.  Re-layout through LDS (rows are indexed by r there).
+    // Line-search layout: lane (g, l) = (lane >> 4, lane & 15) owns rows l, l + 16, .. for trial point g: the
+    // three points of one bracketing iteration (lo_next, hi_next, mid) are evaluated by three 16-lane groups in
+    // one pass -- per row one FMA, one compare/select and three FMAs into the sums (0.5 D Jaref^2, D jv Jaref,
+    // 0.5 D jv^2 over the active rows), three interleaved 16-lane DPP reductions, and the cost / derivatives of
+    // the group's point computed lane-wise.  Re-layout through LDS (rows are indexed by r there).
     w.items(64, [&](int l) {
       const int r = row_of(l);
       if (r >= 0) { s.Jaref[r] = lane_val(vJa, l); s.jv[r] = lane_val(vjv, l); }
     });
     constexpr int NE = M::D::NE, RPL = (NE + 15) / 16;   // rows per line-search lane (Go2: 2, H1: 3)
     const vbool g0 = w.lane_lt(16), g01 = w.lane_lt(32);
-    vfloat lJa[RPL], ljv[RPL], lQ[RPL];
+    vfloat lJa[RPL], ljv[RPL], Q0[RPL], Q1[RPL], Q2[RPL];
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       lJa[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.Jaref[r] : 0.f; });
       ljv[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.jv[r] : 0.f; });
       const vfloat lD = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return (l < 48 && r < NE) ? s.D[r] : 0.f; });
-      lQ[q] = vsel(g0, (lJa[q] * 0.5f) * lJa[q] * lD, vsel(g01, ljv[q] * lJa[q] * lD, (ljv[q] * 0.5f) * ljv[q] * lD));
+      const vfloat dja = lD * lJa[q], djv = lD * ljv[q];
+      Q0[q] = (lJa[q] * 0.5f) * dja;
+      Q1[q] = ljv[q] * dja;
+      Q2[q] = (ljv[q] * 0.5f) * djv;
     }
     struct LsPoint { float alpha, cost, d0, d1; };
-    auto ls_point = [&](float alpha) {
-      vfloat contrib = vzero;
+    // evaluate the points a0, a1, a2 (group g evaluates a_g)
+    auto ls_eval3 = [&](float a0, float a1, float a2, LsPoint& p0_, LsPoint& p1_, LsPoint& p2_) {
+      const vfloat va = vsel(g0, vsplat(a0), vsel(g01, vsplat(a1), vsplat(a2)));
+      vfloat s0 = vzero, s1v = vzero, s2v = vzero;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) contrib = contrib + vsel(vlt0(lJa[q] + ljv[q] * alpha), lQ[q], vzero);
-      const vfloat red = w.row16_sum(contrib);
-      const float q0 = bcast(red, 0) + qg0, q1 = bcast(red, 16) + qg1, q2 = bcast(red, 32) + qg2;
-      LsPoint p;
-      p.alpha = alpha;
-      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
-      p.d0 = 2.f * alpha * q2 + q1;
-      p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      for (int q = 0; q < RPL; q++) {
+        const vfloat act = vsel(vlt0(lJa[q] + ljv[q] * va), vsplat(1.f), vzero);
+        s0 = s0 + act * Q0[q];
+        s1v = s1v + act * Q1[q];
+        s2v = s2v + act * Q2[q];
+      }
+      w.row16_sum3(s0, s1v, s2v);
+      const vfloat q0 = s0 + vsplat(qg0), q1 = s1v + vsplat(qg1), q2 = s2v + vsplat(qg2);
+      const vfloat vcost = (va * va) * q2 + va * q1 + q0;
+      const vfloat vd0 = (va * 2.f) * q2 + q1;
+      const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
+      p0_.alpha = a0; p0_.cost = bcast(vcost, 0); p0_.d0 = bcast(vd0, 0); p0_.d1 = bcast(vd1, 0);
+      p1_.alpha = a1; p1_.cost = bcast(vcost, 16); p1_.d0 = bcast(vd0, 16); p1_.d1 = bcast(vd1, 16);
+      p2_.alpha = a2; p2_.cost = bcast(vcost, 32); p2_.d0 = bcast(vd0, 32); p2_.d1 = bcast(vd1, 32);
+    };
+    auto ls_point = [&](float alpha) {   // single point (the two points that open the bracket)
+      LsPoint p, u1, u2;
+      ls_eval3(alpha, alpha, alpha, p, u1, u2);
       return p;
     };
     LsPoint p0 = ls_point(0.f);
@@ -394,9 +411,8 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     for (;;) {
       const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
       if (ls_done) break;
-      LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
-      LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
-      LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
+      LsPoint lo_next, hi_next, mid;
+      ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
       const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
       if (swap_lo_next) lo = lo_next;
       const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);

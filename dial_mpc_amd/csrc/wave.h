@@ -48,6 +48,7 @@ inline vfloat operator*(const vfloat& a, const vfloat& b) { vfloat r; for (int l
 inline vfloat operator*(const vfloat& a, float b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b; return r; }
 inline vfloat vsel(const vbool& c, const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = c.x[l] ? a.x[l] : b.x[l]; return r; }
 inline vbool vlt0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] < 0.f; return r; }
+inline vbool veq0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] == 0.f; return r; }
 inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
 inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
@@ -134,6 +135,8 @@ struct Wave {
     }
     return r;
   }
+  // three independent 16-lane sums at once (the DPP stages interleave on the GPU)
+  void row16_sum3(vfloat& a, vfloat& b, vfloat& c) { a = row16_sum(a); b = row16_sum(b); c = row16_sum(c); }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
   float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
 };
@@ -182,6 +185,7 @@ using vbool = bool;
 __device__ __forceinline__ vfloat vsplat(float v) { return v; }
 __device__ __forceinline__ vfloat vsel(vbool c, vfloat a, vfloat b) { return c ? a : b; }
 __device__ __forceinline__ vbool vlt0(vfloat a) { return a < 0.f; }
+__device__ __forceinline__ vbool veq0(vfloat a) { return a == 0.f; }
 __device__ __forceinline__ float bcast(vfloat v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -280,6 +284,12 @@ struct Wave {
     v = dialwave::dpp_add<0x141>(v);   // row_half_mirror
     v = dialwave::dpp_add<0x140>(v);   // row_mirror
     return v;
+  }
+  __device__ __forceinline__ void row16_sum3(vfloat& a, vfloat& b, vfloat& c) {   // stage-interleaved: no DPP hazard stalls
+    a = dialwave::dpp_add<0xb1>(a); b = dialwave::dpp_add<0xb1>(b); c = dialwave::dpp_add<0xb1>(c);
+    a = dialwave::dpp_add<0x4e>(a); b = dialwave::dpp_add<0x4e>(b); c = dialwave::dpp_add<0x4e>(c);
+    a = dialwave::dpp_add<0x141>(a); b = dialwave::dpp_add<0x141>(b); c = dialwave::dpp_add<0x141>(c);
+    a = dialwave::dpp_add<0x140>(a); b = dialwave::dpp_add<0x140>(b); c = dialwave::dpp_add<0x140>(c);
   }
 };
 #endif
