@@ -173,12 +173,14 @@ def main():
     alg_bytes = bytes_per_step * n_local * T
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     valu_tflops = flop_per_step * n_local * T / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_busy, valu_per_step = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_rollout_kernel.json")
     if os.path.exists(pmc_path) and args.example == "unitree_go2_trot" and args.nsample_per_gpu == 2048 and world == 1:
         pmc = json.load(open(pmc_path))
         traffic = pmc["hbm_bytes_per_launch"]
         traffic_src = pmc["source"]
+        valu_busy = pmc.get("valu_pipe_busy_frac")              # SQ_ACTIVE_INST_VALU / SIMD cycles (PMC pass)
+        valu_per_step = pmc.get("valu_insts_per_wave_env_step")
     out = {
         "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"
         else f"sample-rollouts/sec (N x H env.steps), {args.example}", "value": value,
@@ -194,8 +196,10 @@ def main():
                      "kernel": "rollout_kernel",
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "path is fp32-VALU/latency bound (170 FLOP/B >> 20 FLOP/B machine balance)",
-                     "valu_tflops_est": valu_tflops, "valu_frac_est": valu_tflops / VALU_PEAK_TFLOPS},
+                     "note": "path is VALU-issue bound, not HBM bound (170 FLOP/B >> 20 FLOP/B machine balance): "
+                             "the VALU pipes are busy 63 % of the time at 2 resident waves per SIMD (PMC)",
+                     "valu_tflops_est": valu_tflops, "valu_frac_est": valu_tflops / VALU_PEAK_TFLOPS,
+                     "valu_pipe_busy_frac_pmc": valu_busy, "valu_insts_per_wave_env_step_pmc": valu_per_step},
         "plan_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
                             "ticks": len(lat), "tick_budget_ms": 20.0,
                             "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},
