@@ -34,6 +34,34 @@ namespace dial {
 // with one ds_bpermute each.
 template <int N> constexpr int kCholStride = (N + 3) & ~3;
 
+// Elimination sequence: any leaves-first order is fill-free; taking the dofs by decreasing depth interleaves the
+// branches (Go2: the four calves, then the four thighs, the four hips, then the base chain), so consecutive
+// columns -- pivot reciprocal, scaling, updates, forward-substitution step -- are independent of each other and
+// their ~10-cycle dependent-issue latencies overlap.  seq[t] is the reversed index k' handled at step t.
+template <class Topo, int N>
+struct ElimOrder {
+  int seq[N > 0 ? N : 1] = {};
+  int nlevel = 0;
+  int lvl[N > 0 ? N + 1 : 2] = {};   // steps lvl[g] .. lvl[g+1]-1 handle the dofs of one depth: mutually independent
+  constexpr ElimOrder() {
+    int depth[N > 0 ? N : 1] = {};
+    int maxd = 0;
+    for (int i = 0; i < N; i++) {
+      int d = 0;
+      for (int j = 0; j < i; j++) d += Topo::anc(i, j) ? 1 : 0;
+      depth[i] = d;
+      maxd = d > maxd ? d : maxd;
+    }
+    int t = 0;
+    for (int d = maxd; d >= 0; d--) {
+      lvl[nlevel++] = t;
+      for (int i = N - 1; i >= 0; i--)
+        if (depth[i] == d) seq[t++] = N - 1 - i;
+    }
+    lvl[nlevel] = t;
+  }
+};
+
 // compile-time list of the reversed column indices j' > k' whose dof is an ancestor of dof k = N-1-k'
 template <class Topo, int N, int KP>
 struct AncList {
@@ -83,24 +111,30 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   }
   vfloat b = w.lane_reverse(bvec, N);
   vfloat dinv = vsplat(0.f);
-  static_for<0, N>([&](auto KP) {
-    constexpr int kp = KP, k = N - 1 - kp;
-    const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
-    const float rinv = fast_rcp(bcast(col, kp));
-    const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
-    a[kp] = lik;
-    dinv = vsel(w.lane_eq(kp), vsplat(rinv), dinv);
-    b = b - lik * bcast(b, kp);   // forward substitution L' z = b fused in: its broadcast/FMA chain fills the
-                                  // hazard slots of the column updates below (and vice versa)
-    // l'_{j'k'} != 0 only when dof j is an ancestor of dof k.  The broadcasts run two updates ahead of the FMAs
-    // that consume them, so that the v_readlane -> VALU scalar-operand hazard is covered by useful work
-    constexpr AncList<Topo, N, kp> L{};
-    float sb[3] = {0.f, 0.f, 0.f};
-    static_for<0, L.n + 2>([&](auto IDX) {
-      constexpr int idx = IDX;
-      if constexpr (idx < L.n) sb[idx % 3] = bcast(col, L.jp[idx]);
-      if constexpr (idx >= 2) { constexpr int jp = L.jp[idx - 2]; a[jp] = a[jp] - lik * sb[(idx - 2) % 3]; }
+  constexpr ElimOrder<Topo, N> EO{};
+  static_for<0, EO.nlevel>([&](auto LV) {
+    constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
+    float bk[l1 - l0 > 0 ? l1 - l0 : 1];
+    static_for<l0, l1>([&](auto STEP) {
+      constexpr int kp = EO.seq[STEP];
+      const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
+      const float rinv = fast_rcp(bcast(col, kp));
+      const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
+      a[kp] = lik;
+      dinv = vsel(w.lane_eq(kp), vsplat(rinv), dinv);
+      bk[STEP - l0] = bcast(b, kp);   // forward substitution L' z = b, fused in: the columns of one depth do not touch
+                                      // each other's b entries, so all their broadcasts precede the updates of b
+      // l'_{j'k'} != 0 only when dof j is an ancestor of dof k.  The broadcasts run two updates ahead of the FMAs
+      // that consume them, so that the v_readlane -> VALU scalar-operand hazard is covered by useful work
+      constexpr AncList<Topo, N, kp> L{};
+      float sb[3] = {0.f, 0.f, 0.f};
+      static_for<0, L.n + 2>([&](auto IDX) {
+        constexpr int idx = IDX;
+        if constexpr (idx < L.n) sb[idx % 3] = bcast(col, L.jp[idx]);
+        if constexpr (idx >= 2) { constexpr int jp = L.jp[idx - 2]; a[jp] = a[jp] - lik * sb[(idx - 2) % 3]; }
+      });
     });
+    static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
   });
   // LDS copy of the factor in ORIGINAL dof order: scratch[k * S + i] = L'[i'][k'] (i = N-1-i', k = N-1-k'), so the
   // lane of dof k finds row k' of L'^T contiguously.  Stored this way the non-zeros fall on the sparsity pattern
@@ -110,23 +144,23 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
     static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
   });
   vfloat x = b * dinv;
-  // backward substitution L'^T x = D^-1 z: lane i' needs u[j'] = L'[j'][i'] = scratch[i * S + j] (0 unless j' > i');
-  // the row is streamed in chunks of four columns j = 4q .. 4q+3 (j' = N-1-j descending, the order of use), one
-  // chunk ahead of its use (8 live registers)
-  constexpr int NQ = S / 4;
-  vfloat u[2][4];
-  const auto fetch = [&](auto Q, vfloat* dst) {
+  // backward substitution L'^T x = D^-1 z: lane i' needs u[j'] = L'[j'][i'] = scratch[i * S + j] (0 unless j' > i'):
+  // its row of the LDS copy, fetched into the registers the factor no longer needs; steps in reverse elimination
+  // order (root first, then the branches interleaved)
+  static_for<0, S / 4>([&](auto Q) {
     constexpr int q = Q;
-    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, dst[0], dst[1], dst[2], dst[3]);
-  };
-  fetch(std::integral_constant<int, 0>{}, u[0]);
-  static_for<0, NQ>([&](auto QQ) {
-    constexpr int q = QQ;
-    if constexpr (q + 1 < NQ) fetch(std::integral_constant<int, q + 1>{}, u[(q + 1) & 1]);
+    vfloat t[4];
+    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
     static_for<0, 4>([&](auto E) {
       constexpr int j = 4 * q + E;
-      if constexpr (j < N) x = x - u[q & 1][E] * bcast(x, N - 1 - j);
+      if constexpr (j < N) a[N - 1 - j] = t[E];
     });
+  });
+  static_for<0, EO.nlevel>([&](auto LVR) {
+    constexpr int lv = EO.nlevel - 1 - LVR, l0 = EO.lvl[lv], l1 = EO.lvl[lv + 1];
+    float xk[l1 - l0 > 0 ? l1 - l0 : 1];
+    static_for<l0, l1>([&](auto STEP) { xk[STEP - l0] = bcast(x, EO.seq[STEP]); });
+    static_for<l0, l1>([&](auto STEP) { x = x - a[EO.seq[STEP]] * xk[STEP - l0]; });
   });
   return w.lane_reverse(x, N);
 }
@@ -182,26 +216,33 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   const vfloat vwarm = w.per_lane([&](int l) { return l < NV ? s.warm[l] : 0.f; });
 
   // acc[dof lane i] = (M v)_i, acc[contact lane r] = (J v)_r
-  auto dotR = [&](const vfloat& v) {   // broadcasts run two FMAs ahead (readlane -> scalar-operand hazard)
-    vfloat acc = vzero;
+  // (a dependent fp32 FMA issues every ~10 cycles on gfx950, an independent one every 2: three partial sums;
+  //  the broadcasts run two FMAs ahead of their use)
+  auto dotR = [&](const vfloat& v) {
+    vfloat acc[3] = {vzero, vzero, vzero};
     float sb[3] = {0.f, 0.f, 0.f};
     static_for<0, NV + 2>([&](auto IDX) {
       constexpr int idx = IDX;
       if constexpr (idx < NV) sb[idx % 3] = bcast(v, idx);
-      if constexpr (idx >= 2) acc = acc + R[idx - 2] * sb[(idx - 2) % 3];
+      if constexpr (idx >= 2) acc[(idx - 2) % 3] = acc[(idx - 2) % 3] + R[idx - 2] * sb[(idx - 2) % 3];
     });
-    return acc;
+    return (acc[0] + acc[1]) + acc[2];
   };
   // row-slot product J_r . v: limit rows are +-e_dof, contact rows come out of the sweep
   auto row_prod = [&](const vfloat& v, const vfloat& sweep) { return vsel(isdof, vls * v, sweep); };
-  auto row_cost = [&](const vfloat& ja) { return w.vsum(vsel(vlt0(ja), vD * ja * ja, vzero)); };
+  auto row_cost_terms = [&](const vfloat& ja) { return vsel(vlt0(ja), vD * ja * ja, vzero); };
 
   // ---- warm-start selection (solver.solve): cost at qacc_warmstart vs cost at qacc_smooth
   const vfloat pW = dotR(vwarm), pS = dotR(vqas);
   const vfloat jaW = row_prod(vwarm, pW) - varef, jaS = row_prod(vqas, pS) - varef;
   const vfloat maW = vsel(isdof, pW, vzero), maS = vsel(isdof, pS, vzero);
-  const float cw = row_cost(jaW), gw = w.vsum((maW - vqfs) * (vwarm - vqas));
-  const float cs = row_cost(jaS), gs = w.vsum((maS - vqfs) * (vqas - vqas));
+  float cw, gw, cs, gs;
+  {
+    vfloat t[4] = {row_cost_terms(jaW), (maW - vqfs) * (vwarm - vqas), row_cost_terms(jaS), (maS - vqfs) * (vqas - vqas)};
+    float r[4];
+    w.vsumN(t, r);
+    cw = r[0]; gw = r[1]; cs = r[2]; gs = r[3];
+  }
   const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
   const bool use_warm = cost_w < cost_s;
   vfloat vqacc = use_warm ? vwarm : vqas;
@@ -239,16 +280,21 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       qfc = qfc + cn * ((f0 + f1) + (f2 + f3)) + c1 * (mu1 * (f0 - f1)) + c2 * (mu2 * (f2 - f3));
     }
     const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
+    float gn = 0.f;
     if (niter > 0) {
-      const float c2 = row_cost(vJa), g2 = w.vsum((vMa - vqfs) * (vqacc - vqas));
-      gauss = 0.5f * g2;
+      vfloat t[3] = {row_cost_terms(vJa), (vMa - vqfs) * (vqacc - vqas), vgrad * vgrad};
+      float r[3];
+      w.vsumN(t, r);
+      gauss = 0.5f * r[1];
       prev_cost = cost;
-      cost = 0.5f * c2 + gauss;
+      cost = 0.5f * r[0] + gauss;
+      gn = r[2];
+    } else if (m->iterations != 1) {
+      gn = w.vsum(vgrad * vgrad);
     }
     DIAL_MARK(w, 4);
     bool done;
     if (m->iterations != 1) {
-      const float gn = w.vsum(vgrad * vgrad);
       const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
       done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
     } else {
@@ -349,9 +395,13 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     const vfloat pv = dotR(vsearch);
     const vfloat vmv = vsel(isdof, pv, vzero);
     const vfloat vjv = row_prod(vsearch, pv);
-    const float sn2 = w.vsum(vsearch * vsearch);
-    const float s1 = w.vsum(vsearch * vMa - vsearch * vqfs);
-    const float s2 = w.vsum(vsearch * vmv);
+    float sn2, s1, s2;
+    {
+      vfloat t[3] = {vsearch * vsearch, vsearch * vMa - vsearch * vqfs, vsearch * vmv};
+      float r[3];
+      w.vsumN(t, r);
+      sn2 = r[0]; s1 = r[1]; s2 = r[2];
+    }
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;

@@ -139,6 +139,8 @@ struct Wave {
   void row16_sum3(vfloat& a, vfloat& b, vfloat& c) { a = row16_sum(a); b = row16_sum(b); c = row16_sum(c); }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
   float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
+  template <int K>
+  void vsumN(vfloat (&v)[K], float (&out)[K]) { for (int k = 0; k < K; k++) out[k] = vsum(v[k]); }
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -278,6 +280,25 @@ struct Wave {
   }
   __device__ __forceinline__ void fence() { sync(); }
   __device__ __forceinline__ float vsum(vfloat v) { return dialwave::wave_sum(v); }
+  // K independent wave sums with their DPP stages interleaved (a dependent DPP add costs ~16 cycles, the K
+  // chains hide each other's latency); results are wave-uniform
+  template <int K>
+  __device__ __forceinline__ void vsumN(vfloat (&v)[K], float (&out)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0xb1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x4e>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x141>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x140>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x142, 0xa>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x143, 0xc>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 63));
+  }
   __device__ __forceinline__ vfloat row16_sum(vfloat v) {
     v = dialwave::dpp_add<0xb1>(v);    // quad_perm [1,0,3,2]
     v = dialwave::dpp_add<0x4e>(v);    // quad_perm [2,3,0,1]
