@@ -290,7 +290,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   const int u0 = o;
   // A1: dead after the cinert/cdof phase ...
-  WS_TAKE(xmat, nbody * 9) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
+  WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
   WS_TAKE(xaxis, njnt * 3)
   const int a1_end = o;
   o = u0;   // ... so the velocity-dependent temporaries written after that phase reuse it

@@ -221,9 +221,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     if (it < nb) {
       const int b = it;
       float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
-      float mat[9], t3[3], qi[4];
-      dm::quat_to_mat(mat, q);
-      for (int k = 0; k < 9; k++) s.xmat[9 * b + k] = mat[k];
+      float mat[9], t3[3], qi[4];   // (xmat is only needed for the free joint's cdof: formed there from xquat)
       float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
       float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
       dm::rotate(t3, ip, q);
@@ -289,8 +287,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       if (m->jnt_type[ji] == DIAL_JNT_FREE) {
         for (int i = 0; i < 3; i++)
           for (int k = 0; k < 6; k++) s.cdof[6 * (da + i) + k] = (k == 3 + i) ? 1.f : 0.f;
+        float bq[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, xm[9];
+        dm::quat_to_mat(xm, bq);
         for (int i = 0; i < 3; i++) {
-          float a[3] = {s.xmat[9 * b + i], s.xmat[9 * b + 3 + i], s.xmat[9 * b + 6 + i]}, cr[3];
+          float a[3] = {xm[i], xm[3 + i], xm[6 + i]}, cr[3];
           dm::cross3(cr, a, off);
           for (int k = 0; k < 3; k++) { s.cdof[6 * (da + 3 + i) + k] = a[k]; s.cdof[6 * (da + 3 + i) + 3 + k] = cr[k]; }
         }
