@@ -372,6 +372,70 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   }
   DIAL_MARK(w, 21);
   // ---- smooth.crb composite inertias (subtree sums) | rne local body forces
+  if (m->nshared >= 0) {
+    // subtree sums as suffix sums: (chain, component) items walk the exclusive tail of their chain leaf -> root
+    // (<= chain length iterations instead of one subtree-sized loop per body); the branching bodies follow below
+    w.items(10 * m->nchain + nb, [&](int it) {
+      if (it < 10 * m->nchain) {
+        const int c = it / 10, k = it - 10 * c;
+        float acc = 0.f;
+        for (int q = m->chain_len[c] - 1; q >= m->chain_excl[c]; q--) {
+          const int b = m->chain_body[c][q];
+          acc += s.cinert[10 * b + k];
+          s.crb[10 * b + k] = acc;
+        }
+      } else {
+        const int b = it - 10 * m->nchain;
+        float ci[10], ca[6], cv[6], f1[6], f2[6], f3[6];
+        for (int k = 0; k < 10; k++) ci[k] = s.cinert[10 * b + k];
+        for (int k = 0; k < 6; k++) { ca[k] = s.cacc[6 * b + k]; cv[k] = s.cvel[6 * b + k]; }
+        dm::inert_mul(f1, ci, ca);
+        dm::inert_mul(f2, ci, cv);
+        dm::motion_cross_force(f3, cv, f2);
+        for (int k = 0; k < 6; k++) s.cfl[6 * b + k] = f1[k] + f3[k];
+      }
+    });
+    w.items(10 + 6 * m->nchain, [&](int it) {
+      if (it < 10) {          // crb of the branching bodies, deepest first (one lane per component: no cross-lane order)
+        const int k = it;
+        s.crb[k] = 0.f;       // world body
+        for (int sh = 0; sh < m->nshared; sh++) {
+          const int b = m->shared_body[sh];
+          float acc = s.cinert[10 * b + k];
+          for (int q = 0; q < m->shared_nchild[sh]; q++) acc += s.crb[10 * m->shared_child[sh][q] + k];
+          s.crb[10 * b + k] = acc;
+        }
+      } else {                // cfrc suffix sums up the exclusive chain tails
+        const int c = (it - 10) / 6, k = (it - 10) - 6 * c;
+        float acc = 0.f;
+        for (int q = m->chain_len[c] - 1; q >= m->chain_excl[c]; q--) {
+          const int b = m->chain_body[c][q];
+          acc += s.cfl[6 * b + k];
+          s.cfrc[6 * b + k] = acc;
+        }
+      }
+    });
+    DIAL_MARK(w, 22);
+    w.items(nv + 6, [&](int it) {
+      if (it < nv) {
+        const int i = it, b = m->dof_bodyid[i];
+        float ci[10], cd[6], f[6];
+        for (int k = 0; k < 10; k++) ci[k] = s.crb[10 * b + k];
+        for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+        dm::inert_mul(f, ci, cd);
+        for (int k = 0; k < 6; k++) s.Fd[6 * i + k] = f[k];
+      } else {                // cfrc of the branching bodies
+        const int k = it - nv;
+        for (int sh = 0; sh < m->nshared; sh++) {
+          const int b = m->shared_body[sh];
+          float acc = s.cfl[6 * b + k];
+          for (int q = 0; q < m->shared_nchild[sh]; q++) acc += s.cfrc[6 * m->shared_child[sh][q] + k];
+          s.cfrc[6 * b + k] = acc;
+        }
+      }
+    });
+    DIAL_MARK(w, 23);
+  } else {
   w.items(11 * nb, [&](int it) {
     if (it < 10 * nb) {
       const int b = it / 10, k = it - 10 * b;
@@ -408,6 +472,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
   });
   DIAL_MARK(w, 23);
+  }
   if constexpr (!M::D::is_static) w.items((nv * (nv + 1)) / 2, [&](int e) { s.M[e] = 0.f; });
   // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
   //      | collision_driver (static contact list)
