@@ -105,12 +105,19 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     DIAL_MARK(w, 11);
     float rew = env_step<false>(w, m, tg, s);
     rsum += rew;
+    // per-step outputs: wave-uniform row pointers (scalar address arithmetic), one pass -- lane i stores element i
+    // of each row that is that long
     const size_t o = (size_t)n * T + st;
-    w.items(nq + nv + nx + 1, [&](int i) {
-      if (i < nq) { if (io.qss) io.qss[o * nq + i] = s.qpos[i]; }
-      else if (i < nq + nv) { if (io.qdss) io.qdss[o * nv + (i - nq)] = s.qvel[i - nq]; }
-      else if (i < nq + nv + nx) { if (io.xss) io.xss[o * nx + (i - nq - nv)] = s.xpos[3 + (i - nq - nv)]; }
-      else { if (io.rewss) io.rewss[o] = rew; }
+    float* const qrow = io.qss ? io.qss + o * nq : nullptr;
+    float* const qdrow = io.qdss ? io.qdss + o * nv : nullptr;
+    float* const xrow = io.xss ? io.xss + o * nx : nullptr;
+    float* const rrow = io.rewss ? io.rewss + o : nullptr;
+    const int nmax = nx > nq ? nx : nq;   // nv < nq
+    w.items(nmax, [&](int i) {
+      if (qrow && i < nq) qrow[i] = s.qpos[i];
+      if (qdrow && i < nv) qdrow[i] = s.qvel[i];
+      if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
+      if (rrow && i == 0) rrow[0] = rew;
     });
   }
 #ifdef DIAL_PROFILE
