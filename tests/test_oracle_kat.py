@@ -135,3 +135,77 @@ def test_reward_lags_action_by_one_step(go2):
     us = rng.uniform(-1, 1, (4, 9, 12))
     rew = orc.rollout(s0, us)[0]
     assert np.allclose(rew[:, 0], rew[0, 0], atol=1e-12) and np.ptp(rew[:, 1]) > 1e-6
+
+
+@pytest.mark.parametrize("example,H", [("unitree_h1_jog", 8), ("unitree_h1_loco", 8)])
+def test_h1_models_free_flight_and_conservation(example, H):
+    """H1 walk / loco (plane-capsule contacts, welded arm links with mesh-inferred inertias): unconstrained free
+    fall is -g for every dof, M is SPD, and torque-free flight conserves linear momentum / kinetic energy."""
+    dc, env, model, task, cfg = setup_case(example, 8, H)
+    nq, nv, nu = model.nq, model.nv, model.nu
+    orc = O.Oracle(model, task, cfg, np.float64)
+    q = np.array(env._init_q)
+    q[2] = 3.0
+    d = orc.forward_dump(q, np.zeros(nv))
+    assert np.all(d["con_dist"] > 0.5) and np.allclose(d["efc_force"], 0)
+    assert abs(d["qacc"][2] + float(np.float32(9.81))) < 1e-9 and np.allclose(np.delete(d["qacc"], 2), 0, atol=1e-8)
+    assert np.allclose(d["qM"], d["qM"].T) and np.all(np.linalg.eigvalsh(d["qM"]) > 0)
+    total_mass = sum(model.body_mass[b] for b in range(model.nbody))
+    assert abs(d["qM"][0, 0] - total_mass) < 1e-4 and abs(d["qM"][2, 2] - total_mass) < 1e-4   # translational block = m I
+    m2, t2 = type(model).from_buffer_copy(model), type(task).from_buffer_copy(task)
+    m2.timestep = 2e-4
+    t2.dt = 2e-4
+    for k in range(3):
+        m2.gravity[k] = 0.0
+    for i in range(nv):
+        m2.dof_damping[i] = 0.0
+    for a in range(nu):
+        t2.kp[a] = 0.0
+        t2.kd[a] = 0.0
+    o2 = O.Oracle(m2, t2, cfg, np.float64)
+    state, _, _ = o2.env_reset(q, np.random.default_rng(11).normal(0, 0.5, nv))
+
+    def momentum_energy(st):
+        dd = o2.forward_dump(st[:nq], st[nq:nq + nv])
+        v = st[nq:nq + nv]
+        return (dd["qM"] @ v)[:3], 0.5 * v @ dd["qM"] @ v
+
+    p0, e0 = momentum_energy(state)
+    for _ in range(300):
+        state, _, _, _ = o2.env_step(state, np.zeros(nu))
+    p1, e1 = momentum_energy(state)
+    assert np.abs(p1 - p0).max() < 1e-4 * max(1.0, np.abs(p0).max())
+    assert abs(e1 - e0) / e0 < 2e-2
+
+
+@pytest.mark.parametrize("example,ncon_per_foot", [("unitree_h1_jog", 2), ("unitree_h1_loco", 4)])
+def test_h1_contact_impulse_balances_momentum(example, ncon_per_foot):
+    """Holding the home pose (the humanoid sways and eventually tips -- only the feet collide): over the first 0.6 s
+    the impulse of the contact normal forces minus weight equals the change of the total vertical momentum
+    (M qd)[2], and the load is shared evenly by the two feet (left/right mirror symmetry of the model, incl. the
+    hull-inferred arm inertias of the loco model).  Exercises the capsule contacts, J^T f and the integrator."""
+    dc, env, model, task, cfg = setup_case(example, 8, 8)
+    nq, nv, nu, nl = model.nq, model.nv, model.nu, model.nlim
+    m2, t2 = type(model).from_buffer_copy(model), type(task).from_buffer_copy(task)
+    m2.timestep = t2.dt = 0.005            # the identity holds up to the O(dt) integrator residual
+    orc = O.Oracle(m2, t2, cfg, np.float64)
+    jr, home = env.joint_range, env._init_q[7:7 + nu]
+    act = np.clip(2 * (home - jr[:, 0]) / (jr[:, 1] - jr[:, 0]) - 1, -1, 1)
+    state, _, _ = orc.env_reset(env._init_q, np.zeros(nv))
+    weight = sum(model.body_mass[b] for b in range(model.nbody)) * float(np.float32(9.81))
+
+    def pz(st):
+        return (orc.forward_dump(st[:nq], st[nq:nq + nv])["qM"] @ st[nq:nq + nv])[2]
+
+    p_start, impulse, dt = pz(state), 0.0, m2.timestep
+    for t in range(120):
+        before = state.copy()
+        state, _, _, ctrl = orc.env_step(state, act)
+        d = orc.forward_dump(before[:nq], before[nq:nq + nv], ctrl, before[nq + nv:nq + 2 * nv])
+        fn = d["efc_force"][nl:].reshape(-1, 4).sum(1)        # normal force per contact in this step
+        impulse += dt * (fn.sum() - weight)
+        left, right = fn[:ncon_per_foot].sum(), fn[ncon_per_foot:].sum()
+        assert abs(left - right) < 0.03 * weight, (t, left, right)
+        assert np.all(fn >= -1e-9)
+    assert 0.3 * weight < fn.sum() < 3 * weight and state[2] > 0.85          # still on its feet
+    assert abs((pz(state) - p_start) - impulse) < 0.01 * weight * 120 * dt
