@@ -62,7 +62,7 @@ struct Dims {
   static constexpr int CHAINLEN = 8;  // max bodies on a chain (Go2: 4, H1: 6)
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
-using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1>;
+using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;
 using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 192>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;

@@ -25,7 +25,8 @@
 // Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
 // WPB wavefronts (= samples) per workgroup share ONE staged copy of the constants; each wavefront has
 // its own workspace.  WPB is chosen per robot so that N+1 = 2049 wavefronts are co-resident (>= 9 per CU):
-// Go2 1 (13 KB/wave), H1 2 (7.7 KB constants + 2 x 10.9 KB), generic 1.  This is the only workgroup-level barrier of the kernel (phase boundaries are
+// Go2 1 (16 KB/wave), H1 3 (10 KB constants + 3 x 13.7 KB: 3 workgroups = 9 wavefronts per CU), H1 loco 2, generic 1.
+// This is the only workgroup-level barrier of the kernel (phase boundaries are
 // wavefront-scope fences, wave.h).
 template <class D, int WPB = 1>
 __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
@@ -352,7 +353,7 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     };
     int urc;
     if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd)) { ctx->inst = 2; ctx->wpb = 2; urc = upload(DimsH1{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd)) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
     else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
@@ -433,7 +434,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
                      st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
                      (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words)
   if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
-  else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 2);
+  else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
