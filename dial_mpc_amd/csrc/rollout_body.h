@@ -616,7 +616,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   if constexpr (M::D::is_static) {
-    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), M::D::square ? s.H : s.L);
+    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
     solve_spd(w, m, s, s.M, s.rhs, s.qas);

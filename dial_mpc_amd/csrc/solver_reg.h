@@ -1,15 +1,21 @@
 // solver_reg.h -- register-resident Newton solver (solver.solve of MJX) for the dimension-specialised
-// instantiations.
+// instantiations (all of which use the square LDS layout, cmodel.h: Dims::square).
 //
 // Lane roles inside the wavefront that owns the sample:
 //   lanes [0, NV)            dof i  -- and the joint-limit row of dof i, if it has one ("row slot")
 //   lanes [32, 32 + 4*NC)    pyramid edge e of contact c (lane 32 + 4c + e)     ("row slot")
 // Persistent registers:
-//   R[NV]   dof lane i: row i of M          contact lane: the constraint row J_r = Jn + f*Jt
+//   R[NV]   dof lane i: row i of M          contact lane: the constraint row J_r = Jn +- mu*Jt
 //   per dof lane: qfs, qas, qacc, Ma, grad, search, mv     per row slot: D, aref, lsign, Jaref, jv
 // One sweep  acc += R[j] * readlane(v, j), j < NV  yields M v in the dof lanes AND J v in the contact lanes;
-// J^T f needs 4*NC readlanes; reductions are DPP butterflies.  LDS is used only to build H = M + J^T D J
-// (lane per matrix entry) and for the packed transpose inside the Cholesky solve.
+// J^T f is formed from the dof-major pyramid rows in LDS (one 16-byte fetch per contact) and 4*NC readlanes;
+// reductions are DPP butterflies, independent ones batched with interleaved stages.  LDS is used to assemble
+// H = M + J^T D J (contact-sparse work list), for the transposed copy of the factor inside the L D L^T solve
+// and to re-layout the constraint rows for the line search.
+//
+// Cost model (tools/ubench/latency.hip, profiles/r01_ubench_latency.txt): an independent VALU instruction issues
+// every ~2 cycles, a dependent one every ~10.6, v_readlane -> VALU ~20, a dependent DPP add ~16, an LDS round
+// trip ~60: the code below is arranged so that independent chains sit next to each other.
 //
 // Semantics are those of rollout_body.h's LDS solver (same iterates: warm-start choice, MJX line search
 // with <= ls_iterations bracket refinements, skipped final factorisation); the wave emulator runs both
@@ -27,10 +33,10 @@ namespace dial {
 // emitted otherwise (Go2: 99 of 153 pairs, H1: 169 of 300).  Per step k': pivot and column entries are
 // broadcast with v_readlane (wave-uniform scalars) and every lane updates its own row.  Both substitutions
 // are column oriented (broadcast one entry, one FMA per lane, unit diagonals so no per-step scaling): the
-// forward one runs on the rows of L' that the factorisation leaves in registers, the backward one on the
-// rows of L'^T, which are fetched from an LDS copy of the factor (N ds_writes, N/4 ds_read_b128 per lane;
-// `scratch` needs N * kCholStride<N> floats).  A row-oriented backward pass needs no transpose but costs one
-// full DPP wave reduction per unknown -- 3x the issue slots.  Right-hand side and solution are lane-reversed
+// forward one is fused into the factorisation, the backward one runs on the rows of L'^T, which are fetched
+// from an LDS copy of the factor (N ds_writes, N/4 ds_read_b128 per lane; `scratch` needs N * kCholStride<N>
+// floats and may be the storage of A itself).  A row-oriented backward pass needs no transpose but costs one
+// full DPP wave reduction per unknown -- 3x the instructions.  Right-hand side and solution are lane-reversed
 // with one ds_bpermute each.
 template <int N> constexpr int kCholStride = (N + 3) & ~3;
 
@@ -79,36 +85,21 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   using Topo = typename D::Topo;
   w.begin_region();
   vfloat a[N];
-  // the lane's dof is i = N-1-l; its descendant / ancestor bit masks decide which entries can be non-zero
-  const auto own_i = [&](int l) { return N - 1 - l; };
-  struct Masks { unsigned desc, anc; };
-  const auto masks_of = [&](int l) -> Masks {
-    Masks k{0u, 0u};
-    if (l < N) { k.desc = m->dof_descmask[own_i(l)]; k.anc = m->dof_ancmask[own_i(l)]; }
-    return k;
-  };
-  if constexpr (D::square) {
-    // A is a full symmetric square with exact zeros off the sparsity pattern: lane l fetches row N-1-l with
-    // S/4 ds_read_b128.  Entries above the diagonal of A' (and everything in lanes >= N) are never used: a
-    // column is masked when it is finalised, broadcasts only read lanes k' <= l < N.
-    static_for<0, S / 4>([&](auto Q) {
-      constexpr int q = Q;
-      vfloat t[4];
-      w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
-      static_for<0, 4>([&](auto E) {
-        constexpr int j = 4 * q + E;
-        if constexpr (j < N) a[N - 1 - j] = t[E];
-      });
+  static_assert(D::square, "the register solver reads M / H from the square LDS layout");
+  const auto own_i = [&](int l) { return N - 1 - l; };   // the lane's dof
+  // A is a full symmetric square with exact zeros off the sparsity pattern: lane l fetches row N-1-l with
+  // S/4 ds_read_b128.  Entries above the diagonal of A' (and everything in lanes >= N) are never used: a
+  // column is masked when it is finalised, broadcasts only read lanes k' <= l < N.
+  static_for<0, S / 4>([&](auto Q) {
+    constexpr int q = Q;
+    vfloat t[4];
+    w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    static_for<0, 4>([&](auto E) {
+      constexpr int j = 4 * q + E;
+      if constexpr (j < N) a[N - 1 - j] = t[E];
     });
-  } else {
-    static_for<0, N>([&](auto JP) {
-      constexpr int jp = JP, j = N - 1 - jp;   // column j' of A' = orig dof j (>= orig i for the lower triangle of A')
-      a[jp] = w.per_lane([&](int l) {
-        if (l >= N || jp > l) return 0.f;
-        return ((masks_of(l).desc >> j) & 1u) ? A[tri_idx(j, own_i(l))] : 0.f;   // A[j][i] != 0 <=> j descends from i
-      });
-    });
-  }
+  });
+  (void)m;
   vfloat b = w.lane_reverse(bvec, N);
   vfloat dinv = vsplat(0.f);
   constexpr ElimOrder<Topo, N> EO{};
@@ -182,7 +173,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   };
   // ---- persistent registers
   vfloat R[NV];
-  if constexpr (M::D::square) {
+  {
     // one strided fetch per register: dof lane i walks row i of the square M (stride 1), contact lane r walks
     // column r of the dof-major pyramid Jacobian (stride T); idle lanes re-read a word that holds 0 (lsign of a contact row)
     constexpr int S = M::D::S, T = M::D::T;
@@ -194,18 +185,6 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
         const int off = l < NV ? l * S : ((l >= C0 && l < C0 + 4 * NC) ? ojc + (l - C0) : ozero);
         const int stride = l < NV ? 1 : ((l >= C0 && l < C0 + 4 * NC) ? T : 0);
         return s.M[off + j * stride];
-      });
-  } else {
-#pragma unroll
-    for (int j = 0; j < NV; j++)
-      R[j] = w.per_lane([&](int l) {
-        if (l < NV) return (((m->dof_ancmask[l] | m->dof_descmask[l]) >> j) & 1u) ? msym(s, l, j) : 0.f;
-        if (l >= C0 && l < C0 + 4 * NC) {
-          const int c = (l - C0) >> 2, e = (l - C0) & 3, tan = 1 + (e >> 1);
-          const float mu = m->con_friction[c][tan - 1];
-          return s.Jc[(c * 3) * NV + j] + s.Jc[(c * 3 + tan) * NV + j] * ((e & 1) ? -mu : mu);
-        }
-        return 0.f;
       });
   }
   const vfloat vD = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.D[r] : 0.f; });
@@ -259,26 +238,13 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     const vbool act = vlt0(vJa);
     const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
     vfloat qfc = vls * vf;  // limit row of the own dof
-    if constexpr (M::D::square) {
-      static_for<0, NC>([&](auto Cc) {
-        constexpr int c = Cc;
-        vfloat jr[4];
-        w.per_lane4([&](int l) { return s.Jc + (l < NV ? l : 0) * M::D::T + 4 * c; }, jr[0], jr[1], jr[2], jr[3]);
-        qfc = qfc + ((jr[0] * bcast(vf, C0 + 4 * c) + jr[1] * bcast(vf, C0 + 4 * c + 1)) +
-                     (jr[2] * bcast(vf, C0 + 4 * c + 2) + jr[3] * bcast(vf, C0 + 4 * c + 3)));
-      });
-    } else
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-      const float f0 = bcast(vf, C0 + 4 * c), f1 = bcast(vf, C0 + 4 * c + 1);
-      const float f2 = bcast(vf, C0 + 4 * c + 2), f3 = bcast(vf, C0 + 4 * c + 3);
-      const float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
-      // column i of the contact's three frame rows, re-read from LDS (keeping them resident costs 3*NC VGPRs)
-      const vfloat cn = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c) * NV + l] : 0.f; });
-      const vfloat c1 = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c + 1) * NV + l] : 0.f; });
-      const vfloat c2 = w.per_lane([&](int l) { return l < NV ? s.Jc[(3 * c + 2) * NV + l] : 0.f; });
-      qfc = qfc + cn * ((f0 + f1) + (f2 + f3)) + c1 * (mu1 * (f0 - f1)) + c2 * (mu2 * (f2 - f3));
-    }
+    static_for<0, NC>([&](auto Cc) {   // J^T f from the dof-major pyramid rows: one 16-byte fetch per contact
+      constexpr int c = Cc;
+      vfloat jr[4];
+      w.per_lane4([&](int l) { return s.Jc + (l < NV ? l : 0) * M::D::T + 4 * c; }, jr[0], jr[1], jr[2], jr[3]);
+      qfc = qfc + ((jr[0] * bcast(vf, C0 + 4 * c) + jr[1] * bcast(vf, C0 + 4 * c + 1)) +
+                   (jr[2] * bcast(vf, C0 + 4 * c + 2) + jr[3] * bcast(vf, C0 + 4 * c + 3)));
+    });
     const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
     float gn = 0.f;
     if (niter > 0) {
@@ -304,7 +270,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
 
     // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
     const vfloat vwgt = vsel(act, vD, vzero);
-    if constexpr (M::D::square) {
+    {
       // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC), then a zero word
       constexpr int S = M::D::S, T = M::D::T, NLP = M::D::NLP, NP = M::D::NHI / 64;
       (void)S;
@@ -362,32 +328,9 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
           }
         });
       });
-    } else {
-    w.items(64, [&](int l) { const int r = row_of(l); if (r >= 0) s.frc[r] = lane_val(vwgt, l); });
-    w.items(m->ntri, [&](int it) {   // structurally non-zero entries only
-      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
-      float acc = 0.f;
-      if (i == j) {
-        const int lr = m->dof_limrow[i];
-        if (lr >= 0) acc += s.frc[lr];
-      }
-#pragma unroll
-      for (int c = 0; c < NC; c++) {
-        const float* jn = s.Jc + (c * 3) * NV;
-        const float jni = jn[i], jnj = jn[j];
-        const float t1i = jn[NV + i], t1j = jn[NV + j], t2i = jn[2 * NV + i], t2j = jn[2 * NV + j];
-        const float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
-        const float* d = s.frc + NL + 4 * c;
-        acc += ((jni + t1i * mu1) * d[0]) * (jnj + t1j * mu1);
-        acc += ((jni - t1i * mu1) * d[1]) * (jnj - t1j * mu1);
-        acc += ((jni + t2i * mu2) * d[2]) * (jnj + t2j * mu2);
-        acc += ((jni - t2i * mu2) * d[3]) * (jnj - t2j * mu2);
-      }
-      s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
-    });
     }
     DIAL_MARK(w, 5);
-    const vfloat vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, M::D::square ? s.H : s.L);
+    const vfloat vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, s.H);
     DIAL_MARK(w, 6);
 
     // ---- solver._linesearch
