@@ -271,7 +271,8 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
 
 // ---- per-wavefront LDS workspace (pointers into one float array) -----------------------------
 // Arrays that are dead before the constraint solver starts share their storage with arrays that only live
-// inside the solver ("union" below); symmetric matrices are stored as packed lower triangles.
+// inside the solver ("union" below); symmetric matrices are stored as packed lower triangles (generic path) or
+// as full nv x S squares (`square`, the dimension-specialised instantiations).
 struct Ws {
   float *qpos, *qvel, *warm, *info, *ctrl, *act, *Y, *ztar, *rpart;
   float *xpos, *xquat, *spos, *com, *cvel, *cdof;
@@ -293,8 +294,7 @@ struct Ws {
 WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 
 // Carve the workspace out of `base`; returns the number of words used (call with base = nullptr to size
-// the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path); otherwise
-// L is the nv x stride transpose scratch of the register solver (solver_reg.h).
+// the dynamic LDS allocation).  `with_L`: keep a packed Cholesky factor in LDS (LDS solver path).
 // `square`: the register solver's square layout (Dims::square): M and H are nv x S squares, Jc holds the dof-major
 // pyramid rows J^T[i][4c + e], the transpose scratch L aliases H, frc is padded so that the contact weights start
 // 16-byte aligned.
@@ -335,7 +335,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(JarefW, ls * nefc) WS_TAKE(JarefS, ls * nefc) WS_TAKE(quad, ls * nefc * 3) WS_TAKE(MaW, ls * nv)
   WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv) WS_TAKE(qfc, ls * nv)
   WS_TAKE(ysol, ls * nv)
-  WS_TAKE(L, with_L ? ntri : (square ? 0 : nv * ((nv + 3) & ~3)))   // Cholesky factor / transpose scratch: only live while the dynamics temporaries are dead   // (square: the callers pass H as scratch -- the factor is written after H has been read into registers)
+  WS_TAKE(L, with_L ? ntri : 0)   // packed Cholesky factor of the LDS solver (the register solver writes its factor over H)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE
