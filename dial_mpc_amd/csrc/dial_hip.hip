@@ -145,25 +145,32 @@ weights_kernel(const float* __restrict__ rews, int B, float temp, float* __restr
 struct WsumSeg { const float* X; float* out; int C; int c0; };
 struct WsumArgs { WsumSeg seg[4]; int nseg, Ctot, n_rows, w_begin, mean_row, mean_widx; };
 
+// Block = 64 columns x 4 wavefronts; wavefront g takes every 4th row of the block's row chunk, the four partial
+// sums are combined in a fixed order through LDS (deterministic, bit-identical on every rank).
 extern "C" __global__ void __launch_bounds__(256)
 wsum_partial_kernel(WsumArgs a, const float* __restrict__ weights, float* __restrict__ partial) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.Ctot) return;
-  int sg = 0;
-  for (int k = 1; k < a.nseg; k++) if (c >= a.seg[k].c0) sg = k;
-  const float* X = a.seg[sg].X;
-  const int C = a.seg[sg].C, cl = c - a.seg[sg].c0;
-  const int chunk = blockIdx.y, per = (a.n_rows + WSUM_CHUNKS - 1) / WSUM_CHUNKS;
-  const int r0 = chunk * per, r1 = (r0 + per < a.n_rows) ? r0 + per : a.n_rows;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float acc = 0.f;
-#pragma unroll 8
-  for (int r = r0; r < r1; r++) {
-    // rows [0, mean_row) are this shard's noisy samples -> weight index w_begin + r; the mean row (if
-    // present and included) uses mean_widx; a mean row that is not included has mean_widx < 0.
-    int wi = (r == a.mean_row) ? a.mean_widx : a.w_begin + r;
-    if (wi >= 0) acc += weights[wi] * X[(size_t)r * C + cl];
+  if (c < a.Ctot) {
+    int sg = 0;
+    for (int k = 1; k < a.nseg; k++) if (c >= a.seg[k].c0) sg = k;
+    const float* X = a.seg[sg].X;
+    const int C = a.seg[sg].C, cl = c - a.seg[sg].c0;
+    const int chunk = blockIdx.y, per = (a.n_rows + WSUM_CHUNKS - 1) / WSUM_CHUNKS;
+    const int r0 = chunk * per, r1 = (r0 + per < a.n_rows) ? r0 + per : a.n_rows;
+#pragma unroll 4
+    for (int r = r0 + g; r < r1; r += 4) {
+      // rows [0, mean_row) are this shard's noisy samples -> weight index w_begin + r; the mean row (if
+      // present and included) uses mean_widx; a mean row that is not included has mean_widx < 0.
+      int wi = (r == a.mean_row) ? a.mean_widx : a.w_begin + r;
+      if (wi >= 0) acc += weights[wi] * X[(size_t)r * C + cl];
+    }
   }
-  partial[(size_t)chunk * a.Ctot + c] = acc;
+  red[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && c < a.Ctot) partial[(size_t)blockIdx.y * a.Ctot + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 extern "C" __global__ void __launch_bounds__(256)
 wsum_final_kernel(WsumArgs a, const float* __restrict__ partial) {
@@ -508,7 +515,7 @@ static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_be
   a.Ctot = a.seg[3].c0 + a.seg[3].C;
   a.n_rows = n_rows; a.w_begin = w_begin; a.mean_row = mean_row; a.mean_widx = mean_widx;
   const int gx = (a.Ctot + 255) / 256;
-  hipLaunchKernelGGL(wsum_partial_kernel, dim3(gx, WSUM_CHUNKS), dim3(256), 0, st, a, weights, ctx->partial);
+  hipLaunchKernelGGL(wsum_partial_kernel, dim3((a.Ctot + 63) / 64, WSUM_CHUNKS), dim3(256), 0, st, a, weights, ctx->partial);
   hipLaunchKernelGGL(wsum_final_kernel, dim3(gx), dim3(256), 0, st, a, (const float*)ctx->partial);
   HIP_TRY(ctx, hipGetLastError());
   return DIAL_OK;
