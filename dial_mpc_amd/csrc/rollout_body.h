@@ -891,6 +891,15 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     const int tb = m->torso_x + 1, ub = m->upright_x + 1;
     float* info = s.info;
     const float step = info[DIAL_INFO_STEP];
+    // torso / upright-body state, fetched once up front by every term lane (same addresses: LDS broadcasts, one
+    // round trip) instead of inside the divergent branches, where each term would pay its own dependent fetch
+    const float tq[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+    const float uq[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+    const float tp[3] = {s.xpos[3 * tb], s.xpos[3 * tb + 1], s.xpos[3 * tb + 2]};
+    const float* cmr = s.com + 3 * m->body_rootid[tb];
+    const float tcom[3] = {cmr[0], cmr[1], cmr[2]};
+    const float tv[6] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2], s.cvel[6 * tb + 3], s.cvel[6 * tb + 4], s.cvel[6 * tb + 5]};
+    const float yaw_tar0 = info[DIAL_INFO_YAW_TAR], pos_tar_z = info[DIAL_INFO_POS_TAR + 2];
     float out = 0.f;
     if (it == 0) {
       if (walk) {
@@ -937,17 +946,17 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         s.rpart[4] = penalty_contact;
       }
     } else if (it == 1) {
-      float rot_u[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+      float rot_u[4] = {uq[0], uq[1], uq[2], uq[3]};
       float up[3] = {0.f, 0.f, 1.f}, vec[3];
       dm::rotate(vec, up, rot_u);
       out = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
     } else if (it == 2) {
-      float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+      float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
       const float yaw = quat_yaw(rot_t);
       if (walk) {
         const float a2 = m->cmd_ang_vel[2];
         const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
-        const float d_yaw = yaw - (info[DIAL_INFO_YAW_TAR] + avt * dt * step);
+        const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
         // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
         const float wy = d_yaw - 6.283185307179586f * DM_RINT(d_yaw * 0.15915494309189535f);
         out = -(wy * wy);
@@ -957,14 +966,13 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       }
     } else if (it == 3 || it == 4) {
       if (walk) {
-        float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
-        const float* c = s.com + 3 * m->body_rootid[tb];
-        float off[3] = {s.xpos[3 * tb] - c[0], s.xpos[3 * tb + 1] - c[1], s.xpos[3 * tb + 2] - c[2]};
-        float ang[3] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2]};
+        float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
+        float off[3] = {tp[0] - tcom[0], tp[1] - tcom[1], tp[2] - tcom[2]};
+        float ang[3] = {tv[0], tv[1], tv[2]};
         if (it == 3) {
           float cr[3], vel[3], vb[3];
           dm::cross3(cr, off, ang);
-          for (int k = 0; k < 3; k++) vel[k] = s.cvel[6 * tb + 3 + k] - cr[k];
+          for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
           dm::inv_rotate(vb, vel, rot_t);
           float vt[2];
           for (int k = 0; k < 2; k++) { const float v = m->cmd_vel[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
@@ -990,13 +998,13 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       } else if (it == 3) {
         const int stage = (int)info[DIAL_INFO_STAGE];
         float rp = 0.f;
-        for (int k = 0; k < 3; k++) { float e = s.xpos[3 * tb + k] - tg->pose_targets[stage][k]; rp += e * e; }
+        for (int k = 0; k < 3; k++) { float e = tp[k] - tg->pose_targets[stage][k]; rp += e * e; }
         out = -rp;
       } else {
         return;  // seq-jump: rpart[4] (penalty) is written by item 0
       }
     } else if (it == 5) {
-      const float dh = s.xpos[3 * tb + 2] - info[DIAL_INFO_POS_TAR + 2];
+      const float dh = tp[2] - pos_tar_z;
       out = -(dh * dh);
     } else if (it == 6) {
       float reward_energy = 0.f;
@@ -1020,7 +1028,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         out = -reward_energy;
       }
     } else {
-      float rot_t[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+      float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
       float up[3] = {0.f, 0.f, 1.f}, upv[3];
       dm::rotate(upv, up, rot_t);
       bool done = upv[2] < 0.f;
@@ -1028,7 +1036,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         float q = s.qpos[7 + a];
         done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
       }
-      done = done || s.xpos[3 * tb + 2] < m->done_height;
+      done = done || tp[2] < m->done_height;
       out = done ? 1.f : 0.f;
     }
     s.rpart[it] = out;
