@@ -95,7 +95,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {
       float u;
-      if (io.us) u = io.us[((size_t)n * T + st) * nu + a];
+      if (io.us) u = io.us[(unsigned)((n * T + st) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
       else {
         u = 0.f;
         for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
