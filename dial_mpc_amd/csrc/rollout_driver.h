@@ -122,7 +122,10 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   }
 #ifdef DIAL_PROFILE
   DIAL_MARK(w, 11);
-  if (io.prof && n == 0 && w.lane == 0) for (int k = 0; k < DIAL_NSEC; k++) io.prof[k] = w.acc[k];
+  if (io.prof && n == 0 && w.lane == 0) for (int k = 0; k < 28; k++) io.prof[k] = w.acc[k];
+  // event counters 28..31 are summed over ALL samples (28/29: Newton iterations 2 / with an unchanged active set,
+  // 30/31: line-search iterations / Newton iterations)
+  if (io.prof && w.lane == 0) for (int k = 28; k < DIAL_NSEC; k++) atomicAdd(&io.prof[k], w.acc[k]);
 #endif
   if (io.rews) {
     const float mean = rsum / (float)T;

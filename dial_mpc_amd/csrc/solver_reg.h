@@ -232,10 +232,21 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
 
+#ifdef DIAL_PROFILE
+  unsigned long long prof_prev_act = 0;
+#endif
   int niter = 0;
   for (;;) {
     // ---- _update_constraint: forces; _update_gradient: grad = Ma - qfrc_smooth - J^T f
     const vbool act = vlt0(vJa);
+#ifdef DIAL_PROFILE
+    {   // how often does the active set (rows with D > 0 and Jaref < 0) survive from one Newton iteration to the next?
+      const unsigned long long cur = __builtin_amdgcn_ballot_w64(act && (vD > 0.f));
+      static_assert(sizeof(cur) == 8, "");
+      if (niter == 1 && w.lane == 0 && w.acc) { w.acc[28] += 1; if (cur == prof_prev_act) w.acc[29] += 1; }
+      prof_prev_act = cur;
+    }
+#endif
     const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
     vfloat qfc = vls * vf;  // limit row of the own dof
     static_for<0, NC>([&](auto Cc) {   // J^T f from the dof-major pyramid rows: one 16-byte fetch per contact

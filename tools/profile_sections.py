@@ -18,7 +18,9 @@ from dial_mpc_amd import _lib  # noqa: E402
 
 NAMES = {0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies, geoms, sites)", 17: "subtree COM", 18: "cinert + cdof", 19: "cvel", 20: "cdof_dot", 21: "cacc", 22: "crb + local forces", 23: "F_i + cfrc", 2: "Jc + efc rows", 3: "chol(M)+solve",
          4: "warmstart select + constraint_grad", 5: "H build", 6: "chol(H)+solve", 7: "linesearch", 8: "post-ls update/sums",
-         9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)"}
+         9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)",
+         28: "EVENTS (all samples, cumulative): 2nd Newton iterations", 29: "  ... with an unchanged active set",
+         30: "  line-search iterations", 31: "  Newton iterations"}
 
 example = sys.argv[1] if len(sys.argv) > 1 else "unitree_go2_trot"
 dc, env, model, task, cfg = setup_case(example, 2048, 16)
