@@ -103,8 +103,9 @@ struct CModel {
   // root-to-leaf chains: prefix sums along a chain give every ancestor sum (cvel, cacc) in one sweep
   int32_t nchain, chain_len[D::NCHAIN];
   uint8_t chain_body[D::NCHAIN][D::CHAINLEN];
-  // subtree sums (crb, cfrc) by suffix sums up the part of each chain that belongs to it alone (from chain_excl[c]
-  // to the leaf), then the few branching bodies, deepest first, from their children; nshared < 0: not available
+  // subtree sums (crb, cfrc) by suffix sums up the part of each chain that belongs to it alone (from
+  // chain_excl[c] to the leaf), then the few bodies no tail covers (the branching bodies and everything above
+  // them), deepest first, from their children; nshared < 0: not available
   int32_t chain_excl[D::NCHAIN];
   int32_t nshared, shared_body[4], shared_nchild[4];
   uint8_t shared_child[4][4];

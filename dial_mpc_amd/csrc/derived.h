@@ -176,15 +176,23 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
       nch++;
     }
     o.nchain = ok ? nch : 0;
-    // branching bodies (>= 2 children) and the exclusive tail of every chain
+    // the exclusive tail of every chain (bodies below its last branching body) and the "shared" bodies that no
+    // tail covers -- the branching bodies and everything above them -- listed deepest first with their children
     o.nshared = -1;
     if (ok) {
       int nchild[DIAL_MAX_BODY] = {0};
+      bool covered[DIAL_MAX_BODY] = {false};
       for (int b = 1; b < m->nbody; b++) nchild[m->body_parent[b]]++;
+      for (int c = 0; c < nch; c++) {
+        int q = o.chain_len[c];
+        while (q > 0 && nchild[o.chain_body[c][q - 1]] < 2) q--;   // first body after the last branching one
+        o.chain_excl[c] = q;
+        for (int r = q; r < o.chain_len[c]; r++) covered[o.chain_body[c][r]] = true;
+      }
       int ns = 0;
       bool fits = true;
       for (int b = m->nbody - 1; b >= 1 && fits; b--) {      // DFS numbering: higher index first = deepest first
-        if (nchild[b] < 2) continue;
+        if (covered[b]) continue;
         if (ns >= 4 || nchild[b] > 4) { fits = false; break; }
         o.shared_body[ns] = b;
         int k = 0;
@@ -192,11 +200,6 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
           if (m->body_parent[c2] == b) o.shared_child[ns][k++] = (uint8_t)c2;
         o.shared_nchild[ns] = k;
         ns++;
-      }
-      for (int c = 0; c < nch && fits; c++) {
-        int q = o.chain_len[c];
-        while (q > 0 && nchild[o.chain_body[c][q - 1]] < 2) q--;   // first body after the last branching one
-        o.chain_excl[c] = q;
       }
       if (fits) o.nshared = ns;
     }
