@@ -196,8 +196,9 @@ def main():
                      "kernel": "rollout_kernel",
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "path is VALU-issue bound, not HBM bound (170 FLOP/B >> 20 FLOP/B machine balance): "
-                             "the VALU pipes are busy 63 % of the time at 2 resident waves per SIMD (PMC)",
+                     "note": "path is bound by dependent VALU-issue latency (~10.6 cycles) x instruction count, not by HBM "
+                             "(170 FLOP/B >> 20 FLOP/B machine balance); PMC: 5.1 k VALU per wave and env.step, 31 % of "
+                             "the VALU issue peak at the 2 resident waves per SIMD that N=2048 provides",
                      "valu_tflops_est": valu_tflops, "valu_frac_est": valu_tflops / VALU_PEAK_TFLOPS,
                      "valu_pipe_busy_frac_pmc": valu_busy, "valu_insts_per_wave_env_step_pmc": valu_per_step},
         "plan_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
