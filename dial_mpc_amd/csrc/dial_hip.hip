@@ -42,7 +42,9 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
     m = reinterpret_cast<const CModel<D>*>(smem);
     wsbase = smem + CMW;
   }
-  if constexpr (WPB > 1) wsbase += (threadIdx.x >> 6) * ws_words;   // WPB == 1: LDS addresses stay immediates
+  // WPB == 1: LDS addresses stay immediates.  WPB > 1: the wavefront's workspace offset is made a scalar (it is
+  // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
+  if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
            dim_ne(m), nnode, dial::kNeedL<D>, D::square);
   return m;

@@ -177,15 +177,19 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     // one strided fetch per register: dof lane i walks row i of the square M (stride 1), contact lane r walks
     // column r of the dof-major pyramid Jacobian (stride T); idle lanes re-read a word that holds 0 (lsign of a contact row)
     constexpr int S = M::D::S, T = M::D::T;
+    const auto fetch = [&](int l, int j) {
+      // (offsets from one base pointer rather than a select of pointers: keeps the accesses in the LDS address space)
+      const int ojc = (int)(s.Jc - s.M), ozero = (int)(s.lsign - s.M) + NL;   // lsign of a contact row is 0
+      const int off = l < NV ? l * S : ((l >= C0 && l < C0 + 4 * NC) ? ojc + (l - C0) : ozero);
+      const int stride = l < NV ? 1 : ((l >= C0 && l < C0 + 4 * NC) ? T : 0);
+      return s.M[off + j * stride];
+    };
 #pragma unroll
-    for (int j = 0; j < NV; j++)
-      R[j] = w.per_lane([&](int l) {
-        // (offsets from one base pointer rather than a select of pointers: keeps the accesses in the LDS address space)
-        const int ojc = (int)(s.Jc - s.M), ozero = (int)(s.lsign - s.M) + NL;   // lsign of a contact row is 0
-        const int off = l < NV ? l * S : ((l >= C0 && l < C0 + 4 * NC) ? ojc + (l - C0) : ozero);
-        const int stride = l < NV ? 1 : ((l >= C0 && l < C0 + 4 * NC) ? T : 0);
-        return s.M[off + j * stride];
-      });
+    for (int j = 0; j < NV; j++) {
+      // large models: keep the NV strided addresses from being hoisted out of the step loop (they would be spilled)
+      if constexpr (NV > 20) R[j] = w.per_lane_r([&](int l) { return fetch(l, j); });
+      else R[j] = w.per_lane([&](int l) { return fetch(l, j); });
+    }
   }
   const vfloat vD = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.D[r] : 0.f; });
   const vfloat varef = w.per_lane([&](int l) { int r = row_of(l); return r >= 0 ? s.aref[r] : 0.f; });

@@ -109,6 +109,8 @@ struct Wave {
   // SPMD helpers: value computed per lane; lane-index predicates
   template <class F>
   vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
+  template <class F>
+  vfloat per_lane_r(F f) { return per_lane(f); }
   // value of the lane whose index differs in bit 0 / bit 1 (neighbours inside a quad; DPP quad_perm on the GPU)
   vfloat quad_xor1(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 1]; return r; }
   vfloat quad_xor2(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 2]; return r; }
@@ -253,6 +255,10 @@ struct Wave {
   }
   template <class F>
   __device__ __forceinline__ vfloat per_lane(F f) { return f(lane); }
+  // same with the region-laundered lane id: address arithmetic derived from it stays inside the region instead of
+  // being hoisted out of the T-step loop as dozens of long-lived address VGPRs (use where that causes spills)
+  template <class F>
+  __device__ __forceinline__ vfloat per_lane_r(F f) { return f(lane_r); }
   __device__ __forceinline__ vfloat quad_xor1(vfloat v) {   // quad_perm [1,0,3,2]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
   }
