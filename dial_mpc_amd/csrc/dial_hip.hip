@@ -1,9 +1,9 @@
 // dial_hip.hip -- gfx950 kernels and the C ABI of libdialhip.so (see include/dial_mpc.h).
 //
 // Kernels
-//   rollout_kernel   K1+K2+K3: one 64-lane workgroup (= one wavefront) per sample; per-sample state in
-//                    LDS, model/task constants through the scalar/vector caches, per-step outputs
-//                    streamed to HBM in the layout of MBDPI.rollout_us_vmap.
+//   rollout_kernel   K1+K2+K3: one wavefront per sample (1-3 wavefronts per workgroup share the staged
+//                    constants); per-sample state and constants in LDS, per-step outputs streamed to HBM in
+//                    the layout of MBDPI.rollout_us_vmap.
 //   weights_kernel   K4a: rew_bar, std, softmax over all N+1 mean rewards (one workgroup, fixed
 //                    reduction order => bit-identical on every GPU of a sharded run).
 //   wsum_*_kernel    K4b: weighted means of Y0s / q / qd / x.pos, two deterministic passes.

@@ -11,8 +11,10 @@
 // 64-lane wavefront: every stage below names the MJX function whose result it reproduces.
 //
 // The file compiles for gfx950 (hipcc) and, with -DDIAL_EMU, for the host wave emulator used by the
-// tests (tests/wave_emu).  Model / task / derived tables are read straight from global memory (they
-// are a few KB shared by every wavefront, i.e. L1/K$-resident); all per-sample state lives in LDS.
+// tests (tests/wave_emu).  All per-sample state lives in LDS.  The constants come as `const M* m`: a
+// dimension-specialised CModel<D> staged in LDS (Go2, H1, H1 loco: compile-time sizes, square matrix layout,
+// register-resident solver of solver_reg.h) or the generic CModel<DimsMax> read from global memory (any model
+// within the ABI capacities: run-time sizes, packed triangles, LDS solver below).
 #pragma once
 #include "derived.h"
 #include "dmath.h"
