@@ -7,6 +7,7 @@ raw device pointers and the current torch stream through the C ABI of include/di
 from __future__ import annotations
 
 import ctypes
+import glob
 import os
 import subprocess
 from typing import Optional
@@ -15,7 +16,6 @@ from dial_mpc_amd import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("DIAL_HIP_LIB", os.path.join(_CSRC, "libdialhip.so"))  # override: profiling builds
-_SOURCES = ("dial_hip.hip", "rollout_driver.h", "rollout_body.h", "derived.h", "dmath.h", "wave.h")
 _lib = None
 
 
@@ -25,7 +25,8 @@ class DialHipError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/dial_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in _SOURCES] + [_abi.HEADER]
+    # every source of the library takes part in the staleness check (a stale .so must never ship silently)
+    srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip"))) + [_abi.HEADER]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -57,6 +58,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
     lib.dial_create.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci]
+    lib.dial_create_sharded.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci, ci]
     lib.dial_destroy.argtypes = [vp]
     lib.dial_destroy.restype = None
     lib.dial_last_error.argtypes = [vp]
@@ -83,7 +85,7 @@ def load():
     return lib
 
 
-EXPORTED = ("dial_create", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
+EXPORTED = ("dial_create", "dial_create_sharded", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
             "dial_shard_rollout_rng", "dial_rng_fill", "dial_shift", "dial_env_step", "dial_env_reset",
             "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
@@ -105,7 +107,8 @@ class Context:
     """One dial_ctx: (device, model, task, cfg).  Not thread-safe (C ABI contract)."""
 
     def __init__(self, model: "_abi.DialModel", task: "_abi.DialTask", cfg: Optional["_abi.DialCfg"],
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, n_local_cap: Optional[int] = None):
+        """n_local_cap: size the rollout scratch for that many local samples (one rank of a sharded run)."""
         import torch
         self.lib = load()
         if not torch.cuda.is_available():
@@ -117,8 +120,12 @@ class Context:
         self.nx = (model.nbody - 1) * 3
         self.state_size = _abi.state_size(model.nq, model.nv)
         h = ctypes.c_void_p()
-        rc = self.lib.dial_create(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
-                                  ctypes.addressof(cfg) if cfg is not None else None, self.device)
+        if n_local_cap is None or cfg is None:
+            rc = self.lib.dial_create(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
+                                      ctypes.addressof(cfg) if cfg is not None else None, self.device)
+        else:
+            rc = self.lib.dial_create_sharded(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
+                                              ctypes.addressof(cfg), self.device, int(n_local_cap))
         if rc != 0:
             raise DialHipError(f"dial_create failed ({rc}): {self.lib.dial_last_error(None).decode()}")
         self.h = h

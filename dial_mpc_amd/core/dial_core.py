@@ -57,15 +57,6 @@ class MBDPI:
         self.node_dt = self.ctrl_dt * args.Hsample / args.Hnode
 
         self.cfg = make_cfg(args)
-        self.ctx = _lib.Context(env.make_model(), env.make_task(), self.cfg, device)
-        dev = self.ctx.torch_device
-        self.device = dev
-        self.sigma_control = torch.as_tensor(sigma_control.copy(), dtype=torch.float32, device=dev)
-        self.step_us = torch.as_tensor(self.step_us_np, dtype=torch.float32, device=dev)
-        self.step_nodes = torch.as_tensor(self.step_nodes_np, dtype=torch.float32, device=dev)
-        self.W = torch.as_tensor(spline.node2u_matrix(args.Hsample, args.Hnode), dtype=torch.float32, device=dev)
-        self.V = torch.as_tensor(spline.u2node_matrix(args.Hsample, args.Hnode), dtype=torch.float32, device=dev)
-
         # sample sharding over torch.distributed ranks (one process per GPU)
         self.rank, self.world = 0, 1
         try:
@@ -76,6 +67,18 @@ class MBDPI:
             pass
         from dial_mpc_amd.core.sharding import partition
         self._per, self.n_begin, self.n_local = partition(args.Nsample, self.rank, self.world)
+        # a rank's rollout scratch is sized by its own shard, not by the global sample count
+        self.ctx = _lib.Context(env.make_model(), env.make_task(), self.cfg, device,
+                                n_local_cap=None if self.world == 1 else self._per)
+        if hasattr(env, "bind_device"):
+            env.bind_device(self.ctx.device)
+        dev = self.ctx.torch_device
+        self.device = dev
+        self.sigma_control = torch.as_tensor(sigma_control.copy(), dtype=torch.float32, device=dev)
+        self.step_us = torch.as_tensor(self.step_us_np, dtype=torch.float32, device=dev)
+        self.step_nodes = torch.as_tensor(self.step_nodes_np, dtype=torch.float32, device=dev)
+        self.W = torch.as_tensor(spline.node2u_matrix(args.Hsample, args.Hnode), dtype=torch.float32, device=dev)
+        self.V = torch.as_tensor(spline.u2node_matrix(args.Hsample, args.Hnode), dtype=torch.float32, device=dev)
 
     # ---- spline maps (constant matrices; dial_core.py:82-101)
     def node2u(self, nodes):
@@ -242,7 +245,7 @@ def main():
             rng, Y0, info = mbdpi.reverse_once(state, rng, Y0, factors[i], want_bars=(i == n_diffuse - 1))
         torch.cuda.synchronize()
         plan_ms.append((time.time() - t0) * 1e3)
-        rews_plan.append(float(info["rews"][-1]))
+        rews_plan.append(float(info["rews"].mean()))         # :266 mean over all N+1 sample rewards of the last iteration
         infos.append(info)
         if t % 20 == 0:
             print(f"step {t:4d}  rew {rews[-1]: .3e}  plan {plan_ms[-1]:.2f} ms")
@@ -252,13 +255,27 @@ def main():
 
     os.makedirs(dial_config.output_dir, exist_ok=True)
     timestamp = time.strftime("%Y%m%d-%H%M%S")
+    states_arr, pred_arr = result_arrays(rollout, infos)
+    np.save(os.path.join(dial_config.output_dir, f"{timestamp}_states"), states_arr)
+    np.save(os.path.join(dial_config.output_dir, f"{timestamp}_predictions"), pred_arr)
+
+
+def result_arrays(rollout, infos):
+    """The two artefacts of the reference's ``main`` (dial_core.py:305-323):
+    ``states``      (n_steps, 1 + nq + nv + nu): [step index | qpos | qvel | ctrl] of every executed state;
+    ``predictions`` (n_steps, Hsample+1, nbody-1, 3): the weighted-mean body positions ``xbar`` of the LAST annealing
+    iteration of every tick -- upstream ``infos[i]["xbar"]`` comes out of ``lax.scan`` with a leading diffusion axis
+    and ``[-1]`` selects that iteration; here ``infos[i]`` already is the last iteration's dict."""
     data, xdata = [], []
-    for i, st in enumerate(rollout):                        # :305-323
+    for i, st in enumerate(rollout):
         ps = st.pipeline_state
-        data.append(np.concatenate([[i], ps.qpos.cpu().numpy(), ps.qvel.cpu().numpy(), ps.ctrl.cpu().numpy()]))
-        xdata.append(infos[i]["xbar"][-1].cpu().numpy())
-    np.save(os.path.join(dial_config.output_dir, f"{timestamp}_states"), np.array(data))
-    np.save(os.path.join(dial_config.output_dir, f"{timestamp}_predictions"), np.array(xdata))
+        data.append(np.concatenate([[i], _np(ps.qpos), _np(ps.qvel), _np(ps.ctrl)]))
+        xdata.append(_np(infos[i]["xbar"]))
+    return np.array(data), np.array(xdata)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
 if __name__ == "__main__":

@@ -140,7 +140,16 @@ weights_kernel(const float* __restrict__ rews, int B, float temp, float* __restr
   acc = 0.f;
   for (int n = tid; n < B; n += WK_THREADS) { float l = (rews[n] - rew_bar) / stdv / temp; acc += expf(l - mx); }
   const float den = block_sum(acc, red);
-  for (int n = tid; n < B; n += WK_THREADS) { float l = (rews[n] - rew_bar) / stdv / temp; weights[n] = expf(l - mx) / den; }
+  // std(rews) == 0 (all rewards identical): the reference divides 0 by 0 (dial_core.py:126) and every weight, hence
+  // Ybar, becomes NaN.  Kept bug-compatible and DEFINED: the NaN is written as a bit pattern, because the device
+  // code is compiled with -fno-honor-nans and a floating-point 0/0 would be undefined there.
+  const bool degenerate = stdv == 0.f;
+  uint32_t* wbits = reinterpret_cast<uint32_t*>(weights);
+  for (int n = tid; n < B; n += WK_THREADS) {
+    float l = (rews[n] - rew_bar) / stdv / temp;
+    const float wv = expf(l - mx) / den;
+    wbits[n] = degenerate ? 0x7fc00000u : __builtin_bit_cast(uint32_t, wv);
+  }
 }
 
 // K4b (dial_core.py:132-135): out[c] = sum_n w[widx(n)] * X_seg[n][c] over the local samples.
@@ -267,7 +276,7 @@ struct dial_ctx {
   void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
-  int B_cap = 0, T = 0, Hn1 = 0, nx = 0;
+  int B_cap = 0, W_cap = 0, T = 0, Hn1 = 0, nx = 0;   // B_cap: rollouts this context can hold (local shard + mean), W_cap: global N + 1
   float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
   float *weights = nullptr, *partial = nullptr;
   unsigned long long* prof = nullptr;
@@ -280,7 +289,7 @@ struct dial_ctx {
   std::string err;
 };
 
-static std::string g_err;
+static thread_local std::string g_err;   // last error of calls that have no context (per calling thread)
 
 static int fail(dial_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -317,7 +326,13 @@ void dial_destroy(dial_ctx* ctx) {
 }
 
 int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device) {
+  return dial_create_sharded(out, model, task, cfg, device, cfg ? cfg->Nsample : 0);
+}
+
+int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device,
+                        int n_local_cap) {
   if (!out || !model || !task) return fail(nullptr, DIAL_ERR_ARG, "dial_create: null argument");
+  if (cfg && (n_local_cap < 0 || n_local_cap > cfg->Nsample)) return fail(nullptr, DIAL_ERR_ARG, "dial_create_sharded: n_local_cap must be in [0, Nsample]");
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -336,7 +351,16 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
   int rc = dial_build_derived(model, &ctx->hd);
   if (rc != DIAL_OK) { delete ctx; return fail(nullptr, rc, "dial_create: unsupported model topology"); }
   ctx->nx = (model->nbody - 1) * 3;
-  HIP_TRY(ctx, hipSetDevice(device));
+  // from here on every failure path releases the half-built context (dial_destroy frees whatever was allocated)
+#define HIP_TRY_CREATE(expr)                                                                          \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      dial_destroy(ctx);                                                                              \
+      return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: " #expr ": ") + hipGetErrorString(e_)); \
+    }                                                                                                 \
+  } while (0)
+  HIP_TRY_CREATE(hipSetDevice(device));
   {
     // pick the kernel instantiation and upload its constants
     auto upload = [&](auto tag) -> int {
@@ -371,8 +395,8 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     dial_destroy(ctx);
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds 64 KiB");
   }
-  HIP_TRY(ctx, hipMalloc(&ctx->dtask, sizeof(dial_task)));
-  HIP_TRY(ctx, hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
+  HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
+  HIP_TRY_CREATE(hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
   if (cfg) {
     if (cfg->Hsample + 1 > DIAL_MAX_T || cfg->Hnode + 1 > DIAL_MAX_NODE || cfg->Hnode < 2 || cfg->Nsample < 1) {
       dial_destroy(ctx);
@@ -380,24 +404,26 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, 
     }
     ctx->hc = *cfg;
     ctx->has_cfg = true;
-    ctx->B_cap = cfg->Nsample + 1;
+    ctx->B_cap = n_local_cap + 1;
+    ctx->W_cap = cfg->Nsample + 1;
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
     const size_t B = ctx->B_cap, T = ctx->T;
-    HIP_TRY(ctx, hipMalloc(&ctx->dcfg, sizeof(dial_cfg)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dcfg, cfg, sizeof(dial_cfg), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc(&ctx->Y0s, sizeof(float) * B * ctx->Hn1 * model->nu));
-    HIP_TRY(ctx, hipMalloc(&ctx->rewss, sizeof(float) * B * T));
-    HIP_TRY(ctx, hipMalloc(&ctx->rews, sizeof(float) * B));
-    HIP_TRY(ctx, hipMalloc(&ctx->qss, sizeof(float) * B * T * model->nq));
-    HIP_TRY(ctx, hipMalloc(&ctx->qdss, sizeof(float) * B * T * model->nv));
-    HIP_TRY(ctx, hipMalloc(&ctx->xss, sizeof(float) * B * T * ctx->nx));
-    HIP_TRY(ctx, hipMalloc(&ctx->weights, sizeof(float) * B));
+    HIP_TRY_CREATE(hipMalloc(&ctx->dcfg, sizeof(dial_cfg)));
+    HIP_TRY_CREATE(hipMemcpy(ctx->dcfg, cfg, sizeof(dial_cfg), hipMemcpyHostToDevice));
+    HIP_TRY_CREATE(hipMalloc(&ctx->Y0s, sizeof(float) * B * ctx->Hn1 * model->nu));
+    HIP_TRY_CREATE(hipMalloc(&ctx->rewss, sizeof(float) * B * T));
+    HIP_TRY_CREATE(hipMalloc(&ctx->rews, sizeof(float) * ctx->W_cap));
+    HIP_TRY_CREATE(hipMalloc(&ctx->qss, sizeof(float) * B * T * model->nq));
+    HIP_TRY_CREATE(hipMalloc(&ctx->qdss, sizeof(float) * B * T * model->nv));
+    HIP_TRY_CREATE(hipMalloc(&ctx->xss, sizeof(float) * B * T * ctx->nx));
+    HIP_TRY_CREATE(hipMalloc(&ctx->weights, sizeof(float) * ctx->W_cap));
     const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
-    HIP_TRY(ctx, hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
-    HIP_TRY(ctx, hipMalloc(&ctx->prof, sizeof(unsigned long long) * 32));
-    HIP_TRY(ctx, hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 32));
+    HIP_TRY_CREATE(hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
+    HIP_TRY_CREATE(hipMalloc(&ctx->prof, sizeof(unsigned long long) * 32));
+    HIP_TRY_CREATE(hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 32));
   }
+#undef HIP_TRY_CREATE
   *out = ctx;
   return DIAL_OK;
 }
@@ -526,13 +552,14 @@ static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_be
 int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin, int n_local, int with_mean,
                       float* packed_out, void* stream) {
   if (!ctx || !rews_all || !packed_out) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: null argument");
-  if (!ctx->has_cfg || n_total + 1 > ctx->B_cap * 64 || n_local + 1 > ctx->B_cap || n_begin < 0 || n_begin + n_local > n_total)
+  if (!ctx->has_cfg || n_local < 0 || n_local + 1 > ctx->B_cap || n_begin < 0 || n_begin + n_local > n_total)
     return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: bad shard description");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  // global weights need n_total+1 floats; reuse ctx->weights when it fits, else fail loudly
-  if (n_total + 1 > ctx->B_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: create the context with Nsample = global sample count");
+  // the global weights need n_total+1 floats of ctx->weights
+  if (n_total + 1 > ctx->W_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: n_total exceeds the context's Nsample (create it with Nsample = global sample count)");
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  HIP_TRY(ctx, hipGetLastError());
   const dial_model& m = ctx->hm;
   float* Yo = packed_out;
   float* qo = Yo + ctx->Hn1 * m.nu;
@@ -547,7 +574,7 @@ int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const flo
                     const float* noise_scale, int ns, float* Ybar_out, void* stream) {
   if (!ctx || !rews_all || !eps_all || !Ybar_in || !noise_scale || !Ybar_out)
     return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: null argument");
-  if (!ctx->has_cfg || n_total + 1 > ctx->B_cap || n_total < 1 || (ns != 1 && ns != ctx->Hn1))
+  if (!ctx->has_cfg || n_total + 1 > ctx->W_cap || n_total < 1 || (ns != 1 && ns != ctx->Hn1))
     return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: bad arguments (create the context with Nsample = global sample count)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
@@ -555,6 +582,7 @@ int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const flo
   if ((size_t)YB_CHUNKS * C > (size_t)WSUM_CHUNKS * ((size_t)C + ctx->T * (ctx->hm.nq + ctx->hm.nv + ctx->nx)))
     return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: scratch too small");
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(ybar_partial_kernel, dim3((C + 63) / 64, YB_CHUNKS), dim3(64), 0, st, (const float*)ctx->weights,
                      eps_all, Ybar_in, noise_scale, ns, n_total, C, ctx->hm.nu, ctx->partial);
   hipLaunchKernelGGL(ybar_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)ctx->partial, C, Ybar_out);
@@ -572,6 +600,7 @@ static int reverse_once_impl(dial_ctx* ctx, const float* state, const float* Yba
   if (rc != DIAL_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
+  HIP_TRY(ctx, hipGetLastError());
   return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st);
 }
 

@@ -81,6 +81,12 @@ class BaseEnv:
 
     def __init__(self, config: BaseEnvConfig):
         assert np.allclose(config.dt % config.timestep, 0.0), "timestep must be divisible by dt"
+        if getattr(config, "randomize_tasks", False):
+            # unitree_go2_env.py:142-155: the reference redraws (vel_tar, ang_vel_tar) from its JAX key every 500
+            # steps (`sample_command`); the kernels bake the fixed command in, so running such a config would be a
+            # different task.  No silent fallback: refuse.
+            raise NotImplementedError("randomize_tasks=True (sample_command every 500 steps) is not implemented by "
+                                      "the HIP path; set randomize_tasks: false")
         self._config = config
         self._n_frames = int(config.dt / config.timestep)
         self.sys = self.make_system(config)
@@ -156,10 +162,16 @@ class BaseEnv:
         return _abi.make_model(self.sys.model)
 
     # ---- HIP-backed reset / step (device tensors in, device tensors out)
+    def bind_device(self, device: Optional[int]):
+        """Run env.reset / env.step on this GPU (MBDPI binds the env to its own device)."""
+        if self._ctx is not None and device is not None and self._ctx.device != int(device):
+            self._ctx = None
+        self._device = device
+
     def _context(self):
         if self._ctx is None:
             from dial_mpc_amd import _lib
-            self._ctx = _lib.Context(self.make_model(), self.make_task(), None)
+            self._ctx = _lib.Context(self.make_model(), self.make_task(), None, getattr(self, "_device", None))
         return self._ctx
 
     def reset(self, rng=None):

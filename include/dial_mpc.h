@@ -236,6 +236,11 @@ typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg);
  * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable. */
 int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task,
                 const dial_cfg* cfg, int device);
+/* Same, for one rank of a sample-sharded run: the rollout scratch is sized for n_local_cap (+1 mean-trajectory)
+ * rollouts instead of cfg->Nsample + 1 -- at BASELINE config 5 (N = 65536 over 8 GPUs) 41 MB instead of 330 MB per
+ * rank; the global reward / weight arrays still hold cfg->Nsample + 1 entries.  0 <= n_local_cap <= cfg->Nsample. */
+int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task* task,
+                        const dial_cfg* cfg, int device, int n_local_cap);
 void dial_destroy(dial_ctx* ctx);
 const char* dial_last_error(const dial_ctx* ctx); /* ctx may be NULL: last global error */
 
@@ -251,7 +256,9 @@ int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, floa
  * reference's jax.random.normal, passed as data); noise_scale:[ns] with ns = Hnode+1 or 1.
  * Outputs: Ybar_out:[Hnode+1,nu], rews:[n_local+1] (last = mean trajectory), qbar:[T,nq],
  * qdbar:[T,nv], xbar:[T,(nbody-1)*3]; with n_local < Nsample the *_out tensors hold this
- * shard's partial (un-normalised) sums -- see dial_reverse_finish.                  */
+ * shard's partial (un-normalised) sums -- see dial_shard_reduce.
+ * Degenerate case, bug-compatible with the reference: when all N+1 mean rewards are identical, std(rews) = 0 and
+ * dial_core.py:126 divides 0 by 0 -- every weight and with it Ybar_out / qbar / qdbar / xbar is NaN.             */
 int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in,
                       const float* noise_scale, int ns, const float* eps, float* Ybar_out,
                       float* rews, float* qbar, float* qdbar, float* xbar, void* stream);

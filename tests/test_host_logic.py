@@ -87,3 +87,38 @@ def test_deploy_example_loads():
     d = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
     dc = load_dataclass_from_dict(DialConfig, d)
     assert dc.Ndiffuse == 1 and dc.env_name == "unitree_go2_walk"
+
+
+def test_result_artefact_layout():
+    """dial_core.py:305-323: states (n, 1+nq+nv+nu) = [i | qpos | qvel | ctrl]; predictions (n, T, nbody-1, 3) =
+    xbar of the last annealing iteration of every tick (the reference's `infos[i]["xbar"][-1]`, where [-1] indexes
+    the diffusion axis that lax.scan stacks)."""
+    from types import SimpleNamespace
+    from dial_mpc_amd.core.dial_core import result_arrays
+    nq, nv, nu, T, nb1, n = 19, 18, 12, 17, 13, 5
+    rng = np.random.default_rng(0)
+    rollout, infos = [], []
+    for i in range(n):
+        ps = SimpleNamespace(qpos=rng.normal(size=nq), qvel=rng.normal(size=nv), ctrl=rng.normal(size=nu))
+        rollout.append(SimpleNamespace(pipeline_state=ps))
+        infos.append({"xbar": rng.normal(size=(T, nb1, 3))})
+    states, preds = result_arrays(rollout, infos)
+    assert states.shape == (n, 1 + nq + nv + nu) and preds.shape == (n, T, nb1, 3)
+    assert np.array_equal(states[:, 0], np.arange(n))
+    assert np.array_equal(states[3, 1:1 + nq], rollout[3].pipeline_state.qpos)
+    assert np.array_equal(states[3, 1 + nq:1 + nq + nv], rollout[3].pipeline_state.qvel)
+    assert np.array_equal(states[3, 1 + nq + nv:], rollout[3].pipeline_state.ctrl)
+    assert np.array_equal(preds[2], infos[2]["xbar"])
+
+
+def test_randomize_tasks_is_refused():
+    """unitree_go2_env.py:142-155 resamples the command every 500 steps; the kernels bake a fixed command in, so a
+    config that asks for it must fail loudly instead of running a different task."""
+    import pytest
+    import yaml
+    from dial_mpc_amd.core.dial_core import load_dial_and_env
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    d = yaml.safe_load(open(get_example_path("unitree_go2_trot.yaml")))
+    d["randomize_tasks"] = True
+    with pytest.raises(NotImplementedError):
+        load_dial_and_env(d)
