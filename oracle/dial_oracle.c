@@ -514,6 +514,9 @@ static void rne(const dial_model* m, odata* d) {
 }
 
 /* ------------------------------------------------------------------ solver.solve (Newton, dense) */
+/* optional decision trace of the current thread (oracle_rollout_trace): which discrete choices the solver made */
+#define TRACE_N 8
+static __thread int* g_trace = 0; /* [use_warm, niter, nactive_start, nactive_end, ls_iters_total, improved_mask, ncontact_on, nlimit_on] */
 typedef struct {
   real qacc[NV], Ma[NV], Jaref[NE], grad[NV], Mgrad[NV], search[NV], qfrc_constraint[NV], efc_force[NE];
   int active[NE];
@@ -643,6 +646,7 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
   }
   int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  if (g_trace) { g_trace[4] += ls_iter; g_trace[5] = (g_trace[5] << 1) | improved; }
   if (improved) {
     for (int i = 0; i < nv; i++) { c->qacc[i] += c->search[i] * alpha; c->Ma[i] += mv[i] * alpha; }
     for (int r = 0; r < ne; r++) c->Jaref[r] += jv[r] * alpha;
@@ -655,6 +659,13 @@ static void solve(const dial_model* m, odata* d) {
   ctx_create(m, d, d->qacc_smooth, &smth, 0);
   const real* q0 = warm.cost < smth.cost ? d->qacc_warmstart : d->qacc_smooth;
   ctx_create(m, d, q0, &c, 1);
+  if (g_trace) {
+    g_trace[0] = warm.cost < smth.cost;
+    g_trace[2] = 0;
+    for (int r = 0; r < m->nefc; r++) g_trace[2] += c.active[r] && d->efc_D[r] > 0;
+    g_trace[4] = 0; g_trace[5] = 0; g_trace[6] = 0; g_trace[7] = 0;
+    for (int r = 0; r < m->nefc; r++) { if (d->efc_D[r] > 0) { if (r < m->nlim) g_trace[7]++; else g_trace[6]++; } }
+  }
   real scale = 1 / ((real)m->meaninertia * (real)(nv > 1 ? nv : 1));
   int niter = 0;
   for (;;) {
@@ -673,6 +684,11 @@ static void solve(const dial_model* m, odata* d) {
     niter++;
   }
   d->solver_niter = niter;
+  if (g_trace) {
+    g_trace[1] = niter;
+    g_trace[3] = 0;
+    for (int r = 0; r < m->nefc; r++) g_trace[3] += c.active[r] && d->efc_D[r] > 0;
+  }
   for (int i = 0; i < nv; i++) { d->qacc[i] = c.qacc[i]; d->qacc_warmstart[i] = c.qacc[i]; d->qfrc_constraint[i] = c.qfrc_constraint[i]; }
   for (int r = 0; r < m->nefc; r++) d->efc_force[r] = c.efc_force[r];
 }
@@ -994,6 +1010,38 @@ int oracle_rollout(const dial_model* m, const dial_task* t, const real* state, c
     }
     free(d);
   }
+  return 0;
+}
+
+/* One rollout with the solver's decision trace: trace [T][TRACE_N] ints per env.step (last physics sub-step). */
+/* noise_mag > 0: before EVERY step qpos, qvel and qacc_warmstart are multiplied by 1 + noise_mag * 2^-24 * u,
+ * u ~ U(-1,1) from a 64-bit LCG seeded with noise_seed -- a rounding-level perturbation applied where the next
+ * solver decision is taken (a perturbation of the start state alone is forgotten by the dissipative contact
+ * dynamics and, for the warm start, after a single step).  Used by the knife-edge witness of the parity tests. */
+int oracle_rollout_trace(const dial_model* m, const dial_task* t, const real* state, const real* us, int T, int* trace,
+                         real* rewss, real* qss, real* qdss, unsigned long long noise_seed, double noise_mag) {
+  odata* d = (odata*)calloc(1, sizeof(odata));
+  real info[DIAL_INFO_N];
+  load_state(m, state, d, info);
+  unsigned long long lcg = noise_seed * 6364136223846793005ULL + 1442695040888963407ULL;
+  for (int s = 0; s < T; s++) {
+    if (noise_mag > 0) {
+      const double sc = noise_mag * 5.9604644775390625e-08;
+#define ORACLE_JITTER(x) do { lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL; \
+        double u_ = (double)(lcg >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0; (x) = (real)((double)(x) * (1.0 + sc * u_)); } while (0)
+      for (int i = 0; i < m->nq; i++) ORACLE_JITTER(d->qpos[i]);
+      for (int i = 0; i < m->nv; i++) { ORACLE_JITTER(d->qvel[i]); ORACLE_JITTER(d->qacc_warmstart[i]); }
+#undef ORACLE_JITTER
+    }
+    g_trace = trace + s * TRACE_N;
+    for (int k = 0; k < TRACE_N; k++) g_trace[k] = 0;
+    real rew = env_step(m, t, d, info, us + (size_t)s * m->nu);
+    g_trace = 0;
+    if (rewss) rewss[s] = rew;
+    if (qss) for (int i = 0; i < m->nq; i++) qss[s * m->nq + i] = d->qpos[i];
+    if (qdss) for (int i = 0; i < m->nv; i++) qdss[s * m->nv + i] = d->qvel[i];
+  }
+  free(d);
   return 0;
 }
 

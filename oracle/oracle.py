@@ -79,6 +79,22 @@ class Oracle:
                                 self._p(us), B, T, self._p(rewss), self._p(qss), self._p(qdss), self._p(xss))
         return rewss, qss, qdss, xss
 
+    def rollout_trace(self, state, us, noise_seed: int = 0, noise_mag: float = 0.0):
+        """One rollout (us [T,nu]) with the solver's decision trace per step:
+        [use_warm, niter, nactive_start, nactive_end, ls_iters_total, improved_mask, ncontact_rows_on, nlimit_rows_on].
+        noise_mag > 0: qpos / qvel / qacc_warmstart are jittered by <= noise_mag ulp (fp32) before every step."""
+        us = self._a(us)
+        T = us.shape[0]
+        trace = np.zeros((T, 8), np.int32)
+        rewss = np.zeros(T, self.dtype)
+        qss = np.zeros((T, self.nq), self.dtype)
+        qdss = np.zeros((T, self.nv), self.dtype)
+        self.lib.oracle_rollout_trace(ctypes.byref(self.model), ctypes.byref(self.task), self._p(self._a(state)),
+                                      self._p(us), T, trace.ctypes.data_as(ctypes.c_void_p), self._p(rewss),
+                                      self._p(qss), self._p(qdss), ctypes.c_ulonglong(int(noise_seed)),
+                                      ctypes.c_double(float(noise_mag)))
+        return trace, rewss, qss, qdss
+
     def reverse_once(self, state, Ybar, noise_scale, eps, full: bool = False):
         cfg = self.cfg
         N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1

@@ -32,11 +32,69 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# ---- tolerances of the fp32 parity gate (HIP vs fp32 oracle on identical inputs).  Measured agreement
-# is ~1e-5; the gate leaves a margin for rollouts that amplify rounding differences.
-TOL = dict(rewss=dict(rtol=2e-3, atol=2e-3), q=dict(rtol=0, atol=1e-3), qd=dict(rtol=2e-3, atol=2e-2),
-           x=dict(rtol=0, atol=1e-3), weights=dict(rtol=2e-2, atol=2e-4), Ybar=dict(rtol=0, atol=2e-3),
-           bar=dict(rtol=0, atol=5e-3))
+# ---- fp32 parity gate (HIP vs fp32 oracle on identical inputs).
+# Measured on MI355X at the BASELINE sizes (tools/parity_survey.py, profiles/r02_parity_survey.json): 99.9 % of the
+# per-step entries agree to  rewards 1.1e-4, q 2e-5, qd 1.2e-3, x.pos 4e-6 (H1 at H=25: 7e-5);  Ybar 1e-5, qbar 1e-5, xbar 2e-6.
+# The gates below sit ~5-10x above that.  What exceeds them is NOT waved through by a blanket tolerance: a rollout that
+# leaves the oracle's trajectory must be REPRODUCED by the fp32 oracle itself after a rounding-level (<= 64 ulp = 4e-6:
+# the size of the GPU's native sin/cos error)
+# jitter of the state before every step -- the truncated Newton solver (2 iterations; H1 loco: 1) makes discrete decisions
+# (`active = Jaref < 0` at the warm-start point, warm-start choice, line-search bracket) that rounding flips, and a
+# flipped decision is a different, equally valid branch (profiles/r02_seq_jump_flips.txt).  `witness_parity` finds the
+# first diverging step of every such rollout and searches the perturbed oracle runs for one that follows the GPU
+# through that step; rollouts without a witness fail the test, and the fraction with one is capped per env.
+TOL = dict(rewss=dict(rtol=5e-4, atol=5e-4), q=dict(rtol=0, atol=3e-4), qd=dict(rtol=2e-3, atol=1e-2),
+           x=dict(rtol=0, atol=2e-4), weights=dict(rtol=2e-3, atol=2e-5), Ybar=dict(rtol=0, atol=3e-4),
+           bar=dict(rtol=0, atol=3e-4), qdbar=dict(rtol=2e-3, atol=5e-3))
+# share of the rollouts that may sit on a solver knife edge (measured: Go2 / H1 <= 0.1 %, H1 loco 0.5 %)
+KNIFE_EDGE_FRAC = {"unitree_go2_trot": 0.01, "unitree_go2_seq_jump": 0.01, "unitree_h1_jog": 0.01, "unitree_h1_loco": 0.03,
+                   "allegro_reorient": 0.03}
+# envs whose aggregates (Ybar, qbar ...) inherit the flips of a 1-iteration solver get a wider aggregate gate
+TOL_AGG_SCALE = {"unitree_h1_loco": 8.0}
+
+
+def _within(a, b, tol):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) <= tol["atol"] + tol["rtol"] * np.abs(b)
+
+
+def witness_parity(o32, s0, us, got, example, nstate, max_draws=256):
+    """Per-rollout parity of `got` = (rewss, qss, qdss, xss) [B,T,...] against the fp32 oracle `o32` run on the same
+    controls `us` [B,T,nu] from the packed start state `s0`.  Returns a report dict; raises AssertionError when a
+    rollout neither matches within TOL nor has a knife-edge witness, or when too many rollouts need one.
+    The witness search re-runs the oracle with qpos / qvel / qacc_warmstart jittered by <= 1, 4, 16, 64 ulp before
+    every step (oracle_rollout_trace) until a run follows the GPU through the first step outside the gate."""
+    ref = o32.rollout(s0, us)
+    B, T = us.shape[:2]
+    ok_t = np.ones((B, T), bool)
+    for name, g, r in zip(("rewss", "q", "qd", "x"), got, ref):
+        w = _within(g, r, TOL[name])
+        ok_t &= w if w.ndim == 2 else w.reshape(B, T, -1).all(-1)
+    bad = np.flatnonzero(~ok_t.all(1))
+    report = dict(rollouts=B, outside_tol=int(bad.size), witnessed=0, details=[])
+    for n in bad:
+        t_star = int(np.argmin(ok_t[n]))                  # first step outside the gate
+        found = None
+        for k in range(max_draws):
+            mag = (1, 4, 16, 64)[k * 4 // max_draws]
+            _, rw, qp, qdp = o32.rollout_trace(s0, us[n], noise_seed=1000 * int(n) + k + 1, noise_mag=mag)
+            pre = slice(0, t_star + 1)
+            if (_within(got[0][n][pre], rw[pre], TOL["rewss"]).all() and _within(got[1][n][pre], qp[pre], TOL["q"]).all()
+                    and _within(got[2][n][pre], qdp[pre], TOL["qd"]).all()):
+                found = (k, mag)
+                break
+        report["details"].append(dict(sample=int(n), first_step=t_star, witness=found))
+        assert found is not None, (f"{example}: rollout {n} leaves the oracle's trajectory at step {t_star} and no <= 64 ulp "
+                                   f"per-step jitter of the oracle's state reproduces the GPU's branch")
+        report["witnessed"] += 1
+    frac = report["witnessed"] / B
+    assert frac <= max(KNIFE_EDGE_FRAC[example], 4.5 / B), (example, report)       # small batches: at most 4 rollouts
+    return report
+
+
+def agg_tol(example, name):
+    t = dict(TOL[name])
+    sc = TOL_AGG_SCALE.get(example, 1.0)
+    return dict(rtol=t["rtol"] * sc, atol=t["atol"] * sc)
 
 
 def setup_case(example: str, N: int, H: int, Hnode=None):

@@ -1,13 +1,15 @@
 """GPU parity gate: libdialhip.so (through the C ABI) vs the fp32 CPU oracle on identical seeded inputs.
 
-Tolerances (fp32, stated in conftest.TOL): rewards 2e-3 (abs+rel), q / x.pos 1e-3, qd 2e-2, softmax
-weights 2e-2 rel, Ybar 2e-3, weighted means 5e-3.  Measured agreement is ~1e-5."""
+Tolerances (fp32, stated in conftest.TOL, ~5-10x the error measured at the BASELINE sizes): per-step rewards 5e-4
+(abs + rel), q 3e-4, qd 1e-2 + 2e-3 rel, x.pos 2e-4, softmax weights 2e-3 rel, Ybar / qbar / xbar 3e-4, qdbar 5e-3.
+Rollouts outside the gate need a knife-edge witness (conftest.witness_parity): the fp32 oracle, restarted from a
+state perturbed by <= 64 ulp, must reproduce the GPU's branch."""
 import ctypes
 
 import numpy as np
 import pytest
 
-from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case
+from conftest import CASES, TOL, agg_tol, perturbed_state, seeded_inputs, setup_case, witness_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -66,11 +68,8 @@ def test_rollout_matches_oracle(example, N, H):
         q, qd = (env._init_q, np.zeros(model.nv)) if seed is None else perturbed_state(env, seed)
         s0, _, _ = o32.env_reset(q, qd)
         us = rng.uniform(-0.8, 0.8, (16, H + 1, model.nu)).astype(np.float32)
-        r_o = o32.rollout(s0, us)
-        r_g = ctx.rollout(_dev(s0), _dev(us))
-        for name, a, b in zip(("rewss", "q", "qd", "x"), r_o, r_g):
-            b = b.cpu().numpy()
-            assert _close(b, a, TOL[name]), (example, seed, name, float(np.abs(a - b).max()))
+        r_g = [t.cpu().numpy() for t in ctx.rollout(_dev(s0), _dev(us))]
+        witness_parity(o32, s0, us, r_g, example, model.nq + 2 * model.nv)
 
 
 @pytest.mark.parametrize("example,N,H", CASES + [("unitree_go2_trot", 256, 16)])
@@ -88,14 +87,26 @@ def test_reverse_once_matches_oracle_stagewise(example, N, H):
     Y0s_ref = np.clip(np.concatenate([eps * sigma[None, :, None] + Ybar, Ybar[None]], 0), -1, 1)
     Y0s_ref[:-1, 0] = np.clip(Ybar[0], -1, 1)
     assert np.allclose(sc["Y0s"], Y0s_ref, rtol=0, atol=2.5e-7)          # K1: exact up to one fused multiply-add rounding
-    assert _close(sc["rewss"], ro["rewss"], TOL["rewss"])               # K2 + K3
-    assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=2e-3, atol=1e-3)
-    assert _close(sc["weights"], ro["weights"], TOL["weights"])         # K4a
+    rep = witness_parity(o32, s0, ro["us"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), example,
+                         model.nq + 2 * model.nv)                        # K2 + K3, every rollout, every step
+    if rep["witnessed"] == 0:                                            # aggregates are only comparable branch for branch
+        assert np.allclose(out["rews"].cpu().numpy(), ro["rews"], rtol=5e-4, atol=5e-4)
+        assert _close(sc["weights"], ro["weights"], TOL["weights"])         # K4a
+        assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], agg_tol(example, "Ybar"))   # K4b
+        assert _close(out["qbar"].cpu().numpy(), ro["qbar"], agg_tol(example, "bar"))
+        assert _close(out["qdbar"].cpu().numpy(), ro["qdbar"], agg_tol(example, "qdbar"))
+        assert _close(out["xbar"].cpu().numpy(), ro["xbar"], agg_tol(example, "bar"))
     assert abs(sc["weights"].sum() - 1) < 1e-4
-    assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], TOL["Ybar"])   # K4b
-    assert _close(out["qbar"].cpu().numpy(), ro["qbar"], TOL["bar"])
-    assert _close(out["qdbar"].cpu().numpy(), ro["qdbar"], dict(rtol=1e-2, atol=5e-2))
-    assert _close(out["xbar"].cpu().numpy(), ro["xbar"], TOL["bar"])
+    # K4 on its own, independent of any branch: weights and weighted means recomputed in fp64 from the GPU's own rewards / rollouts
+    rews_g = out["rews"].cpu().numpy().astype(np.float64)
+    logp = (rews_g - rews_g[-1]) / rews_g.std() / float(cfg.temp_sample)
+    w_ref = np.exp(logp - logp.max())
+    w_ref /= w_ref.sum()
+    assert np.allclose(sc["weights"], w_ref, rtol=2e-3, atol=1e-7)
+    assert np.allclose(out["Ybar"].cpu().numpy(), np.einsum("n,nka->ka", w_ref, sc["Y0s"].astype(np.float64)), atol=2e-5)
+    assert np.allclose(out["qbar"].cpu().numpy(), np.einsum("n,nti->ti", w_ref, sc["qss"].astype(np.float64)), atol=2e-5)
+    assert np.allclose(out["qdbar"].cpu().numpy(), np.einsum("n,nti->ti", w_ref, sc["qdss"].astype(np.float64)), atol=5e-4)
+    assert np.allclose(out["xbar"].cpu().numpy(), np.einsum("n,nti->ti", w_ref, sc["xss"].astype(np.float64)), atol=2e-5)
 
 
 def test_shift_matches_oracle():
@@ -276,15 +287,61 @@ def test_full_size_properties_other_configs(example, N, H):
     assert np.array_equal(out3["rews"].cpu().numpy()[:-1], rews[:-1][perm])                            # equivariance
     assert np.allclose(out3["Ybar"].cpu().numpy(), out1["Ybar"].cpu().numpy(), atol=1e-4)
     assert np.ptp(sc["rewss"][:, 0]) < 1e-5                       # first reward is action independent
-    # a random subset of the samples agrees with the oracle rollout of exactly those controls
+
+
+FULL_SIZE = [("unitree_go2_trot", 2048, 16), ("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16),
+             ("unitree_h1_loco", 1024, 20)]
+
+
+@pytest.mark.parametrize("example,N,H", FULL_SIZE)
+def test_full_size_oracle_parity(example, N, H):
+    """BASELINE headline / configs 2 and 3 (+ H1 loco) at FULL size against the OpenMP fp32 oracle: every one of the
+    (N+1) x (H+1) per-step rewards, q, qd, x.pos, then the weights and the weighted means."""
     import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    ctx = _lib.Context(model, task, cfg)
     o32 = O.Oracle(model, task, cfg, np.float32)
-    W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(H + 1)], np.float32)
-    idx = np.random.default_rng(2).choice(N, 12, replace=False)
-    us = np.einsum("tk,bka->bta", W, sc["Y0s"][idx])
-    s0_host = s0.cpu().numpy()
-    r_o = o32.rollout(s0_host, us)[0]
-    assert np.allclose(sc["rewss"][idx], r_o, **TOL["rewss"])
+    for seed in (0, 1):
+        q, qd = (env._init_q, np.zeros(model.nv)) if seed == 0 else perturbed_state(env, seed)
+        s0, _, _ = o32.env_reset(q, qd)
+        eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=seed, Ybar_scale=0.2)
+        ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+        out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+        sc = ctx.debug_scratch()
+        rep = witness_parity(o32, s0, ro["us"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), example,
+                             model.nq + 2 * model.nv)
+        print(f"{example} N={N} seed={seed}: {rep['outside_tol']} of {rep['rollouts']} rollouts on a knife edge, all witnessed")
+        # product outputs: the few knife-edge rollouts carry softmax weight ~1/N each, so the aggregates stay comparable
+        assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], agg_tol(example, "Ybar"))
+        assert _close(out["qbar"].cpu().numpy(), ro["qbar"], agg_tol(example, "bar"))
+        assert _close(out["xbar"].cpu().numpy(), ro["xbar"], agg_tol(example, "bar"))
+        assert _close(out["qdbar"].cpu().numpy(), ro["qdbar"], agg_tol(example, "qdbar"))
+
+
+@pytest.mark.parametrize("example,H", [("unitree_go2_trot", 16), ("unitree_go2_seq_jump", 20), ("unitree_h1_jog", 25),
+                                       ("unitree_h1_loco", 20)])
+def test_stress_parity_perturbed_states(example, H):
+    """The widest net (was tools/stress_parity.py): six perturbed start states per env at the example's own horizon,
+    plans away from zero (Ybar_scale 0.3) so that contacts make and break inside the horizon."""
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, 192, H)
+    ctx = _lib.Context(model, task, cfg)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    witnessed = 0
+    for seed in range(6):
+        q, qd = (env._init_q, np.zeros(model.nv)) if seed == 0 else perturbed_state(env, seed)
+        s0, _, _ = o32.env_reset(q, qd)
+        eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=seed, Ybar_scale=0.3)
+        ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+        ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+        sc = ctx.debug_scratch()
+        witnessed += witness_parity(o32, s0, ro["us"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), example,
+                                    model.nq + 2 * model.nv)["witnessed"]
+    print(f"{example}: {witnessed} of {6 * 193} rollouts needed a knife-edge witness")
+    from conftest import KNIFE_EDGE_FRAC
+    assert witnessed <= max(2, KNIFE_EDGE_FRAC[example] * 6 * 193)
 
 
 def test_edge_cases_small_and_async_schedule():
@@ -331,3 +388,27 @@ def test_in_kernel_rng_replays_exactly_and_is_standard_normal():
     rews = torch.zeros(257, device="cuda")
     ctx.shard_rollout_rng(s0, _dev(Ybar), _dev(sigma), seed, counter, 1024, 256, True, rews)
     assert torch.equal(rews[:256], out_rng["rews"][1024:1280]) and torch.equal(rews[256], out_rng["rews"][2048])
+
+
+def test_degenerate_std_is_nan_like_the_reference():
+    """All N+1 mean rewards identical => std = 0 and dial_core.py:126 divides 0 by 0: weights / Ybar are NaN in the
+    reference (numpy restatement below) and, by definition (include/dial_mpc.h), here."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 63, 8)      # B = 64: the mean of equal values is exact
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
+    ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))               # fills the rollout scratch the sums read
+    rews = np.full(64, -1.25, np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logp0 = (rews - rews[-1]) / rews.std() / np.float32(cfg.temp_sample)
+    assert np.isnan(logp0).all()                                            # the reference's value
+    packed = torch.zeros(ctx.packed_size(), device="cuda")
+    ctx.shard_reduce(_dev(rews), 63, 0, 63, True, packed)
+    torch.cuda.synchronize()
+    assert torch.isnan(packed[:(dc.Hnode + 1) * 12]).all()
+    # one reward differs: finite again
+    rews[3] = -1.0
+    ctx.shard_reduce(_dev(rews), 63, 0, 63, True, packed)
+    assert torch.isfinite(packed).all()

@@ -1,0 +1,265 @@
+"""First-principles pins of the oracle's physics that need neither MuJoCo/MJX nor the oracle's own machinery.
+
+The JAX reference cannot run here and ships no vectors ("parity unpinned").  What CAN be done
+is to check the oracle against independent derivations of the same quantities:
+
+  * mass matrix         <- second derivative of the kinetic energy  sum_b 1/2 (m |v_com|^2 + w^T I w), with body
+                           velocities obtained by finite differences of plain forward kinematics (no cdof / CRB);
+  * bias forces         <- Lagrange's equations  d/dt(dT/dv) - dT/dq + dV/dq  on the hinge coordinates (no RNE);
+  * contact Jacobians   <- finite-difference velocity of the material contact point;
+  * impedance / aref    <- MuJoCo's documented solref / solimp formulas, restated vectorised (MJX code shape);
+  * Newton solver       <- SciPy minimisation of the documented primal cost
+                           1/2 (a - a0)^T M (a - a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2 .
+Conventions checked on the way: free joint = world-frame linear velocity + BODY-frame angular velocity, semi-implicit
+Euler with quaternion exponential, [ang; lin] spatial vectors."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import perturbed_state, setup_case
+from dial_mpc_amd import mjcf
+
+ROBOTS = [("unitree_go2_trot", 8), ("unitree_h1_jog", 8), ("unitree_h1_loco", 8)]
+
+
+def _integrate(m, q, v, eps):
+    """mj_integratePos: q (+) eps * v."""
+    q2 = np.array(q, dtype=np.float64)
+    for j in range(m["njnt"]):
+        qa, da = int(m["jnt_qposadr"][j]), int(m["jnt_dofadr"][j])
+        if m["jnt_type"][j] == mjcf.JNT_FREE:
+            q2[qa:qa + 3] += eps * v[da:da + 3]
+            w = eps * np.asarray(v[da + 3:da + 6])
+            ang = np.linalg.norm(w)
+            dq = np.array([1.0, 0, 0, 0]) if ang == 0 else np.concatenate([[np.cos(ang / 2)], w / ang * np.sin(ang / 2)])
+            q2[qa + 3:qa + 7] = mjcf.quat_mul(q2[qa + 3:qa + 7], dq)         # body-frame angular velocity
+        else:
+            q2[qa] += eps * v[da]
+    return q2
+
+
+def _body_velocities(m, q, v, eps=1e-6):
+    kp, km = mjcf.host_kinematics(m, _integrate(m, q, v, eps)), mjcf.host_kinematics(m, _integrate(m, q, v, -eps))
+    vcom = (kp["xipos"] - km["xipos"]) / (2 * eps)
+    omega = np.zeros_like(vcom)
+    for b in range(m["nbody"]):
+        dR = kp["xmat"][b] @ km["xmat"][b].T                                  # ~ I + 2 eps [w]x
+        omega[b] = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / (4 * eps)
+    return vcom, omega
+
+
+def _kinetic_bilinear(m, q, v1, v2):
+    k0 = mjcf.host_kinematics(m, q)
+    vc1, w1 = _body_velocities(m, q, v1)
+    vc2, w2 = _body_velocities(m, q, v2)
+    t = 0.0
+    for b in range(1, m["nbody"]):
+        I = k0["ximat"][b] @ np.diag(m["body_inertia"][b]) @ k0["ximat"][b].T
+        t += m["body_mass"][b] * vc1[b] @ vc2[b] + w1[b] @ I @ w2[b]
+    return t
+
+
+def _case(example, seed):
+    dc, env, model, task, cfg = setup_case(example, 8, 8)
+    md = env.sys.model
+    q, qd = perturbed_state(env, seed)
+    return env, md, model, task, cfg, np.asarray(q, np.float64), np.asarray(qd, np.float64)
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS)
+def test_mass_matrix_is_the_hessian_of_the_kinetic_energy(example, _n):
+    env, md, model, task, cfg, q, qd = _case(example, 3)
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    M = o64.forward_dump(q, np.zeros(md["nv"]))["qM"]
+    nv = md["nv"]
+    rng = np.random.default_rng(0)
+    # full bilinear form on random velocity pairs + every diagonal entry
+    for _ in range(6):
+        a, b = rng.normal(size=nv), rng.normal(size=nv)
+        ref = _kinetic_bilinear(md, q, a, b) + a @ (np.asarray(md["dof_armature"]) * b)
+        assert abs(a @ M @ b - ref) < 1e-6 * max(1.0, abs(ref)), (example, a @ M @ b, ref)
+    for i in range(nv):
+        e = np.zeros(nv)
+        e[i] = 1.0
+        ref = _kinetic_bilinear(md, q, e, e) + md["dof_armature"][i]
+        assert abs(M[i, i] - ref) < 1e-6 * max(1.0, abs(ref)), (example, i)
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS)
+def test_bias_forces_satisfy_lagranges_equations_on_the_hinges(example, _n):
+    """Base at rest: on the hinge coordinates c = sum_k dM/dq_k qd_k qd - 1/2 d(qd^T M qd)/dq + dV/dq."""
+    env, md, model, task, cfg, q, qd = _case(example, 5)
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    nv, nq = md["nv"], md["nq"]
+    v = np.array(qd)
+    v[:6] = 0.0
+    bias = o64.forward_dump(q, v)["qfrc_bias"]
+    g = np.asarray(md["gravity"], np.float64)
+
+    def Mh(qq):
+        return o64.forward_dump(qq, np.zeros(nv))["qM"][6:, 6:]
+
+    def V(qq):
+        k = mjcf.host_kinematics(md, qq)
+        return -sum(md["body_mass"][b] * g @ k["xipos"][b] for b in range(1, md["nbody"]))
+
+    h, nh = 1e-5, nv - 6
+    th = v[6:]
+    dM = np.zeros((nh, nh, nh))       # dM[k] = dM/dtheta_k
+    dV = np.zeros(nh)
+    for k in range(nh):
+        e = np.zeros(nq)
+        e[7 + k] = h
+        dM[k] = (Mh(q + e) - Mh(q - e)) / (2 * h)
+        dV[k] = (V(q + e) - V(q - e)) / (2 * h)
+    Mdot = np.einsum("kij,k->ij", dM, th)
+    c = Mdot @ th - 0.5 * np.einsum("kij,i,j->k", dM, th, th) + dV
+    assert np.allclose(bias[6:], c, rtol=1e-5, atol=2e-5), (example, np.abs(bias[6:] - c).max())
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS[:2])
+def test_contact_jacobian_is_the_velocity_of_the_material_contact_point(example, _n):
+    env, md, model, task, cfg, _, _ = _case(example, 0)
+    q = np.array(env._init_q, np.float64)                     # home pose: every foot contact is active
+    nv = md["nv"]
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    d = o64.forward_dump(q, np.zeros(nv))
+    assert np.all(d["con_dist"] < 0)
+    k0 = mjcf.host_kinematics(md, q)
+    nl, nc = md["nlim"], md["ncon"]
+    rng = np.random.default_rng(1)
+    eps = 1e-6
+    for c in range(nc):
+        b2 = int(md["con_body2"][c])
+        p = d["con_pos"][c]
+        ploc = k0["xmat"][b2].T @ (p - k0["xpos"][b2])
+        rows = d["efc_J"][nl + 4 * c: nl + 4 * c + 4]
+        mu = md["con_friction"][c][0]
+        Jn, Jt1, Jt2 = (rows[0] + rows[1]) / 2, (rows[0] - rows[1]) / (2 * mu), (rows[2] - rows[3]) / (2 * mu)
+        # contact frame: normal = plane normal (0,0,1); tangents from the oracle's rows are checked for orthonormality
+        for _ in range(3):
+            v = rng.normal(size=nv)
+            kp, km = mjcf.host_kinematics(md, _integrate(md, q, v, eps)), mjcf.host_kinematics(md, _integrate(md, q, v, -eps))
+            vel = ((kp["xpos"][b2] + kp["xmat"][b2] @ ploc) - (km["xpos"][b2] + km["xmat"][b2] @ ploc)) / (2 * eps)
+            comp = np.array([Jn @ v, Jt1 @ v, Jt2 @ v])
+            assert abs(comp[0] - vel[2]) < 1e-6 * max(1, abs(vel[2]))                  # normal = +z
+            assert abs(np.linalg.norm(comp) - np.linalg.norm(vel)) < 1e-6 * max(1, np.linalg.norm(vel))   # orthonormal frame
+
+
+def _impedance_rows(md, q, v, d):
+    """constraint.make_constraint's (D, aref) restated vectorised from the documented solref / solimp formulas:
+    rows = limits then 4 pyramid edges per contact."""
+    nl, nc, nv = md["nlim"], md["ncon"], md["nv"]
+    dt = float(md["timestep"])
+    ji = np.asarray(md["lim_jnt"][:nl], int)
+    qa, da = np.asarray(md["jnt_qposadr"])[ji], np.asarray(md["jnt_dofadr"])[ji]
+    rng_ = np.asarray(md["jnt_range"])[ji]
+    dmin_, dmax_ = q[qa] - rng_[:, 0], rng_[:, 1] - q[qa]
+    pos_l = np.minimum(dmin_, dmax_) - np.asarray(md["jnt_margin"])[ji]
+    sgn = np.where(dmin_ < dmax_, 1.0, -1.0)
+    vel_l = sgn * v[da]
+    invw_l = np.asarray(md["dof_invweight0"])[da]
+    pos_c = np.repeat(d["con_dist"][:nc] - np.asarray(md["con_margin"])[:nc], 4)
+    biw = np.asarray(md["body_invweight0"])[:, 0]
+    t = biw[np.asarray(md["con_body1"][:nc], int)] + biw[np.asarray(md["con_body2"][:nc], int)]
+    mu = np.asarray(md["con_friction"])[:nc, 0]
+    invw_c = np.repeat((t + mu * mu * t) * 2 * mu * mu / float(md["impratio"]), 4)
+    vel_c = d["efc_J"][nl:] @ v
+    pos = np.concatenate([pos_l, pos_c])
+    vel = np.concatenate([vel_l, vel_c])
+    invw = np.concatenate([invw_l, invw_c])
+    solref = np.concatenate([np.asarray(md["jnt_solref"])[ji], np.repeat(np.asarray(md["con_solref"])[:nc], 4, 0)])
+    solimp = np.concatenate([np.asarray(md["jnt_solimp"])[ji], np.repeat(np.asarray(md["con_solimp"])[:nc], 4, 0)])
+    tc = np.maximum(solref[:, 0], 2 * dt)
+    dr = solref[:, 1]
+    d0, dm, width, mid, power = (np.clip(solimp[:, 0], 1e-4, 0.9999), np.clip(solimp[:, 1], 1e-4, 0.9999),
+                                 np.maximum(solimp[:, 2], 1e-15), np.clip(solimp[:, 3], 1e-4, 0.9999),
+                                 np.maximum(solimp[:, 4], 1))
+    k = 1 / (dm * dm * tc * tc * dr * dr)
+    b = 2 / (dm * tc)
+    x = np.abs(pos) / width
+    y = np.where(x < mid, x ** power / mid ** (power - 1), 1 - (1 - x) ** power / (1 - mid) ** (power - 1))
+    imp = np.where(x > 1, dm, np.clip(d0 + y * (dm - d0), d0, dm))
+    active = pos < 0
+    R = np.maximum(invw * (1 - imp) / imp, 1e-15)
+    return np.where(active, 1 / R, 0.0), np.where(active, -b * vel - k * imp * pos, 0.0)
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS)
+def test_constraint_rows_match_the_documented_impedance_formulas(example, _n):
+    env, md, model, task, cfg, q, qd = _case(example, 2)
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    for qq, vv in ((np.array(env._init_q, np.float64), np.zeros(md["nv"])), (q, qd)):
+        if example == "unitree_go2_trot":
+            qq = qq.copy()
+            qq[9] = -0.84          # a calf joint past its upper limit (-0.85...): a limit row becomes active
+        d = o64.forward_dump(qq, vv)
+        D, aref = _impedance_rows(md, qq, vv, d)
+        assert np.allclose(d["efc_D"], D, rtol=1e-5, atol=0), (example, np.abs(d["efc_D"] - D).max())
+        assert np.allclose(d["efc_aref"], aref, rtol=1e-5, atol=1e-7 * (1 + np.abs(aref).max()))
+        assert (D > 0).sum() > 0
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS)
+def test_converged_newton_solution_minimises_the_primal_cost(example, _n):
+    """Run the oracle's solver to convergence (iterations = 100) and compare qacc with SciPy's minimiser of the
+    primal cost built from the oracle's own (M, a0, J, D, aref) -- checks the solver, its line search and the
+    active-set logic independently of how they are coded."""
+    from scipy.optimize import minimize
+    env, md, model, task, cfg, q, qd = _case(example, 4)
+    m2 = type(model).from_buffer_copy(model)
+    m2.iterations, m2.ls_iterations = 100, 50
+    o64 = O.Oracle(m2, task, cfg, np.float64)
+    nv = md["nv"]
+    for qq, vv in ((np.array(env._init_q, np.float64), np.zeros(nv)), (q, 0.2 * qd)):
+        d = o64.forward_dump(qq, vv, ctrl=np.zeros(md["nu"]))
+        M, a0, J, D, aref = d["qM"], d["qacc_smooth"], d["efc_J"], d["efc_D"], d["efc_aref"]
+
+        def cost(a):
+            r = J @ a - aref
+            ra = np.minimum(r, 0)
+            return 0.5 * (a - a0) @ M @ (a - a0) + 0.5 * np.sum(D * ra * ra)
+
+        def grad(a):
+            r = J @ a - aref
+            return M @ (a - a0) + J.T @ (D * np.minimum(r, 0))
+
+        def hess(a):
+            act = (J @ a - aref) < 0
+            return M + (J.T * (D * act)) @ J
+
+        res = minimize(cost, a0, jac=grad, hess=hess, method="trust-exact", options=dict(gtol=1e-10, maxiter=500))
+        assert np.linalg.norm(grad(res.x)) < 1e-6 * (1 + np.linalg.norm(M @ a0))
+        scale = 1 + np.abs(res.x).max()
+        assert np.abs(d["qacc"] - res.x).max() < 1e-5 * scale, (example, np.abs(d["qacc"] - res.x).max(), d["niter"])
+        assert cost(d["qacc"]) <= cost(res.x) * (1 + 1e-9) + 1e-9
+        # the truncated solve the envs use (2 iterations) is a descent from both start points, never worse than them
+        o_trunc = O.Oracle(model, task, cfg, np.float64)
+        dt = o_trunc.forward_dump(qq, vv, ctrl=np.zeros(md["nu"]))
+        assert cost(dt["qacc"]) <= cost(a0) + 1e-9 and cost(dt["qacc"]) >= cost(res.x) - 1e-7 * (1 + abs(cost(res.x)))
+
+
+def test_free_joint_integration_uses_the_quaternion_exponential_of_the_body_rate():
+    """Torque-free, gravity-free, contact-free: after one step qpos' = integrate(qpos, qvel', dt) (semi-implicit)."""
+    from scipy.spatial.transform import Rotation as R
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8)
+    m2, t2 = type(model).from_buffer_copy(model), type(task).from_buffer_copy(task)
+    for k in range(3):
+        m2.gravity[k] = 0.0
+    for a in range(12):
+        t2.kp[a] = t2.kd[a] = 0.0
+    o64 = O.Oracle(m2, t2, cfg, np.float64)
+    q = np.array(env._init_q, np.float64)
+    q[2] = 3.0
+    qd = np.random.default_rng(3).normal(0, 1.0, 18)
+    s0, _, _ = o64.env_reset(q, qd)
+    s1, _, _, _ = o64.env_step(s0, np.zeros(12))
+    v1 = s1[19:37]
+    dt = float(m2.timestep)
+    assert np.allclose(s1[:3], s0[:3] + dt * v1[:3], atol=1e-12)
+    r0 = R.from_quat(np.roll(s0[3:7], -1))
+    r1 = r0 * R.from_rotvec(dt * v1[3:6])                     # right-multiplication = body-frame rate
+    q1 = np.roll(r1.as_quat(), 1)
+    q1 *= np.sign(q1[0]) * np.sign(s1[3])
+    assert np.allclose(s1[3:7], q1, atol=1e-9)
+    assert np.allclose(s1[7:19], s0[7:19] + dt * v1[6:], atol=1e-12)

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Export golden vectors from the JAX reference (run on a machine that HAS jax, brax, mujoco, jax_cosmo and
-the reference checkout on PYTHONPATH; it cannot run in the build container).
+the reference checkout on PYTHONPATH; it cannot run in the build container).  Pinned environment + the exact
+command sequence: tools/reference_env.txt.
 
     python tools/export_reference_vectors.py --example unitree_go2_trot --nsample 64 --hsample 8 --out ref.npz
 
 It monkey-patches `jax.random.normal` so that `MBDPI.reverse_once` consumes a fixed NumPy-generated `eps`
 (the same generator as tests/conftest.py: seeded_inputs), then dumps state, eps, Ybar_in, noise_scale, rewss,
 qss, qdss, xss, Ybar, weights.  Place the file under tests/golden/reference/ — tests/test_reference_vectors.py
-compares the HIP path against it with the fp32 tolerances of conftest.TOL and otherwise reports
-"golden vectors absent -- parity vs JAX unverified".
+compares the oracle (CPU leg) and the HIP path (`-m gpu` leg) against it with the fp32 tolerances of conftest.TOL
+and otherwise reports an XFAIL "golden vectors absent -- parity vs JAX unpinned".
 """
 import argparse
 
@@ -56,7 +57,9 @@ def main():
     rewss, ps = mbdpi.rollout_us_vmap(state, us)
     _, Ybar_out, info = mbdpi.reverse_once(state, jax.random.PRNGKey(1), jnp.asarray(Ybar), jnp.asarray(sigma))
     ps0 = state.pipeline_state
-    np.savez_compressed(args.out, qpos=np.asarray(ps0.qpos), qvel=np.asarray(ps0.qvel),
+    import importlib.metadata as md
+    versions = {p: md.version(p) for p in ("jax", "jaxlib", "mujoco", "mujoco-mjx", "brax", "jax-cosmo", "numpy")}
+    np.savez_compressed(args.out, versions=np.array(repr(versions)), qpos=np.asarray(ps0.qpos), qvel=np.asarray(ps0.qvel),
                         qacc_warmstart=np.asarray(ps0.qacc_warmstart), eps=eps, noise_scale=sigma, Ybar_in=Ybar,
                         us=np.asarray(us), rewss=np.asarray(rewss), qss=np.asarray(ps.q), qdss=np.asarray(ps.qd),
                         xss=np.asarray(ps.x.pos), Ybar=np.asarray(Ybar_out), rews=np.asarray(info["rews"]),
