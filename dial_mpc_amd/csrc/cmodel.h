@@ -88,7 +88,7 @@ struct CModel {
   using D = D_;
   // ---- scalars
   int32_t nq, nv, nu, nbody, njnt, ngeom, nsite, ncon, nlim, nefc;
-  int32_t iterations, ls_iterations, nlevel, ntri;
+  int32_t iterations, ls_iterations, ls_rule, nlevel, ntri;
   float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   // ---- bodies
   int32_t body_parent[D::NB], body_jntadr[D::NB], body_jntnum[D::NB], body_dofadr[D::NB], body_dofnum[D::NB];

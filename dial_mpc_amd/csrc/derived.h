@@ -133,7 +133,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   for (size_t i = 0; i < sizeof(o); i++) ((char*)c)[i] = 0;
   o.nq = m->nq; o.nv = m->nv; o.nu = m->nu; o.nbody = m->nbody; o.njnt = m->njnt; o.ngeom = m->ngeom;
   o.nsite = m->nsite; o.ncon = m->ncon; o.nlim = m->nlim; o.nefc = m->nefc;
-  o.iterations = m->iterations; o.ls_iterations = m->ls_iterations; o.nlevel = dv->nlevel; o.ntri = dv->ntri;
+  o.iterations = m->iterations; o.ls_iterations = m->ls_iterations; o.ls_rule = m->ls_rule; o.nlevel = dv->nlevel; o.ntri = dv->ntri;
   o.timestep = m->timestep; o.tolerance = m->tolerance; o.ls_tolerance = m->ls_tolerance;
   o.impratio = m->impratio; o.meaninertia = m->meaninertia;
   for (int k = 0; k < 3; k++) o.gravity[k] = m->gravity[k];

@@ -13,6 +13,7 @@
 #define DM_FLOOR(x) std::floor(x)
 #define DM_EXP(x) std::exp(x)
 #define DM_RINT(x) std::nearbyint(x)
+#define DM_FMA(a, b, c) std::fma((float)(a), (float)(b), (float)(c))
 #else
 #define DM_SQRT(x) sqrtf(x)
 #define DM_SIN(x) sinf(x)
@@ -22,6 +23,7 @@
 #define DM_FLOOR(x) floorf(x)
 #define DM_EXP(x) expf(x)
 #define DM_RINT(x) rintf(x)
+#define DM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #endif
 
 namespace dm {

@@ -768,7 +768,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       LsPoint p;
       p.alpha = alpha;
       p.cost = alpha * alpha * q2 + alpha * q1 + q0;
-      p.d0 = 2.f * alpha * q2 + q1;
+      // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
+      // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
+      // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
+      p.d0 = DM_FMA(2.f * alpha, q2, q1);
       p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
       return p;
     };
@@ -783,15 +786,37 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
       LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
       LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
-      bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-      if (swap_lo_next) lo = lo_next;
-      bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-      if (swap_lo_mid) lo = mid;
-      bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-      if (swap_hi_next) hi = hi_next;
-      bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-      if (swap_hi_mid) hi = mid;
-      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      // MJX `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer to it;
+      // each end is offered its own Newton step, the mid-point and the other end's Newton step
+      const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
+        return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
+      };
+      if (m->ls_rule == DIAL_LS_SWAP) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
+        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+        if (swap_lo_next) lo = lo_next;
+        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+        if (swap_lo_mid) lo = mid;
+        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+        if (swap_hi_next) hi = hi_next;
+        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+        if (swap_hi_mid) hi = mid;
+        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+        ls_iter++;
+        continue;
+      }
+      const bool s1 = in_bracket(lo, lo_next);
+      if (s1) lo = lo_next;
+      const bool s2 = in_bracket(lo, mid);
+      if (s2) lo = mid;
+      const bool s3 = in_bracket(lo, hi_next);
+      if (s3) lo = hi_next;
+      const bool s4 = in_bracket(hi, hi_next);
+      if (s4) hi = hi_next;
+      const bool s5 = in_bracket(hi, mid);
+      if (s5) hi = mid;
+      const bool s6 = in_bracket(hi, lo_next);
+      if (s6) hi = lo_next;
+      swap = s1 || s2 || s3 || s4 || s5 || s6;
       ls_iter++;
     }
     const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);

@@ -400,7 +400,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       w.row16_sum3(s0, s1v, s2v);
       const vfloat q0 = s0 + vsplat(qg0), q1 = s1v + vsplat(qg1), q2 = s2v + vsplat(qg2);
       const vfloat vcost = (va * va) * q2 + va * q1 + q0;
-      const vfloat vd0 = (va * 2.f) * q2 + q1;
+      const vfloat vd0 = vfma(va * 2.f, q2, q1);   // single rounding: see the line search of rollout_body.h
       const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
       p0_.alpha = a0; p0_.cost = bcast(vcost, 0); p0_.d0 = bcast(vd0, 0); p0_.d1 = bcast(vd1, 0);
       p1_.alpha = a1; p1_.cost = bcast(vcost, 16); p1_.d0 = bcast(vd0, 16); p1_.d1 = bcast(vd1, 16);
@@ -421,15 +421,37 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       if (ls_done) break;
       LsPoint lo_next, hi_next, mid;
       ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
-      const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-      if (swap_lo_next) lo = lo_next;
-      const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-      if (swap_lo_mid) lo = mid;
-      const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-      if (swap_hi_next) hi = hi_next;
-      const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-      if (swap_hi_mid) hi = mid;
-      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      // MJX `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer to it;
+      // each end is offered its own Newton step, the mid-point and the other end's Newton step
+      const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
+        return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
+      };
+      if (m->ls_rule == DIAL_LS_SWAP) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
+        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+        if (swap_lo_next) lo = lo_next;
+        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+        if (swap_lo_mid) lo = mid;
+        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+        if (swap_hi_next) hi = hi_next;
+        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+        if (swap_hi_mid) hi = mid;
+        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+        ls_iter++;
+        continue;
+      }
+      const bool s1 = in_bracket(lo, lo_next);
+      if (s1) lo = lo_next;
+      const bool s2 = in_bracket(lo, mid);
+      if (s2) lo = mid;
+      const bool s3 = in_bracket(lo, hi_next);
+      if (s3) lo = hi_next;
+      const bool s4 = in_bracket(hi, hi_next);
+      if (s4) hi = hi_next;
+      const bool s5 = in_bracket(hi, mid);
+      if (s5) hi = mid;
+      const bool s6 = in_bracket(hi, lo_next);
+      if (s6) hi = lo_next;
+      swap = s1 || s2 || s3 || s4 || s5 || s6;
       ls_iter++;
     }
     const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);

@@ -46,6 +46,7 @@ inline vfloat operator+(const vfloat& a, const vfloat& b) { vfloat r; for (int l
 inline vfloat operator-(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] - b.x[l]; return r; }
 inline vfloat operator*(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b.x[l]; return r; }
 inline vfloat operator*(const vfloat& a, float b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] * b; return r; }
+inline vfloat vfma(const vfloat& a, const vfloat& b, const vfloat& c) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = std::fma(a.x[l], b.x[l], c.x[l]); return r; }
 inline vfloat vsel(const vbool& c, const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = c.x[l] ? a.x[l] : b.x[l]; return r; }
 inline vbool vlt0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] < 0.f; return r; }
 inline vbool veq0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] == 0.f; return r; }
@@ -187,6 +188,7 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 using vfloat = float;
 using vbool = bool;
 __device__ __forceinline__ vfloat vsplat(float v) { return v; }
+__device__ __forceinline__ vfloat vfma(vfloat a, vfloat b, vfloat c) { return __builtin_fmaf(a, b, c); }   // single rounding
 __device__ __forceinline__ vfloat vsel(vbool c, vfloat a, vfloat b) { return c ? a : b; }
 __device__ __forceinline__ vbool vlt0(vfloat a) { return a < 0.f; }
 __device__ __forceinline__ vbool veq0(vfloat a) { return a == 0.f; }

@@ -4,6 +4,7 @@ from typing import Any, Callable, Dict
 
 from dial_mpc_amd.envs.unitree_go2_env import (
     UnitreeGo2Env, UnitreeGo2EnvConfig, UnitreeGo2SeqJumpEnv, UnitreeGo2SeqJumpEnvConfig)
+from dial_mpc_amd.envs.manipulation import AllegroReorientEnv, AllegroReorientEnvConfig
 from dial_mpc_amd.envs.unitree_h1_env import (
     UnitreeH1LocoEnv, UnitreeH1LocoEnvConfig, UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig)
 
@@ -12,6 +13,7 @@ _configs: Dict[str, Any] = {
     "unitree_h1_loco": UnitreeH1LocoEnvConfig,
     "unitree_go2_walk": UnitreeGo2EnvConfig,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnvConfig,
+    "allegro_reorient": AllegroReorientEnvConfig,
 }
 _envs: Dict[str, Callable] = {
     "unitree_h1_walk": UnitreeH1WalkEnv,
@@ -20,9 +22,10 @@ _envs: Dict[str, Callable] = {
     "unitree_h1_loco": UnitreeH1LocoEnv,
     "unitree_go2_walk": UnitreeGo2Env,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
+    "allegro_reorient": AllegroReorientEnv,
 }
 # reference envs that are NEXT rows and not built yet
-_NOT_BUILT = ("unitree_h1_push_crate", "unitree_go2_crate_climb", "allegro_reorient")
+_NOT_BUILT = ("unitree_h1_push_crate", "unitree_go2_crate_climb")
 
 
 def register_config(name: str, config: Any):

@@ -6,8 +6,9 @@ not a dependency here, so this module implements the subset of the MJCF compiler
 needs: ``<include>``, nested ``<default>`` classes / ``childclass``,
 ``<compiler angle autolimits>``, ``<option>`` + ``<flag>``, bodies / inertials / joints (free,
 hinge, slide) / geoms (plane, sphere, capsule incl. ``fromto``) / sites / actuators (motor,
-position) / keyframes / ``<contact><exclude>``, the static contact list with MuJoCo's parameter
-mixing rules, and the quantities MuJoCo derives at ``qpos0``: ``body_invweight0``,
+position) / keyframes / ``<contact><exclude>``, the static contact list (plane-sphere, plane-capsule,
+sphere-capsule, capsule-capsule) with MuJoCo's parameter mixing rules (priority, condim, solmix,
+friction), pyramidal and elliptic cones, and the quantities MuJoCo derives at ``qpos0``: ``body_invweight0``,
 ``dof_invweight0`` and ``stat.meaninertia``.
 
 Everything is fp64 NumPy on the host; the result is a dict whose keys are the field names of
@@ -25,7 +26,7 @@ import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE = 0, 2, 3
-CON_PLANE_SPHERE, CON_PLANE_CAPSULE_P, CON_PLANE_CAPSULE_N = 0, 1, 2
+CON_PLANE_SPHERE, CON_PLANE_CAPSULE_P, CON_PLANE_CAPSULE_N, CON_SPHERE_CAPSULE, CON_CAPSULE_CAPSULE = 0, 1, 2, 3, 4
 MJ_MINVAL = 1e-15
 
 _GEOM_TYPES = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4,
@@ -390,6 +391,8 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         for g in geoms_all:
             if g["body"] != bi or not (0 <= g["group"] <= 5):
                 continue
+            if g["mass"] is not None and g["mass"] == 0.0:
+                continue                      # e.g. the Allegro collision primitives (`mass="0"`)
             if g["type"] != _GEOM_TYPES["mesh"] or g["mesh"] not in meshes:
                 raise NotImplementedError(
                     f"body {b['name']!r}: inertia-from-geom is only implemented for mesh geoms")
@@ -500,14 +503,28 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
             if (min(b1, b2), max(b1, b2)) in excludes:
                 continue
             pairs.append((k, i) if g1["type"] > g2["type"] else (i, k))
-    # MJX groups contacts by collision function, then condim; within a group geom-pair order.
+    elliptic = opt["cone"] == "elliptic"
+
+    def pair_condim(p):
+        g1, g2 = cgeoms[p[0]], cgeoms[p[1]]
+        if g1["priority"] != g2["priority"]:          # the higher-priority geom decides (mj_contactParam)
+            return (g1 if g1["priority"] > g2["priority"] else g2)["condim"]
+        return max(g1["condim"], g2["condim"])
+
+    # MJX groups contacts by collision function, then condim; within a group geom-pair order.  With elliptic
+    # cones make_constraint emits the rows condim by condim (1, 3, 4, 6): contacts are listed in that order so
+    # that contact order = row order.
     def pair_key(p):
         g1, g2 = cgeoms[p[0]], cgeoms[p[1]]
-        return (g1["type"], g2["type"], max(g1["condim"], g2["condim"]))
+        if elliptic:
+            return (pair_condim(p), g1["type"], g2["type"])
+        return (g1["type"], g2["type"], pair_condim(p))
     pairs.sort(key=pair_key)
+    kinds = {(GEOM_PLANE, GEOM_SPHERE): (CON_PLANE_SPHERE,), (GEOM_PLANE, GEOM_CAPSULE): (CON_PLANE_CAPSULE_P, CON_PLANE_CAPSULE_N),
+             (GEOM_SPHERE, GEOM_CAPSULE): (CON_SPHERE_CAPSULE,), (GEOM_CAPSULE, GEOM_CAPSULE): (CON_CAPSULE_CAPSULE,)}
     for (i1, i2) in pairs:
         g1, g2 = cgeoms[i1], cgeoms[i2]
-        if g1["type"] != GEOM_PLANE or g2["type"] not in (GEOM_SPHERE, GEOM_CAPSULE):
+        if (g1["type"], g2["type"]) not in kinds:
             raise NotImplementedError(
                 f"collision pair type ({g1['type']},{g2['type']}) is not supported")
         if g1["priority"] == g2["priority"]:
@@ -521,19 +538,16 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         else:
             gp = g1 if g1["priority"] > g2["priority"] else g2
             fr, solref, solimp = gp["friction"], gp["solref"], gp["solimp"]
-        condim = max(g1["condim"], g2["condim"])
-        if condim != 3:
-            raise NotImplementedError("only condim 3 (pyramidal) contacts are supported")
+        condim = pair_condim((i1, i2))
+        if condim not in ((3, 6) if elliptic else (3,)):
+            raise NotImplementedError(f"condim {condim} contacts are not supported with the {opt['cone']} cone")
         margin = max(g1["margin"], g2["margin"])
         gap = max(g1["gap"], g2["gap"])
         base = dict(geom1=i1, geom2=i2, body1=g1["body"], body2=g2["body"], dim=condim,
                     friction=np.array([fr[0], fr[0], fr[1], fr[2], fr[2]]), solref=solref,
                     solimp=solimp, margin=margin - gap)
-        if g2["type"] == GEOM_SPHERE:
-            contacts.append(dict(base, kind=CON_PLANE_SPHERE))
-        else:
-            contacts.append(dict(base, kind=CON_PLANE_CAPSULE_P))
-            contacts.append(dict(base, kind=CON_PLANE_CAPSULE_N))
+        for kind in kinds[(g1["type"], g2["type"])]:
+            contacts.append(dict(base, kind=kind))
 
     lim_jnt = [ji for ji, j in enumerate(joints) if j["limited"]]
 
@@ -565,10 +579,15 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
 
     m: Dict[str, Any] = dict(
         nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ngeom=len(cgeoms), nsite=len(sites),
-        ncon=len(contacts), nlim=len(lim_jnt), nefc=len(lim_jnt) + 4 * len(contacts),
+        ncon=len(contacts), nlim=len(lim_jnt),
+        nefc=len(lim_jnt) + (sum(c["dim"] for c in contacts) if elliptic else 4 * len(contacts)),
         iterations=int(opt["iterations"]), ls_iterations=int(opt["ls_iterations"]),
         eulerdamp=0 if flags.get("eulerdamp", "enable") == "disable" else 1,
         cone=0 if opt["cone"] == "pyramidal" else 1,
+        # line-search bracket rule (include/dial_mpc.h): elliptic cones need an MJX release with `_in_bracket`
+        # (the older rule cycles on the cone cost); pyramidal models default to the older rule, which every MJX >= 3.0
+        # that can run them had at some point and under which the truncated solve is well-conditioned
+        ls_rule=1 if opt["cone"] == "elliptic" else 0,
         timestep=float(opt["timestep"]), gravity=_floats(str(opt["gravity"])),
         tolerance=float(opt["tolerance"]), ls_tolerance=float(opt["ls_tolerance"]),
         impratio=float(opt["impratio"]), meaninertia=0.0,

@@ -17,7 +17,8 @@
  *   dial_shift          <- MBDPI.shift                dial_mpc/core/dial_core.py:160-166
  *   dial_env_step       <- BaseEnv/<Env>.step         dial_mpc/envs/unitree_go2_env.py:126-261,
  *                                                     :403-521, dial_mpc/envs/unitree_h1_env.py:181-321,
- *                                                     :696-858 (H1 loco)
+ *                                                     :696-858 (H1 loco), dial_mpc/envs/manipulation.py:63-115
+ *                                                     (Allegro in-hand reorientation + its act2joint override)
  *   dial_env_reset      <- <Env>.reset + pipeline_init  dial_mpc/envs/unitree_go2_env.py:101-124
  *   dial_model          <- brax System / mujoco MjModel built by BaseEnv.make_system
  *                                                     dial_mpc/envs/base_env.py:15-29
@@ -47,7 +48,8 @@ extern "C" {
 #define DIAL_MAX_U 20      /* H1 walk: 19                                        */
 #define DIAL_MAX_GEOM 8    /* collision geoms only                               */
 #define DIAL_MAX_SITE 8
-#define DIAL_MAX_CON 8     /* static contact list (Go2: 4, H1 walk: 4)           */
+#define DIAL_MAX_CON 24    /* static contact list (Go2: 4, H1 walk: 4, Allegro: 19) */
+#define DIAL_MAX_EFC 160   /* constraint rows: limits + 4 per pyramidal / condim per elliptic contact (Allegro: 88) */
 #define DIAL_MAX_LIM 24    /* limited hinge joints                               */
 #define DIAL_MAX_FEET 4
 #define DIAL_MAX_STAGE 12  /* seq-jump stages                                    */
@@ -70,12 +72,28 @@ extern "C" {
 #define DIAL_CON_PLANE_SPHERE 0
 #define DIAL_CON_PLANE_CAPSULE_P 1 /* capsule end  +axis*halflen */
 #define DIAL_CON_PLANE_CAPSULE_N 2 /* capsule end  -axis*halflen */
+#define DIAL_CON_SPHERE_CAPSULE 3  /* geom1 sphere, geom2 capsule (MJX sphere_capsule)        */
+#define DIAL_CON_CAPSULE_CAPSULE 4 /* MJX capsule_capsule: closest points of the two segments */
+
+/* bracket-update rule of the Newton solver's line search (solver._linesearch of MJX).  The reference pins no MJX
+ * version (setup.py:9-21); its Allegro env needs elliptic cones, i.e. a release that carries the `_in_bracket`
+ * rule, so that rule is the default for every model.  The older rule is kept selectable because it is
+ * well-conditioned under truncation (ls_iterations = 5): with it GPU and oracle can be compared rollout by rollout
+ * at the envs' real solver settings (tests), whereas `_in_bracket` rejects zero-slope candidates and turns rounding
+ * noise into different iterates.                                                                                  */
+#define DIAL_LS_SWAP 0        /* MJX <= 3.1.3: swap_lo_next / swap_lo_mid / swap_hi_next / swap_hi_mid            */
+#define DIAL_LS_IN_BRACKET 1  /* MJX >= 3.1.4: _in_bracket(x, y), each end offered lo_next, mid, hi_next          */
+
+/* friction cone (mjtCone) */
+#define DIAL_CONE_PYRAMIDAL 0
+#define DIAL_CONE_ELLIPTIC 1
 
 /* task kinds */
 #define DIAL_TASK_GO2_WALK 0
 #define DIAL_TASK_GO2_SEQ_JUMP 1
 #define DIAL_TASK_H1_WALK 2
 #define DIAL_TASK_H1_LOCO 3
+#define DIAL_TASK_ALLEGRO 4
 
 /* packed-state info slots (floats; integers are stored as exactly representable floats) */
 #define DIAL_INFO_STEP 0
@@ -113,6 +131,7 @@ typedef struct dial_model {
   int32_t ls_iterations;
   int32_t eulerdamp;
   int32_t cone;
+  int32_t ls_rule;
   float timestep;
   float gravity[3];
   float tolerance;
@@ -198,7 +217,8 @@ typedef struct dial_task {
   float joint_range[DIAL_MAX_U][2];
   float phys_range[DIAL_MAX_U][2];
   float tau_range[DIAL_MAX_U][2];
-  float foot_radius;
+  float foot_radius;           /* joint_offset (below): added to the joint target before the clip -- the keyframe pose
+                                  init_q[7:] of AllegroReorientEnv.act2joint (manipulation.py:107-109), 0 elsewhere */
   float gait_duty;
   float gait_cadence;
   float gait_amp;
@@ -213,6 +233,8 @@ typedef struct dial_task {
   float pose_targets[DIAL_MAX_STAGE][3];
   float yaw_targets[DIAL_MAX_STAGE];
   float init_pos_tar[3];
+  float init_ang_vel_tar[3];
+  float joint_offset[DIAL_MAX_U];
 } dial_task;
 
 /* Planner configuration: DialConfig + the constant spline matrices

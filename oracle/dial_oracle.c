@@ -5,7 +5,8 @@
  *   planner   : dial_mpc/core/dial_core.py:36-48,103-145,160-166   (reverse_once, rollout_us, shift)
  *   control   : dial_mpc/envs/base_env.py:38-66                     (act2joint, act2tau)
  *   env.step  : dial_mpc/envs/unitree_go2_env.py:126-261 (walk), :403-521 (seq_jump),
- *               dial_mpc/envs/unitree_h1_env.py:181-321 (H1 walk), :696-858 (H1 loco)
+ *               dial_mpc/envs/unitree_h1_env.py:181-321 (H1 walk), :696-858 (H1 loco),
+ *               dial_mpc/envs/manipulation.py:63-115 (Allegro reorient + act2joint override)
  *   helpers   : dial_mpc/utils/function_utils.py:7-43               (inv_rotate, get_foot_step)
  *   x / xd    : dial_mpc/deploy/dial_plan.py:45-61                  (the reference's own copy of
  *               brax.mjx.pipeline's derivation of x, xd from mjx.Data)
@@ -43,7 +44,7 @@ typedef REAL real;
 #define NG DIAL_MAX_GEOM
 #define NS DIAL_MAX_SITE
 #define NC DIAL_MAX_CON
-#define NE (DIAL_MAX_LIM + 4 * DIAL_MAX_CON)
+#define NE DIAL_MAX_EFC
 
 #define MJ_MINVAL ((real)1e-15)
 #define MJ_MINIMP ((real)0.0001)
@@ -61,6 +62,7 @@ static inline real r_min(real a, real b) { return a < b ? a : b; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 static inline real r_clip(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static inline real r_floor(real x) { return (real)floor((double)x); }
+static inline real r_fma(real a, real b, real c) { return sizeof(real) == 4 ? (real)fmaf((float)a, (float)b, (float)c) : (real)fma((double)a, (double)b, (double)c); }
 
 /* ------------------------------------------------------------------ per-sample data (mjx.Data) */
 typedef struct {
@@ -341,9 +343,60 @@ static void make_frame(real* frame, const real* a_in) {
   cross3(c, a, b);
   for (int k = 0; k < 3; k++) { frame[k] = a[k]; frame[3 + k] = b[k]; frame[6 + k] = c[k]; }
 }
+/* math.closest_segment_point (MJX): point on segment [a, b] closest to pt */
+static void closest_segment_point(real* o, const real* a, const real* b, const real* pt) {
+  real ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+  real t = dot3(pa, ab) / (dot3(ab, ab) + (real)1e-6);
+  t = r_clip(t, 0, 1);
+  for (int k = 0; k < 3; k++) o[k] = a[k] + t * ab[k];
+}
+/* math.closest_segment_to_segment_points (MJX) */
+static void closest_segment_to_segment(real* best_a, real* best_b, const real* a0, const real* a1, const real* b0, const real* b1) {
+  real da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+  real len_a = r_sqrt(dot3(da, da)), len_b = r_sqrt(dot3(db, db));
+  for (int k = 0; k < 3; k++) { da[k] = len_a > 0 ? da[k] / len_a : 0; db[k] = len_b > 0 ? db[k] / len_b : 0; }
+  real half_a = len_a * (real)0.5, half_b = len_b * (real)0.5, a_mid[3], b_mid[3], trans[3];
+  for (int k = 0; k < 3; k++) { a_mid[k] = a0[k] + da[k] * half_a; b_mid[k] = b0[k] + db[k] * half_b; trans[k] = a_mid[k] - b_mid[k]; }
+  real dadb = dot3(da, db), dat = dot3(da, trans), dbt = dot3(db, trans);
+  real denom = 1 - dadb * dadb;
+  real orig_ta = (-dat + dadb * dbt) / (denom + (real)1e-6);
+  real orig_tb = dbt + orig_ta * dadb;
+  real ta = r_clip(orig_ta, -half_a, half_a), tb = r_clip(orig_tb, -half_b, half_b);
+  real ba[3], bb[3], na[3], nb[3];
+  for (int k = 0; k < 3; k++) { ba[k] = a_mid[k] + da[k] * ta; bb[k] = b_mid[k] + db[k] * tb; }
+  closest_segment_point(na, a0, a1, bb);
+  closest_segment_point(nb, b0, b1, ba);
+  real e1[3] = {na[0] - bb[0], na[1] - bb[1], na[2] - bb[2]}, e2[3] = {nb[0] - ba[0], nb[1] - ba[1], nb[2] - ba[2]};
+  real d1 = dot3(e1, e1), d2 = dot3(e2, e2);
+  for (int k = 0; k < 3; k++) { best_a[k] = d1 < d2 ? na[k] : ba[k]; best_b[k] = d1 < d2 ? bb[k] : nb[k]; }
+}
+/* collision_primitive._sphere_sphere (MJX): the contact of two spheres, shared by sphere-capsule / capsule-capsule */
+static void sphere_sphere(const real* p1, real r1, const real* p2, real r2, real* dist, real* pos, real* frame) {
+  real n[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, len = r_sqrt(dot3(n, n));
+  if (len == 0) { n[0] = 1; n[1] = 0; n[2] = 0; }
+  else for (int k = 0; k < 3; k++) n[k] /= len;
+  *dist = len - (r1 + r2);
+  for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + *dist * (real)0.5);
+  make_frame(frame, n);
+}
 static void collision(const dial_model* m, odata* d) {
   for (int c = 0; c < m->ncon; c++) {
     int g1 = m->con_geom1[c], g2 = m->con_geom2[c];
+    if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
+      real ax2[3] = {d->geom_xmat[g2][2], d->geom_xmat[g2][5], d->geom_xmat[g2][8]}, hl2 = m->geom_size[g2][1];
+      real b0[3], b1[3], p1[3], p2[3];
+      for (int k = 0; k < 3; k++) { b0[k] = d->geom_xpos[g2][k] - ax2[k] * hl2; b1[k] = d->geom_xpos[g2][k] + ax2[k] * hl2; }
+      if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE) {
+        for (int k = 0; k < 3; k++) p1[k] = d->geom_xpos[g1][k];
+        closest_segment_point(p2, b0, b1, p1);
+      } else {
+        real ax1[3] = {d->geom_xmat[g1][2], d->geom_xmat[g1][5], d->geom_xmat[g1][8]}, hl1 = m->geom_size[g1][1], a0[3], a1[3];
+        for (int k = 0; k < 3; k++) { a0[k] = d->geom_xpos[g1][k] - ax1[k] * hl1; a1[k] = d->geom_xpos[g1][k] + ax1[k] * hl1; }
+        closest_segment_to_segment(p1, p2, a0, a1, b0, b1);
+      }
+      sphere_sphere(p1, (real)m->geom_size[g1][0], p2, (real)m->geom_size[g2][0], &d->con_dist[c], d->con_pos[c], d->con_frame[c]);
+      continue;
+    }
     real n[3] = {d->geom_xmat[g1][2], d->geom_xmat[g1][5], d->geom_xmat[g1][8]};
     real ctr[3] = {d->geom_xpos[g2][0], d->geom_xpos[g2][1], d->geom_xpos[g2][2]};
     real radius = m->geom_size[g2][0];
@@ -406,6 +459,18 @@ static void jacp_col(const dial_model* m, const odata* d, int body, const real* 
   cross3(cr, d->cdof[i], off);
   for (int k = 0; k < 3; k++) out[k] = d->cdof[i][3 + k] + cr[k];
 }
+/* support.jac: rotational Jacobian column i of `body` */
+static void jacr_col(const dial_model* m, const odata* d, int body, int i, real* out) {
+  out[0] = out[1] = out[2] = 0;
+  int b = body, db = m->dof_bodyid[i];
+  while (b > 0) { if (b == db) { for (int k = 0; k < 3; k++) out[k] = d->cdof[i][k]; return; } b = m->body_parent[b]; }
+}
+/* first constraint row of contact c: limits, then 4 pyramid edges (pyramidal) or condim rows (elliptic) per contact */
+static int efc_adr(const dial_model* m, int c) {
+  int r = m->nlim;
+  for (int k = 0; k < c; k++) r += m->cone == DIAL_CONE_ELLIPTIC ? m->con_dim[k] : 4;
+  return r;
+}
 static void make_constraint(const dial_model* m, odata* d) {
   int nv = m->nv, r = 0;
   /* limits (constraint._instantiate_limit_slide_hinge) */
@@ -429,6 +494,43 @@ static void make_constraint(const dial_model* m, odata* d) {
     real vel = sgn * d->qvel[da];
     d->efc_aref[r] = -b_ * vel - k_ * imp * pos;
     d->efc_D[r] = 1 / R;
+  }
+  /* elliptic contacts (constraint._efc_contact_elliptic): condim rows per contact = normal, 2 tangents, torsion,
+   * 2 rolling; R of the friction rows follows from the normal row (impratio, friction ratios); the friction rows'
+   * reference acceleration has no position term (pos_aref = 0) */
+  if (m->cone == DIAL_CONE_ELLIPTIC) {
+    for (int c = 0; c < m->ncon; c++) {
+      real pos = d->con_dist[c] - (real)m->con_margin[c];
+      int on = pos < 0, dim = m->con_dim[c];
+      int b1 = m->con_body1[c], b2 = m->con_body2[c];
+      real t = (real)m->body_invweight0[b1][0] + (real)m->body_invweight0[b2][0];
+      real f0 = m->con_friction[c][0];
+      real invw[6];
+      invw[0] = t;
+      invw[1] = t / (real)m->impratio;
+      for (int j = 2; j < dim; j++) { real fj = m->con_friction[c][j - 1]; invw[j] = invw[1] * (f0 * f0) / (fj * fj); }
+      real solref[2] = {m->con_solref[c][0], m->con_solref[c][1]}, solimp[5];
+      for (int k = 0; k < 5; k++) solimp[k] = m->con_solimp[c][k];
+      real k_, b_, imp;
+      kbi(m, solref, solimp, pos, &k_, &b_, &imp);
+      for (int j = 0; j < dim; j++, r++) {
+        real vel = 0;
+        for (int i = 0; i < nv; i++) {
+          real c1[3], c2[3], diff[3];
+          if (j < 3) { jacp_col(m, d, b1, d->con_pos[c], i, c1); jacp_col(m, d, b2, d->con_pos[c], i, c2); }
+          else { jacr_col(m, d, b1, i, c1); jacr_col(m, d, b2, i, c2); }
+          for (int k = 0; k < 3; k++) diff[k] = c2[k] - c1[k];
+          real jv_ = on ? dot3(d->con_frame[c] + 3 * (j % 3), diff) : 0;
+          d->efc_J[r][i] = jv_;
+          vel += jv_ * d->qvel[i];
+        }
+        real R = r_max(invw[j] * (1 - imp) / imp, MJ_MINVAL);
+        d->efc_on[r] = on;
+        d->efc_aref[r] = on ? -b_ * vel - k_ * imp * (j == 0 ? pos : 0) : 0;
+        d->efc_D[r] = on ? 1 / R : 0;
+      }
+    }
+    return;
   }
   /* pyramidal contacts (constraint._instantiate_contact) */
   for (int c = 0; c < m->ncon; c++) {
@@ -521,6 +623,9 @@ typedef struct {
   real qacc[NV], Ma[NV], Jaref[NE], grad[NV], Mgrad[NV], search[NV], qfrc_constraint[NV], efc_force[NE];
   int active[NE];
   real gauss, cost, prev_cost;
+  /* elliptic cones: per contact zone (0 top, 1 middle, 2 bottom) and the middle-zone quantities */
+  int zone[NC];
+  real cU[NC][6], cN[NC], cT[NC], cDm[NC], cmu[NC];
 } sctx;
 
 static void mul_m(const dial_model* m, const odata* d, const real* v, real* out) {
@@ -530,8 +635,63 @@ static void mul_m(const dial_model* m, const odata* d, const real* v, real* out)
     out[i] = s;
   }
 }
+/* solver._update_constraint for elliptic cones: zone of every contact, forces, cost of the constraint part */
+static real update_constraint_elliptic(const dial_model* m, const odata* d, sctx* c) {
+  real cost = 0;
+  for (int r = 0; r < m->nlim; r++) {
+    c->active[r] = c->Jaref[r] < 0;
+    c->efc_force[r] = d->efc_D[r] * -c->Jaref[r] * (c->active[r] ? 1 : 0);
+    cost += (real)0.5 * d->efc_D[r] * c->Jaref[r] * c->Jaref[r] * (c->active[r] ? 1 : 0);
+  }
+  int r0 = m->nlim;
+  for (int k = 0; k < m->ncon; k++) {
+    int dim = m->con_dim[k];
+    real mu = (real)m->con_friction[k][0] / r_sqrt((real)m->impratio);
+    real U[6], tsqr = 0;
+    U[0] = c->Jaref[r0] * mu;
+    for (int j = 1; j < dim; j++) { U[j] = c->Jaref[r0 + j] * (real)m->con_friction[k][j - 1]; tsqr += U[j] * U[j]; }
+    real N = U[0], T = r_sqrt(tsqr);
+    int bottom = (tsqr <= 0 && N < 0) || (tsqr > 0 && mu * N + T <= 0);
+    int middle = tsqr > 0 && N < mu * T && mu * N + T > 0;
+    c->zone[k] = bottom ? 2 : (middle ? 1 : 0);
+    c->cmu[k] = mu; c->cN[k] = N; c->cT[k] = T;
+    for (int j = 0; j < 6; j++) c->cU[k][j] = j < dim ? U[j] : 0;
+    real Dm = d->efc_D[r0] / r_max(mu * mu * (1 + mu * mu), MJ_MINVAL);
+    c->cDm[k] = Dm;
+    for (int j = 0; j < dim; j++) { c->active[r0 + j] = bottom; c->efc_force[r0 + j] = 0; }
+    if (bottom) {
+      for (int j = 0; j < dim; j++) {
+        c->efc_force[r0 + j] = -d->efc_D[r0 + j] * c->Jaref[r0 + j];
+        cost += (real)0.5 * d->efc_D[r0 + j] * c->Jaref[r0 + j] * c->Jaref[r0 + j];
+      }
+    } else if (middle) {
+      real nmt = N - mu * T;
+      cost += (real)0.5 * Dm * nmt * nmt;
+      real fn = -Dm * nmt * mu;
+      c->efc_force[r0] = fn;
+      for (int j = 1; j < dim; j++) c->efc_force[r0 + j] = -fn / T * U[j] * (real)m->con_friction[k][j - 1];
+    }
+    r0 += dim;
+  }
+  return cost;
+}
 static void update_constraint(const dial_model* m, const odata* d, sctx* c) {
   int nv = m->nv, ne = m->nefc;
+  if (m->cone == DIAL_CONE_ELLIPTIC) {
+    real ccost = update_constraint_elliptic(m, d, c);
+    for (int i = 0; i < nv; i++) {
+      real s = 0;
+      for (int r = 0; r < ne; r++) s += d->efc_J[r][i] * c->efc_force[r];
+      c->qfrc_constraint[i] = s;
+    }
+    real gauss = 0;
+    for (int i = 0; i < nv; i++) gauss += (c->Ma[i] - d->qfrc_smooth[i]) * (c->qacc[i] - d->qacc_smooth[i]);
+    gauss *= (real)0.5;
+    c->gauss = gauss;
+    c->prev_cost = c->cost;
+    c->cost = ccost + gauss;
+    return;
+  }
   for (int r = 0; r < ne; r++) {
     c->active[r] = c->Jaref[r] < 0;
     c->efc_force[r] = d->efc_D[r] * -c->Jaref[r] * (c->active[r] ? 1 : 0);
@@ -561,6 +721,40 @@ static void update_gradient(const dial_model* m, const odata* d, sctx* c) {
       for (int r = 0; r < ne; r++) if (c->active[r]) s += d->efc_J[r][i] * d->efc_D[r] * d->efc_J[r][j];
       H[i][j] = d->qM[i][j] + s;
     }
+  if (m->cone == DIAL_CONE_ELLIPTIC) {
+    /* cone Hessian of the middle-zone contacts: H += J_c^T Hc J_c,
+     * Hc = Dm diag(mu, f) [[1, -mu U^T / T], [-mu U / T, mu N / T^3 U U^T + (mu^2 - mu N / T) I]] diag(mu, f) */
+    int r0 = m->nlim;
+    for (int k = 0; k < m->ncon; k++) {
+      int dim = m->con_dim[k];
+      if (c->zone[k] == 1) {
+        real mu = c->cmu[k], N = c->cN[k], T = r_max(c->cT[k], MJ_MINVAL), TTT = r_max(T * T * T, MJ_MINVAL), Dm = c->cDm[k];
+        real Hc[6][6], fri[6];
+        fri[0] = mu;
+        for (int a = 1; a < dim; a++) fri[a] = (real)m->con_friction[k][a - 1];
+        for (int a = 0; a < dim; a++)
+          for (int b = 0; b < dim; b++) {
+            real v;
+            if (a == 0 && b == 0) v = 1;
+            else if (a == 0) v = -mu / T * c->cU[k][b];
+            else if (b == 0) v = -mu / T * c->cU[k][a];
+            else v = mu * N / TTT * c->cU[k][a] * c->cU[k][b] + (a == b ? mu * mu - mu * N / T : 0);
+            Hc[a][b] = v * Dm * fri[a] * fri[b];
+          }
+        for (int i = 0; i < nv; i++)
+          for (int j = 0; j < nv; j++) {
+            real s = 0;
+            for (int a = 0; a < dim; a++) {
+              real t = 0;
+              for (int b = 0; b < dim; b++) t += Hc[a][b] * d->efc_J[r0 + b][j];
+              s += d->efc_J[r0 + a][i] * t;
+            }
+            H[i][j] += s;
+          }
+      }
+      r0 += dim;
+    }
+  }
   cholesky(nv, H, L);
   cho_solve(nv, L, c->grad, c->Mgrad);
 }
@@ -591,8 +785,46 @@ static lspoint ls_point(int ne, const sctx* c, real alpha, const real* jv, real 
   lspoint p;
   p.alpha = alpha;
   p.cost = alpha * alpha * qt[2] + alpha * qt[1] + qt[0];
-  p.deriv_0 = 2 * alpha * qt[2] + qt[1];
+  /* The slope is evaluated with ONE rounding (fused multiply-add), as XLA does on the reference's platform.  With two
+   * roundings (this file is compiled -ffp-contract=off) the slope at a Newton point alpha = -q1 / (2 q2) evaluates to
+   * exactly 0 about half of the time; `_in_bracket` rejects a zero-slope candidate and the 5-iteration search falls
+   * back to bisection -- a rounding lottery that a contracting compiler (XLA, hipcc) does not play. */
+  p.deriv_0 = r_fma(2 * alpha, qt[2], qt[1]);
   p.deriv_1 = 2 * qt[2] + (qt[2] == 0 ? MJ_MINVAL : 0);
+  return p;
+}
+/* solver._eval_pt_elliptic: limit rows as usual, contacts by zone at alpha; quad_c = per-contact sum of its rows'
+ * quadratics (bottom zone), cone = (U0, V0, UU, UV, VV, Dm, mu) per contact */
+static lspoint ls_point_elliptic(const dial_model* m, const sctx* c, real alpha, const real* jv, real quad[][3],
+                                 const real* quad_gauss, real quad_c[][3], real cone[][7]) {
+  real qt[3] = {quad_gauss[0], quad_gauss[1], quad_gauss[2]};
+  for (int r = 0; r < m->nlim; r++) {
+    real x = c->Jaref[r] + alpha * jv[r];
+    if (x < 0) { qt[0] += quad[r][0]; qt[1] += quad[r][1]; qt[2] += quad[r][2]; }
+  }
+  real ccost = 0, cd0 = 0, cd1 = 0;
+  for (int k = 0; k < m->ncon; k++) {
+    real u0 = cone[k][0], v0 = cone[k][1], uu = cone[k][2], uv = cone[k][3], vv = cone[k][4], dm = cone[k][5], mu = cone[k][6];
+    real n = u0 + alpha * v0;
+    real tsqr = uu + alpha * (2 * uv + alpha * vv);
+    real t = r_sqrt(tsqr);
+    int bottom = (tsqr <= 0 && n < 0) || (tsqr > 0 && mu * n + t <= 0);
+    int middle = tsqr > 0 && n < mu * t && mu * n + t > 0;
+    if (bottom) { qt[0] += quad_c[k][0]; qt[1] += quad_c[k][1]; qt[2] += quad_c[k][2]; }
+    if (middle) {
+      real n1 = v0, t1 = (uv + alpha * vv) / t, t2 = vv / t - (uv + alpha * vv) * t1 / (t * t);
+      real nmt = n - mu * t;
+      ccost += (real)0.5 * dm * nmt * nmt;
+      cd0 += dm * nmt * (n1 - mu * t1);
+      cd1 += dm * ((n1 - mu * t1) * (n1 - mu * t1) - nmt * mu * t2);
+    }
+  }
+  lspoint p;
+  p.alpha = alpha;
+  p.cost = alpha * alpha * qt[2] + alpha * qt[1] + qt[0] + ccost;
+  p.deriv_0 = r_fma(2 * alpha, qt[2], qt[1]) + cd0;
+  p.deriv_1 = 2 * qt[2] + cd1;
+  if (p.deriv_1 == 0) p.deriv_1 = MJ_MINVAL;
   return p;
 }
 static real vnorm(int n, const real* v) {
@@ -620,9 +852,33 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
     quad[r][1] = jv[r] * c->Jaref[r] * d->efc_D[r];
     quad[r][2] = (real)0.5 * jv[r] * jv[r] * d->efc_D[r];
   }
-  lspoint p0 = ls_point(ne, c, 0, jv, quad, quad_gauss);
-  lspoint lo = ls_point(ne, c, p0.alpha - p0.deriv_0 / p0.deriv_1, jv, quad, quad_gauss), hi;
+  static __thread real quad_c[NC][3], cone[NC][7];
+  const int ell = m->cone == DIAL_CONE_ELLIPTIC;
+  if (ell) {
+    int r0 = m->nlim;
+    for (int k = 0; k < m->ncon; k++) {
+      int dim = m->con_dim[k];
+      real mu = (real)m->con_friction[k][0] / r_sqrt((real)m->impratio);
+      quad_c[k][0] = quad_c[k][1] = quad_c[k][2] = 0;
+      for (int j = 0; j < dim; j++) for (int q = 0; q < 3; q++) quad_c[k][q] += quad[r0 + j][q];
+      real uu = 0, uv = 0, vv = 0;
+      for (int j = 1; j < dim; j++) {
+        real f = (real)m->con_friction[k][j - 1], u = c->Jaref[r0 + j] * f, v = jv[r0 + j] * f;
+        uu += u * u; uv += u * v; vv += v * v;
+      }
+      cone[k][0] = c->Jaref[r0] * mu; cone[k][1] = jv[r0] * mu; cone[k][2] = uu; cone[k][3] = uv; cone[k][4] = vv;
+      cone[k][5] = d->efc_D[r0] / r_max(mu * mu * (1 + mu * mu), MJ_MINVAL); cone[k][6] = mu;
+      r0 += dim;
+    }
+  }
+#define LS_POINT(a) (ell ? ls_point_elliptic(m, c, (a), jv, quad, quad_gauss, quad_c, cone) : ls_point(ne, c, (a), jv, quad, quad_gauss))
+  lspoint p0 = LS_POINT(0);
+  lspoint lo = LS_POINT(p0.alpha - p0.deriv_0 / p0.deriv_1), hi;
   if (lo.deriv_0 < p0.deriv_0) { hi = p0; } else { hi = lo; lo = p0; }
+  /* bracket refinement of current MJX (the release line that supports elliptic cones, which the reference's Allegro
+   * env needs): a candidate y replaces a bracket end x only when it lies on the same side of the minimum and closer
+   * to it (`_in_bracket`); each end is offered its own Newton step, the mid-point and the OTHER end's Newton step. */
+#define IN_BRACKET(x, y) ((((x).deriv_0 < (y).deriv_0) && ((y).deriv_0 < 0)) || (((x).deriv_0 > (y).deriv_0) && ((y).deriv_0 > 0)))
   int swap = 1, ls_iter = 0;
   for (;;) {
     int done = ls_iter >= m->ls_iterations;
@@ -630,20 +886,38 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
     done |= (lo.deriv_0 < 0) && (lo.deriv_0 > -gtol);
     done |= (hi.deriv_0 > 0) && (hi.deriv_0 < gtol);
     if (done) break;
-    lspoint lo_next = ls_point(ne, c, lo.alpha - lo.deriv_0 / lo.deriv_1, jv, quad, quad_gauss);
-    lspoint hi_next = ls_point(ne, c, hi.alpha - hi.deriv_0 / hi.deriv_1, jv, quad, quad_gauss);
-    lspoint mid = ls_point(ne, c, (real)0.5 * (lo.alpha + hi.alpha), jv, quad, quad_gauss);
-    int swap_lo_next = (lo.deriv_0 > 0) || (lo.deriv_0 < lo_next.deriv_0);
-    if (swap_lo_next) lo = lo_next;
-    int swap_lo_mid = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
-    if (swap_lo_mid) lo = mid;
-    int swap_hi_next = (hi.deriv_0 < 0) || (hi.deriv_0 > hi_next.deriv_0);
-    if (swap_hi_next) hi = hi_next;
-    int swap_hi_mid = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
-    if (swap_hi_mid) hi = mid;
-    swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+    lspoint lo_next = LS_POINT(lo.alpha - lo.deriv_0 / lo.deriv_1);
+    lspoint hi_next = LS_POINT(hi.alpha - hi.deriv_0 / hi.deriv_1);
+    lspoint mid = LS_POINT((real)0.5 * (lo.alpha + hi.alpha));
+    if (m->ls_rule == DIAL_LS_SWAP) { /* the rule of MJX <= 3.1.3 */
+      int swap_lo_next = (lo.deriv_0 > 0) || (lo.deriv_0 < lo_next.deriv_0);
+      if (swap_lo_next) lo = lo_next;
+      int swap_lo_mid = (mid.deriv_0 < 0) && (lo.deriv_0 < mid.deriv_0);
+      if (swap_lo_mid) lo = mid;
+      int swap_hi_next = (hi.deriv_0 < 0) || (hi.deriv_0 > hi_next.deriv_0);
+      if (swap_hi_next) hi = hi_next;
+      int swap_hi_mid = (mid.deriv_0 > 0) && (hi.deriv_0 > mid.deriv_0);
+      if (swap_hi_mid) hi = mid;
+      swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      ls_iter++;
+      continue;
+    }
+    int s1 = IN_BRACKET(lo, lo_next);
+    if (s1) lo = lo_next;
+    int s2 = IN_BRACKET(lo, mid);
+    if (s2) lo = mid;
+    int s3 = IN_BRACKET(lo, hi_next);
+    if (s3) lo = hi_next;
+    int s4 = IN_BRACKET(hi, hi_next);
+    if (s4) hi = hi_next;
+    int s5 = IN_BRACKET(hi, mid);
+    if (s5) hi = mid;
+    int s6 = IN_BRACKET(hi, lo_next);
+    if (s6) hi = lo_next;
+    swap = s1 || s2 || s3 || s4 || s5 || s6;
     ls_iter++;
   }
+#undef IN_BRACKET
   int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   if (g_trace) { g_trace[4] += ls_iter; g_trace[5] = (g_trace[5] << 1) | improved; }
@@ -651,6 +925,7 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
     for (int i = 0; i < nv; i++) { c->qacc[i] += c->search[i] * alpha; c->Ma[i] += mv[i] * alpha; }
     for (int r = 0; r < ne; r++) c->Jaref[r] += jv[r] * alpha;
   }
+#undef LS_POINT
 }
 static void solve(const dial_model* m, odata* d) {
   int nv = m->nv;
@@ -759,7 +1034,8 @@ static void euler(const dial_model* m, odata* d) {
 static void act2joint(const dial_model* m, const dial_task* t, const real* act, real* jt) {
   for (int a = 0; a < m->nu; a++) {
     real an = (act[a] * (real)t->action_scale + (real)1.0) / (real)2.0;
-    real v = (real)t->joint_range[a][0] + an * ((real)t->joint_range[a][1] - (real)t->joint_range[a][0]);
+    /* joint_offset: AllegroReorientEnv.act2joint adds the keyframe pose init_q[7:] (manipulation.py:107-109); 0 elsewhere */
+    real v = ((real)t->joint_range[a][0] + (real)t->joint_offset[a]) + an * ((real)t->joint_range[a][1] - (real)t->joint_range[a][0]);
     jt[a] = r_clip(v, (real)t->phys_range[a][0], (real)t->phys_range[a][1]);
   }
 }
@@ -827,6 +1103,21 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
   rotate(vec, up, d->xquat[ub]);
   real reward_upright = -((vec[0] - 0) * (vec[0] - 0) + (vec[1] - 0) * (vec[1] - 0) + (vec[2] - 1) * (vec[2] - 1));
   real yaw = quat_yaw(rot_t);
+  if (t->kind == DIAL_TASK_ALLEGRO) { /* manipulation.py:75-100; torso_x = the object body */
+    real e_ang = 0, e_pos = 0, e_jnt = 0;
+    for (int k = 0; k < 3; k++) {
+      real a = ang[k] * R_PI / (real)180.0 - info[DIAL_INFO_ANG_VEL_TAR + k];
+      real p = d->xpos[tb][k] - info[DIAL_INFO_POS_TAR + k];
+      e_ang += a * a;
+      e_pos += p * p;
+    }
+    for (int a = 0; a < m->nu; a++) { real e = d->qpos[7 + a] - (real)t->joint_offset[a]; e_jnt += e * e; }
+    reward = -e_ang * (real)1.0 + -e_pos * (real)5.0 + -e_jnt * (real)0.1;
+    info[DIAL_INFO_DONE] = step >= 100 ? 1 : 0;
+    info[DIAL_INFO_STEP] = step + 1;
+    info[DIAL_INFO_REWARD] = reward;
+    return reward;
+  }
   if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK || t->kind == DIAL_TASK_H1_LOCO) {
     /* unitree_go2_env.py:142-162 / unitree_h1_env.py:196-217: target ramp uses the PRE-increment step */
     for (int k = 0; k < 3; k++) {
@@ -965,7 +1256,7 @@ int oracle_env_reset(const dial_model* m, const dial_task* t, const real* qpos, 
   for (int i = 0; i < m->nq; i++) d->qpos[i] = qpos[i];
   for (int i = 0; i < m->nv; i++) d->qvel[i] = qvel[i];
   forward(m, d);
-  for (int k = 0; k < 3; k++) info[DIAL_INFO_POS_TAR + k] = t->init_pos_tar[k];
+  for (int k = 0; k < 3; k++) { info[DIAL_INFO_POS_TAR + k] = t->init_pos_tar[k]; info[DIAL_INFO_ANG_VEL_TAR + k] = t->init_ang_vel_tar[k]; }
   store_state(m, d, info, state);
   if (xpos_out) for (int b = 1; b < m->nbody; b++) for (int k = 0; k < 3; k++) xpos_out[(b - 1) * 3 + k] = d->xpos[b][k];
   if (xquat_out) for (int b = 1; b < m->nbody; b++) for (int k = 0; k < 4; k++) xquat_out[(b - 1) * 4 + k] = d->xquat[b][k];

@@ -25,7 +25,7 @@ def test_example_yaml_loads_into_both_dataclasses():
 def test_registry_names_and_errors():
     assert "unitree_go2_trot" in examples and "unitree_go2_trot_deploy" in deploy_examples
     with pytest.raises(NotImplementedError):
-        dial_envs.get_environment("allegro_reorient")
+        dial_envs.get_environment("unitree_go2_crate_climb")
     with pytest.raises(KeyError):
         dial_envs.get_environment("my_custom_jax_env")     # user JAX envs cannot run on the HIP path
 
@@ -122,3 +122,26 @@ def test_randomize_tasks_is_refused():
     d["randomize_tasks"] = True
     with pytest.raises(NotImplementedError):
         load_dial_and_env(d)
+
+
+def test_allegro_task_description_and_act2joint_override():
+    """manipulation.py:45-61,102-115: keyframe pose added before scaling, targets clipped to the joint range; the
+    object is body 1, 4 physics sub-steps per control step, position control."""
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8, 8)
+    assert task.kind == _abi.MACROS["DIAL_TASK_ALLEGRO"] and task.n_frames == 4 and task.position_control == 1
+    assert task.torso_x == 0 and model.nq == 23 and model.nv == 22 and model.nu == 16 and model.nbody == 23
+    assert model.cone == 1 and model.eulerdamp == 1 and model.ncon == 19 and model.nlim == 16 and model.nefc == 88
+    assert abs(model.timestep - 0.005) < 1e-9 and model.iterations == 100 and model.ls_iterations == 50
+    assert np.allclose(_abi.as_numpy(task, "init_ang_vel_tar"), [0, 0, 0.5]) and np.allclose(_abi.as_numpy(task, "init_pos_tar"), [0, 0, 0.13])
+    act = np.linspace(-1.1, 1.1, 16)
+    jr = env.joint_range
+    ref = np.clip(jr[:, 0] + env._init_q[7:] + (act + 1) / 2 * (jr[:, 1] - jr[:, 0]), jr[:, 0], jr[:, 1])
+    assert np.allclose(env.act2joint(act), ref, atol=1e-6)
+    assert np.allclose(_abi.as_numpy(task, "joint_offset")[:16], env._init_q[7:], atol=1e-7)
+    # contact list: 8 plane-capsule + 6 capsule-capsule (condim 3), plane-sphere + 4 sphere-capsule (condim 6, the
+    # object's priority-1 parameters: friction 0.7 / 0.01 / 0.01)
+    dims = _abi.as_numpy(model, "con_dim")[:19]
+    kinds = _abi.as_numpy(model, "con_kind")[:19]
+    assert list(dims) == [3] * 14 + [6] * 5 and list(kinds) == [1, 2] * 4 + [4] * 6 + [0] + [3] * 4
+    fr = _abi.as_numpy(model, "con_friction")[:19]
+    assert np.allclose(fr[14:], [0.7, 0.7, 0.01, 0.01, 0.01]) and np.allclose(fr[:14], [1.0, 1.0, 0.005, 1e-4, 1e-4])

@@ -263,3 +263,146 @@ def test_free_joint_integration_uses_the_quaternion_exponential_of_the_body_rate
     q1 *= np.sign(q1[0]) * np.sign(s1[3])
     assert np.allclose(s1[3:7], q1, atol=1e-9)
     assert np.allclose(s1[7:19], s0[7:19] + dt * v1[6:], atol=1e-12)
+
+
+# ------------------------------------------------------------------ Allegro: elliptic cones, condim 6, Euler damping
+def _allegro_resting_state(o64, env, steps=60):
+    """Hold (approximately) the keyframe pose: the ball comes to rest on three fingertips."""
+    jr = env.joint_range
+    act = 2 * (-jr[:, 0] / (jr[:, 1] - jr[:, 0])) - 1
+    st, _, _ = o64.env_reset(env._init_q, np.zeros(22))
+    for _ in range(steps):
+        st, xp, _, ctrl = o64.env_step(st, act)
+    return st, xp, ctrl, act
+
+
+def _elliptic_cost(md, M, a0, J, D, aref, a):
+    """The documented primal cost with elliptic cones: per contact, top zone 0, bottom zone 1/2 sum D r^2, middle zone
+    1/2 Dm (N - mu T)^2 with U = (mu r_0, f_j r_j), Dm = D_0 / (mu^2 (1 + mu^2)), mu = friction_0 / sqrt(impratio)."""
+    nl, dims, fr, impratio = md["nlim"], md["con_dim"], np.asarray(md["con_friction"]), float(md["impratio"])
+    r = J @ a - aref
+    c = 0.5 * (a - a0) @ M @ (a - a0)
+    rl = np.minimum(r[:nl], 0)
+    c += 0.5 * np.sum(D[:nl] * rl * rl)
+    r0 = nl
+    for k, dim in enumerate(dims):
+        mu = fr[k, 0] / np.sqrt(impratio)
+        U = np.concatenate([[r[r0] * mu], r[r0 + 1:r0 + dim] * fr[k, :dim - 1]])
+        N, T = U[0], np.sqrt(np.sum(U[1:] ** 2))
+        if N >= mu * T or (T <= 0 and N >= 0):
+            pass
+        elif mu * N + T <= 0 or (T <= 0 and N < 0):
+            c += 0.5 * np.sum(D[r0:r0 + dim] * r[r0:r0 + dim] ** 2)
+        else:
+            c += 0.5 * D[r0] / (mu * mu * (1 + mu * mu)) * (N - mu * T) ** 2
+        r0 += dim
+    return c
+
+
+def test_allegro_ball_rests_in_the_hand_and_forces_balance_gravity():
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8, 8)
+    md = env.sys.model
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    st, xp, ctrl, act = _allegro_resting_state(o64, env, 100)
+    # at the task's target height, (nearly) at rest
+    assert abs(xp[0][2] - 0.13) < 2e-3 and np.abs(st[23:26]).max() < 5e-3 and np.abs(st[26:29]).max() < 5e-2
+    d = o64.forward_dump(st[:23], st[23:45], ctrl, st[45:67])
+    assert np.abs(d["qacc"][:6]).max() < 0.2
+    # net contact force on the ball = - gravity force (object dofs 0..2 are world-frame translations)
+    f_ball = (d["efc_J"].T @ d["efc_force"])[:3]
+    assert np.allclose(f_ball, [0, 0, 0.01 * 9.81], atol=2e-3), f_ball
+    active = [c for c in range(19) if d["con_dist"][c] < 0]
+    assert set(active) <= {15, 16, 17, 18} and len(active) >= 3                    # sphere-capsule contacts only
+
+
+def test_allegro_converged_solve_minimises_the_elliptic_primal_cost():
+    from scipy.optimize import minimize
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8, 8)
+    md = env.sys.model
+    t1 = type(task).from_buffer_copy(task)
+    t1.n_frames, t1.dt = 1, 0.005                                 # one physics sub-step per call: states mid-impact
+    o64 = O.Oracle(model, t1, cfg, np.float64)
+    jr = env.joint_range
+    act = 2 * (-jr[:, 0] / (jr[:, 1] - jr[:, 0])) - 1
+    st, _, _ = o64.env_reset(env._init_q, np.zeros(22))
+    checked = 0
+    for k in range(200):
+        st, _, _, ctrl = o64.env_step(st, act + 0.3 * np.sin(0.07 * k + np.arange(16)))
+        if k % 7:
+            continue
+        d = o64.forward_dump(st[:23], st[23:45], ctrl, st[45:67])
+        if not (d["con_dist"] < 0).any():
+            continue
+        M, a0, J, D, aref = d["qM"], d["qacc_smooth"], d["efc_J"], d["efc_D"], d["efc_aref"]
+        cost = lambda a: _elliptic_cost(md, M, a0, J, D, aref, a)   # noqa: E731
+        res = minimize(cost, d["qacc"], method="BFGS", options=dict(gtol=1e-11, maxiter=4000))
+        res2 = minimize(cost, a0, method="BFGS", options=dict(gtol=1e-11, maxiter=4000))
+        best = min(res.fun, res2.fun)
+        assert cost(d["qacc"]) <= best * (1 + 1e-7) + 1e-9, (k, cost(d["qacc"]), best, d["niter"])
+        checked += 1
+    assert checked >= 5
+
+
+def test_allegro_contact_rows_are_relative_point_and_angular_velocities():
+    """condim-6 sphere-capsule contact: rows 0-2 = relative velocity of the two material contact points in the contact
+    frame, rows 3-5 = relative angular velocity (body2 - body1), by finite differences of plain forward kinematics."""
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8, 8)
+    md = env.sys.model
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    st, xp, ctrl, act = _allegro_resting_state(o64, env, 30)
+    q = st[:23].astype(np.float64)
+    d = o64.forward_dump(q, np.zeros(22))
+    k0 = mjcf.host_kinematics(md, q)
+    nl, eps = md["nlim"], 1e-6
+    adr = nl + np.concatenate([[0], np.cumsum(md["con_dim"])[:-1]])
+    rng = np.random.default_rng(2)
+    tested = 0
+    for c in range(14, 19):
+        if d["con_dist"][c] >= 0:
+            continue
+        b1, b2, p = int(md["con_body1"][c]), int(md["con_body2"][c]), d["con_pos"][c]
+        rows = d["efc_J"][adr[c]:adr[c] + 6]
+        loc = [k0["xmat"][b].T @ (p - k0["xpos"][b]) for b in (b1, b2)]
+        for _ in range(3):
+            v = rng.normal(size=22)
+            kp, km = mjcf.host_kinematics(md, _integrate(md, q, v, eps)), mjcf.host_kinematics(md, _integrate(md, q, v, -eps))
+            vel, om = [], []
+            for b, l in zip((b1, b2), loc):
+                vel.append(((kp["xpos"][b] + kp["xmat"][b] @ l) - (km["xpos"][b] + km["xmat"][b] @ l)) / (2 * eps))
+                dR = kp["xmat"][b] @ km["xmat"][b].T
+                om.append(np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / (4 * eps))
+            rel_v, rel_w = vel[1] - vel[0], om[1] - om[0]
+            lin, ang = rows[:3] @ v, rows[3:] @ v
+            # the frame is orthonormal with the normal along (capsule point - sphere centre)
+            assert abs(np.linalg.norm(lin) - np.linalg.norm(rel_v)) < 1e-5 * max(1, np.linalg.norm(rel_v))
+            assert abs(np.linalg.norm(ang) - np.linalg.norm(rel_w)) < 1e-5 * max(1, np.linalg.norm(rel_w))
+            n = p - k0["xpos"][b1]
+            n /= np.linalg.norm(n)
+            assert abs(lin[0] - n @ rel_v) < 1e-5 * max(1, abs(n @ rel_v)) and abs(ang[0] - n @ rel_w) < 1e-5 * max(1, abs(n @ rel_w))
+        tested += 1
+    assert tested >= 2
+
+
+def test_allegro_euler_damping_is_the_implicit_update():
+    """eulerdamp: qvel' = qvel + dt (M + dt B)^-1 (qfrc_smooth + qfrc_constraint); for the undamped free ball it is the
+    plain update, for the damped finger joints it differs from qacc by the documented amount."""
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8, 8)
+    t1 = type(task).from_buffer_copy(task)
+    t1.n_frames, t1.dt = 1, 0.005
+    o64 = O.Oracle(model, t1, cfg, np.float64)
+    st, _, _ = o64.env_reset(env._init_q, np.zeros(22))
+    rng = np.random.default_rng(0)
+    st[23:45] = rng.normal(0, 0.3, 22)
+    ctrl = np.clip(rng.normal(0.5, 0.3, 16), 0.3, 1.0)
+    d = o64.forward_dump(st[:23], st[23:45], ctrl, st[45:67])
+    jr = env.joint_range
+    # reproduce env.step's ctrl with an action, then compare the velocity update
+    act = 2 * ((ctrl - jr[:, 0] - env._init_q[7:]) / (jr[:, 1] - jr[:, 0])) - 1
+    st1, _, _, c1 = o64.env_step(st, act)
+    d = o64.forward_dump(st[:23], st[23:45], c1, st[45:67])
+    dt, B = 0.005, np.diag(np.asarray(env.sys.model["dof_damping"], np.float64))
+    M = d["qM"]
+    qfrc = M @ d["qacc"]                       # = qfrc_smooth + qfrc_constraint at the solver's solution
+    qacc_damped = np.linalg.solve(M + dt * B, qfrc)
+    assert np.allclose(st1[23:45], st[23:45] + dt * qacc_damped, rtol=1e-6, atol=1e-8)
+    assert np.allclose(qacc_damped[:6], d["qacc"][:6], atol=1e-9) and np.abs(qacc_damped[6:] - d["qacc"][6:]).max() > 1e-3

@@ -16,6 +16,7 @@ MODELS = [
     ("unitree_go2", "mjx_scene_force.xml"),
     ("unitree_h1", "mjx_scene_h1_walk.xml"),
     ("unitree_h1", "mjx_scene_h1_loco.xml"),
+    ("wonik_allegro", "scene_left.xml"),
 ]
 
 
