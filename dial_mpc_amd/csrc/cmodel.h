@@ -34,6 +34,11 @@ struct TopoH1 {    // free pelvis, 2 legs of 5, torso (dof 16), 2 arms of 4 hang
   static constexpr ParentTable<25> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5, 16, 17, 18, 19, 16, 21, 22, 23}};
   static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
 };
+struct TopoAllegro {  // free object (0..5) and four independent 4-hinge fingers; the palm is welded to the world
+  static constexpr bool dense = false;
+  static constexpr ParentTable<22> T{{-1, 0, 1, 2, 3, 4, -1, 6, 7, 8, -1, 10, 11, 12, -1, 14, 15, 16, -1, 18, 19, 20}};
+  static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
+};
 struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms are welded to the torso
   static constexpr bool dense = false;
   static constexpr ParentTable<17> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5}};
@@ -44,13 +49,23 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
 // index arithmetic or sparsity masks are needed when rows are fetched into registers), the contact Jacobian as
 // dof-major pyramid rows (J^T[i][4c + e]) and H is assembled from a contact-sparse work list (NHI = its capacity).
 // Costs LDS, so it is opt-in per robot.
+// ELL: elliptic friction cones (condim rows per contact, NE = NE_ELL_ rows in total): the contact Jacobian is stored
+// compactly (per contact only the dofs that move its two bodies, JCW_ words in total) and the Newton solver is
+// solver_cone.h instead of solver_reg.h; H couples all dofs, so it is factorised with the dense elimination order.
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
-          class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2>
+          class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2, bool ELL_ = false, int NE_ELL_ = 0, int JCW_ = 4>
 struct Dims {
   using Topo = Topo_;
   static constexpr bool is_static = STATIC;
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
-  static constexpr int NE = NL_ + 4 * NC_;
+  static constexpr bool ell = ELL_;
+  static constexpr int NE = ELL_ ? NE_ELL_ : NL_ + 4 * NC_;
+  static constexpr int JCW = JCW_;            // words of the compact contact Jacobian (elliptic models)
+  static constexpr int NCE = ELL_ ? NC_ : 1;  // extent of the per-contact tables only elliptic models carry
+  static constexpr int NVE = ELL_ ? NV_ : 1;
+  static constexpr int NCD = 10;              // max dofs that move the two bodies of one contact (Allegro: 6 + 4)
+  static constexpr int NDC = 8;               // max contacts that touch one dof (Allegro: 6)
+  static constexpr int NSA = NS_ > 0 ? NS_ : 1;   // extent of the site tables (no zero-length arrays)
   static constexpr bool square = SQUARE_;
   static constexpr int NHI = NHI_;            // capacity of the H work list (square layout)
   static constexpr int S = (NV_ + 3) & ~3;    // row stride of the square matrices
@@ -64,6 +79,8 @@ struct Dims {
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;
 using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 192>;
+// Allegro: 19 contacts (14 x condim 3 + 5 x condim 6 = 72 rows) + 16 limits; compact Jacobian 8x3x4 + 6x3x8 + 6x6 + 4x6x10
+using DimsAllegro = Dims<true, 23, 22, 16, 23, 17, 6, 0, 19, 16, TopoAllegro, true, 64, true, 88, 516>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -129,18 +146,25 @@ struct CModel {
   // ---- geoms / sites / contacts / limits / actuators
   int32_t geom_bodyid[D::NG];
   float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];
-  int32_t site_bodyid[D::NS];
-  float site_pos[D::NS][3], site_quat[D::NS][4];
+  int32_t site_bodyid[D::NSA];
+  float site_pos[D::NSA][3], site_quat[D::NSA][4];
   int32_t con_kind[D::NC], con_geom1[D::NC], con_geom2[D::NC], con_body1[D::NC], con_body2[D::NC];
   float con_friction[D::NC][5], con_solref[D::NC][2], con_solimp[D::NC][5], con_margin[D::NC];
+  // elliptic models: rows / dofs of every contact and the contacts of every dof (static, from the body tree)
+  int32_t cone, eulerdamp;
+  int32_t con_dim[D::NCE], con_adr[D::NCE];      // condim and first constraint row
+  int32_t con_ndof[D::NCE], con_joff[D::NCE];    // dofs that move body1 or body2; word offset of J_c (dim x ndof, row-major)
+  uint8_t con_dof[D::NCE][D::NCD];
+  int32_t dof_ncon[D::NVE];
+  uint16_t dof_con[D::NVE][D::NDC];              // contact | (index of the dof in the contact's dof list) << 8
   int32_t lim_jnt[D::NL];
   int32_t act_qposadr[D::NU], act_ctrllimited[D::NU], act_isposition[D::NU];
   float act_gear[D::NU], act_kp[D::NU], act_ctrlrange[D::NU][2];
   // ---- task (dial_task; the seq-jump stage tables stay in the global dial_task)
   int32_t kind, n_frames, position_control, torso_x, upright_x, nfeet, n_stage, feet_site[DIAL_MAX_FEET];
   float dt, action_scale, foot_radius, gait_duty, gait_cadence, gait_amp, gait_phase[DIAL_MAX_FEET];
-  float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3];
-  float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2];
+  float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3], init_ang_vel_tar[3];
+  float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2], joint_offset[D::NU];
 };
 
 // ---- runtime / compile-time dimension accessors

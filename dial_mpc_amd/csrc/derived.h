@@ -71,12 +71,13 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
     for (int j = 0; j <= i; j++)
       if ((dv->dof_ancmask[i] >> j) & 1u) dv->tri[t++] = (uint16_t)((i << 8) | j);
   dv->ntri = t;
+  dv->nhitem = 0;
+  for (int p = 0; p < 8; p++) dv->hpass_n[p] = 0;
+  if (m->cone == DIAL_CONE_ELLIPTIC) { dv->nhitem = 0; return DIAL_OK; }   // solver_cone.h assembles H per contact
   for (int c = 0; c < m->ncon; c++)
     if (m->con_body1[c] != 0) return DIAL_ERR_UNSUPPORTED;   // body-body contacts would fill H between branches
   // ---- H work list.  Contact c (world vs body2) touches dof i iff i moves body2; j is an ancestor of i, so
   // entry (i, j) is touched by exactly the contacts that touch i.
-  dv->nhitem = 0;
-  for (int p = 0; p < 8; p++) dv->hpass_n[p] = 0;
   if (m->ncon <= 8) {
     int chunk = 4;
     for (int i = 0; i < m->nv; i++) {
@@ -122,8 +123,29 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
 // Host: does the derived H work list fit the instantiation's capacity (square layout only)?
 template <class D>
 static inline bool derived_fits(const dial_derived* dv) {
-  if constexpr (D::square) return dv->nhitem > 0 && dv->nhitem <= D::NHI;
+  if constexpr (D::ell) return true;
+  else if constexpr (D::square) return dv->nhitem > 0 && dv->nhitem <= D::NHI;
   else return true;
+}
+
+// Host: does an elliptic model fit the per-contact tables of the instantiation?
+template <class D>
+static inline bool ell_fits(const dial_model* m, const dial_derived* dv) {
+  if constexpr (!D::ell) return m->cone != DIAL_CONE_ELLIPTIC;
+  else {
+    if (m->cone != DIAL_CONE_ELLIPTIC) return false;
+    int ne = m->nlim, jcw = 0, dofc[DIAL_MAX_V] = {0};
+    for (int c = 0; c < m->ncon; c++) {
+      if (m->con_dim[c] != 3 && m->con_dim[c] != 6) return false;
+      const uint32_t mask = dv->body_ancmask[m->con_body1[c]] | dv->body_ancmask[m->con_body2[c]];
+      int nd = 0;
+      for (int i = 0; i < m->nv; i++) if ((mask >> i) & 1u) { nd++; if (++dofc[i] > D::NDC) return false; }
+      if (nd > D::NCD) return false;
+      ne += m->con_dim[c];
+      jcw += m->con_dim[c] * nd;
+    }
+    return ne == D::NE && ne == m->nefc && jcw == D::JCW;
+  }
 }
 
 // Host: capacity-sized ABI structs -> CModel<D>.  The caller has checked dims_match<D>() for static D.
@@ -220,7 +242,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
   }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
-  if constexpr (D::square) {
+  if constexpr (D::square && !D::ell) {
     static_assert(D::NHI % 64 == 0 && D::NV * D::T < 1024 && D::NV * D::S < 1024 && D::NE + 4 < 64, "hrec field widths");
     o.nhitem = dv->nhitem <= D::NHI ? dv->nhitem : 0;
     for (int p = 0; p < 8; p++) o.hpass_n[p] = dv->hpass_n[p];
@@ -255,6 +277,28 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 5; k++) { o.con_friction[cidx][k] = m->con_friction[cidx][k]; o.con_solimp[cidx][k] = m->con_solimp[cidx][k]; }
     for (int k = 0; k < 2; k++) o.con_solref[cidx][k] = m->con_solref[cidx][k];
   }
+  o.cone = m->cone; o.eulerdamp = m->eulerdamp;
+  if constexpr (D::ell) {
+    int adr = m->nlim, joff = 0;
+    for (int i = 0; i < m->nv; i++) o.dof_ncon[i] = 0;
+    for (int cidx = 0; cidx < m->ncon; cidx++) {
+      o.con_dim[cidx] = m->con_dim[cidx];
+      o.con_adr[cidx] = adr;
+      adr += m->con_dim[cidx];
+      const uint32_t mask = dv->body_ancmask[m->con_body1[cidx]] | dv->body_ancmask[m->con_body2[cidx]];
+      int nd = 0;
+      for (int i = 0; i < m->nv; i++)
+        if ((mask >> i) & 1u) {
+          if (nd < D::NCD) o.con_dof[cidx][nd] = (uint8_t)i;
+          if (o.dof_ncon[i] < D::NDC) o.dof_con[i][o.dof_ncon[i]] = (uint16_t)(cidx | (nd << 8));
+          o.dof_ncon[i]++;
+          nd++;
+        }
+      o.con_ndof[cidx] = nd;
+      o.con_joff[cidx] = joff;
+      joff += m->con_dim[cidx] * nd;
+    }
+  }
   for (int l = 0; l < m->nlim; l++) o.lim_jnt[l] = m->lim_jnt[l];
   for (int a = 0; a < m->nu; a++) {
     o.act_qposadr[a] = m->act_qposadr[a]; o.act_ctrllimited[a] = m->act_ctrllimited[a];
@@ -262,6 +306,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.act_ctrlrange[a][0] = m->act_ctrlrange[a][0]; o.act_ctrlrange[a][1] = m->act_ctrlrange[a][1];
     o.kp[a] = t->kp[a]; o.kd[a] = t->kd[a];
     for (int k = 0; k < 2; k++) { o.joint_range[a][k] = t->joint_range[a][k]; o.phys_range[a][k] = t->phys_range[a][k]; o.tau_range[a][k] = t->tau_range[a][k]; }
+    o.joint_offset[a] = t->joint_offset[a];
   }
   o.kind = t->kind; o.n_frames = t->n_frames; o.position_control = t->position_control; o.torso_x = t->torso_x;
   o.upright_x = t->upright_x; o.nfeet = t->nfeet; o.n_stage = t->n_stage;
@@ -269,7 +314,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   o.dt = t->dt; o.action_scale = t->action_scale; o.foot_radius = t->foot_radius; o.gait_duty = t->gait_duty;
   o.gait_cadence = t->gait_cadence; o.gait_amp = t->gait_amp; o.ramp_up_time = t->ramp_up_time;
   o.done_height = t->done_height; o.jump_dt = t->jump_dt;
-  for (int k = 0; k < 3; k++) { o.cmd_vel[k] = t->cmd_vel[k]; o.cmd_ang_vel[k] = t->cmd_ang_vel[k]; o.init_pos_tar[k] = t->init_pos_tar[k]; }
+  for (int k = 0; k < 3; k++) { o.cmd_vel[k] = t->cmd_vel[k]; o.cmd_ang_vel[k] = t->cmd_ang_vel[k]; o.init_pos_tar[k] = t->init_pos_tar[k]; o.init_ang_vel_tar[k] = t->init_ang_vel_tar[k]; }
 }
 
 // ---- per-wavefront LDS workspace (pointers into one float array) -----------------------------
@@ -286,6 +331,9 @@ struct Ws {
   float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd;
   // ... aliased by solver-only arrays
   float *H, *JarefW, *JarefS, *jv, *frc, *quad, *MaW, *MaS, *grad, *search, *mv, *qfc, *ysol;
+  // elliptic models (solver_cone.h): contact-on flags, per-contact cone Hessian weights, per-dof vectors that the row
+  // products gather from
+  float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1;
 };
 
 #if defined(__HIPCC__)
@@ -302,10 +350,11 @@ WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 // pyramid rows J^T[i][4c + e], the transpose scratch L aliases H, frc is padded so that the contact weights start
 // 16-byte aligned.
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
-                   int ncon, int nefc, int nnode, bool with_L, bool square = false) {
+                   int ncon, int nefc, int nnode, bool with_L, bool square = false, int ell_jcw = 0) {
   int o = 0;
   const int ntri = square ? nv * ((nv + 3) & ~3) : (nv * (nv + 1)) / 2;
-  const int njc = square ? nv * 4 * ncon : ncon * 3 * nv;
+  const int njc = ell_jcw > 0 ? ell_jcw : (square ? nv * 4 * ncon : ncon * 3 * nv);
+  const int ell = ell_jcw > 0 ? 1 : 0;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
   WS_TAKE(act, nu) WS_TAKE(ztar, DIAL_MAX_FEET) WS_TAKE(rpart, 10)
@@ -315,6 +364,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, njc)
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
+  WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv)
   const int u0 = o;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
@@ -334,9 +384,12 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   const int u1 = o;
   o = u0;
   WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4)
+  WS_TAKE(cwd, ell * ncon * 6) WS_TAKE(cwa, ell * ncon * 6) WS_TAKE(cwb, ell * ncon * 6) WS_TAKE(ccf, ell * ncon * 4)
+  WS_TAKE(vec0, ell * nv) WS_TAKE(vec1, ell * nv)
   const int ls = with_L ? 1 : 0;   // the rest is LDS-solver state; the register solver keeps it in VGPRs
   WS_TAKE(JarefW, ls * nefc) WS_TAKE(JarefS, ls * nefc) WS_TAKE(quad, ls * nefc * 3) WS_TAKE(MaW, ls * nv)
-  WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv) WS_TAKE(qfc, ls * nv)
+  WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv)
+  if (!ell) { WS_TAKE(qfc, ls * nv) }
   WS_TAKE(ysol, ls * nv)
   WS_TAKE(L, with_L ? ntri : 0)   // packed Cholesky factor of the LDS solver (the register solver writes its factor over H)
   o = o > u1 ? o : u1;

@@ -46,7 +46,7 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
   if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), nnode, dial::kNeedL<D>, D::square);
+           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
   return m;
 }
 
@@ -272,7 +272,7 @@ struct dial_ctx {
   dial_cfg hc;
   dial_derived hd;
   bool has_cfg = false;
-  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1, 3 H1 loco
+  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1, 3 H1 loco, 4 Allegro (elliptic cones)
   void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
@@ -338,11 +338,18 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, DIAL_ERR_HIP, "dial_create: no HIP device available (the HIP path has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
-  if (model->eulerdamp) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: eulerdamp-enabled models are not supported");
-  if (model->cone != 0) return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: only pyramidal cones are supported");
-  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_H1_LOCO)
+  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_ALLEGRO)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
-  if (model->nefc > 64 || model->nv > DIAL_MAX_V || model->nq + 2 * model->nv + DIAL_INFO_N > 4096)
+  if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
+    return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
+  if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)
+    return fail(nullptr, DIAL_ERR_ARG, "dial_create: unknown line-search rule");
+  // pyramidal models: <= 64 constraint rows (one row per lane), explicit Euler damping off;
+  // elliptic models run on their dimension-specialised instantiation only (checked below)
+  if (model->cone == DIAL_CONE_PYRAMIDAL && model->eulerdamp)
+    return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: eulerdamp is only supported on the elliptic-cone instantiations");
+  if ((model->cone == DIAL_CONE_PYRAMIDAL && model->nefc > 64) || model->nefc > DIAL_MAX_EFC || model->nv > DIAL_MAX_V ||
+      model->nq + 2 * model->nv + DIAL_INFO_N > 4096)
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: model exceeds kernel capacities");
   dial_ctx* ctx = new dial_ctx();
   ctx->device = device;
@@ -370,9 +377,11 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       Ws s;
       const int nnode = cfg ? cfg->Hnode + 1 : 0;
       const int ws0 = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
-                               model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>, D::square);
+                               model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>, D::square,
+                               D::ell ? D::JCW : 0);
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
-                               model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square);
+                               model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square,
+                               D::ell ? D::JCW : 0);
       ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
@@ -388,12 +397,24 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
     else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd)) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
     else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
+    else if (model->cone == DIAL_CONE_ELLIPTIC) {
+      if (!(dims_match<DimsAllegro>(model) && ell_fits<DimsAllegro>(model, &ctx->hd))) {
+        dial_destroy(ctx);
+        return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: elliptic-cone models need a dimension-specialised instantiation (built: Allegro hand)");
+      }
+      ctx->inst = 4; ctx->wpb = 4; urc = upload(DimsAllegro{});
+    }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
-  if (ctx->lds_rollout > 64 * 1024) {
+  if (ctx->lds_rollout > 160 * 1024 || ctx->lds_bytes > 64 * 1024) {
     dial_destroy(ctx);
-    return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds 64 KiB");
+    return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds the 160 KiB of a CU");
+  }
+  if (ctx->lds_rollout > 64 * 1024) {   // more than the default dynamic-LDS limit of a launch: opt in (gfx950: 160 KiB per workgroup)
+    hipError_t e = hipSuccess;
+    if (ctx->inst == 4) e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+    if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
   HIP_TRY_CREATE(hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
@@ -471,6 +492,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
   if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
+  else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, 4);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
   HIP_TRY(ctx, hipGetLastError());
@@ -638,6 +660,7 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
   if (ctx->inst == 1) DIAL_LAUNCH_STEP(DimsGo2);
   else if (ctx->inst == 2) DIAL_LAUNCH_STEP(DimsH1);
   else if (ctx->inst == 3) DIAL_LAUNCH_STEP(DimsH1Loco);
+  else if (ctx->inst == 4) DIAL_LAUNCH_STEP(DimsAllegro);
   else DIAL_LAUNCH_STEP(DimsMax);
 #undef DIAL_LAUNCH_STEP
   HIP_TRY(ctx, hipGetLastError());
@@ -654,6 +677,7 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
   if (ctx->inst == 1) DIAL_LAUNCH_RESET(DimsGo2);
   else if (ctx->inst == 2) DIAL_LAUNCH_RESET(DimsH1);
   else if (ctx->inst == 3) DIAL_LAUNCH_RESET(DimsH1Loco);
+  else if (ctx->inst == 4) DIAL_LAUNCH_RESET(DimsAllegro);
   else DIAL_LAUNCH_RESET(DimsMax);
 #undef DIAL_LAUNCH_RESET
   HIP_TRY(ctx, hipGetLastError());

@@ -154,8 +154,52 @@ DIAL_DEV void kbi(const M* m, const float* solref, const float* solimp, float po
   imp = im;
 }
 
+// ---------------------------------------------------------------- MJX narrow phase helpers (collision_primitive / math)
+// math.closest_segment_point: point on [a, b] closest to pt (the 1e-6 in the denominator is MJX's)
+DIAL_DEV void closest_segment_point(float* o, const float* a, const float* b, const float* pt) {
+  const float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+  const float t = dm::clip(dm::dot3(pa, ab) / (dm::dot3(ab, ab) + 1e-6f), 0.f, 1.f);
+  for (int k = 0; k < 3; k++) o[k] = a[k] + t * ab[k];
+}
+// math.closest_segment_to_segment_points
+DIAL_DEV void closest_segment_to_segment(float* best_a, float* best_b, const float* a0, const float* a1, const float* b0, const float* b1) {
+  float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+  const float len_a = DM_SQRT(dm::dot3(da, da)), len_b = DM_SQRT(dm::dot3(db, db));
+  for (int k = 0; k < 3; k++) { da[k] = len_a > 0.f ? da[k] / len_a : 0.f; db[k] = len_b > 0.f ? db[k] / len_b : 0.f; }
+  const float half_a = len_a * 0.5f, half_b = len_b * 0.5f;
+  float a_mid[3], b_mid[3], trans[3];
+  for (int k = 0; k < 3; k++) { a_mid[k] = a0[k] + da[k] * half_a; b_mid[k] = b0[k] + db[k] * half_b; trans[k] = a_mid[k] - b_mid[k]; }
+  const float dadb = dm::dot3(da, db), dat = dm::dot3(da, trans), dbt = dm::dot3(db, trans);
+  const float denom = 1.f - dadb * dadb;
+  const float orig_ta = (-dat + dadb * dbt) / (denom + 1e-6f);
+  const float orig_tb = dbt + orig_ta * dadb;
+  const float ta = dm::clip(orig_ta, -half_a, half_a), tb = dm::clip(orig_tb, -half_b, half_b);
+  float ba[3], bb[3], na[3], nb[3];
+  for (int k = 0; k < 3; k++) { ba[k] = a_mid[k] + da[k] * ta; bb[k] = b_mid[k] + db[k] * tb; }
+  closest_segment_point(na, a0, a1, bb);
+  closest_segment_point(nb, b0, b1, ba);
+  const float e1[3] = {na[0] - bb[0], na[1] - bb[1], na[2] - bb[2]}, e2[3] = {nb[0] - ba[0], nb[1] - ba[1], nb[2] - ba[2]};
+  const float d1 = dm::dot3(e1, e1), d2 = dm::dot3(e2, e2);
+  for (int k = 0; k < 3; k++) { best_a[k] = d1 < d2 ? na[k] : ba[k]; best_b[k] = d1 < d2 ? bb[k] : nb[k]; }
+}
+// collision_primitive make_frame(a): a normalised, b = the more orthogonal of y / z made orthonormal, c = a x b
+DIAL_DEV void make_frame(float* fr, const float* a_in) {
+  float a[3] = {a_in[0], a_in[1], a_in[2]}, nn = DM_SQRT(dm::dot3(a, a));
+  for (int k = 0; k < 3; k++) a[k] /= nn;
+  float bb[3] = {0.f, 0.f, 0.f};
+  if (-0.5f < a[1] && a[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
+  const float ab = dm::dot3(a, bb);
+  for (int k = 0; k < 3; k++) bb[k] -= a[k] * ab;
+  nn = DM_SQRT(dm::dot3(bb, bb));
+  for (int k = 0; k < 3; k++) bb[k] /= nn;
+  float cc[3];
+  dm::cross3(cc, a, bb);
+  for (int k = 0; k < 3; k++) { fr[k] = a[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
+}
+
 }  // namespace dial
 #include "solver_reg.h"
+#include "solver_cone.h"
 namespace dial {
 
 // ================================================================ mjx.forward
@@ -510,19 +554,36 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
       float radius = m->geom_size[g2][0];
       float* fr = s.cframe + 9 * c;
+      if constexpr (M::D::ell) {
+        if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
+          // MJX sphere_capsule / capsule_capsule: closest points on the capsule segment(s), then _sphere_sphere
+          const float ax2[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]}, hl2 = m->geom_size[g2][1];
+          float b0[3], b1[3], p1[3], p2[3];
+          for (int k = 0; k < 3; k++) { b0[k] = ctr[k] - ax2[k] * hl2; b1[k] = ctr[k] + ax2[k] * hl2; }
+          if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE) {
+            for (int k = 0; k < 3; k++) p1[k] = s.gpos[3 * g1 + k];
+            closest_segment_point(p2, b0, b1, p1);
+          } else {
+            const float hl1 = m->geom_size[g1][1];
+            float a0[3], a1[3];
+            for (int k = 0; k < 3; k++) { a0[k] = s.gpos[3 * g1 + k] - n[k] * hl1; a1[k] = s.gpos[3 * g1 + k] + n[k] * hl1; }
+            closest_segment_to_segment(p1, p2, a0, a1, b0, b1);
+          }
+          const float r1 = m->geom_size[g1][0];
+          float nn[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+          const float len = DM_SQRT(dm::dot3(nn, nn));
+          if (len == 0.f) { nn[0] = 1.f; nn[1] = 0.f; nn[2] = 0.f; }
+          else for (int k = 0; k < 3; k++) nn[k] /= len;
+          const float dist = len - (r1 + radius);
+          s.cdist[c] = dist;
+          for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = p1[k] + nn[k] * (r1 + dist * 0.5f);
+          make_frame(fr, nn);
+          s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
+          return;
+        }
+      }
       if (m->con_kind[c] == DIAL_CON_PLANE_SPHERE) {
-        // collision_primitive make_frame(n)
-        float a[3] = {n[0], n[1], n[2]}, nn = DM_SQRT(dm::dot3(a, a));
-        for (int k = 0; k < 3; k++) a[k] /= nn;
-        float bb[3] = {0.f, 0.f, 0.f};
-        if (-0.5f < a[1] && a[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
-        float ab = dm::dot3(a, bb);
-        for (int k = 0; k < 3; k++) bb[k] -= a[k] * ab;
-        nn = DM_SQRT(dm::dot3(bb, bb));
-        for (int k = 0; k < 3; k++) bb[k] /= nn;
-        float cc[3];
-        dm::cross3(cc, a, bb);
-        for (int k = 0; k < 3; k++) { fr[k] = a[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
+        make_frame(fr, n);   // collision_primitive make_frame(n)
       } else {
         float axis[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]};
         float na = dm::dot3(n, axis), bb[3];
@@ -544,10 +605,42 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float dist = dm::dot3(diff, n) - radius;
       s.cdist[c] = dist;
       for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = ctr[k] - n[k] * (radius + 0.5f * dist);
+      if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
     }
   });
   // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
   DIAL_MARK(w, 1);
+  if constexpr (M::D::ell) {
+    // compact rows: J_c is dim x ndof over the dofs that move body1 or body2 (support.jac of both bodies at the contact
+    // point, translational rows in the contact frame, then -- condim 6 -- the rotational ones); one item per (contact, dof)
+    w.items(M::D::NC * M::D::NCD, [&](int it) {
+      const int c = it / M::D::NCD, a = it - c * M::D::NCD;
+      const int nd = m->con_ndof[c];
+      if (a >= nd || s.con_on[c] == 0.f) return;
+      const int i = m->con_dof[c][a], b1 = m->con_body1[c], b2 = m->con_body2[c], dim = m->con_dim[c];
+      float cd[6];
+      for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+      const float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
+      float dp[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f};
+      if ((m->body_ancmask[b2] >> i) & 1u) {
+        const float* cm = s.com + 3 * m->body_rootid[b2];
+        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
+        float cr[3];
+        dm::cross3(cr, cd, off);
+        for (int k = 0; k < 3; k++) { dp[k] += cd[3 + k] + cr[k]; dr[k] += cd[k]; }
+      }
+      if ((m->body_ancmask[b1] >> i) & 1u) {
+        const float* cm = s.com + 3 * m->body_rootid[b1];
+        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
+        float cr[3];
+        dm::cross3(cr, cd, off);
+        for (int k = 0; k < 3; k++) { dp[k] -= cd[3 + k] + cr[k]; dr[k] -= cd[k]; }
+      }
+      float* J = s.Jc + m->con_joff[c] + a;
+      for (int k = 0; k < 3; k++) J[k * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dp);
+      if (dim == 6) for (int k = 0; k < 3; k++) J[(3 + k) * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dr);
+    });
+  } else
   w.items(nc * nv, [&](int it) {
     const int c = it / nv, i = it - c * nv;
     const int b1 = m->con_body1[c], b2 = m->con_body2[c];
@@ -577,6 +670,48 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
   });
   // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
+  if constexpr (M::D::ell) {
+    // elliptic cones (_efc_contact_elliptic): one item per limit row and per contact; the friction rows' R follows
+    // from the normal row (impratio, friction ratios) and their reference acceleration has no position term
+    w.items(nl + M::D::NC, [&](int it) {
+      if (it < nl) {
+        const int r = it, ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+        const float q = s.qpos[qa];
+        const float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+        const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+        const float sgn = dist_min < dist_max ? 1.f : -1.f;
+        s.lsign[r] = sgn;
+        if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+        float k_, b_, imp;
+        kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+        const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
+        s.aref[r] = -b_ * (sgn * s.qvel[da]) - k_ * imp * pos;
+        s.D[r] = 1.f / R;
+        return;
+      }
+      const int c = it - nl, r0 = m->con_adr[c], dim = m->con_dim[c], nd = m->con_ndof[c];
+      if (s.con_on[c] == 0.f) {
+        for (int j = 0; j < dim; j++) { s.D[r0 + j] = 0.f; s.aref[r0 + j] = 0.f; }
+        return;
+      }
+      const float pos = s.cdist[c] - m->con_margin[c];
+      const float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
+      const float f0 = m->con_friction[c][0];
+      float k_, b_, imp;
+      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
+      const float* J = s.Jc + m->con_joff[c];
+      const float iw1 = t / m->impratio;
+      for (int j = 0; j < dim; j++) {
+        float invw = j == 0 ? t : iw1;
+        if (j >= 2) { const float fj = m->con_friction[c][j - 1]; invw = iw1 * (f0 * f0) / (fj * fj); }
+        float vel = 0.f;
+        for (int a = 0; a < nd; a++) vel += J[j * nd + a] * s.qvel[m->con_dof[c][a]];
+        const float R = dm::fmaxf_(invw * (1.f - imp) / imp, MJ_MINVAL);
+        s.aref[r0 + j] = -b_ * vel - k_ * imp * (j == 0 ? pos : 0.f);
+        s.D[r0 + j] = 1.f / R;
+      }
+    });
+  } else
   w.items(ne, [&](int r) {
     if (r < nl) {
       const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
@@ -628,7 +763,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
     return;
   }
-  if constexpr (M::D::is_static) {
+  if constexpr (M::D::ell) {
+    solver_cone(w, m, s);  // elliptic cones: per-contact Newton solver (solver_cone.h)
+    return;
+  } else if constexpr (M::D::is_static) {
     solver_reg(w, m, s);   // register-resident Newton solver (solver_reg.h)
     return;
   }
@@ -838,6 +976,22 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 template <class W, class M>
 DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
   const float dt = m->timestep;
+  if constexpr (M::D::ell) {
+    if (m->eulerdamp) {
+      // implicit joint damping (forward.euler): qacc <- (M + dt diag(damping))^-1 (qfrc_smooth + qfrc_constraint);
+      // qacc_warmstart keeps the solver's solution.  M + dt B has M's sparsity: the tree elimination order applies.
+      constexpr int NV = M::D::NV, S = M::D::S;
+      w.items(NV * S, [&](int e) {
+        const int i = e / S, j = e - i * S;
+        s.H[e] = s.M[e] + (i == j ? dt * m->dof_damping[i] : 0.f);
+      });
+      const vfloat rhs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] + s.qfc[l] : 0.f; });
+      const vfloat x = reg_chol_solve_v<typename M::D>(w, m, s.H, rhs, s.H);
+      w.items(NV, [&](int i) { s.qvel[i] += lane_val(x, i) * dt; });
+    } else {
+      w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
+    }
+  } else
   w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
   w.items(dim_nj(m), [&](int ji) {
     const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
@@ -886,7 +1040,8 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     if (it < nu) {
       const int a = it;
       float an = (s.act[a] * m->action_scale + 1.0f) / 2.0f;
-      float jt = m->joint_range[a][0] + an * (m->joint_range[a][1] - m->joint_range[a][0]);
+      // joint_offset: the keyframe pose AllegroReorientEnv.act2joint adds (manipulation.py:107-109), 0 elsewhere
+      float jt = (m->joint_range[a][0] + m->joint_offset[a]) + an * (m->joint_range[a][1] - m->joint_range[a][0]);
       jt = dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
       float c;
       if (m->position_control) c = jt;
@@ -909,6 +1064,30 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     forward(w, m, s);
     euler(w, m, s);
     DIAL_MARK(w, 9);
+  }
+  if (m->kind == DIAL_TASK_ALLEGRO) {
+    // manipulation.py:75-100 (torso_x = the object body): three sums of squares, one lane each
+    w.items(3, [&](int it) {
+      const int ob = m->torso_x + 1;
+      float acc = 0.f;
+      if (it == 0) {
+        for (int k = 0; k < 3; k++) { const float e = s.cvel[6 * ob + k] * DIAL_PI / 180.0f - s.info[DIAL_INFO_ANG_VEL_TAR + k]; acc += e * e; }
+      } else if (it == 1) {
+        for (int k = 0; k < 3; k++) { const float e = s.xpos[3 * ob + k] - s.info[DIAL_INFO_POS_TAR + k]; acc += e * e; }
+      } else {
+        for (int a = 0; a < nu; a++) { const float e = s.qpos[7 + a] - m->joint_offset[a]; acc += e * e; }
+      }
+      s.rpart[it] = acc;
+    });
+    w.items(1, [&](int) {
+      const float step = s.info[DIAL_INFO_STEP];
+      const float reward = -s.rpart[0] * 1.0f + -s.rpart[1] * 5.0f + -s.rpart[2] * 0.1f;
+      if (FULL_INFO) s.info[DIAL_INFO_DONE] = step >= 100.f ? 1.f : 0.f;
+      s.info[DIAL_INFO_STEP] = step + 1.f;
+      s.info[DIAL_INFO_REWARD] = reward;
+    });
+    DIAL_MARK(w, 10);
+    return s.info[DIAL_INFO_REWARD];
   }
   // ---- reward terms, one per lane (all read the PRE-integration forward quantities)
   //   rpart: 0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty

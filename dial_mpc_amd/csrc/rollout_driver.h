@@ -164,7 +164,8 @@ DIAL_DEV void env_reset_single(W& w, const M* m, const Ws& s, const float* qpos,
     else if (i < nq + 2 * nv) s.warm[i - nq - nv] = 0.f;
     else if (i < nq + 2 * nv + DIAL_INFO_N) {
       const int k = i - nq - 2 * nv;
-      s.info[k] = (k >= DIAL_INFO_POS_TAR && k < DIAL_INFO_POS_TAR + 3) ? m->init_pos_tar[k - DIAL_INFO_POS_TAR] : 0.f;
+      s.info[k] = (k >= DIAL_INFO_POS_TAR && k < DIAL_INFO_POS_TAR + 3) ? m->init_pos_tar[k - DIAL_INFO_POS_TAR]
+                  : ((k >= DIAL_INFO_ANG_VEL_TAR && k < DIAL_INFO_ANG_VEL_TAR + 3) ? m->init_ang_vel_tar[k - DIAL_INFO_ANG_VEL_TAR] : 0.f);
     } else s.ctrl[i - nq - 2 * nv - DIAL_INFO_N] = 0.f;
   });
   forward(w, m, s);

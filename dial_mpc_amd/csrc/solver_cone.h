@@ -1,0 +1,375 @@
+// solver_cone.h -- Newton solver (solver.solve of MJX) for models with ELLIPTIC friction cones (Dims::ell: the
+// Allegro hand, 16 limit rows + 14 condim-3 + 5 condim-6 contacts = 88 rows, more than a wavefront has lanes).
+//
+// One wavefront owns the sample, so every data-dependent decision (contact on / off, cone zone, convergence) is
+// wave-uniform and costs no divergence.  The solver is organised around CONTACTS, not rows:
+//   * "unit" lane u < NL + NC owns limit row u or contact u - NL: zone classification, forces, cost, the cone's
+//     Hessian weights and the line-search terms of its unit (35 lanes for Allegro);
+//   * dof lane i < NV keeps qacc, Ma, grad, search, M search in registers;
+//   * row products J v run over (contact, row) items with the compact Jacobian (only the <= 10 dofs that move the
+//     contact's two bodies), J^T f over the static contact list of every dof;
+//   * H = M + sum_c J_c^T W_c J_c is accumulated contact by contact over (dof, dof) pairs of the contact's dof set;
+//     contacts that are off (dist >= margin) or in the cone's top zone are skipped outright -- with the ball resting
+//     on three fingertips 3 of the 19 contacts do any work;
+//   * H couples every dof with every other, so it is factorised by the register L D L^T of solver_reg.h with the
+//     dense elimination order; M (and M + dt B of the implicit damping) keep the tree order.
+//
+// Per contact (rows r0 .. r0+dim-1, friction f, mu = f_0 / sqrt(impratio)), with U = (mu r_0, f_1 r_1, ...),
+// N = U_0, T = |U_1..|:  top zone (N >= mu T): nothing;  bottom zone (mu N + T <= 0): the rows are plain quadratic
+// rows;  middle zone: cost 1/2 Dm (N - mu T)^2, Dm = D_0 / (mu^2 (1 + mu^2)), force and Hessian
+//   Hc = Dm F [[1, c0 U^T], [c0 U, c2 U U^T + c1 I]] F,  F = diag(mu, f),  c0 = -mu / T, c1 = mu^2 - mu N / T, c2 = mu N / T^3
+// (solver._update_constraint / _update_gradient / _eval_pt_elliptic of MJX; the oracle restates the same formulas).
+#pragma once
+// (included from rollout_body.h after solver_reg.h)
+
+namespace dial {
+
+template <class W, class M>
+DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
+  using D = typename M::D;
+  constexpr int NV = D::NV, NC = D::NC, NL = D::NL, S = D::S, NCD = D::NCD, NU_ = NL + NC;
+  static_assert(D::ell && D::square && NU_ <= 64 && NV <= 32, "unit lanes / dof lanes must fit one wavefront");
+  w.begin_region();
+  const vfloat vzero = vsplat(0.f);
+  const vbool isdof = w.lane_lt(NV);
+  const float mu_scale = 1.f / DM_SQRT(m->impratio);   // mu = friction_0 / sqrt(impratio)
+
+  // ---- row products  out[r] = J_r . vec  (two vectors at once when vecB != nullptr); off contacts give 0
+  auto row_products = [&](const float* vecA, float* outA, const float* vecB, float* outB) {
+    w.items(NL + 6 * NC, [&](int it) {
+      if (it < NL) {
+        const int dof = m->jnt_dofadr[m->lim_jnt[it]];
+        outA[it] = s.lsign[it] * vecA[dof];
+        if (vecB) outB[it] = s.lsign[it] * vecB[dof];
+        return;
+      }
+      const int c = (it - NL) / 6, k = (it - NL) - 6 * c;
+      if (k >= m->con_dim[c]) return;
+      const int r = m->con_adr[c] + k;
+      float a = 0.f, b = 0.f;
+      if (s.con_on[c] != 0.f) {
+        const int nd = m->con_ndof[c];
+        const float* J = s.Jc + m->con_joff[c] + k * nd;
+        for (int q = 0; q < nd; q++) {
+          const int i = m->con_dof[c][q];
+          a += J[q] * vecA[i];
+          if (vecB) b += J[q] * vecB[i];
+        }
+      }
+      outA[r] = a;
+      if (vecB) outB[r] = b;
+    });
+  };
+  // ---- unit evaluation: cost of limit row / contact u at the row values ja[]; STORE additionally writes the forces,
+  // the zone (lsign of the contact's first row doubles as storage) and the Hessian weights
+  auto unit_cost = [&](int u, const float* ja, const float* aref_or_null, bool store) -> float {
+    // value of row r: ja[r] - aref[r] when aref is given (initial points), ja[r] otherwise
+    auto val = [&](int r) { return aref_or_null ? ja[r] - aref_or_null[r] : ja[r]; };
+    if (u < NL) {
+      const float j = val(u), d = s.D[u];
+      const bool act = j < 0.f;
+      if (store) s.frc[u] = act ? -d * j : 0.f;
+      return act ? 0.5f * d * j * j : 0.f;
+    }
+    const int c = u - NL, r0 = m->con_adr[c], dim = m->con_dim[c];
+    if (s.con_on[c] == 0.f) {
+      if (store) { s.lsign[r0] = 0.f; for (int k = 0; k < dim; k++) s.frc[r0 + k] = 0.f; }
+      return 0.f;
+    }
+    const float mu = m->con_friction[c][0] * mu_scale;
+    float U[6], jr[6], fr[6], tsqr = 0.f;
+    jr[0] = val(r0);
+    fr[0] = mu;
+    U[0] = jr[0] * mu;
+    for (int k = 1; k < dim; k++) { jr[k] = val(r0 + k); fr[k] = m->con_friction[c][k - 1]; U[k] = jr[k] * fr[k]; tsqr += U[k] * U[k]; }
+    const float N = U[0], T = DM_SQRT(tsqr);
+    const bool bottom = (tsqr <= 0.f && N < 0.f) || (tsqr > 0.f && mu * N + T <= 0.f);
+    const bool middle = tsqr > 0.f && N < mu * T && mu * N + T > 0.f;
+    const float Dm = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL);
+    float cost = 0.f;
+    if (bottom) {
+      for (int k = 0; k < dim; k++) cost += 0.5f * s.D[r0 + k] * jr[k] * jr[k];
+    } else if (middle) {
+      const float nmt = N - mu * T;
+      cost = 0.5f * Dm * nmt * nmt;
+    }
+    if (store) {
+      s.lsign[r0] = bottom ? 2.f : (middle ? 1.f : 0.f);
+      if (bottom) {
+        for (int k = 0; k < dim; k++) { s.frc[r0 + k] = -s.D[r0 + k] * jr[k]; s.cwd[6 * c + k] = s.D[r0 + k]; }
+      } else if (middle) {
+        const float nmt = N - mu * T, fn = -Dm * nmt * mu;
+        s.frc[r0] = fn;
+        for (int k = 1; k < dim; k++) s.frc[r0 + k] = -fn / T * U[k] * fr[k];
+        const float Tg = dm::fmaxf_(T, MJ_MINVAL), TTT = dm::fmaxf_(Tg * Tg * Tg, MJ_MINVAL);
+        for (int k = 0; k < dim; k++) { s.cwa[6 * c + k] = fr[k]; s.cwb[6 * c + k] = U[k]; }
+        s.ccf[4 * c] = Dm;
+        s.ccf[4 * c + 1] = -mu / Tg;             // c0
+        s.ccf[4 * c + 2] = mu * mu - mu * N / Tg;  // c1
+        s.ccf[4 * c + 3] = mu * N / TTT;         // c2
+      } else {
+        for (int k = 0; k < dim; k++) s.frc[r0 + k] = 0.f;
+      }
+    }
+    return cost;
+  };
+
+  // ---- persistent registers of the dof lanes
+  const vfloat vqfs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] : 0.f; });
+  const vfloat vqas = w.per_lane([&](int l) { return l < NV ? s.qas[l] : 0.f; });
+  const vfloat vwarm = w.per_lane([&](int l) { return l < NV ? s.warm[l] : 0.f; });
+  // M v for the dof lanes, v gathered from LDS (M is block diagonal; full-row fetches keep it simple)
+  auto mul_m = [&](const float* vec) {
+    return w.per_lane([&](int l) {
+      if (l >= NV) return 0.f;
+      float acc = 0.f;
+      for (int j = 0; j < NV; j++) acc += s.M[l * S + j] * vec[j];
+      return acc;
+    });
+  };
+
+  // ---- warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
+  w.items(NV, [&](int i) { s.vec0[i] = s.warm[i]; s.vec1[i] = s.qas[i]; });
+  row_products(s.vec0, s.Jaref, s.vec1, s.jv);     // J warm, J qacc_smooth (aref subtracted on the fly below)
+  const vfloat maW = mul_m(s.vec0), maS = mul_m(s.vec1);
+  float cw, gw, cs, gs;
+  {
+    vfloat t[4];
+    t[0] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, s.aref, false) : 0.f; });
+    t[1] = (maW - vqfs) * (vwarm - vqas);
+    t[2] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.jv, s.aref, false) : 0.f; });
+    t[3] = (maS - vqfs) * (vqas - vqas);
+    float r[4];
+    w.vsumN(t, r);
+    cw = r[0]; gw = r[1]; cs = r[2]; gs = r[3];
+  }
+  const float cost_w = cw + 0.5f * gw, cost_s = cs + 0.5f * gs;
+  const bool use_warm = cost_w < cost_s;
+  vfloat vqacc = use_warm ? vwarm : vqas;
+  vfloat vMa = use_warm ? maW : maS;
+  w.items(D::NE, [&](int r) { s.Jaref[r] = (use_warm ? s.Jaref[r] : s.jv[r]) - s.aref[r]; });
+  float cost = use_warm ? cost_w : cost_s;
+  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
+  float prev_cost = INFINITY;
+  const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
+
+  int niter = 0;
+  for (;;) {
+    // ---- _update_constraint: zones, forces, Hessian weights (unit lanes); cost
+    const vfloat ucost = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, nullptr, true) : 0.f; });
+    w.fence();
+    // ---- J^T f per dof lane: own limit row + the contacts that move the dof
+    const vfloat qfc = w.per_lane([&](int l) {
+      if (l >= NV) return 0.f;
+      const int lr = m->dof_limrow[l];
+      float acc = lr >= 0 ? s.lsign[lr] * s.frc[lr] : 0.f;
+      const int ncn = m->dof_ncon[l];
+      for (int q = 0; q < ncn; q++) {
+        const int c = m->dof_con[l][q] & 255, a = m->dof_con[l][q] >> 8;
+        if (s.con_on[c] == 0.f || s.lsign[m->con_adr[c]] == 0.f) continue;   // off, or top zone: no force
+        const int nd = m->con_ndof[c], dim = m->con_dim[c], r0 = m->con_adr[c];
+        const float* J = s.Jc + m->con_joff[c] + a;
+        for (int k = 0; k < dim; k++) acc += J[k * nd] * s.frc[r0 + k];
+      }
+      return acc;
+    });
+    const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
+    float gn;
+    {
+      vfloat t[3] = {ucost, (vMa - vqfs) * (vqacc - vqas), vgrad * vgrad};
+      float r[3];
+      w.vsumN(t, r);
+      if (niter > 0) {
+        gauss = 0.5f * r[1];
+        prev_cost = cost;
+        cost = r[0] + gauss;
+      }
+      gn = r[2];
+    }
+    DIAL_MARK(w, 4);
+    bool done;
+    if (m->iterations != 1) {
+      const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+    } else {
+      done = niter >= 1;
+    }
+    if (done) {
+      w.items(NV, [&](int i) { s.qfc[i] = lane_val(qfc, i); });   // qfrc_constraint of the final point (Euler damping)
+      break;
+    }
+
+    // ---- H = M + limit rows + per-contact blocks
+    w.items(NV * S, [&](int e) { s.H[e] = s.M[e]; });
+    w.items(NL, [&](int r) {
+      if (s.Jaref[r] < 0.f) { const int i = m->jnt_dofadr[m->lim_jnt[r]]; s.H[i * S + i] += s.D[r]; }
+    });
+    for (int c = 0; c < NC; c++) {
+      if (s.con_on[c] == 0.f) continue;            // wave-uniform
+      const float zone = s.lsign[m->con_adr[c]];
+      if (zone == 0.f) continue;                    // top zone: no curvature
+      const int nd = m->con_ndof[c], dim = m->con_dim[c];
+      const float* J = s.Jc + m->con_joff[c];
+      w.items(NCD * NCD, [&](int it) {
+        const int a = it / NCD, b = it - a * NCD;
+        if (a >= nd || b >= nd) return;
+        float acc;
+        if (zone == 2.f) {                          // bottom zone: plain quadratic rows
+          acc = 0.f;
+          for (int k = 0; k < dim; k++) acc += (J[k * nd + a] * s.cwd[6 * c + k]) * J[k * nd + b];
+        } else {                                    // middle zone: cone Hessian
+          const float Dm = s.ccf[4 * c], c0 = s.ccf[4 * c + 1], c1 = s.ccf[4 * c + 2], c2 = s.ccf[4 * c + 3];
+          const float x0 = s.cwa[6 * c] * J[a], y0 = s.cwa[6 * c] * J[b];
+          float ux = 0.f, uy = 0.f, xty = 0.f;
+          for (int k = 1; k < dim; k++) {
+            const float xk = s.cwa[6 * c + k] * J[k * nd + a], yk = s.cwa[6 * c + k] * J[k * nd + b], uk = s.cwb[6 * c + k];
+            ux += uk * xk;
+            uy += uk * yk;
+            xty += xk * yk;
+          }
+          acc = Dm * (x0 * y0 + c0 * (x0 * uy + ux * y0) + c2 * (ux * uy) + c1 * xty);
+        }
+        s.H[m->con_dof[c][a] * S + m->con_dof[c][b]] += acc;
+      });
+    }
+    DIAL_MARK(w, 5);
+    const vfloat vsearch = vzero - reg_chol_solve_v<D, TopoDense>(w, m, s.H, vgrad, s.H);
+    DIAL_MARK(w, 6);
+
+    // ---- solver._linesearch
+    w.begin_region();
+    w.items(NV, [&](int i) { s.vec0[i] = lane_val(vsearch, i); });
+    row_products(s.vec0, s.jv, nullptr, nullptr);
+    const vfloat vmv = mul_m(s.vec0);
+    float sn2, s1, s2;
+    {
+      vfloat t[3] = {vsearch * vsearch, vsearch * vMa - vsearch * vqfs, vsearch * vmv};
+      float r[3];
+      w.vsumN(t, r);
+      sn2 = r[0]; s1 = r[1]; s2 = r[2];
+    }
+    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
+    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
+    // per-unit line-search registers: limit row: (Jaref, jv | q0 q1 q2); contact: (u0 v0 uu uv vv Dm mu | quad_c)
+    vfloat L[10];
+    w.per_lane_n(L, [&](int u, float* o) {
+      for (int k = 0; k < 10; k++) o[k] = 0.f;
+      if (u >= NU_) return;
+      if (u < NL) {
+        const float ja = s.Jaref[u], jv = s.jv[u], d = s.D[u];
+        o[0] = ja; o[1] = jv;
+        o[7] = 0.5f * ja * ja * d; o[8] = jv * ja * d; o[9] = 0.5f * jv * jv * d;
+        return;
+      }
+      const int c = u - NL;
+      if (s.con_on[c] == 0.f) return;
+      const int r0 = m->con_adr[c], dim = m->con_dim[c];
+      const float mu = m->con_friction[c][0] * mu_scale;
+      float uu = 0.f, uv = 0.f, vv = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+      for (int k = 0; k < dim; k++) {
+        const float ja = s.Jaref[r0 + k], jv = s.jv[r0 + k], d = s.D[r0 + k];
+        q0 += 0.5f * ja * ja * d; q1 += jv * ja * d; q2 += 0.5f * jv * jv * d;
+        if (k > 0) { const float f = m->con_friction[c][k - 1], a = ja * f, b = jv * f; uu += a * a; uv += a * b; vv += b * b; }
+      }
+      o[0] = s.Jaref[r0] * mu; o[1] = s.jv[r0] * mu; o[2] = uu; o[3] = uv; o[4] = vv;
+      o[5] = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL); o[6] = mu;
+      o[7] = q0; o[8] = q1; o[9] = q2;
+    });
+    struct LsPoint { float alpha, cost, d0, d1; };
+    auto ls_point = [&](float alpha) {
+      vfloat t[6];
+      w.per_lane_n(t, [&](int u, float* o) {
+        for (int k = 0; k < 6; k++) o[k] = 0.f;
+        if (u >= NU_) return;
+        if (u < NL) {
+          if (lane_val(L[0], u) + alpha * lane_val(L[1], u) < 0.f) { o[0] = lane_val(L[7], u); o[1] = lane_val(L[8], u); o[2] = lane_val(L[9], u); }
+          return;
+        }
+        const float u0 = lane_val(L[0], u), v0 = lane_val(L[1], u), uu = lane_val(L[2], u), uv = lane_val(L[3], u), vv = lane_val(L[4], u);
+        const float dmc = lane_val(L[5], u), mu = lane_val(L[6], u);
+        const float n = u0 + alpha * v0;
+        const float tsqr = uu + alpha * (2.f * uv + alpha * vv);
+        const float tt = DM_SQRT(tsqr);
+        const bool bottom = (tsqr <= 0.f && n < 0.f) || (tsqr > 0.f && mu * n + tt <= 0.f);
+        const bool middle = tsqr > 0.f && n < mu * tt && mu * n + tt > 0.f;
+        if (bottom) { o[0] = lane_val(L[7], u); o[1] = lane_val(L[8], u); o[2] = lane_val(L[9], u); }
+        if (middle) {
+          const float n1 = v0, t1 = (uv + alpha * vv) / tt, t2 = vv / tt - (uv + alpha * vv) * t1 / (tt * tt);
+          const float nmt = n - mu * tt, g = n1 - mu * t1;
+          o[3] = 0.5f * dmc * nmt * nmt;
+          o[4] = dmc * nmt * g;
+          o[5] = dmc * (g * g - nmt * mu * t2);
+        }
+      });
+      float r[6];
+      w.vsumN(t, r);
+      const float q0 = r[0] + qg0, q1 = r[1] + qg1, q2 = r[2] + qg2;
+      LsPoint p;
+      p.alpha = alpha;
+      p.cost = alpha * alpha * q2 + alpha * q1 + q0 + r[3];
+      p.d0 = DM_FMA(2.f * alpha, q2, q1) + r[4];   // single-rounding slope, see rollout_body.h
+      p.d1 = 2.f * q2 + r[5];
+      if (p.d1 == 0.f) p.d1 = MJ_MINVAL;
+      return p;
+    };
+    LsPoint p0 = ls_point(0.f);
+    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
+    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    bool swap = true;
+    int ls_iter = 0;
+    for (;;) {
+      const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      if (ls_done) break;
+      const LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
+      const LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
+      const LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
+      if (m->ls_rule == DIAL_LS_SWAP) {
+        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+        if (swap_lo_next) lo = lo_next;
+        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+        if (swap_lo_mid) lo = mid;
+        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+        if (swap_hi_next) hi = hi_next;
+        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+        if (swap_hi_mid) hi = mid;
+        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+      } else {
+        const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
+          return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
+        };
+        const bool s1 = in_bracket(lo, lo_next);
+        if (s1) lo = lo_next;
+        const bool s2b = in_bracket(lo, mid);
+        if (s2b) lo = mid;
+        const bool s3 = in_bracket(lo, hi_next);
+        if (s3) lo = hi_next;
+        const bool s4 = in_bracket(hi, hi_next);
+        if (s4) hi = hi_next;
+        const bool s5 = in_bracket(hi, mid);
+        if (s5) hi = mid;
+        const bool s6 = in_bracket(hi, lo_next);
+        if (s6) hi = lo_next;
+        swap = s1 || s2b || s3 || s4 || s5 || s6;
+      }
+      ls_iter++;
+    }
+    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    if (improved) {
+      vqacc = vqacc + vsearch * alpha;
+      vMa = vMa + vmv * alpha;
+      w.items(D::NE, [&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
+    }
+    niter++;
+    DIAL_MARK(w, 7);
+  }
+  w.items(NV, [&](int i) {
+    const float q = lane_val(vqacc, i);
+    s.qacc[i] = q;
+    s.warm[i] = q;
+  });
+  DIAL_MARK(w, 8);
+}
+
+}  // namespace dial

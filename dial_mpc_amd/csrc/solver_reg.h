@@ -79,10 +79,11 @@ struct AncList {
   }
 };
 
-template <class D, class W, class M>
+// TopoT: the fill pattern of A -- the robot's dof tree for M (and M + dt B), TopoDense for a matrix that couples all dofs
+template <class D, class TopoT = typename D::Topo, class W, class M>
 DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch) {
   constexpr int N = D::NV, S = kCholStride<N>;
-  using Topo = typename D::Topo;
+  using Topo = TopoT;
   w.begin_region();
   vfloat a[N];
   static_assert(D::square, "the register solver reads M / H from the square LDS layout");

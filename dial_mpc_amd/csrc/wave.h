@@ -112,6 +112,11 @@ struct Wave {
   vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l); return r; }
   template <class F>
   vfloat per_lane_r(F f) { return per_lane(f); }
+  // K values per lane at once: f(lane, float out[K])
+  template <int K, class F>
+  void per_lane_n(vfloat (&out)[K], F f) {
+    for (int l = 0; l < 64; l++) { float o[K]; f(l, o); for (int k = 0; k < K; k++) out[k].x[l] = o[k]; }
+  }
   // value of the lane whose index differs in bit 0 / bit 1 (neighbours inside a quad; DPP quad_perm on the GPU)
   vfloat quad_xor1(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 1]; return r; }
   vfloat quad_xor2(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[l ^ 2]; return r; }
@@ -261,6 +266,13 @@ struct Wave {
   // being hoisted out of the T-step loop as dozens of long-lived address VGPRs (use where that causes spills)
   template <class F>
   __device__ __forceinline__ vfloat per_lane_r(F f) { return f(lane_r); }
+  template <int K, class F>
+  __device__ __forceinline__ void per_lane_n(vfloat (&out)[K], F f) {
+    float o[K];
+    f(lane, o);
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = o[k];
+  }
   __device__ __forceinline__ vfloat quad_xor1(vfloat v) {   // quad_perm [1,0,3,2]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
   }

@@ -22,12 +22,12 @@ struct Runner {
     fill_cmodel(&cm, m, t, dv);
     Ws s;
     ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square);
+                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
   }
   void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
     lds.assign(ws_words, 0.f);
     ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
-             DIAL_MAX_NODE, dial::kNeedL<D>, D::square);
+             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
     w.lds = lds.data();
     w.lds_words = ws_words;
     w.check_races = check_races != 0;
@@ -74,6 +74,11 @@ int run_env_reset(const dial_model* m, const dial_task* t, const dial_derived* d
 }
 
 #define DISPATCH(path, m, CALL)                                        \
+  if ((m)->cone == DIAL_CONE_ELLIPTIC) {                                \
+    if (dims_match<DimsAllegro>(m) && ell_fits<DimsAllegro>(m, &dv)) return CALL(DimsAllegro); \
+    return DIAL_ERR_UNSUPPORTED;   /* elliptic cones: dimension-specialised instantiations only */ \
+  }                                                                    \
+  if ((m)->eulerdamp) return DIAL_ERR_UNSUPPORTED;                     \
   if ((path) == 0 && dims_match<DimsGo2>(m)) return CALL(DimsGo2);     \
   if ((path) == 0 && dims_match<DimsH1>(m)) return CALL(DimsH1);       \
   if ((path) == 0 && dims_match<DimsH1Loco>(m)) return CALL(DimsH1Loco); \
@@ -90,7 +95,6 @@ int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, co
   dial_derived dv;
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
-  if (m->eulerdamp) return DIAL_ERR_UNSUPPORTED;
   dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr, 0, 0u, 0u, 0u, 0};
 #define CALL(D) run_rollout<D>(m, t, &dv, cfg, io, B, check_races)
   DISPATCH(path, m, CALL)
@@ -124,6 +128,7 @@ int emu_sizes(const dial_model* m, int* cmodel_bytes, int* ws_words) {
   if (dims_match<DimsGo2>(m)) { Runner<DimsGo2> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 1; }
   if (dims_match<DimsH1>(m)) { Runner<DimsH1> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 2; }
   if (dims_match<DimsH1Loco>(m)) { Runner<DimsH1Loco> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 3; }
+  if (dims_match<DimsAllegro>(m) && ell_fits<DimsAllegro>(m, &dv)) { Runner<DimsAllegro> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 4; }
   Runner<DimsMax> r(m, &t, &dv);
   *cmodel_bytes = (int)sizeof(r.cm);
   *ws_words = r.ws_words;

@@ -19,7 +19,8 @@ from conftest import seeded_inputs, setup_case  # noqa: E402
 for name, example, N, H in [("go2_trot_N64_H8", "unitree_go2_trot", 64, 8),
                             ("go2_seq_jump_N48_H16", "unitree_go2_seq_jump", 48, 16),
                             ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16),
-                            ("h1_loco_N32_H20", "unitree_h1_loco", 32, 20)]:
+                            ("h1_loco_N32_H20", "unitree_h1_loco", 32, 20),
+                            ("allegro_reorient_N64_H8", "allegro_reorient", 64, 8)]:
     dc, env, model, task, cfg = setup_case(example, N, H)
     o64 = O.Oracle(model, task, cfg, np.float64)
     s0, _, _ = o64.env_reset(env._init_q, np.zeros(model.nv))
