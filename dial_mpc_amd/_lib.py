@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-fno-hip-fp32-correctly-rounded-divide-sqrt",
            "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
            "-Xarch_device", "-fno-slp-vectorize", "-Xarch_device", "-fno-honor-nans", "-o", LIB_PATH,
-           os.path.join(_CSRC, "dial_hip.hip")]
+           os.path.join(_CSRC, "dial_hip.hip")] + os.environ.get("DIAL_HIPCC_EXTRA", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -134,6 +134,7 @@ struct CModel {
   int32_t dof_bodyid[D::NV], dof_jntid[D::NV], dof_act[D::NV], dof_limrow[D::NV];
   uint32_t dof_ancmask[D::NV];           // bit j: dof j is an ancestor-or-self of dof i
   uint32_t dof_descmask[D::NV];          // bit j: dof j is a descendant-or-self of dof i
+  int32_t dof_blk0[D::NV], dof_blk1[D::NV];   // dofs of the same kinematic tree: the non-zero columns of row i of M
   float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
   uint16_t tri[D::NTRI + (D::NTRI & 1)];
   // H work list (square layout), derived from dial_derived::hitem and padded with no-op items to whole passes:

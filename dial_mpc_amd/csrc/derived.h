@@ -241,6 +241,13 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int j = 0; j < m->nv; j++) if ((dv->dof_ancmask[j] >> i) & 1u) o.dof_descmask[i] |= (1u << j);
     o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
   }
+  for (int i = 0; i < m->nv; i++) {   // dof range of the kinematic tree that holds dof i (dofs of a tree are contiguous)
+    const int root = m->body_rootid[m->dof_bodyid[i]];
+    int lo = i, hi = i + 1;
+    while (lo > 0 && m->body_rootid[m->dof_bodyid[lo - 1]] == root) lo--;
+    while (hi < m->nv && m->body_rootid[m->dof_bodyid[hi]] == root) hi++;
+    o.dof_blk0[i] = lo; o.dof_blk1[i] = hi;
+  }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
   if constexpr (D::square && !D::ell) {
     static_assert(D::NHI % 64 == 0 && D::NV * D::T < 1024 && D::NV * D::S < 1024 && D::NE + 4 < 64, "hrec field widths");
@@ -333,7 +340,7 @@ struct Ws {
   float *H, *JarefW, *JarefS, *jv, *frc, *quad, *MaW, *MaS, *grad, *search, *mv, *qfc, *ysol;
   // elliptic models (solver_cone.h): contact-on flags, per-contact cone Hessian weights, per-dof vectors that the row
   // products gather from
-  float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1;
+  float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1, *ulist;
 };
 
 #if defined(__HIPCC__)
@@ -364,7 +371,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(cdist, ncon) WS_TAKE(cpos, ncon * 3) WS_TAKE(cframe, ncon * 9) WS_TAKE(Jc, njc)
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
-  WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv)
+  WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv) WS_TAKE(ulist, ell * (nefc > 0 ? 68 : 0))
   const int u0 = o;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)

@@ -21,6 +21,18 @@
 
 #define WSUM_CHUNKS 64
 
+// wavefronts per workgroup (they share one staged copy of the constants) / occupancy target of the Go2 instantiations:
+// small batches (every sample co-resident at 1 wavefront per workgroup) and large ones (LDS per wavefront matters)
+#ifndef DIAL_GO2_WPB_LARGE
+#define DIAL_GO2_WPB_LARGE 4
+#endif
+#ifndef DIAL_GO2_OCC_LARGE
+#define DIAL_GO2_OCC_LARGE 3
+#endif
+#ifndef DIAL_GO2_LARGE_B
+#define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
+#endif
+
 // ------------------------------------------------------------------ kernels
 // Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
 // WPB wavefronts (= samples) per workgroup share ONE staged copy of the constants; each wavefront has
@@ -50,8 +62,9 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   return m;
 }
 
-template <class D, int WPB>
-__global__ void __launch_bounds__(64 * WPB, 3)
+// OCC: minimum resident wavefronts per SIMD the register allocation must allow (3: <= 168 VGPRs, 4: <= 128)
+template <class D, int WPB, int OCC = 3>
+__global__ void __launch_bounds__(64 * WPB, OCC)
 rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
                const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -282,6 +295,7 @@ struct dial_ctx {
   unsigned long long* prof = nullptr;
   size_t lds_bytes = 0;        // env_step / env_reset kernels (one wavefront, no node array)
   size_t lds_rollout = 0;      // rollout kernel: constants + DIAL_WPB workspaces
+  size_t lds_large = 0;        // Go2 large-batch instantiation (more wavefronts per workgroup)
   int ws_words = 0, cm_bytes = 0, wpb = 1;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -411,9 +425,13 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     dial_destroy(ctx);
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds the 160 KiB of a CU");
   }
-  if (ctx->lds_rollout > 64 * 1024) {   // more than the default dynamic-LDS limit of a launch: opt in (gfx950: 160 KiB per workgroup)
+  if (ctx->inst == 1) ctx->lds_large = ctx->cm_bytes + (size_t)DIAL_GO2_WPB_LARGE * ctx->ws_words * sizeof(float);
+  {   // more than the default 64 KiB dynamic-LDS limit of a launch: opt in (gfx950: up to 160 KiB per workgroup)
     hipError_t e = hipSuccess;
-    if (ctx->inst == 4) e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+    if (ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+    if (e == hipSuccess && ctx->inst == 1 && ctx->lds_large > 64 * 1024)
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
@@ -489,7 +507,11 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
   hipLaunchKernelGGL((rollout_kernel<D, WPB>), dim3((B + WPB - 1) / WPB), dim3(64 * WPB), ctx->lds_rollout, \
                      st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
                      (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words)
-  if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
+  if (ctx->inst == 1 && B > DIAL_GO2_LARGE_B)
+    hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>), dim3((B + DIAL_GO2_WPB_LARGE - 1) / DIAL_GO2_WPB_LARGE),
+                       dim3(64 * DIAL_GO2_WPB_LARGE), ctx->lds_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask,
+                       (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words);
+  else if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
   else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, 4);

@@ -11,6 +11,10 @@
 //   * H = M + sum_c J_c^T W_c J_c is accumulated contact by contact over (dof, dof) pairs of the contact's dof set;
 //     contacts that are off (dist >= margin) or in the cone's top zone are skipped outright -- with the ball resting
 //     on three fingertips 3 of the 19 contacts do any work;
+//   * the units that can contribute at all (contacts that are on, limit rows past their range) are compacted into a
+//     list once per solve (ballot + mbcnt): row products, the Jaref update and the line search run over that list --
+//     with <= 16 such units the three trial points of a line-search iteration are evaluated in ONE pass by three
+//     16-lane groups (six interleaved 16-lane DPP reductions per pass);
 //   * H couples every dof with every other, so it is factorised by the register L D L^T of solver_reg.h with the
 //     dense elimination order; M (and M + dt B of the implicit damping) keep the tree order.
 //
@@ -34,30 +38,40 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   const vbool isdof = w.lane_lt(NV);
   const float mu_scale = 1.f / DM_SQRT(m->impratio);   // mu = friction_0 / sqrt(impratio)
 
-  // ---- row products  out[r] = J_r . vec  (two vectors at once when vecB != nullptr); off contacts give 0
+  // ---- units that can contribute: limit rows past their range (D > 0) and contacts that are on
+  const int n_on = w.compact(NU_, [&](int u) { return u < NL ? s.D[u] > 0.f : s.con_on[u - NL] != 0.f; }, s.ulist);
+  // ---- row products  out[r] = J_r . vec  over the rows of those units (two vectors at once when vecB != nullptr)
   auto row_products = [&](const float* vecA, float* outA, const float* vecB, float* outB) {
-    w.items(NL + 6 * NC, [&](int it) {
-      if (it < NL) {
-        const int dof = m->jnt_dofadr[m->lim_jnt[it]];
-        outA[it] = s.lsign[it] * vecA[dof];
-        if (vecB) outB[it] = s.lsign[it] * vecB[dof];
+    w.items(6 * n_on, [&](int it) {
+      const int idx = it / 6, k = it - 6 * idx, u = (int)s.ulist[idx];
+      if (u < NL) {
+        if (k != 0) return;
+        const int dof = m->jnt_dofadr[m->lim_jnt[u]];
+        outA[u] = s.lsign[u] * vecA[dof];
+        if (vecB) outB[u] = s.lsign[u] * vecB[dof];
         return;
       }
-      const int c = (it - NL) / 6, k = (it - NL) - 6 * c;
+      const int c = u - NL;
       if (k >= m->con_dim[c]) return;
-      const int r = m->con_adr[c] + k;
+      const int r = m->con_adr[c] + k, nd = m->con_ndof[c];
+      const float* J = s.Jc + m->con_joff[c] + k * nd;
       float a = 0.f, b = 0.f;
-      if (s.con_on[c] != 0.f) {
-        const int nd = m->con_ndof[c];
-        const float* J = s.Jc + m->con_joff[c] + k * nd;
-        for (int q = 0; q < nd; q++) {
-          const int i = m->con_dof[c][q];
-          a += J[q] * vecA[i];
-          if (vecB) b += J[q] * vecB[i];
-        }
+      for (int q = 0; q < nd; q++) {
+        const int i = m->con_dof[c][q];
+        a += J[q] * vecA[i];
+        if (vecB) b += J[q] * vecB[i];
       }
       outA[r] = a;
       if (vecB) outB[r] = b;
+    });
+  };
+  // rows of the contributing units: r -> f(r)
+  auto for_on_rows = [&](auto f) {
+    w.items(6 * n_on, [&](int it) {
+      const int idx = it / 6, k = it - 6 * idx, u = (int)s.ulist[idx];
+      if (u < NL) { if (k == 0) f(u); return; }
+      const int c = u - NL;
+      if (k < m->con_dim[c]) f(m->con_adr[c] + k);
     });
   };
   // ---- unit evaluation: cost of limit row / contact u at the row values ja[]; STORE additionally writes the forces,
@@ -66,7 +80,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     // value of row r: ja[r] - aref[r] when aref is given (initial points), ja[r] otherwise
     auto val = [&](int r) { return aref_or_null ? ja[r] - aref_or_null[r] : ja[r]; };
     if (u < NL) {
-      const float j = val(u), d = s.D[u];
+      const float d = s.D[u];
+      if (d == 0.f) { if (store) s.frc[u] = 0.f; return 0.f; }   // inside its range: the row is off (and was never written)
+      const float j = val(u);
       const bool act = j < 0.f;
       if (store) s.frc[u] = act ? -d * j : 0.f;
       return act ? 0.5f * d * j * j : 0.f;
@@ -122,8 +138,8 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   auto mul_m = [&](const float* vec) {
     return w.per_lane([&](int l) {
       if (l >= NV) return 0.f;
-      float acc = 0.f;
-      for (int j = 0; j < NV; j++) acc += s.M[l * S + j] * vec[j];
+      float acc = 0.f;   // M is block diagonal: the columns of the dof's own kinematic tree
+      for (int j = m->dof_blk0[l]; j < m->dof_blk1[l]; j++) acc += s.M[l * S + j] * vec[j];
       return acc;
     });
   };
@@ -147,7 +163,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   const bool use_warm = cost_w < cost_s;
   vfloat vqacc = use_warm ? vwarm : vqas;
   vfloat vMa = use_warm ? maW : maS;
-  w.items(D::NE, [&](int r) { s.Jaref[r] = (use_warm ? s.Jaref[r] : s.jv[r]) - s.aref[r]; });
+  for_on_rows([&](int r) { s.Jaref[r] = (use_warm ? s.Jaref[r] : s.jv[r]) - s.aref[r]; });
   float cost = use_warm ? cost_w : cost_s;
   float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
   float prev_cost = INFINITY;
@@ -200,9 +216,12 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     }
 
     // ---- H = M + limit rows + per-contact blocks
-    w.items(NV * S, [&](int e) { s.H[e] = s.M[e]; });
+    w.items(NV * S / 4, [&](int e) {   // 16-byte copies
+      const float a = s.M[4 * e], b = s.M[4 * e + 1], c2 = s.M[4 * e + 2], d2 = s.M[4 * e + 3];
+      s.H[4 * e] = a; s.H[4 * e + 1] = b; s.H[4 * e + 2] = c2; s.H[4 * e + 3] = d2;
+    });
     w.items(NL, [&](int r) {
-      if (s.Jaref[r] < 0.f) { const int i = m->jnt_dofadr[m->lim_jnt[r]]; s.H[i * S + i] += s.D[r]; }
+      if (s.D[r] > 0.f && s.Jaref[r] < 0.f) { const int i = m->jnt_dofadr[m->lim_jnt[r]]; s.H[i * S + i] += s.D[r]; }
     });
     for (int c = 0; c < NC; c++) {
       if (s.con_on[c] == 0.f) continue;            // wave-uniform
@@ -251,13 +270,22 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    // per-unit line-search registers: limit row: (Jaref, jv | q0 q1 q2); contact: (u0 v0 uu uv vv Dm mu | quad_c)
+    // per-unit line-search registers: limit row: (Jaref, jv | q0 q1 q2); contact: (u0 v0 uu uv vv Dm mu | quad_c).
+    // fast layout (<= 16 contributing units): lane (g, j) = (lane >> 4, lane & 15), g < 3, holds unit ulist[j] -- the
+    // three 16-lane groups evaluate the three trial points of an iteration in one pass; otherwise lane u holds unit u
+    const bool fast = n_on <= 16;
+    auto unit_of_lane = [&](int l) -> int {
+      if (fast) { const int j = l & 15; return (l < 48 && j < n_on) ? (int)s.ulist[j] : -1; }
+      return l < NU_ ? l : -1;
+    };
     vfloat L[10];
-    w.per_lane_n(L, [&](int u, float* o) {
+    w.per_lane_n(L, [&](int l, float* o) {
       for (int k = 0; k < 10; k++) o[k] = 0.f;
-      if (u >= NU_) return;
+      const int u = unit_of_lane(l);
+      if (u < 0) return;
       if (u < NL) {
         const float ja = s.Jaref[u], jv = s.jv[u], d = s.D[u];
+        if (d == 0.f) return;
         o[0] = ja; o[1] = jv;
         o[7] = 0.5f * ja * ja * d; o[8] = jv * ja * d; o[9] = 0.5f * jv * jv * d;
         return;
@@ -276,34 +304,33 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       o[5] = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL); o[6] = mu;
       o[7] = q0; o[8] = q1; o[9] = q2;
     });
+    // is the lane's unit a limit row?  (mu = L[6] is > 0 exactly for contacts)
     struct LsPoint { float alpha, cost, d0, d1; };
-    auto ls_point = [&](float alpha) {
-      vfloat t[6];
-      w.per_lane_n(t, [&](int u, float* o) {
-        for (int k = 0; k < 6; k++) o[k] = 0.f;
-        if (u >= NU_) return;
-        if (u < NL) {
-          if (lane_val(L[0], u) + alpha * lane_val(L[1], u) < 0.f) { o[0] = lane_val(L[7], u); o[1] = lane_val(L[8], u); o[2] = lane_val(L[9], u); }
-          return;
-        }
-        const float u0 = lane_val(L[0], u), v0 = lane_val(L[1], u), uu = lane_val(L[2], u), uv = lane_val(L[3], u), vv = lane_val(L[4], u);
-        const float dmc = lane_val(L[5], u), mu = lane_val(L[6], u);
-        const float n = u0 + alpha * v0;
-        const float tsqr = uu + alpha * (2.f * uv + alpha * vv);
-        const float tt = DM_SQRT(tsqr);
-        const bool bottom = (tsqr <= 0.f && n < 0.f) || (tsqr > 0.f && mu * n + tt <= 0.f);
-        const bool middle = tsqr > 0.f && n < mu * tt && mu * n + tt > 0.f;
-        if (bottom) { o[0] = lane_val(L[7], u); o[1] = lane_val(L[8], u); o[2] = lane_val(L[9], u); }
-        if (middle) {
-          const float n1 = v0, t1 = (uv + alpha * vv) / tt, t2 = vv / tt - (uv + alpha * vv) * t1 / (tt * tt);
-          const float nmt = n - mu * tt, g = n1 - mu * t1;
-          o[3] = 0.5f * dmc * nmt * nmt;
-          o[4] = dmc * nmt * g;
-          o[5] = dmc * (g * g - nmt * mu * t2);
-        }
-      });
-      float r[6];
-      w.vsumN(t, r);
+    // the six sums of one unit at alpha: quadratic part (q0 q1 q2) + cone part (cost, slope, curvature)
+    auto unit_terms = [&](int l, float alpha, float* o) {
+      for (int k = 0; k < 6; k++) o[k] = 0.f;
+      const float mu = lane_val(L[6], l);
+      if (mu == 0.f) {   // limit row (or an idle lane: all registers 0)
+        if (lane_val(L[0], l) + alpha * lane_val(L[1], l) < 0.f) { o[0] = lane_val(L[7], l); o[1] = lane_val(L[8], l); o[2] = lane_val(L[9], l); }
+        return;
+      }
+      const float u0 = lane_val(L[0], l), v0 = lane_val(L[1], l), uu = lane_val(L[2], l), uv = lane_val(L[3], l), vv = lane_val(L[4], l);
+      const float dmc = lane_val(L[5], l);
+      const float n = u0 + alpha * v0;
+      const float tsqr = uu + alpha * (2.f * uv + alpha * vv);
+      const float tt = DM_SQRT(tsqr);
+      const bool bottom = (tsqr <= 0.f && n < 0.f) || (tsqr > 0.f && mu * n + tt <= 0.f);
+      const bool middle = tsqr > 0.f && n < mu * tt && mu * n + tt > 0.f;
+      if (bottom) { o[0] = lane_val(L[7], l); o[1] = lane_val(L[8], l); o[2] = lane_val(L[9], l); }
+      if (middle) {
+        const float n1 = v0, t1 = (uv + alpha * vv) / tt, t2 = vv / tt - (uv + alpha * vv) * t1 / (tt * tt);
+        const float nmt = n - mu * tt, g = n1 - mu * t1;
+        o[3] = 0.5f * dmc * nmt * nmt;
+        o[4] = dmc * nmt * g;
+        o[5] = dmc * (g * g - nmt * mu * t2);
+      }
+    };
+    auto finish = [&](float alpha, const float* r) {
       const float q0 = r[0] + qg0, q1 = r[1] + qg1, q2 = r[2] + qg2;
       LsPoint p;
       p.alpha = alpha;
@@ -313,6 +340,25 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (p.d1 == 0.f) p.d1 = MJ_MINVAL;
       return p;
     };
+    auto ls_point = [&](float alpha) {
+      vfloat t[6];
+      w.per_lane_n(t, [&](int l, float* o) {
+        unit_terms(l, alpha, o);
+        if (fast && l >= 16) for (int k = 0; k < 6; k++) o[k] = 0.f;   // the groups hold copies: count one
+      });
+      float r[6];
+      w.vsumN(t, r);
+      return finish(alpha, r);
+    };
+    auto ls_eval3 = [&](float a0, float a1, float a2, LsPoint& P0, LsPoint& P1, LsPoint& P2) {
+      if (!fast) { P0 = ls_point(a0); P1 = ls_point(a1); P2 = ls_point(a2); return; }
+      vfloat t[6];
+      w.per_lane_n(t, [&](int l, float* o) { unit_terms(l, l < 16 ? a0 : (l < 32 ? a1 : a2), o); });
+      w.row16_sumN(t);
+      float r0[6], r1[6], r2[6];
+      for (int k = 0; k < 6; k++) { r0[k] = bcast(t[k], 0); r1[k] = bcast(t[k], 16); r2[k] = bcast(t[k], 32); }
+      P0 = finish(a0, r0); P1 = finish(a1, r1); P2 = finish(a2, r2);
+    };
     LsPoint p0 = ls_point(0.f);
     LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
@@ -321,9 +367,8 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     for (;;) {
       const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
       if (ls_done) break;
-      const LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
-      const LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
-      const LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
+      LsPoint lo_next, hi_next, mid;
+      ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
       if (m->ls_rule == DIAL_LS_SWAP) {
         const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
         if (swap_lo_next) lo = lo_next;
@@ -359,11 +404,17 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     if (improved) {
       vqacc = vqacc + vsearch * alpha;
       vMa = vMa + vmv * alpha;
-      w.items(D::NE, [&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
+      for_on_rows([&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
     }
     niter++;
+#ifdef DIAL_PROFILE
+    if (w.lane == 0 && w.acc) { w.acc[30] += ls_iter; w.acc[31] += 1; w.acc[29] += fast ? 1 : 0; }
+#endif
     DIAL_MARK(w, 7);
   }
+#ifdef DIAL_PROFILE
+  if (w.lane == 0 && w.acc) { w.acc[28] += 1; w.acc[27] += n_on; }
+#endif
   w.items(NV, [&](int i) {
     const float q = lane_val(vqacc, i);
     s.qacc[i] = q;

@@ -145,6 +145,16 @@ struct Wave {
   }
   // three independent 16-lane sums at once (the DPP stages interleave on the GPU)
   void row16_sum3(vfloat& a, vfloat& b, vfloat& c) { a = row16_sum(a); b = row16_sum(b); c = row16_sum(c); }
+  // stream compaction: list[rank] = lane index of every lane < count whose predicate holds; returns how many
+  template <class F>
+  int compact(int count, F pred, float* list) {
+    int n = 0;
+    for (int l = 0; l < count && l < 64; l++) if (pred(l)) list[n++] = (float)l;
+    return n;
+  }
+  // K independent 16-lane sums (results replicated in every lane of the group)
+  template <int K>
+  void row16_sumN(vfloat (&v)[K]) { for (int k = 0; k < K; k++) v[k] = row16_sum(v[k]); }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
   float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
   template <int K>
@@ -325,6 +335,26 @@ struct Wave {
     v = dialwave::dpp_add<0x141>(v);   // row_half_mirror
     v = dialwave::dpp_add<0x140>(v);   // row_mirror
     return v;
+  }
+  template <class F>
+  __device__ __forceinline__ int compact(int count, F pred, float* list) {
+    const bool p = lane < count && pred(lane);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(p);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    if (p) list[rank] = (float)lane;
+    sync();
+    return __builtin_popcountll(b);
+  }
+  template <int K>
+  __device__ __forceinline__ void row16_sumN(vfloat (&v)[K]) {   // K chains, DPP stages interleaved
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0xb1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x4e>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x141>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x140>(v[k]);
   }
   __device__ __forceinline__ void row16_sum3(vfloat& a, vfloat& b, vfloat& c) {   // stage-interleaved: no DPP hazard stalls
     a = dialwave::dpp_add<0xb1>(a); b = dialwave::dpp_add<0xb1>(b); c = dialwave::dpp_add<0xb1>(c);

@@ -84,7 +84,7 @@ def one_step_consistency(o32, s0, us, got, rollouts, nq, nv, tol_scale=1.0):
     return worst
 
 
-def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed_ok=0):
+def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed_ok=0, max_frac=None):
     """Per-rollout parity of `got` = (rewss, qss, qdss, xss) [B,T,...] against the fp32 oracle `o32` run on the same
     controls `us` [B,T,nu] from the packed start state `s0`.  Returns a report dict; raises AssertionError when a
     rollout neither matches within TOL nor has a knife-edge witness (beyond `unwitnessed_ok` of them: chaotic long
@@ -118,8 +118,21 @@ def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed
                 f"per-step jitter of the oracle's state reproduces the GPU's branch")
         report["witnessed"] += 1
     frac = report["witnessed"] / B
-    assert frac <= max(KNIFE_EDGE_FRAC[example], 4.5 / B), (example, report)       # small batches: at most 4 rollouts
+    cap = KNIFE_EDGE_FRAC[example] if max_frac is None else max_frac
+    assert frac <= max(cap, 4.5 / B), (example, report)       # small batches: at most 4 rollouts
     return report
+
+
+def with_solver(model, ls_rule=None, iterations=None, ls_iterations=None):
+    """Copy of the model struct with other solver settings (line-search rule, iteration caps)."""
+    m2 = type(model).from_buffer_copy(model)
+    if ls_rule is not None:
+        m2.ls_rule = ls_rule
+    if iterations is not None:
+        m2.iterations = iterations
+    if ls_iterations is not None:
+        m2.ls_iterations = ls_iterations
+    return m2
 
 
 def agg_tol(example, name):

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import CASES, TOL, agg_tol, one_step_consistency, perturbed_state, seeded_inputs, setup_case, witness_parity
+from conftest import CASES, TOL, agg_tol, one_step_consistency, perturbed_state, seeded_inputs, setup_case, with_solver, witness_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -433,3 +433,30 @@ def test_degenerate_std_is_nan_like_the_reference():
     rews[3] = -1.0
     ctx.shard_reduce(_dev(rews), 63, 0, 63, True, packed)
     assert torch.isfinite(packed).all()
+
+
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 2048, 16), ("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16),
+                                         ("unitree_h1_loco", 1024, 20)])
+def test_in_bracket_rule_at_full_size(example, N, H):
+    """DIAL_LS_IN_BRACKET (the line-search rule of MJX >= 3.1.4) at the BASELINE sizes.  Converged solver (50 / 50): every
+    rollout within the tight gate, no witness needed.  Truncated (the envs' own settings): every rollout outside the
+    gate has a witness; how many need one is reported, not capped (the rule is a rounding lottery there)."""
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.2)
+    for m2, strict in ((with_solver(model, ls_rule=1, iterations=50, ls_iterations=50), True), (with_solver(model, ls_rule=1), False)):
+        ctx = _lib.Context(m2, task, cfg)
+        o32 = O.Oracle(m2, task, cfg, np.float32)
+        s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+        ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+        out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+        sc = ctx.debug_scratch()
+        got = (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"])
+        if strict:
+            rep = witness_parity(o32, s0, ro["us"], got, example, model.nq + 2 * model.nv, max_frac=0.002)
+            assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], agg_tol(example, "Ybar"))
+        else:
+            sub = np.random.default_rng(0).choice(N + 1, 256, replace=False)     # the witness search is sequential Python
+            rep = witness_parity(o32, s0, ro["us"][sub], tuple(g[sub] for g in got), example, model.nq + 2 * model.nv, max_frac=1.0)
+        print(f"{example} rule=in_bracket {'converged' if strict else 'truncated'}: {rep['outside_tol']} of {rep['rollouts']} outside the gate, all witnessed")

@@ -8,7 +8,7 @@ import pytest
 
 import emu_lib
 import oracle as O
-from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case, witness_parity
+from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case, with_solver, witness_parity
 
 
 def _close(a, b, tol):
@@ -69,3 +69,23 @@ def test_emulated_env_step_sequence():
         s_e, xp_e, xq_e, c_e = emu.env_step(s_e, a, check_races=(k == 0))
     assert np.allclose(s_o[:19], s_e[:19], atol=1e-3) and np.allclose(c_o, c_e, atol=1e-2)
     assert s_o[55] == 20.0 and s_e[55] == 20.0                     # info.step advanced
+
+
+@pytest.mark.parametrize("example,N,H", CASES[:4])
+def test_in_bracket_rule_converged_and_truncated(example, N, H):
+    """The `_in_bracket` line-search rule (MJX >= 3.1.4, DIAL_LS_IN_BRACKET) on the pyramidal models.  Run to
+    convergence (50 / 50 iterations) the solve does not depend on the search path: kernel logic and oracle agree on
+    EVERY rollout within the tight gate.  At the envs' truncated settings the rule turns rounding noise into different
+    iterates (a zero-slope candidate is rejected): every rollout that leaves the gate must be a branch
+    the oracle itself takes under <= 64 ulp of jitter."""
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+    for m2, strict in ((with_solver(model, ls_rule=1, iterations=50, ls_iterations=50), True), (with_solver(model, ls_rule=1), False)):
+        o32 = O.Oracle(m2, task, cfg, np.float32)
+        emu = emu_lib.Emu(m2, task, cfg, path=0)
+        s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+        ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+        re = emu.rollout_nodes(s0, Ybar, sigma, eps, check_races=False)
+        rep = witness_parity(o32, s0, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), example,
+                             model.nq + 2 * model.nv, max_frac=0.0 if strict else 0.95)
+        assert not strict or rep["outside_tol"] == 0

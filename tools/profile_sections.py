@@ -21,9 +21,14 @@ NAMES = {0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies
          9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)",
          28: "EVENTS (all samples, cumulative): 2nd Newton iterations", 29: "  ... with an unchanged active set",
          30: "  line-search iterations", 31: "  Newton iterations"}
+if len(sys.argv) > 1 and sys.argv[1] == "allegro_reorient":
+    NAMES.update({27: "EVENTS (all samples): contributing units (sum over solves)", 28: "  constraint solves (physics sub-steps)",
+                  29: "  Newton iterations on the 3-points-per-pass line search (<= 16 units)"})
 
 example = sys.argv[1] if len(sys.argv) > 1 else "unitree_go2_trot"
-dc, env, model, task, cfg = setup_case(example, 2048, 16)
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+HS = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+dc, env, model, task, cfg = setup_case(example, NS, HS)
 ctx = _lib.Context(model, task, cfg)
 dev = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device="cuda")  # noqa: E731
 s0, _, _ = ctx.env_reset(dev(env._init_q), dev(np.zeros(model.nv)))
@@ -31,7 +36,7 @@ eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
 lib = ctx.lib
 lib.dial_debug_prof.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
 W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(dc.Hsample + 1)], np.float32)
-for label, B in (("B=1", 1), ("B=2049", 2049)):
+for label, B in (("B=1", 1), (f"B={NS + 1}", NS + 1)):
     if B == 1:
         us = dev((W @ np.clip(Ybar, -1, 1))[None])
         ctx.rollout(s0, us)
