@@ -3,10 +3,15 @@
 
 Workload (BASELINE.json `metric`): unitree_go2_trot, Nsample = 2048 per GPU, Hsample = 16, Hnode = 4.
 One "step" = one annealing iteration `MBDPI.reverse_once` (K1..K4: sample -> spline -> (N+1) x 17
-env.steps -> softmax -> weighted means) over synthetic Go2 states that are already resident in HBM.
+env.steps -> softmax -> weighted means) over synthetic Go2 states that are already resident in HBM.  The
+noise is drawn INSIDE the timed region, like the reference's `jax.random.normal` inside reverse_once: by the
+in-kernel Philox generator of the rollout prologue (`kernel_rng=True`, the production setting).
 `value` = sample-rollouts/s over all ranks ((N_total + 1) rollouts per step; one rollout = Hsample+1
-env.steps).  Weak scaling: every GPU rolls out 2048 samples, N_total = 2048 * n_gpus (BASELINE config 5 is
-the 8-GPU instance of the same sharding with 8192 samples per GPU).
+env.steps).  `--scaling weak` (default): every GPU rolls out `--nsample-per-gpu` samples, N_total grows with
+the GPU count.  `--scaling strong --nsample-total 65536`: BASELINE config 5 -- a fixed global sample count
+sharded over the ranks (8192 per GPU on 8 GPUs), the configuration on which the >= 6x strong-scaling target
+of `north_star` can be shown (the headline N = 2048 runs at the single-wavefront latency floor once it is
+split 8 ways).
 
 Extra objects on the JSON line:
   roofline      dominant kernel = rollout_kernel; achieved = ALGORITHMIC HBM bytes (356 B per
@@ -67,11 +72,22 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nsample-per-gpu", type=int, default=2048)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--nsample-total", type=int, default=65536, help="global sample count of --scaling strong (BASELINE config 5)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="1 GPU only: run the sharded code path (1-rank RCCL group, all-gather + all-reduce) to measure its overhead")
+    ap.add_argument("--host-noise", action="store_true", help="feed pre-generated eps from HBM instead of the in-kernel RNG")
     ap.add_argument("--hsample", type=int, default=None, help="default: the example's own Hsample (Go2 trot: 16)")
     ap.add_argument("--example", default="unitree_go2_trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON record: whatever libraries print while the run is in progress (RCCL
+    # prints a version banner to stdout when a process group is created) is routed to stderr at the file-descriptor level
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -86,20 +102,25 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only compute path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.force_sharded:
+        os.environ["DIAL_FORCE_SHARDED"] = "1"
 
     from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
     from dial_mpc_amd.utils.io_utils import get_example_path
 
     cfgd = yaml.safe_load(open(get_example_path(args.example + ".yaml")))
-    N_total = args.nsample_per_gpu * world
+    N_total = args.nsample_per_gpu * world if args.scaling == "weak" else args.nsample_total
+    if args.scaling == "strong":
+        args.nsample_per_gpu = (N_total + world - 1) // world
     if args.hsample is None:
         args.hsample = int(cfgd["Hsample"])
     cfgd["Nsample"], cfgd["Hsample"] = N_total, args.hsample
     dial_config, env_config, env = load_dial_and_env(cfgd)
-    mbdpi = MBDPI(dial_config, env)
+    mbdpi = MBDPI(dial_config, env, kernel_rng=not args.host_noise)
     dev = mbdpi.device
     T, Hn1, nu = dial_config.Hsample + 1, dial_config.Hnode + 1, mbdpi.nu
 
@@ -113,12 +134,14 @@ def main():
         states.append(st)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0)                              # same stream on every rank: eps is the global array
-    eps_pool = [torch.randn((N_total, Hn1, nu), generator=gen, device=dev, dtype=torch.float32) for _ in range(4)]
+    eps_pool = [torch.randn((N_total, Hn1, nu), generator=gen, device=dev, dtype=torch.float32) for _ in range(4)] \
+        if args.host_noise else [None] * 4
     sigma = mbdpi.sigma_control.clone()
     Y = torch.zeros((Hn1, nu), dtype=torch.float32, device=dev)
 
     def one_step(i, Y):
-        _, Y, info = mbdpi.reverse_once(states[i % len(states)], None, Y, sigma, eps=eps_pool[i % len(eps_pool)])
+        eps = eps_pool[i % len(eps_pool)] if args.host_noise else None     # None: Philox noise inside the rollout kernel
+        _, Y, info = mbdpi.reverse_once(states[i % len(states)], None, Y, sigma, eps=eps)
         return Y
 
     for i in range(args.warmup):
@@ -152,14 +175,13 @@ def main():
         Yp = mbdpi.shift(Yp)
         for i in range(dial_config.Ndiffuse):
             _, Yp, _ = mbdpi.reverse_once(state, None, Yp, sigma * dial_config.traj_diffuse_factor ** i,
-                                          eps=eps_pool[(tick + i) % len(eps_pool)])
+                                          eps=eps_pool[(tick + i) % len(eps_pool)], want_bars=(i == dial_config.Ndiffuse - 1))
         torch.cuda.synchronize()
         if tick > 0:
             lat.append((time.perf_counter() - a) * 1e3)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     B_global = N_total + 1
@@ -185,12 +207,15 @@ def main():
         "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"
         else f"sample-rollouts/sec (N x H env.steps), {args.example}", "value": value,
         "unit": "sample-rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.example} reverse_once: Nsample={args.nsample_per_gpu}/GPU "
                                f"(N_total={N_total}), Hsample={args.hsample}, Hnode={dial_config.Hnode}, "
-                               f"8 synthetic robot states (home + 7 perturbed), eps ~ N(0,1) resident in HBM",
-                   "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)"},
+                               f"8 synthetic robot states (home + 7 perturbed); noise: " +
+                               ("eps ~ N(0,1) pre-generated, resident in HBM" if args.host_noise else
+                                "Philox4x32-10 + Box-Muller inside the rollout kernel, i.e. inside the timed region"),
+                   "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)" +
+                   (" (sharded code path forced: 1-rank RCCL all-gather + all-reduce per iteration)" if args.force_sharded else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "rollout_kernel",
@@ -208,8 +233,11 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.example, args.nsample_per_gpu, args.hsample)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
-    if world > 1:
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+    if world > 1 or args.force_sharded:
         dist.destroy_process_group()
 
 

@@ -72,6 +72,8 @@ def load():
     lib.dial_reverse_once_rng.argtypes = [vp, fp, fp, fp, ci, u64, u32, fp, fp, fp, fp, fp, vp]
     lib.dial_shard_rollout_rng.argtypes = [vp, fp, fp, fp, ci, u64, u32, ci, ci, ci, fp, vp]
     lib.dial_rng_fill.argtypes = [vp, u64, u32, ci, ci, fp, vp]
+    lib.dial_shard_ybar_rng.argtypes = [vp, fp, ci, u64, u32, fp, fp, ci, fp, vp]
+    lib.dial_shard_pack_rewards.argtypes = [vp, fp, ci, ci, ci, fp, vp]
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
@@ -87,7 +89,7 @@ def load():
 
 EXPORTED = ("dial_create", "dial_create_sharded", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
-            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shift", "dial_env_step", "dial_env_reset",
+            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset",
             "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
@@ -237,6 +239,15 @@ class Context:
         ns = int(noise_scale.numel())
         self._check(self.lib.dial_shard_ybar(self.h, _ptr(rews_all), n_total, _ptr(eps_all), _ptr(Ybar), _ptr(noise_scale),
                                              ns, _ptr(Ybar_out), _stream()), "dial_shard_ybar")
+
+    def shard_ybar_rng(self, rews_all, n_total: int, seed: int, counter: int, Ybar, noise_scale, Ybar_out):
+        self._check(self.lib.dial_shard_ybar_rng(self.h, _ptr(rews_all), n_total, int(seed), int(counter), _ptr(Ybar),
+                                                 _ptr(noise_scale), int(noise_scale.numel()), _ptr(Ybar_out), _stream()),
+                    "dial_shard_ybar_rng")
+
+    def shard_pack_rewards(self, gathered, world: int, per: int, n_total: int, rews_all):
+        self._check(self.lib.dial_shard_pack_rewards(self.h, _ptr(gathered), world, per, n_total, _ptr(rews_all), _stream()),
+                    "dial_shard_pack_rewards")
 
     def packed_size(self) -> int:
         T, Hn1 = self.cfg.Hsample + 1, self.cfg.Hnode + 1

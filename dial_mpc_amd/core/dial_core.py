@@ -44,6 +44,9 @@ class MBDPI:
         import torch
         self.kernel_rng = bool(kernel_rng)
         self._rng_counter = 0
+        self._plan = None    # preallocated buffers of the sharded iteration (core/sharding.py)
+        # measurement hook: run the sharded code path (collectives included) on a 1-rank process group
+        self._force_sharded = os.environ.get("DIAL_FORCE_SHARDED", "0") == "1"
         self.args = args
         self.env = env
         self.nu = env.action_size
@@ -123,24 +126,26 @@ class MBDPI:
         all-reduce, leaving one collective per annealing iteration (core/sharding.py)."""
         import torch
         packed = _packed(state)
-        if eps is None and self.kernel_rng and self.world == 1:
-            import torch
+        if eps is None and self.kernel_rng:
             Yb = torch.as_tensor(Ybar_i, dtype=torch.float32, device=self.device).contiguous()
             nsc = torch.as_tensor(noise_scale, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
-            out = self.ctx.reverse_once_rng(packed, Yb, nsc, int(self.args.seed), self._rng_counter)
-            self._rng_counter += 1
             T, nb1 = self.args.Hsample + 1, self.ctx.nbody - 1
-            return rng, out["Ybar"], {"rews": out["rews"], "qbar": out["qbar"], "qdbar": out["qdbar"],
-                                      "xbar": out["xbar"].reshape(T, nb1, 3), "new_noise_scale": nsc}
-        if eps is None and self.kernel_rng:
-            eps = self.ctx.rng_fill(int(self.args.seed), self._rng_counter, 0, self.args.Nsample)   # sharded: full array
+            counter = self._rng_counter
             self._rng_counter += 1
+            if self.world == 1 and not self._force_sharded:
+                out = self.ctx.reverse_once_rng(packed, Yb, nsc, int(self.args.seed), counter)
+                Ybar, rews, qbar, qdbar, xbar = out["Ybar"], out["rews"], out["qbar"], out["qdbar"], out["xbar"]
+            else:   # sharded: every rank draws its own shard's noise (and, for the mean action, everybody's) in-kernel
+                Ybar, rews, qbar, qdbar, xbar = self._reverse_once_sharded(packed, Yb, nsc, None, want_bars,
+                                                                           rng=(int(self.args.seed), counter))
+            return rng, Ybar, {"rews": rews, "qbar": qbar, "qdbar": qdbar,
+                               "xbar": xbar.reshape(T, nb1, 3) if xbar is not None else None, "new_noise_scale": nsc}
         if eps is None:
             rng, eps = self.sample_eps(rng)
         Ybar_i = torch.as_tensor(Ybar_i, dtype=torch.float32, device=self.device).contiguous()
         noise_scale = torch.as_tensor(noise_scale, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
         T, nb1 = self.args.Hsample + 1, self.ctx.nbody - 1
-        if self.world == 1:
+        if self.world == 1 and not self._force_sharded:
             out = self.ctx.reverse_once(packed, Ybar_i, noise_scale, eps.contiguous())
             Ybar, rews = out["Ybar"], out["rews"]
             qbar, qdbar, xbar = out["qbar"], out["qdbar"], out["xbar"]
@@ -150,11 +155,15 @@ class MBDPI:
                 "new_noise_scale": noise_scale}
         return rng, Ybar, info
 
-    def _reverse_once_sharded(self, packed, Ybar_i, noise_scale, eps, want_bars=True):
+    def _reverse_once_sharded(self, packed, Ybar_i, noise_scale, eps, want_bars=True, rng=None):
         import torch.distributed as dist
-        from dial_mpc_amd.core.sharding import sharded_reverse_once
-        return sharded_reverse_once(self.ctx, dist, self.rank, self.world, self.args.Nsample,
-                                    self.args.Hsample + 1, self.args.Hnode + 1, packed, Ybar_i, noise_scale, eps, want_bars)
+        from dial_mpc_amd.core.sharding import ShardPlan, sharded_reverse_once
+        if self._plan is None:
+            self._plan = ShardPlan(self.ctx, self.rank, self.world, self.args.Nsample, self.args.Hsample + 1,
+                                   self.args.Hnode + 1)
+        return sharded_reverse_once(self.ctx, dist, self.rank, self.world, self.args.Nsample, self.args.Hsample + 1,
+                                    self.args.Hnode + 1, packed, Ybar_i, noise_scale,
+                                    eps.contiguous() if eps is not None else None, want_bars, plan=self._plan, rng=rng)
 
     # ---- receding-horizon shift (dial_core.py:160-172)
     def shift(self, Y):

@@ -2,19 +2,21 @@
 
 The reference has no multi-device code.  The N noisy samples are partitioned contiguously by rank; every
 rank additionally rolls out the mean trajectory (the appended sample, dial_core.py:114) so ``rew_Ybar_i`` is
-available everywhere.  The softmax couples all samples through the global std / max, hence:
+available everywhere.  The softmax couples all samples through the global std / max, hence per annealing iteration:
 
-  1. all-gather of the per-sample mean rewards (4*N/world bytes per rank) -> every rank forms the SAME N+1
-     weights with the same fixed-order reduction (bit-identical Ybar on all ranks, otherwise plans diverge);
-  2a. want_bars=False (every annealing iteration but the last): the weighted mean action is formed LOCALLY on
-     every rank from the full noise array (all candidate nodes are regenerated, 8e option (a)) -- the all-gather
-     is the ONLY collective of the iteration;
-  2b. want_bars=True (last iteration of a plan, whose qbar/qdbar/xbar the drivers read): all-reduce (sum) of
-     the packed partial weighted sums [Ybar | qbar | qdbar | xbar] (5.4 KB for Go2).
+  1. ONE all-gather of the per-sample mean rewards (4 (N/world + 1) bytes per rank; the rollout kernel writes them
+     straight into the send buffer) -> every rank forms the SAME N+1 weights with the same fixed-order reduction
+     (bit-identical Ybar on all ranks, otherwise the plans diverge);
+  2a. want_bars=False (every annealing iteration but the last): the weighted mean action is formed LOCALLY on every
+     rank -- all candidate nodes are rebuilt from the noise, which with the in-kernel Philox generator is regenerated
+     from (seed, iteration, sample index), so no noise array exists anywhere -- the all-gather is the ONLY collective;
+  2b. want_bars=True (last iteration of a plan, whose qbar/qdbar/xbar the drivers read): all-reduce (sum) of the
+     packed partial weighted sums [Ybar | qbar | qdbar | xbar] (5.4 KB for Go2).
 
-Both messages are KB-sized, i.e. latency-bound on xGMI.  The compute backend is passed in as ``ctx``
-(``dial_mpc_amd._lib.Context`` in production) so that the partition / collective logic is testable with
-world_size-2 gloo on CPU against a stand-in context.
+Both messages are KB-sized, i.e. latency-bound on xGMI.  Every buffer is allocated once (``ShardPlan``); an iteration
+is 1 rollout launch + the all-gather + 1 packing launch + 3 K4 launches (+ the all-reduce).  The compute backend is
+passed in as ``ctx`` (``dial_mpc_amd._lib.Context`` in production) so that the partition / collective logic is
+testable with gloo on CPU against a stand-in context.
 """
 from __future__ import annotations
 
@@ -25,35 +27,54 @@ def partition(N: int, rank: int, world: int):
     return per, n_begin, min(per, N - n_begin)
 
 
+class ShardPlan:
+    """Preallocated buffers of one rank's sharded iteration."""
+
+    def __init__(self, ctx, rank: int, world: int, N: int, T: int, Hn1: int):
+        import torch
+        self.ctx, self.rank, self.world, self.N, self.T, self.Hn1 = ctx, rank, world, N, T, Hn1
+        self.per, self.n_begin, self.n_local = partition(N, rank, world)
+        if world > 1 and partition(N, 0, world)[2] != self.per:
+            raise ValueError("sample sharding needs Nsample >= world size")
+        dev = ctx.torch_device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.send = torch.zeros(self.per + 1, **f32)               # [n_local noisy rewards ... | slot `per`: unused unless full]
+        self.gathered = torch.empty(world * (self.per + 1), **f32)
+        self.rews_all = torch.empty(N + 1, **f32)
+        self.Ybar = torch.empty((Hn1, ctx.nu), **f32)
+        self.packed = torch.empty(ctx.packed_size(), **f32)
+
+
 def sharded_reverse_once(ctx, dist, rank: int, world: int, N: int, T: int, Hn1: int, packed_state, Ybar_i,
-                         noise_scale, eps, want_bars: bool = True):
-    import torch
-    dev = ctx.torch_device
-    per, n_begin, n_local = partition(N, rank, world)
-    eps_local = eps[n_begin:n_begin + n_local].contiguous()
-    tmp = torch.empty(n_local + 1, dtype=torch.float32, device=dev)
-    ctx.shard_rollout(packed_state, Ybar_i, noise_scale, eps_local, n_local, True, tmp)
-    rews_local = torch.zeros(per + 1, dtype=torch.float32, device=dev)
-    rews_local[:n_local] = tmp[:n_local]
-    rews_local[per] = tmp[n_local]
-    flat = torch.empty(world * (per + 1), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(flat, rews_local)
-    gathered = flat.reshape(world, per + 1)
-    rews_all = torch.cat([gathered[:, :per].reshape(-1)[:N], gathered[0, per:per + 1]]).contiguous()
+                         noise_scale, eps, want_bars: bool = True, plan: ShardPlan = None, rng=None):
+    """eps: the GLOBAL noise array [N, Hn1, nu] (parity runs), or None with rng = (seed, counter): in-kernel noise."""
+    if plan is None:
+        plan = ShardPlan(ctx, rank, world, N, T, Hn1)
+    per, n_begin, n_local = plan.per, plan.n_begin, plan.n_local
+    # phase A: this rank's rollouts; rewards land in the all-gather send buffer ([0, n_local) noisy, [n_local] mean;
+    # rank 0 always holds a full shard, so its mean reward sits in slot `per`, where dial_shard_pack_rewards reads it)
+    if eps is None:
+        seed, counter = rng
+        ctx.shard_rollout_rng(packed_state, Ybar_i, noise_scale, seed, counter, n_begin, n_local, True, plan.send)
+    else:
+        ctx.shard_rollout(packed_state, Ybar_i, noise_scale, eps[n_begin:n_begin + n_local], n_local, True, plan.send)
+    dist.all_gather_into_tensor(plan.gathered, plan.send)
+    ctx.shard_pack_rewards(plan.gathered, world, per, N, plan.rews_all)
     if not want_bars:
-        Ybar = torch.empty((Hn1, ctx.nu), dtype=torch.float32, device=dev)
-        ctx.shard_ybar(rews_all, N, eps.contiguous(), Ybar_i, noise_scale, Ybar)
-        return Ybar, rews_all, None, None, None
-    packed_out = torch.empty(ctx.packed_size(), dtype=torch.float32, device=dev)
-    ctx.shard_reduce(rews_all, N, n_begin, n_local, rank == 0, packed_out)
-    dist.all_reduce(packed_out, op=dist.ReduceOp.SUM)
+        if eps is None:
+            ctx.shard_ybar_rng(plan.rews_all, N, seed, counter, Ybar_i, noise_scale, plan.Ybar)
+        else:
+            ctx.shard_ybar(plan.rews_all, N, eps, Ybar_i, noise_scale, plan.Ybar)
+        return plan.Ybar, plan.rews_all, None, None, None
+    ctx.shard_reduce(plan.rews_all, N, n_begin, n_local, rank == 0, plan.packed)
+    dist.all_reduce(plan.packed, op=dist.ReduceOp.SUM)
     nq, nv, nx, nu = ctx.nq, ctx.nv, ctx.nx, ctx.nu
     o = 0
-    Ybar = packed_out[o:o + Hn1 * nu].reshape(Hn1, nu)
+    Ybar = plan.packed[o:o + Hn1 * nu].reshape(Hn1, nu)
     o += Hn1 * nu
-    qbar = packed_out[o:o + T * nq].reshape(T, nq)
+    qbar = plan.packed[o:o + T * nq].reshape(T, nq)
     o += T * nq
-    qdbar = packed_out[o:o + T * nv].reshape(T, nv)
+    qdbar = plan.packed[o:o + T * nv].reshape(T, nv)
     o += T * nv
-    xbar = packed_out[o:o + T * nx].reshape(T, nx)
-    return Ybar, rews_all, qbar, qdbar, xbar
+    xbar = plan.packed[o:o + T * nx].reshape(T, nx)
+    return Ybar, plan.rews_all, qbar, qdbar, xbar

@@ -213,7 +213,7 @@ wsum_final_kernel(WsumArgs a, const float* __restrict__ partial) {
 extern "C" __global__ void __launch_bounds__(64)
 ybar_partial_kernel(const float* __restrict__ weights, const float* __restrict__ eps, const float* __restrict__ Ybar,
                     const float* __restrict__ noise_scale, int ns, int n_total, int C, int nu,
-                    float* __restrict__ partial) {
+                    float* __restrict__ partial, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   const int k = c / nu, chunk = blockIdx.y, per = (n_total + 1 + YB_CHUNKS - 1) / YB_CHUNKS;
@@ -221,7 +221,16 @@ ybar_partial_kernel(const float* __restrict__ weights, const float* __restrict__
   const float yb = Ybar[c], sc = noise_scale[ns == 1 ? 0 : k], y0 = Ybar[c - k * nu];
   float acc = 0.f;
   for (int n = r0; n < r1; n++) {
-    float v = n < n_total ? (k == 0 ? y0 : eps[(size_t)n * C + c] * sc + yb) : yb;
+    float e = 0.f;
+    if (n < n_total && k != 0) {
+      if (eps) e = eps[(size_t)n * C + c];
+      else {   // regenerate the sample's noise exactly as the rollout prologue drew it (Philox keyed by seed / iteration / sample / quad)
+        float z[4];
+        dial::normal_quad((uint32_t)n, (uint32_t)(c >> 2), iter, seed_lo, seed_hi, z);
+        e = z[c & 3];
+      }
+    }
+    float v = n < n_total ? (k == 0 ? y0 : e * sc + yb) : yb;
     v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
     acc += weights[n] * v;
   }
@@ -247,6 +256,15 @@ rng_fill_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t iter, int n_begin, 
   dial::normal_quad((uint32_t)(n_begin + n), (uint32_t)q, iter, seed_lo, seed_hi, z);
   for (int e = 0; e < 4; e++)
     if (4 * q + e < C) eps_out[(size_t)n * C + 4 * q + e] = z[e];
+}
+
+// Sharded runs: the all-gather delivers [world][per + 1] mean rewards (every rank's noisy samples, then its copy of the
+// mean-trajectory reward); K4 wants [n_total noisy | mean].  One tiny launch instead of slicing / concatenating tensors.
+extern "C" __global__ void __launch_bounds__(256)
+pack_rewards_kernel(const float* __restrict__ gathered, int per, int n_total, float* __restrict__ rews_all) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < n_total) rews_all[n] = gathered[(size_t)(n / per) * (per + 1) + (n % per)];
+  else if (n == n_total) rews_all[n] = gathered[per];   // rank 0's mean-trajectory reward (bit-identical on every rank)
 }
 
 // K5 (dial_core.py:160-166): u = W Y; u = roll(u,-1); u[-1] = 0; Y = V u.  One small workgroup.
@@ -614,22 +632,46 @@ int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_b
   return launch_wsum(ctx, ctx->weights, n_local + 1, n_begin, n_local, with_mean ? n_total : -1, Yo, qo, qdo, xo, st);
 }
 
-int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, const float* Ybar_in,
-                    const float* noise_scale, int ns, float* Ybar_out, void* stream) {
-  if (!ctx || !rews_all || !eps_all || !Ybar_in || !noise_scale || !Ybar_out)
-    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: null argument");
+static int shard_ybar_impl(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, int use_rng, uint64_t seed,
+                           uint32_t counter, const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out,
+                           void* stream, const char* who) {
+  if (!ctx || !rews_all || (!eps_all && !use_rng) || !Ybar_in || !noise_scale || !Ybar_out)
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
   if (!ctx->has_cfg || n_total + 1 > ctx->W_cap || n_total < 1 || (ns != 1 && ns != ctx->Hn1))
-    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: bad arguments (create the context with Nsample = global sample count)");
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": bad arguments (create the context with Nsample = global sample count)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   const int C = ctx->Hn1 * ctx->hm.nu;
   if ((size_t)YB_CHUNKS * C > (size_t)WSUM_CHUNKS * ((size_t)C + ctx->T * (ctx->hm.nq + ctx->hm.nv + ctx->nx)))
-    return fail(ctx, DIAL_ERR_ARG, "dial_shard_ybar: scratch too small");
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": scratch too small");
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(ybar_partial_kernel, dim3((C + 63) / 64, YB_CHUNKS), dim3(64), 0, st, (const float*)ctx->weights,
-                     eps_all, Ybar_in, noise_scale, ns, n_total, C, ctx->hm.nu, ctx->partial);
+                     eps_all, Ybar_in, noise_scale, ns, n_total, C, ctx->hm.nu, ctx->partial,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter);
   hipLaunchKernelGGL(ybar_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)ctx->partial, C, Ybar_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return DIAL_OK;
+}
+
+int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, const float* Ybar_in,
+                    const float* noise_scale, int ns, float* Ybar_out, void* stream) {
+  return shard_ybar_impl(ctx, rews_all, n_total, eps_all, 0, 0, 0, Ybar_in, noise_scale, ns, Ybar_out, stream, "dial_shard_ybar");
+}
+
+int dial_shard_ybar_rng(dial_ctx* ctx, const float* rews_all, int n_total, uint64_t seed, uint32_t counter,
+                        const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out, void* stream) {
+  return shard_ybar_impl(ctx, rews_all, n_total, nullptr, 1, seed, counter, Ybar_in, noise_scale, ns, Ybar_out, stream,
+                         "dial_shard_ybar_rng");
+}
+
+int dial_shard_pack_rewards(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, float* rews_all,
+                            void* stream) {
+  if (!ctx || !gathered || !rews_all || world < 1 || per < 1 || n_total < 1 || (long long)world * per < n_total)
+    return fail(ctx, DIAL_ERR_ARG, "dial_shard_pack_rewards: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(pack_rewards_kernel, dim3((n_total + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, gathered, per,
+                     n_total, rews_all);
   HIP_TRY(ctx, hipGetLastError());
   return DIAL_OK;
 }

@@ -314,6 +314,14 @@ int dial_shard_rollout_rng(dial_ctx* ctx, const float* state, const float* Ybar_
                            float* rews_local, void* stream);
 int dial_rng_fill(dial_ctx* ctx, uint64_t seed, uint32_t counter, int n_begin, int n_count, float* eps_out,
                   void* stream);
+/* dial_shard_ybar with the noise of ALL n_total samples regenerated inside the kernel (same Philox keys as
+ * dial_shard_rollout_rng): no noise array exists anywhere in a sharded run.                              */
+int dial_shard_ybar_rng(dial_ctx* ctx, const float* rews_all, int n_total, uint64_t seed, uint32_t counter,
+                        const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out, void* stream);
+/* gathered:[world][per+1] (the all-gather of every rank's dial_shard_rollout output) -> rews_all:[n_total+1]
+ * = [all noisy samples | mean trajectory], the layout dial_shard_reduce / dial_shard_ybar* consume.      */
+int dial_shard_pack_rewards(dial_ctx* ctx, const float* gathered, int world, int per, int n_total,
+                            float* rews_all, void* stream);
 
 /* K5. MBDPI.shift (dial_core.py:160-166): Y:[Hnode+1,nu] in place. */
 int dial_shift(dial_ctx* ctx, float* Y, void* stream);

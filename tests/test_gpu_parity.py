@@ -208,6 +208,15 @@ def test_sharded_path_on_one_rank_matches_unsharded():
                                                      _dev(sigma), _dev(eps), want_bars=False)
         assert qb1 is None and torch.equal(rews1, ref["rews"])
         assert torch.allclose(Yb1, ref["Ybar"], rtol=0, atol=1e-5)
+        # in-kernel noise: shard rollouts + locally rebuilt mean action without any noise array == the fused RNG path
+        seed, counter = 0xC0FFEE, 3
+        ref_rng = {k: v.clone() for k, v in ctx.reverse_once_rng(s0, _dev(Ybar), _dev(sigma), seed, counter).items()}
+        Yb2, rews2, qb2, _, xb2 = sharded_reverse_once(ctx, dist, 0, 1, 256, 17, dc.Hnode + 1, s0, _dev(Ybar), _dev(sigma),
+                                                       None, rng=(seed, counter))
+        assert torch.equal(rews2, ref_rng["rews"]) and torch.equal(Yb2, ref_rng["Ybar"]) and torch.equal(qb2, ref_rng["qbar"])
+        Yb3, rews3, _, _, _ = sharded_reverse_once(ctx, dist, 0, 1, 256, 17, dc.Hnode + 1, s0, _dev(Ybar), _dev(sigma),
+                                                   None, want_bars=False, rng=(seed, counter))
+        assert torch.equal(rews3, ref_rng["rews"]) and torch.allclose(Yb3, ref_rng["Ybar"], rtol=0, atol=1e-5)
     finally:
         if created:
             dist.destroy_process_group()

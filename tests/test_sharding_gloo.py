@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the sample-sharding / collective logic of reverse_once.
+"""world_size-2 and -4 gloo tests (CPU) of the sample-sharding / collective logic of reverse_once.
 
 The compute backend is a stand-in context (wave emulator for the rollouts + NumPy for the K4 algebra) --
 the production backend is dial_mpc_amd._lib.Context on a GPU; what is under test here is the partition,
@@ -48,8 +48,12 @@ class FakeCtx:
                                e._p(e._a(Ybar.numpy())), e._p(ns), int(ns.size), n_local, B, T, Hn1, e._p(Y0s),
                                e._p(rewss), e._p(rews), e._p(qss), e._p(qdss), e._p(xss), 0, 0)
         assert rc == 0
-        rews_out.copy_(torch.from_numpy(rews))
+        rews_out[:B].copy_(torch.from_numpy(rews))   # the kernel writes n_local + 1 entries of the (per + 1)-sized send buffer
         self.last = (Y0s, qss, qdss, xss)
+
+    def shard_pack_rewards(self, gathered, world, per, n_total, rews_all):
+        g = gathered.numpy().reshape(world, per + 1)
+        rews_all.copy_(torch.from_numpy(np.concatenate([g[:, :per].reshape(-1)[:n_total], g[0, per:per + 1]])))
 
     def shard_ybar(self, rews_all, n_total, eps_all, Ybar, noise_scale, Ybar_out):
         r = rews_all.numpy().astype(np.float32)
@@ -73,6 +77,7 @@ class FakeCtx:
 
 
 def _worker(rank, world, port, N, H, ret):
+    torch.set_num_threads(1)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -84,21 +89,24 @@ def _worker(rank, world, port, N, H, ret):
         o32 = O.Oracle(model, task, cfg, np.float32)
         s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
         eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)
-        out = sharded_reverse_once(ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0),
-                                   torch.from_numpy(Ybar), torch.from_numpy(sigma), torch.from_numpy(eps))
-        one = sharded_reverse_once(ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0),
-                                   torch.from_numpy(Ybar), torch.from_numpy(sigma), torch.from_numpy(eps),
-                                   want_bars=False)     # single-collective variant
+        from dial_mpc_amd.core.sharding import ShardPlan
+        plan = ShardPlan(ctx, rank, world, N, H + 1, dc.Hnode + 1)        # one set of buffers, reused like the driver does
+        args = (ctx, dist, rank, world, N, H + 1, dc.Hnode + 1, torch.from_numpy(s0), torch.from_numpy(Ybar),
+                torch.from_numpy(sigma), torch.from_numpy(eps))
+        # the driver's pattern: want_bars only on the last annealing iteration of a plan
+        one = sharded_reverse_once(*args, want_bars=False, plan=plan)     # single-collective variant
         assert one[2] is None and one[3] is None and one[4] is None
-        ret[rank] = [o.numpy().copy() for o in out] + [one[0].numpy().copy()]
+        Yb_single = one[0].numpy().copy()
+        out = sharded_reverse_once(*args, want_bars=True, plan=plan)
+        ret[rank] = [o.numpy().copy() for o in out] + [Yb_single]
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N", [64, 37])   # 37: ragged last shard
-def test_sharded_reverse_once_equals_unsharded(N):
+@pytest.mark.parametrize("N,world", [(64, 2), (37, 2), (64, 4), (37, 4)])   # 37: ragged last shard
+def test_sharded_reverse_once_equals_unsharded(N, world):
     import oracle as O
-    H, world = 8, 2
+    H = 8
     port = 29500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -114,5 +122,6 @@ def test_sharded_reverse_once_equals_unsharded(N):
         assert np.allclose(rews, ref["rews"], atol=1e-3)
         assert np.allclose(Yb, ref["Ybar"], atol=2e-3) and np.allclose(qbar, ref["qbar"], atol=5e-3)
         assert np.allclose(xbar, ref["xbar"].reshape(xbar.shape), atol=5e-3)
-    for a, b in zip(ret[0], ret[1]):                    # every rank holds bit-identical results
-        assert np.array_equal(a, b)
+    for rank in range(1, world):                        # every rank holds bit-identical results
+        for a, b in zip(ret[0], ret[rank]):
+            assert np.array_equal(a, b)
