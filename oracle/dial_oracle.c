@@ -35,6 +35,12 @@
 #define REAL double
 #endif
 typedef REAL real;
+/* tools/opcount builds this file as C++ with REAL = an operation-counting type (FLOP count of the dense formulation) */
+#ifdef DIAL_OPCOUNT
+#define OPC(field) (g_ops.field++)
+#else
+#define OPC(field) ((void)0)
+#endif
 
 #define NB DIAL_MAX_BODY
 #define NJ DIAL_MAX_JNT
@@ -51,18 +57,18 @@ typedef REAL real;
 #define MJ_MAXIMP ((real)0.9999)
 #define R_PI ((real)3.14159265358979323846)
 
-static inline real r_sqrt(real x) { return (real)sqrt((double)x); }
-static inline real r_sin(real x) { return sizeof(real) == 4 ? (real)sinf((float)x) : (real)sin((double)x); }
-static inline real r_cos(real x) { return sizeof(real) == 4 ? (real)cosf((float)x) : (real)cos((double)x); }
-static inline real r_atan2(real y, real x) { return sizeof(real) == 4 ? (real)atan2f((float)y, (float)x) : (real)atan2((double)y, (double)x); }
-static inline real r_asin(real x) { return sizeof(real) == 4 ? (real)asinf((float)x) : (real)asin((double)x); }
-static inline real r_pow(real x, real y) { return sizeof(real) == 4 ? (real)powf((float)x, (float)y) : (real)pow((double)x, (double)y); }
+static inline real r_sqrt(real x) { OPC(sqrt_); return (real)sqrt((double)x); }
+static inline real r_sin(real x) { OPC(trans); return sizeof(real) == 4 ? (real)sinf((float)x) : (real)sin((double)x); }
+static inline real r_cos(real x) { OPC(trans); return sizeof(real) == 4 ? (real)cosf((float)x) : (real)cos((double)x); }
+static inline real r_atan2(real y, real x) { OPC(trans); return sizeof(real) == 4 ? (real)atan2f((float)y, (float)x) : (real)atan2((double)y, (double)x); }
+static inline real r_asin(real x) { OPC(trans); return sizeof(real) == 4 ? (real)asinf((float)x) : (real)asin((double)x); }
+static inline real r_pow(real x, real y) { OPC(trans); return sizeof(real) == 4 ? (real)powf((float)x, (float)y) : (real)pow((double)x, (double)y); }
 static inline real r_abs(real x) { return x < 0 ? -x : x; }
 static inline real r_min(real a, real b) { return a < b ? a : b; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 static inline real r_clip(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static inline real r_floor(real x) { return (real)floor((double)x); }
-static inline real r_fma(real a, real b, real c) { return sizeof(real) == 4 ? (real)fmaf((float)a, (float)b, (float)c) : (real)fma((double)a, (double)b, (double)c); }
+static inline real r_fma(real a, real b, real c) { OPC(mul); OPC(add); return sizeof(real) == 4 ? (real)fmaf((float)a, (float)b, (float)c) : (real)fma((double)a, (double)b, (double)c); }
 
 /* ------------------------------------------------------------------ per-sample data (mjx.Data) */
 typedef struct {
