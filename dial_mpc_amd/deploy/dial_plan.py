@@ -108,7 +108,8 @@ class MBDPublisher:
                                                              want_bars=(i == n_diffuse - 1))
         return info
 
-    def main_loop(self, max_ticks: Optional[int] = None, sleep_when_idle: float = 0.0):
+    def main_loop(self, max_ticks: Optional[int] = None, sleep_when_idle: float = 0.0, on_tick=None):
+        """on_tick(tick): called after every published plan (tests use it to advance the plant inside ONE loop)."""
         import torch
         last_plan_time = float(self.time_shared[0])
         state = self.init_mjx_state(self.state_shared[: self.nq].copy(), self.state_shared[self.nq:].copy(),
@@ -150,6 +151,8 @@ class MBDPublisher:
             latencies.append(dt_wall)
             if dt_wall > self.ctrl_dt:
                 print(f"[WRAN] real overtime {dt_wall * 1000:.1f} ms")
+            if on_tick is not None:
+                on_tick(ticks)
             ticks += 1
             if sleep_when_idle:
                 time.sleep(sleep_when_idle)

@@ -469,3 +469,78 @@ def test_in_bracket_rule_at_full_size(example, N, H):
             sub = np.random.default_rng(0).choice(N + 1, 256, replace=False)     # the witness search is sequential Python
             rep = witness_parity(o32, s0, ro["us"][sub], tuple(g[sub] for g in got), example, model.nq + 2 * model.nv, max_frac=1.0)
         print(f"{example} rule=in_bracket {'converged' if strict else 'truncated'}: {rep['outside_tol']} of {rep['rollouts']} outside the gate, all witnessed")
+
+
+def test_async_planner_replay_matches_oracle_restatement():
+    """SURVEY 8f row 1 as a PARITY row: the (t, q, qd) sequence a plant publishes is replayed through an oracle-side
+    restatement of the reference's planner loop (dial_plan.py:172-229: state injection with info.step = int(t / dt),
+    time-based plan shift by spline re-evaluation, Ndiffuse_init + Ndiffuse annealing iterations with the ASYNC noise
+    schedule traj_diffuse_factor**i of shape (1,), node2u, act2joint / act2tau, body-position references without the
+    root body) on the same noise draws; what MBDPublisher wrote to acts_shm / tau_shm / refs_shm / plan_time_shm must
+    match tick by tick."""
+    import uuid
+    import torch
+    import yaml
+    import oracle as O
+    from dial_mpc_amd.core import spline
+    from dial_mpc_amd.core.dial_core import load_dial_and_env, make_cfg
+    from dial_mpc_amd.deploy.dial_plan import FakePlant, MBDPublisher
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    cfgd = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
+    cfgd["Nsample"], cfgd["Ndiffuse_init"] = 256, 3
+    dial_config, env_config, env = load_dial_and_env(cfgd)
+    prefix = "r" + uuid.uuid4().hex[:8] + "_"
+    plant = FakePlant(env, dial_config, shm_prefix=prefix)
+    record = []
+    try:
+        pub = MBDPublisher(env, env_config, dial_config, shm_prefix=prefix)
+        inputs = [(float(plant._seg["time_shm"][1][0]), plant._seg["state_shm"][1].copy())]
+
+        def on_tick(tick):
+            t_in, x_in = inputs[-1]
+            record.append(dict(t=t_in, x=x_in, acts=plant._seg["acts_shm"][1].copy(), tau=plant._seg["tau_shm"][1].copy(),
+                               refs=plant._seg["refs_shm"][1].copy(), plan_time=float(plant._seg["plan_time_shm"][1][0])))
+            # an irregular plant: 1, 2, 1, 1 control periods between plans (exercises the time-based shift)
+            for _ in range(2 if tick == 1 else 1):
+                plant.step_with_action(pub.Y[0])
+            inputs.append((float(plant._seg["time_shm"][1][0]), plant._seg["state_shm"][1].copy()))
+
+        pub.main_loop(max_ticks=5, on_tick=on_tick)        # ONE loop: plan shifts and the initial diffusion happen once
+        pub.close()
+    finally:
+        plant.close()
+    # ---- oracle-side restatement on the recorded inputs
+    model, task, cfg = env.make_model(), env.make_task(), make_cfg(dial_config)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    nq, nv, nu = model.nq, model.nv, model.nu
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(int(dial_config.seed))
+    draw = lambda: torch.randn((dial_config.Nsample, dial_config.Hnode + 1, nu), generator=gen, device="cuda",  # noqa: E731
+                               dtype=torch.float32).cpu().numpy()
+    nodes = np.linspace(0, 0.02 * dial_config.Hsample, dial_config.Hnode + 1)
+    W = spline.node2u_matrix(dial_config.Hsample, dial_config.Hnode).astype(np.float32)
+    state, _, _ = o32.env_reset(env._init_q, np.zeros(nv))
+    Y = np.zeros((dial_config.Hnode + 1, nu), np.float32)
+    last_plan_time, first = record[0]["t"], True
+    for k, rec in enumerate(record):
+        state[:nq], state[nq:nq + nv] = rec["x"][:nq], rec["x"][nq:]
+        state[nq + 2 * nv] = int(rec["t"] / env_config.dt)                      # info.step
+        shift_time = rec["t"] - last_plan_time
+        Y = (spline.interp_matrix(nodes, nodes + shift_time).astype(np.float32) @ Y).astype(np.float32)
+        out = None
+        for n_diffuse in ([dial_config.Ndiffuse_init] if first else []) + [dial_config.Ndiffuse]:
+            for i in range(n_diffuse):
+                out = o32.reverse_once(state, Y, np.array([dial_config.traj_diffuse_factor ** i], np.float32), draw())
+                Y = out["Ybar"].astype(np.float32)
+        first = False
+        us = W @ Y
+        acts = np.stack([env.act2joint(u) for u in us])
+        ps = type("PS", (), dict(qpos=state[:nq], qvel=state[nq:nq + nv]))
+        tau = np.stack([env.act2tau(u, ps) for u in us])
+        refs = out["xbar"].reshape(dial_config.Hsample + 1, -1, 3)[:, 1:, :]
+        assert rec["plan_time"] == np.float32(rec["t"])
+        assert np.allclose(rec["acts"], acts, atol=3e-3), (k, float(np.abs(rec["acts"] - acts).max()))
+        assert np.allclose(rec["tau"], tau, atol=0.1), (k, float(np.abs(rec["tau"] - tau).max()))       # kp = 30 x the act gate
+        n = min(rec["refs"].shape[1], refs.shape[1])
+        assert np.allclose(rec["refs"][:, :n], refs[:, :n], atol=3e-3), (k, float(np.abs(rec["refs"][:, :n] - refs[:, :n]).max()))
+        last_plan_time = rec["t"]
