@@ -806,6 +806,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
 
   // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
   auto constraint_grad = [&]() {
@@ -929,7 +930,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
         return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
       };
-      if (m->ls_rule == DIAL_LS_SWAP) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
+      if (rule_swap) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
         const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
         if (swap_lo_next) lo = lo_next;
         const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
@@ -1089,10 +1090,14 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     DIAL_MARK(w, 10);
     return s.info[DIAL_INFO_REWARD];
   }
-  // ---- reward terms, one per lane (all read the PRE-integration forward quantities)
-  //   rpart: 0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty
-  //          5 height            6 energy    7 done
-  w.items(FULL_INFO ? 8 : 7, [&](int it) {
+  // ---- reward terms (all read the PRE-integration forward quantities)
+  //   0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty   5 height   6 energy   7 done
+  // The terms are independent scalar chains.  One term per lane sounds parallel but is not: lanes that take different
+  // branches are SERIALISED by the SIMD, each chain paying the ~10-cycle dependent-issue latency on its own.  Instead ONE
+  // lane evaluates all of them in straight-line code (term index = compile-time constant): the scheduler interleaves the
+  // independent chains, which then issue back to back.
+  auto term = [&](auto IT) -> float {
+    constexpr int it = decltype(IT)::value;
     const float dt = m->dt;
     const int tb = m->torso_x + 1, ub = m->upright_x + 1;
     float* info = s.info;
@@ -1207,7 +1212,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         for (int k = 0; k < 3; k++) { float e = tp[k] - tg->pose_targets[stage][k]; rp += e * e; }
         out = -rp;
       } else {
-        return;  // seq-jump: rpart[4] (penalty) is written by item 0
+        return s.rpart[4];  // seq-jump: the penalty count, written by term 0
       }
     } else if (it == 5) {
       const float dh = tp[2] - pos_tar_z;
@@ -1245,17 +1250,26 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       done = done || tp[2] < m->done_height;
       out = done ? 1.f : 0.f;
     }
-    s.rpart[it] = out;
-  });
-  // ---- total in the reference's summation order + info update (one lane; last_ctrl by nu lanes)
+    return out;
+  };
+  // ---- terms, total in the reference's summation order and info update (one lane; last_ctrl by nu lanes)
   w.items(1 + nu, [&](int it) {
     float* info = s.info;
     if (it > 0) {
       if (!walk) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
       return;
     }
+    float r[9];
+    r[0] = term(std::integral_constant<int, 0>{});
+    r[1] = term(std::integral_constant<int, 1>{});
+    r[2] = term(std::integral_constant<int, 2>{});
+    r[3] = term(std::integral_constant<int, 3>{});
+    r[4] = term(std::integral_constant<int, 4>{});
+    r[5] = term(std::integral_constant<int, 5>{});
+    r[6] = term(std::integral_constant<int, 6>{});
+    r[7] = FULL_INFO ? term(std::integral_constant<int, 7>{}) : 0.f;
+    r[8] = m->kind == DIAL_TASK_H1_LOCO ? s.rpart[8] : 0.f;      // foot-level term, written by term 6
     const float dt = m->dt, step = info[DIAL_INFO_STEP];
-    const float* r = s.rpart;
     float reward;
     if (m->kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239
       reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;

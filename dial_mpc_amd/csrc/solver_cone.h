@@ -168,6 +168,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
+  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
+  const int max_iter = m->iterations, max_ls = m->ls_iterations;
+  const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
 
   int niter = 0;
   for (;;) {
@@ -204,9 +207,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     }
     DIAL_MARK(w, 4);
     bool done;
-    if (m->iterations != 1) {
+    if (max_iter != 1) {
       const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
-      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+      done = niter >= max_iter || improvement < tol || gradient < tol;
     } else {
       done = niter >= 1;
     }
@@ -267,8 +270,8 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       w.vsumN(t, r);
       sn2 = r[0]; s1 = r[1]; s2 = r[2];
     }
-    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
-    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float smag = DM_SQRT(sn2) * meaninertia * (float)(NV > 1 ? NV : 1);
+    const float gtol = tol * ls_tol * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
     // per-unit line-search registers: limit row: (Jaref, jv | q0 q1 q2); contact: (u0 v0 uu uv vv Dm mu | quad_c).
     // fast layout (<= 16 contributing units): lane (g, j) = (lane >> 4, lane & 15), g < 3, holds unit ulist[j] -- the
@@ -365,11 +368,11 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
-      const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      const bool ls_done = ls_iter >= max_ls || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
       if (ls_done) break;
       LsPoint lo_next, hi_next, mid;
       ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
-      if (m->ls_rule == DIAL_LS_SWAP) {
+      if (rule_swap) {
         const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
         if (swap_lo_next) lo = lo_next;
         const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);

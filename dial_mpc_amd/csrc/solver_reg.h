@@ -236,6 +236,9 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
+  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;   // fetched once: the constants live in LDS
+  const int max_iter = m->iterations, max_ls = m->ls_iterations;
+  const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
 
 #ifdef DIAL_PROFILE
   unsigned long long prof_prev_act = 0;
@@ -271,14 +274,14 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       prev_cost = cost;
       cost = 0.5f * r[0] + gauss;
       gn = r[2];
-    } else if (m->iterations != 1) {
+    } else if (max_iter != 1) {
       gn = w.vsum(vgrad * vgrad);
     }
     DIAL_MARK(w, 4);
     bool done;
-    if (m->iterations != 1) {
+    if (max_iter != 1) {
       const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
-      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+      done = niter >= max_iter || improvement < tol || gradient < tol;
     } else {
       done = niter >= 1;
     }
@@ -361,8 +364,8 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       w.vsumN(t, r);
       sn2 = r[0]; s1 = r[1]; s2 = r[2];
     }
-    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(NV > 1 ? NV : 1);
-    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float smag = DM_SQRT(sn2) * meaninertia * (float)(NV > 1 ? NV : 1);
+    const float gtol = tol * ls_tol * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
     // Line-search layout: lane (g, l) = (lane >> 4, lane & 15) owns rows l, l + 16, .. for trial point g: the
     // three points of one bracketing iteration (lo_next, hi_next, mid) are evaluated by three 16-lane groups in
@@ -418,7 +421,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
-      const bool ls_done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      const bool ls_done = ls_iter >= max_ls || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
       if (ls_done) break;
       LsPoint lo_next, hi_next, mid;
       ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
@@ -427,7 +430,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
         return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
       };
-      if (m->ls_rule == DIAL_LS_SWAP) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
+      if (rule_swap) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
         const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
         if (swap_lo_next) lo = lo_next;
         const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
