@@ -158,6 +158,8 @@ struct CModel {
   uint8_t con_dof[D::NCE][D::NCD];
   int32_t dof_ncon[D::NVE];
   uint16_t dof_con[D::NVE][D::NDC];              // contact | (index of the dof in the contact's dof list) << 8
+  uint8_t con_dofpos[D::NCE][(D::NVE + 3) & ~3]; // index of dof i in the contact's dof list, 255 = the dof does not move it
+  uint8_t pair_a[D::ell ? 56 : 4], pair_b[D::ell ? 56 : 4];   // the unordered pairs (a >= b) of a contact's <= 10 dofs
   int32_t lim_jnt[D::NL];
   int32_t act_qposadr[D::NU], act_ctrllimited[D::NU], act_isposition[D::NU];
   float act_gear[D::NU], act_kp[D::NU], act_ctrlrange[D::NU][2];

@@ -288,6 +288,10 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   if constexpr (D::ell) {
     int adr = m->nlim, joff = 0;
     for (int i = 0; i < m->nv; i++) o.dof_ncon[i] = 0;
+    {
+      int e = 0;
+      for (int a = 0; a < D::NCD; a++) for (int b = 0; b <= a; b++) { o.pair_a[e] = (uint8_t)a; o.pair_b[e] = (uint8_t)b; e++; }
+    }
     for (int cidx = 0; cidx < m->ncon; cidx++) {
       o.con_dim[cidx] = m->con_dim[cidx];
       o.con_adr[cidx] = adr;
@@ -301,6 +305,8 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
           o.dof_ncon[i]++;
           nd++;
         }
+      for (int i = 0; i < m->nv; i++) o.con_dofpos[cidx][i] = 255;
+      for (int q = 0; q < nd && q < D::NCD; q++) o.con_dofpos[cidx][o.con_dof[cidx][q]] = (uint8_t)q;
       o.con_ndof[cidx] = nd;
       o.con_joff[cidx] = joff;
       joff += m->con_dim[cidx] * nd;

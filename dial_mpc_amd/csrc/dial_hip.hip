@@ -29,6 +29,12 @@
 #ifndef DIAL_GO2_OCC_LARGE
 #define DIAL_GO2_OCC_LARGE 3
 #endif
+// Allegro: 15.3 KB of workspace per wavefront + 10.5 KB of shared constants.  9 wavefronts per workgroup = 148 KB = one
+// workgroup per CU = 2304 resident rollouts: the example's N + 1 = 2049 run in ONE round (8 per CU would leave the
+// 2049th rollout for a second round and double the launch time), BASELINE config 4 (4097) in two instead of three.
+#ifndef DIAL_ALLEGRO_WPB
+#define DIAL_ALLEGRO_WPB 9
+#endif
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
@@ -80,7 +86,16 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   if (w.lane < 32) w.acc[w.lane] = 0;
   __syncthreads();
 #endif
+#ifdef DIAL_PROFILE
+  const unsigned long long t_start = wall_clock64();
+#endif
   dial::rollout_sample(w, m, tg, cfg, s, io, n);
+#ifdef DIAL_PROFILE
+  if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
+    unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
+    p[0] = t_start; p[1] = wall_clock64(); p[2] = w.acc[27]; p[3] = w.acc[28]; p[4] = w.acc[30]; p[5] = w.acc[31];
+  }
+#endif
 }
 
 template <class D>
@@ -434,7 +449,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
         dial_destroy(ctx);
         return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: elliptic-cone models need a dimension-specialised instantiation (built: Allegro hand)");
       }
-      ctx->inst = 4; ctx->wpb = 4; urc = upload(DimsAllegro{});
+      ctx->inst = 4; ctx->wpb = DIAL_ALLEGRO_WPB; urc = upload(DimsAllegro{});
     }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
@@ -447,7 +462,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   {   // more than the default 64 KiB dynamic-LDS limit of a launch: opt in (gfx950: up to 160 KiB per workgroup)
     hipError_t e = hipSuccess;
     if (ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
-      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
     if (e == hipSuccess && ctx->inst == 1 && ctx->lds_large > 64 * 1024)
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -477,8 +492,9 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipMalloc(&ctx->weights, sizeof(float) * ctx->W_cap));
     const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
     HIP_TRY_CREATE(hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
-    HIP_TRY_CREATE(hipMalloc(&ctx->prof, sizeof(unsigned long long) * 32));
-    HIP_TRY_CREATE(hipMemset(ctx->prof, 0, sizeof(unsigned long long) * 32));
+    // 32 section / event counters + (profile builds) a start / end timestamp per rollout of the last launch
+    HIP_TRY_CREATE(hipMalloc(&ctx->prof, sizeof(unsigned long long) * (32 + 6 * B)));
+    HIP_TRY_CREATE(hipMemset(ctx->prof, 0, sizeof(unsigned long long) * (32 + 6 * B)));
   }
 #undef HIP_TRY_CREATE
   *out = ctx;
@@ -532,7 +548,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
   else if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
-  else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, 4);
+  else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, DIAL_ALLEGRO_WPB);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
   HIP_TRY(ctx, hipGetLastError());
@@ -769,6 +785,12 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
   return DIAL_OK;
 }
 int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_rollout : -1; }
+// DIAL_PROFILE builds: 6 words per rollout of the last launch -- start / end wall-clock timestamps (100 MHz), then
+// the rollout's own event counters 27, 28, 30, 31
+int dial_debug_wave_times(dial_ctx* ctx, unsigned long long* out, int n) {
+  if (!ctx || !ctx->prof || n < 0 || n > ctx->B_cap) return DIAL_ERR_ARG;
+  return hipMemcpy(out, ctx->prof + 32, sizeof(unsigned long long) * 6 * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
+}
 // DIAL_PROFILE builds: cycle counters of sample 0 of the last rollout launch (16 sections)
 int dial_debug_prof(dial_ctx* ctx, unsigned long long* out16 /* 32 entries */) {
   if (!ctx || !ctx->prof) return DIAL_ERR_ARG;

@@ -14,6 +14,7 @@
 #define DM_EXP(x) std::exp(x)
 #define DM_RINT(x) std::nearbyint(x)
 #define DM_FMA(a, b, c) std::fma((float)(a), (float)(b), (float)(c))
+#define DM_OPAQUE(x) ((void)0)
 #else
 #define DM_SQRT(x) sqrtf(x)
 #define DM_SIN(x) sinf(x)
@@ -24,6 +25,8 @@
 #define DM_EXP(x) expf(x)
 #define DM_RINT(x) rintf(x)
 #define DM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+// hides a VGPR value's provenance from the optimiser (stops select chains from becoming scratch-array lookups)
+#define DM_OPAQUE(x) asm("" : "+v"(x))
 #endif
 
 namespace dm {

@@ -182,11 +182,14 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (l >= NV) return 0.f;
       const int lr = m->dof_limrow[l];
       float acc = lr >= 0 ? s.lsign[lr] * s.frc[lr] : 0.f;
-      const int ncn = m->dof_ncon[l];
-      for (int q = 0; q < ncn; q++) {
-        const int c = m->dof_con[l][q] & 255, a = m->dof_con[l][q] >> 8;
-        if (s.con_on[c] == 0.f || s.lsign[m->con_adr[c]] == 0.f) continue;   // off, or top zone: no force
-        const int nd = m->con_ndof[c], dim = m->con_dim[c], r0 = m->con_adr[c];
+      for (int idx = 0; idx < n_on; idx++) {          // wave-uniform loop over the contributing units
+        const int u = (int)s.ulist[idx];
+        if (u < NL) continue;
+        const int c = u - NL, r0 = m->con_adr[c];
+        if (s.lsign[r0] == 0.f) continue;             // top zone: no force (uniform)
+        const int a = m->con_dofpos[c][l];            // where dof l sits in the contact's dof list, or 255
+        if (a == 255) continue;
+        const int nd = m->con_ndof[c], dim = m->con_dim[c];
         const float* J = s.Jc + m->con_joff[c] + a;
         for (int k = 0; k < dim; k++) acc += J[k * nd] * s.frc[r0 + k];
       }
@@ -232,9 +235,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (zone == 0.f) continue;                    // top zone: no curvature
       const int nd = m->con_ndof[c], dim = m->con_dim[c];
       const float* J = s.Jc + m->con_joff[c];
-      w.items(NCD * NCD, [&](int it) {
-        const int a = it / NCD, b = it - a * NCD;
-        if (a >= nd || b >= nd) return;
+      w.items(NCD * (NCD + 1) / 2, [&](int it) {
+        const int a = m->pair_a[it], b = m->pair_b[it];   // a >= b
+        if (a >= nd) return;
         float acc;
         if (zone == 2.f) {                          // bottom zone: plain quadratic rows
           acc = 0.f;
@@ -251,7 +254,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
           }
           acc = Dm * (x0 * y0 + c0 * (x0 * uy + ux * y0) + c2 * (ux * uy) + c1 * xty);
         }
-        s.H[m->con_dof[c][a] * S + m->con_dof[c][b]] += acc;
+        const int i = m->con_dof[c][a], j = m->con_dof[c][b];
+        s.H[i * S + j] += acc;
+        if (a != b) s.H[j * S + i] += acc;
       });
     }
     DIAL_MARK(w, 5);
@@ -321,12 +326,18 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       const float dmc = lane_val(L[5], l);
       const float n = u0 + alpha * v0;
       const float tsqr = uu + alpha * (2.f * uv + alpha * vv);
-      const float tt = DM_SQRT(tsqr);
+      // T and 1 / T from one v_rsq and a Newton correction each (both then within an ulp of sqrt / divide: the zone
+      // tests below sit on the oracle's decisions) instead of a square root and three divisions
+      const float rt0 = tsqr > 0.f ? fast_rsqrt(tsqr) : 0.f;
+      const float tt0 = tsqr * rt0;
+      const float tt = DM_FMA(DM_FMA(-tt0, tt0, tsqr), 0.5f * rt0, tt0);
+      const float rt = DM_FMA(rt0, DM_FMA(-tt, rt0, 1.f), rt0);
       const bool bottom = (tsqr <= 0.f && n < 0.f) || (tsqr > 0.f && mu * n + tt <= 0.f);
       const bool middle = tsqr > 0.f && n < mu * tt && mu * n + tt > 0.f;
       if (bottom) { o[0] = lane_val(L[7], l); o[1] = lane_val(L[8], l); o[2] = lane_val(L[9], l); }
       if (middle) {
-        const float n1 = v0, t1 = (uv + alpha * vv) / tt, t2 = vv / tt - (uv + alpha * vv) * t1 / (tt * tt);
+        const float w1 = uv + alpha * vv;
+        const float n1 = v0, t1 = w1 * rt, t2 = vv * rt - w1 * t1 * (rt * rt);
         const float nmt = n - mu * tt, g = n1 - mu * t1;
         o[3] = 0.5f * dmc * nmt * nmt;
         o[4] = dmc * nmt * g;
@@ -356,11 +367,28 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     auto ls_eval3 = [&](float a0, float a1, float a2, LsPoint& P0, LsPoint& P1, LsPoint& P2) {
       if (!fast) { P0 = ls_point(a0); P1 = ls_point(a1); P2 = ls_point(a2); return; }
       vfloat t[6];
-      w.per_lane_n(t, [&](int l, float* o) { unit_terms(l, l < 16 ? a0 : (l < 32 ? a1 : a2), o); });
+      // (two opaque v_cndmask selects: left to itself the compiler stores the three trial steps to a scratch array and
+      // loads a[lane >> 4] back -- a memory round trip in every line-search iteration)
+      const auto group_alpha = [a0, a1, a2](int l) {
+        float a = a2;
+        DM_OPAQUE(a);
+        if (l < 32) a = a1;
+        DM_OPAQUE(a);
+        if (l < 16) a = a0;
+        return a;
+      };
+      w.per_lane_n(t, [&](int l, float* o) { unit_terms(l, group_alpha(l), o); });
       w.row16_sumN(t);
-      float r0[6], r1[6], r2[6];
-      for (int k = 0; k < 6; k++) { r0[k] = bcast(t[k], 0); r1[k] = bcast(t[k], 16); r2[k] = bcast(t[k], 32); }
-      P0 = finish(a0, r0); P1 = finish(a1, r1); P2 = finish(a2, r2);
+      // cost / slope / curvature of the group's point, lane-wise (every lane of a group holds the six sums)
+      vfloat res[3];
+      w.per_lane_n(res, [&](int l, float* o) {
+        const float r6[6] = {lane_val(t[0], l), lane_val(t[1], l), lane_val(t[2], l), lane_val(t[3], l), lane_val(t[4], l), lane_val(t[5], l)};
+        const LsPoint p = finish(group_alpha(l), r6);
+        o[0] = p.cost; o[1] = p.d0; o[2] = p.d1;
+      });
+      P0.alpha = a0; P0.cost = bcast(res[0], 0); P0.d0 = bcast(res[1], 0); P0.d1 = bcast(res[2], 0);
+      P1.alpha = a1; P1.cost = bcast(res[0], 16); P1.d0 = bcast(res[1], 16); P1.d1 = bcast(res[2], 16);
+      P2.alpha = a2; P2.cost = bcast(res[0], 32); P2.d0 = bcast(res[1], 32); P2.d1 = bcast(res[2], 32);
     };
     LsPoint p0 = ls_point(0.f);
     LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;

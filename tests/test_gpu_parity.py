@@ -330,8 +330,8 @@ def test_full_size_oracle_parity(example, N, H):
               f"{rep.get('unwitnessed', 0)} without a witness")
         if chaotic:
             idx = np.random.default_rng(seed).choice(N + 1, 96, replace=False)
-            worst = one_step_consistency(o32, s0, ro["us"], got, idx, model.nq, model.nv, tol_scale=3.0)   # measured: 1.3
-            print(f"   one-step consistency along 96 GPU trajectories x {H} steps: worst error / gate = {worst}")
+            osc = one_step_consistency(o32, s0, ro["us"], got, idx, model.nq, model.nv)
+            print(f"   one-step consistency along 96 GPU trajectories x {H} steps: {osc}")
         if not chaotic:
             # product outputs: the few knife-edge rollouts carry softmax weight ~1/N each, so the aggregates stay comparable
             assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], agg_tol(example, "Ybar"))

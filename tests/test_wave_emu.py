@@ -8,7 +8,7 @@ import pytest
 
 import emu_lib
 import oracle as O
-from conftest import CASES, TOL, perturbed_state, seeded_inputs, setup_case, with_solver, witness_parity
+from conftest import CASES, TOL, one_step_consistency, perturbed_state, seeded_inputs, setup_case, with_solver, witness_parity
 
 
 def _close(a, b, tol):
@@ -37,6 +37,20 @@ def test_emulated_kernel_matches_oracle(example, N, H, path):
     Y0s_ref = np.clip(np.concatenate([eps * sigma[None, :, None] + Ybar, Ybar[None]], 0), -1, 1)
     Y0s_ref[:-1, 0] = np.clip(Ybar[0], -1, 1)
     assert np.array_equal(re["Y0s"], Y0s_ref.astype(np.float32))
+
+
+def test_emulated_allegro_one_step_consistency():
+    """Converged-solver gate of the Allegro kernel logic (the GPU suite runs the same check at full size): restarted from
+    the emulated kernel's own state after every step, the oracle must land on the kernel's next state within TOL."""
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 48, 12)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.3)
+    ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+    re = emu.rollout_nodes(s0, Ybar, sigma, eps, check_races=False)
+    rep = one_step_consistency(o32, s0, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), range(49), model.nq, model.nv)
+    assert rep["transitions"] == 49 * 12 and rep["direct_worst"] <= 1.0
 
 
 @pytest.mark.parametrize("example,N,H", CASES[:2])
