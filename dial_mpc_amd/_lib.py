@@ -83,6 +83,7 @@ def load():
     lib.dial_selftest.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.dial_debug_scratch.argtypes = [vp] + [ctypes.POINTER(vp)] * 6
     lib.dial_lds_bytes.argtypes = [vp]
+    lib.dial_debug_resident_rollouts.argtypes = [vp, ctypes.c_int]
     _lib = lib
     return lib
 

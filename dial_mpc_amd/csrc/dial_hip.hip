@@ -72,11 +72,11 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
 template <class D, int WPB, int OCC = 3>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
-               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words) {
+               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
   const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words);
-  const int n = WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x;
+  int n = WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x;
   if (n >= B) return;
   Wave w;
   w.lane = threadIdx.x & 63;
@@ -87,15 +87,30 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   __syncthreads();
 #endif
 #ifdef DIAL_PROFILE
-  const unsigned long long t_start = wall_clock64();
+  unsigned long long t_start = wall_clock64();
 #endif
-  dial::rollout_sample(w, m, tg, cfg, s, io, n);
+  // `next` == nullptr: the grid covers the batch, one rollout per wavefront.  Otherwise the grid is exactly what the chip
+  // keeps resident and every wavefront draws its next rollout from the queue head when it finishes one: rollouts differ
+  // in length (solver iterations), and a workgroup's LDS is only handed to a new workgroup when its slowest wavefront
+  // is done -- the queue keeps every wavefront slot busy until the batch is empty
+  for (;;) {
+    dial::rollout_sample(w, m, tg, cfg, s, io, n);
 #ifdef DIAL_PROFILE
-  if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
-    unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
-    p[0] = t_start; p[1] = wall_clock64(); p[2] = w.acc[27]; p[3] = w.acc[28]; p[4] = w.acc[30]; p[5] = w.acc[31];
-  }
+    if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
+      unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
+      p[0] = t_start; p[1] = wall_clock64(); p[2] = w.acc[27]; p[3] = w.acc[28]; p[4] = w.acc[30]; p[5] = w.acc[31];
+      for (int k = 27; k < 32; k++) w.acc[k] = 0;
+    }
 #endif
+    if (!next) break;
+    int nn = 0;
+    if (w.lane == 0) nn = atomicAdd(next, 1);
+    n = __builtin_amdgcn_readfirstlane(nn);
+    if (n >= B) break;
+#ifdef DIAL_PROFILE
+    t_start = wall_clock64();
+#endif
+  }
 }
 
 template <class D>
@@ -330,6 +345,8 @@ struct dial_ctx {
   size_t lds_rollout = 0;      // rollout kernel: constants + DIAL_WPB workspaces
   size_t lds_large = 0;        // Go2 large-batch instantiation (more wavefronts per workgroup)
   int ws_words = 0, cm_bytes = 0, wpb = 1;
+  int* next = nullptr;         // rollout queue head (batches larger than the chip keeps resident)
+  int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -364,7 +381,7 @@ int dial_abi_sizes(int* a, int* b, int* c) {
 void dial_destroy(dial_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
+  void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->next, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
                   ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -467,6 +484,28 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
+  {   // how many workgroups of the rollout kernel the chip keeps resident (larger batches go through the rollout queue)
+    hipDeviceProp_t prop;
+    HIP_TRY_CREATE(hipGetDeviceProperties(&prop, device));
+    int nb = 0;
+    hipError_t e = hipSuccess;
+#define DIAL_RESIDENT(D, WPB) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<D, WPB>, 64 * WPB, ctx->lds_rollout)
+    if (ctx->inst == 1) DIAL_RESIDENT(DimsGo2, 1);
+    else if (ctx->inst == 2) DIAL_RESIDENT(DimsH1, 3);
+    else if (ctx->inst == 3) DIAL_RESIDENT(DimsH1Loco, 2);
+    else if (ctx->inst == 4) DIAL_RESIDENT(DimsAllegro, DIAL_ALLEGRO_WPB);
+    else DIAL_RESIDENT(DimsMax, 1);
+#undef DIAL_RESIDENT
+    if (e == hipSuccess) ctx->resident_blocks = nb * prop.multiProcessorCount;
+    if (e == hipSuccess && ctx->inst == 1) {
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>,
+                                                       64 * DIAL_GO2_WPB_LARGE, ctx->lds_large);
+      if (e == hipSuccess) ctx->resident_blocks_large = nb * prop.multiProcessorCount;
+    }
+    if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: occupancy query: ") + hipGetErrorString(e)); }
+    if (getenv("DIAL_NO_QUEUE")) ctx->resident_blocks = ctx->resident_blocks_large = 0;   // measurement switch: one wavefront per rollout at any batch size
+    HIP_TRY_CREATE(hipMalloc(&ctx->next, sizeof(int)));
+  }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
   HIP_TRY_CREATE(hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
   if (cfg) {
@@ -537,14 +576,26 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
     ctx->events_used++;
     HIP_TRY(ctx, hipEventRecord(e0, st));
   }
+  // batches beyond what the chip keeps resident: launch exactly the resident grid and let the wavefronts draw the
+  // remaining rollouts from a queue (see rollout_kernel); the queue head starts behind the grid's own first rollouts
+  const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B;
+  const int wpb = large ? DIAL_GO2_WPB_LARGE : ctx->wpb;
+  const int resident = large ? ctx->resident_blocks_large : ctx->resident_blocks;
+  int blocks = (B + wpb - 1) / wpb;
+  int* next = nullptr;
+  if (resident > 0 && blocks > resident && ctx->next) {
+    blocks = resident;
+    next = ctx->next;
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
+  }
 #define DIAL_LAUNCH_ROLLOUT(D, WPB)                                                                         \
-  hipLaunchKernelGGL((rollout_kernel<D, WPB>), dim3((B + WPB - 1) / WPB), dim3(64 * WPB), ctx->lds_rollout, \
+  hipLaunchKernelGGL((rollout_kernel<D, WPB>), dim3(blocks), dim3(64 * WPB), ctx->lds_rollout,              \
                      st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
-                     (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words)
-  if (ctx->inst == 1 && B > DIAL_GO2_LARGE_B)
-    hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>), dim3((B + DIAL_GO2_WPB_LARGE - 1) / DIAL_GO2_WPB_LARGE),
+                     (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, next)
+  if (large)
+    hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>), dim3(blocks),
                        dim3(64 * DIAL_GO2_WPB_LARGE), ctx->lds_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask,
-                       (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words);
+                       (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, next);
   else if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
@@ -785,6 +836,12 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
   return DIAL_OK;
 }
 int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_rollout : -1; }
+// wavefront slots of the rollout kernel on the whole chip for a batch of B rollouts (B > slots: the rollout queue runs)
+int dial_debug_resident_rollouts(dial_ctx* ctx, int B) {
+  if (!ctx) return -1;
+  const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B;
+  return large ? ctx->resident_blocks_large * DIAL_GO2_WPB_LARGE : ctx->resident_blocks * ctx->wpb;
+}
 // DIAL_PROFILE builds: 6 words per rollout of the last launch -- start / end wall-clock timestamps (100 MHz), then
 // the rollout's own event counters 27, 28, 30, 31
 int dial_debug_wave_times(dial_ctx* ctx, unsigned long long* out, int n) {

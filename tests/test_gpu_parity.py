@@ -420,6 +420,51 @@ def test_in_kernel_rng_replays_exactly_and_is_standard_normal():
     assert torch.equal(rews[:256], out_rng["rews"][1024:1280]) and torch.equal(rews[256], out_rng["rews"][2048])
 
 
+def test_rollout_queue_beyond_the_resident_batch():
+    """Batches larger than the chip keeps resident run through the rollout queue (a resident grid whose wavefronts draw
+    the remaining rollouts from an atomic head): every rollout is produced exactly once, the result does not depend on
+    the draw order (bit-identical across runs and against the one-wavefront-per-rollout launch), and it is the oracle's."""
+    import os
+    import oracle as O
+    import torch
+    from dial_mpc_amd import _lib
+    N = 6000
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, 16)
+    ctx = _lib.Context(model, task, cfg)
+    slots = ctx.lib.dial_debug_resident_rollouts(ctx.h, N + 1)
+    assert 0 < slots < N + 1, slots                                   # the queue path is what runs
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=3, Ybar_scale=0.1)
+    runs = []
+    for _ in range(2):
+        out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        sc = ctx.debug_scratch()
+        runs.append(({k: v.clone() for k, v in out.items()}, {k: np.array(v) for k, v in sc.items()}))
+    for k in ("Ybar", "rews", "qbar", "xbar"):
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), k
+    assert np.array_equal(runs[0][1]["rewss"], runs[1][1]["rewss"])
+    os.environ["DIAL_NO_QUEUE"] = "1"
+    try:
+        ctx1 = _lib.Context(model, task, cfg)
+    finally:
+        del os.environ["DIAL_NO_QUEUE"]
+    assert ctx1.lib.dial_debug_resident_rollouts(ctx1.h, N + 1) == 0
+    out1 = ctx1.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    sc1 = ctx1.debug_scratch()
+    for k in ("Ybar", "rews", "qbar", "xbar"):
+        assert torch.equal(runs[0][0][k], out1[k]), k
+    for k in ("rewss", "qss", "qdss", "xss"):
+        assert np.array_equal(runs[0][1][k], sc1[k]), k
+    # oracle parity of a sample of the rollouts (late ones included: those were drawn from the queue)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    ro = o32.reverse_once(s0.cpu().numpy(), Ybar, sigma, eps, full=True)
+    idx = np.concatenate([np.random.default_rng(0).choice(N, 160, replace=False), np.arange(N - 31, N + 1)])
+    sc = runs[0][1]
+    rep = witness_parity(o32, s0.cpu().numpy(), ro["us"][idx], tuple(sc[k][idx] for k in ("rewss", "qss", "qdss", "xss")),
+                         "unitree_go2_trot", model.nq + 2 * model.nv)
+    assert rep["rollouts"] == len(idx)
+
+
 def test_degenerate_std_is_nan_like_the_reference():
     """All N+1 mean rewards identical => std = 0 and dial_core.py:126 divides 0 by 0: weights / Ybar are NaN in the
     reference (numpy restatement below) and, by definition (include/dial_mpc.h), here."""
