@@ -69,7 +69,9 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
 }
 
 // OCC: minimum resident wavefronts per SIMD the register allocation must allow (3: <= 168 VGPRs, 4: <= 128)
-template <class D, int WPB, int OCC = 3>
+// QUEUE: the rollout-queue variant (see the loop below); the one-rollout-per-wavefront variant keeps nothing live across
+// rollouts (the loop costs the headline kernel 6 spilled VGPRs, H1 21)
+template <class D, int WPB, int OCC = 3, bool QUEUE = false>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
                const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
@@ -102,6 +104,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
       for (int k = 27; k < 32; k++) w.acc[k] = 0;
     }
 #endif
+    if constexpr (!QUEUE) break;
     if (!next) break;
     int nn = 0;
     if (w.lane == 0) nn = atomicAdd(next, 1);
@@ -480,8 +483,10 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     hipError_t e = hipSuccess;
     if (ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+    if (e == hipSuccess && ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
     if (e == hipSuccess && ctx->inst == 1 && ctx->lds_large > 64 * 1024)
-      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
   {   // how many workgroups of the rollout kernel the chip keeps resident (larger batches go through the rollout queue)
@@ -498,7 +503,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
 #undef DIAL_RESIDENT
     if (e == hipSuccess) ctx->resident_blocks = nb * prop.multiProcessorCount;
     if (e == hipSuccess && ctx->inst == 1) {
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>,
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>,
                                                        64 * DIAL_GO2_WPB_LARGE, ctx->lds_large);
       if (e == hipSuccess) ctx->resident_blocks_large = nb * prop.multiProcessorCount;
     }
@@ -583,25 +588,32 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io, int B, hipSt
   const int resident = large ? ctx->resident_blocks_large : ctx->resident_blocks;
   int blocks = (B + wpb - 1) / wpb;
   int* next = nullptr;
-  if (resident > 0 && blocks > resident && ctx->next) {
+  const bool has_queue_variant = large || ctx->inst != 1;   // Go2's small-batch kernel never exceeds the resident set (B <= DIAL_GO2_LARGE_B)
+  if (has_queue_variant && resident > 0 && blocks > resident && ctx->next) {
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
   }
-#define DIAL_LAUNCH_ROLLOUT(D, WPB)                                                                         \
-  hipLaunchKernelGGL((rollout_kernel<D, WPB>), dim3(blocks), dim3(64 * WPB), ctx->lds_rollout,              \
+#define DIAL_LAUNCH_ROLLOUT_Q(D, WPB, Q)                                                                    \
+  hipLaunchKernelGGL((rollout_kernel<D, WPB, 3, Q>), dim3(blocks), dim3(64 * WPB), ctx->lds_rollout,        \
                      st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
                      (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, next)
+#define DIAL_LAUNCH_ROLLOUT(D, WPB)                                        \
+  do {                                                                     \
+    if (next) DIAL_LAUNCH_ROLLOUT_Q(D, WPB, true);                         \
+    else DIAL_LAUNCH_ROLLOUT_Q(D, WPB, false);                             \
+  } while (0)
   if (large)
-    hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE>), dim3(blocks),
+    hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>), dim3(blocks),
                        dim3(64 * DIAL_GO2_WPB_LARGE), ctx->lds_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask,
                        (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, next);
-  else if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT(DimsGo2, 1);
+  else if (ctx->inst == 1) DIAL_LAUNCH_ROLLOUT_Q(DimsGo2, 1, false);
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
   else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, DIAL_ALLEGRO_WPB);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
+#undef DIAL_LAUNCH_ROLLOUT_Q
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
   return DIAL_OK;

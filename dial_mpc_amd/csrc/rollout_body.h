@@ -613,10 +613,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   if constexpr (M::D::ell) {
     // compact rows: J_c is dim x ndof over the dofs that move body1 or body2 (support.jac of both bodies at the contact
     // point, translational rows in the contact frame, then -- condim 6 -- the rotational ones); one item per (contact, dof)
-    w.items(M::D::NC * M::D::NCD, [&](int it) {
-      const int c = it / M::D::NCD, a = it - c * M::D::NCD;
+    // -- over the list of contacts that are on (2-4 of the 19 with the ball in the hand: one pass instead of three)
+    const int n_con = w.compact(M::D::NC, [&](int c) { return s.con_on[c] != 0.f; }, s.ulist);
+    w.items(n_con * M::D::NCD, [&](int it) {
+      const int idx = it / M::D::NCD, a = it - idx * M::D::NCD, c = (int)s.ulist[idx];
       const int nd = m->con_ndof[c];
-      if (a >= nd || s.con_on[c] == 0.f) return;
+      if (a >= nd) return;
       const int i = m->con_dof[c][a], b1 = m->con_body1[c], b2 = m->con_body2[c], dim = m->con_dim[c];
       float cd[6];
       for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
@@ -639,6 +641,16 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float* J = s.Jc + m->con_joff[c] + a;
       for (int k = 0; k < 3; k++) J[k * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dp);
       if (dim == 6) for (int k = 0; k < 3; k++) J[(3 + k) * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dr);
+    });
+    // row velocities J_c qvel, one item per (contact, row) -- not a dim x ndof double loop inside the contact's lane
+    w.items(6 * n_con, [&](int it) {
+      const int idx = it / 6, k = it - 6 * idx, c = (int)s.ulist[idx];
+      if (k >= m->con_dim[c]) return;
+      const int nd = m->con_ndof[c];
+      const float* J = s.Jc + m->con_joff[c] + k * nd;
+      float vel = 0.f;
+      for (int a = 0; a < nd; a++) vel += J[a] * s.qvel[m->con_dof[c][a]];
+      s.jv[m->con_adr[c] + k] = vel;
     });
   } else
   w.items(nc * nv, [&](int it) {
@@ -689,7 +701,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         s.D[r] = 1.f / R;
         return;
       }
-      const int c = it - nl, r0 = m->con_adr[c], dim = m->con_dim[c], nd = m->con_ndof[c];
+      const int c = it - nl, r0 = m->con_adr[c], dim = m->con_dim[c];
       if (s.con_on[c] == 0.f) {
         for (int j = 0; j < dim; j++) { s.D[r0 + j] = 0.f; s.aref[r0 + j] = 0.f; }
         return;
@@ -699,13 +711,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       const float f0 = m->con_friction[c][0];
       float k_, b_, imp;
       kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
-      const float* J = s.Jc + m->con_joff[c];
       const float iw1 = t / m->impratio;
       for (int j = 0; j < dim; j++) {
         float invw = j == 0 ? t : iw1;
         if (j >= 2) { const float fj = m->con_friction[c][j - 1]; invw = iw1 * (f0 * f0) / (fj * fj); }
-        float vel = 0.f;
-        for (int a = 0; a < nd; a++) vel += J[j * nd + a] * s.qvel[m->con_dof[c][a]];
+        const float vel = s.jv[r0 + j];
         const float R = dm::fmaxf_(invw * (1.f - imp) / imp, MJ_MINVAL);
         s.aref[r0 + j] = -b_ * vel - k_ * imp * (j == 0 ? pos : 0.f);
         s.D[r0 + j] = 1.f / R;

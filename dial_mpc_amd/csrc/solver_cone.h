@@ -400,33 +400,40 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (ls_done) break;
       LsPoint lo_next, hi_next, mid;
       ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
+      // (bitwise & / | on the comparison results and whole-struct selects: straight-line v_cmp + s_and / s_or +
+      // v_cndmask instead of ~20 short-circuit branches per iteration)
+      const auto pick = [](bool c, const LsPoint& a, const LsPoint& b) {
+        LsPoint r;
+        r.alpha = c ? a.alpha : b.alpha; r.cost = c ? a.cost : b.cost; r.d0 = c ? a.d0 : b.d0; r.d1 = c ? a.d1 : b.d1;
+        return r;
+      };
       if (rule_swap) {
-        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-        if (swap_lo_next) lo = lo_next;
-        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-        if (swap_lo_mid) lo = mid;
-        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-        if (swap_hi_next) hi = hi_next;
-        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-        if (swap_hi_mid) hi = mid;
-        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
+        const bool swap_lo_next = (lo.d0 > 0.f) | (lo.d0 < lo_next.d0);
+        lo = pick(swap_lo_next, lo_next, lo);
+        const bool swap_lo_mid = (mid.d0 < 0.f) & (lo.d0 < mid.d0);
+        lo = pick(swap_lo_mid, mid, lo);
+        const bool swap_hi_next = (hi.d0 < 0.f) | (hi.d0 > hi_next.d0);
+        hi = pick(swap_hi_next, hi_next, hi);
+        const bool swap_hi_mid = (mid.d0 > 0.f) & (hi.d0 > mid.d0);
+        hi = pick(swap_hi_mid, mid, hi);
+        swap = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
       } else {
         const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
-          return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
+          return ((x.d0 < y.d0) & (y.d0 < 0.f)) | ((x.d0 > y.d0) & (y.d0 > 0.f));
         };
         const bool s1 = in_bracket(lo, lo_next);
-        if (s1) lo = lo_next;
+        lo = pick(s1, lo_next, lo);
         const bool s2b = in_bracket(lo, mid);
-        if (s2b) lo = mid;
+        lo = pick(s2b, mid, lo);
         const bool s3 = in_bracket(lo, hi_next);
-        if (s3) lo = hi_next;
+        lo = pick(s3, hi_next, lo);
         const bool s4 = in_bracket(hi, hi_next);
-        if (s4) hi = hi_next;
+        hi = pick(s4, hi_next, hi);
         const bool s5 = in_bracket(hi, mid);
-        if (s5) hi = mid;
+        hi = pick(s5, mid, hi);
         const bool s6 = in_bracket(hi, lo_next);
-        if (s6) hi = lo_next;
-        swap = s1 || s2b || s3 || s4 || s5 || s6;
+        hi = pick(s6, lo_next, hi);
+        swap = s1 | s2b | s3 | s4 | s5 | s6;
       }
       ls_iter++;
     }
