@@ -25,8 +25,13 @@ cd $ROOT
 find $OUT/kstats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 bash tools/pmc_passes.sh r02/pmc > $OUT/pmc_passes.log 2>&1
 python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_rollout_kernel.txt 2>&1
-for a in "unitree_go2_trot 2048 16" "unitree_h1_jog 2048 25" "unitree_h1_loco 2048 20" "allegro_reorient 4096 24"; do
+for a in "unitree_go2_trot 2048 16" "unitree_h1_jog 2048 25" "unitree_h1_loco 2048 20" "allegro_reorient 2048 20"; do
   set -- $a
   DIAL_HIP_LIB=$ROOT/build/libdialhip_prof.so python tools/profile_sections.py $1 $2 $3 > $OUT/sections_$1.txt 2>/dev/null
 done
+# per-rollout start / end times and solver iteration counts (profile build): what sets the launch duration
+(for a in "unitree_go2_trot 2048 16 1" "unitree_go2_trot 8192 16 4" "unitree_h1_jog 2048 25 3" "allegro_reorient 2048 20 9" "allegro_reorient 4096 24 9"; do
+  set -- $a
+  DIAL_HIP_LIB=$ROOT/build/libdialhip_prof.so python tools/wave_times.py $1 $2 $3 $4 2>/dev/null
+done) > $OUT/wave_times.txt
 ls -la $OUT | head -40
