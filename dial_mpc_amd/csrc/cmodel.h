@@ -113,7 +113,8 @@ struct CModel {
   uint32_t body_ancmask[D::NB];
   int32_t body_nanc[D::NB];              // number of ancestor-or-own dofs of body b ...
   uint8_t body_anc[D::NB][D::NANC];      // ... and their indices, root first
-  int32_t body_flags[D::NB];             // bit 0: body_quat is identity, bit 1: all joint anchors at the body origin
+  int32_t body_flags[D::NB];             // bit 0: body_quat is identity, bit 1: all joint anchors at the body origin, bit 2: free joint
+  int32_t kin_fast;                      // every body has at most one joint: parent-independent local transforms (forward())
   float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
   float body_mass[D::NB], body_inertia[D::NB][3], body_invweight0[D::NB];
   int32_t lvl_start[D::NB + 1], lvl_body[D::NB];

@@ -159,6 +159,8 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   o.timestep = m->timestep; o.tolerance = m->tolerance; o.ls_tolerance = m->ls_tolerance;
   o.impratio = m->impratio; o.meaninertia = m->meaninertia;
   for (int k = 0; k < 3; k++) o.gravity[k] = m->gravity[k];
+  o.kin_fast = 1;
+  for (int b = 0; b < m->nbody; b++) if (m->body_jntnum[b] > 1) o.kin_fast = 0;
   for (int b = 0; b < m->nbody; b++) {
     o.body_parent[b] = m->body_parent[b]; o.body_jntadr[b] = m->body_jntadr[b]; o.body_jntnum[b] = m->body_jntnum[b];
     o.body_dofadr[b] = m->body_dofadr[b]; o.body_dofnum[b] = m->body_dofnum[b];
@@ -175,6 +177,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
       for (int ji = m->body_jntadr[b]; ji >= 0 && ji < m->body_jntadr[b] + m->body_jntnum[b]; ji++)
         origin = origin && m->jnt_pos[ji][0] == 0.f && m->jnt_pos[ji][1] == 0.f && m->jnt_pos[ji][2] == 0.f;
       if (origin) flags |= 2;
+      if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == DIAL_JNT_FREE) flags |= 4;
       o.body_flags[b] = flags;
     }
     for (int k = 0; k < 3; k++) { o.body_pos[b][k] = m->body_pos[b][k]; o.body_ipos[b][k] = m->body_ipos[b][k]; o.body_inertia[b][k] = m->body_inertia[b][k]; }
@@ -341,7 +344,7 @@ struct Ws {
   float *cdist, *cpos, *cframe, *Jc;
   float *D, *aref, *lsign, *Jaref, *qfs, *qas, *qacc, *Ma, *rhs;
   // dynamics temporaries (dead after the contact-Jacobian phase) ...
-  float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd;
+  float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd, *lq, *lp;
   // ... aliased by solver-only arrays
   float *H, *JarefW, *JarefS, *jv, *frc, *quad, *MaW, *MaS, *grad, *search, *mv, *qfc, *ysol;
   // elliptic models (solver_cone.h): contact-on flags, per-contact cone Hessian weights, per-dof vectors that the row
@@ -379,6 +382,8 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv) WS_TAKE(ulist, ell * (nefc > 0 ? 68 : 0))
   const int u0 = o;
+  // local body transforms of the kinematics sweep: dead before the frames phase writes xipos / ximat over them
+  s.lq = base + u0; s.lp = base + u0 + 4 * nbody;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
   WS_TAKE(xaxis, njnt * 3)

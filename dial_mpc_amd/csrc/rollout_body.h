@@ -209,7 +209,73 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   const int ne = dim_ne(m), nl = dim_nl(m), ntri = m->ntri;   // ntri: structurally non-zero entries of M / H
 
   DIAL_MARK(w, 15);
-  // ---- smooth.kinematics: level-synchronous sweep over the body tree
+  // ---- smooth.kinematics
+  const bool kin_fast = m->kin_fast != 0;   // every body has at most one joint (wave-uniform)
+  if (kin_fast) {
+    // The transform of a body RELATIVE to its parent does not depend on the parent: with q_b = body_quat * q_joint,
+    //   hinge:  l_q = q_b,        l_p = body_pos + R(body_quat) jnt_pos - R(q_b) jnt_pos
+    //   slide:  l_q = body_quat,  l_p = body_pos + R(body_quat) jnt_axis * (q - q0)
+    // (MJX composes the same maps body by body: anchor = pos + R jnt_pos, rotate, pos = anchor - R' jnt_pos).  One
+    // fully parallel phase evaluates every joint's sin / cos and local transform; the level sweep that follows is one
+    // quaternion product and one rotation per body instead of the whole per-joint chain with its table look-ups.
+    w.items(nb, [&](int b) {
+      if (b == 0) return;
+      const int bflags = m->body_flags[b];
+      float lq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+      float lp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
+      if (m->body_jntnum[b] == 1) {
+        const int ji = m->body_jntadr[b], qa = m->jnt_qposadr[ji], type = m->jnt_type[ji];
+        const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+        const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+        if (type == DIAL_JNT_FREE) {          // absolute pose: the sweep copies it
+          for (int k = 0; k < 3; k++) lp[k] = s.qpos[qa + k];
+          for (int k = 0; k < 4; k++) lq[k] = s.qpos[qa + 3 + k];
+          dm::normalize4(lq);
+          for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = lq[k];
+        } else if (type == DIAL_JNT_HINGE) {
+          float qloc[4], qb[4], t0[3], t1[3];
+          dm::axis_angle_to_quat(qloc, ja, s.qpos[qa] - m->qpos0[qa]);
+          if (bflags & 1) { qb[0] = qloc[0]; qb[1] = qloc[1]; qb[2] = qloc[2]; qb[3] = qloc[3]; }
+          else dm::quat_mul(qb, lq, qloc);
+          if (!(bflags & 2)) {
+            if (bflags & 1) { t0[0] = jp[0]; t0[1] = jp[1]; t0[2] = jp[2]; }
+            else dm::rotate(t0, jp, lq);
+            dm::rotate(t1, jp, qb);
+            for (int k = 0; k < 3; k++) lp[k] += t0[k] - t1[k];
+          }
+          for (int k = 0; k < 4; k++) lq[k] = qb[k];
+        } else {
+          float ax[3];
+          dm::rotate(ax, ja, lq);
+          const float disp = s.qpos[qa] - m->qpos0[qa];
+          for (int k = 0; k < 3; k++) lp[k] += ax[k] * disp;
+        }
+      }
+      for (int k = 0; k < 4; k++) s.lq[4 * b + k] = lq[k];
+      for (int k = 0; k < 3; k++) s.lp[3 * b + k] = lp[k];
+    });
+    for (int d = 1; d <= m->nlevel; d++) {
+      const int b0 = m->lvl_start[d - 1];
+      w.items(m->lvl_start[d] - b0, [&](int idx) {
+        const int b = m->lvl_body[b0 + idx], p = m->body_parent[b];
+        const float lq[4] = {s.lq[4 * b], s.lq[4 * b + 1], s.lq[4 * b + 2], s.lq[4 * b + 3]};
+        const float lp[3] = {s.lp[3 * b], s.lp[3 * b + 1], s.lp[3 * b + 2]};
+        float pos[3], quat[4];
+        if (m->body_flags[b] & 4) {           // free joint: absolute
+          for (int k = 0; k < 3; k++) pos[k] = lp[k];
+          for (int k = 0; k < 4; k++) quat[k] = lq[k];
+        } else {
+          const float pq[4] = {s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+          dm::rotate(pos, lp, pq);
+          for (int k = 0; k < 3; k++) pos[k] += s.xpos[3 * p + k];
+          dm::quat_mul(quat, pq, lq);
+        }
+        for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = pos[k];
+        for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = quat[k];
+      });
+    }
+  } else
+  // generic models: level-synchronous sweep over the body tree, joints applied one after the other
   for (int d = 1; d <= m->nlevel; d++) {
     const int b0 = m->lvl_start[d - 1];
     w.items(m->lvl_start[d] - b0, [&](int idx) {
@@ -329,7 +395,19 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     } else {
       const int ji = it - nb, b = m->jnt_bodyid[ji], da = m->jnt_dofadr[ji];
       const float* c = s.com + 3 * m->body_rootid[b];
-      float off[3] = {c[0] - s.xanchor[3 * ji], c[1] - s.xanchor[3 * ji + 1], c[2] - s.xanchor[3 * ji + 2]};
+      float anchor[3], jaxis[3];
+      if (kin_fast) {   // anchor = xpos + R(xquat) jnt_pos, axis = R(xquat) jnt_axis (a hinge leaves its own axis in place)
+        const float bq[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+        const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+        const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+        if ((m->body_flags[b] & 2) || m->jnt_type[ji] == DIAL_JNT_FREE) { anchor[0] = 0.f; anchor[1] = 0.f; anchor[2] = 0.f; }
+        else dm::rotate(anchor, jp, bq);
+        for (int k = 0; k < 3; k++) anchor[k] += s.xpos[3 * b + k];
+        dm::rotate(jaxis, ja, bq);
+      } else {
+        for (int k = 0; k < 3; k++) { anchor[k] = s.xanchor[3 * ji + k]; jaxis[k] = s.xaxis[3 * ji + k]; }
+      }
+      float off[3] = {c[0] - anchor[0], c[1] - anchor[1], c[2] - anchor[2]};
       if (m->jnt_type[ji] == DIAL_JNT_FREE) {
         for (int i = 0; i < 3; i++)
           for (int k = 0; k < 6; k++) s.cdof[6 * (da + i) + k] = (k == 3 + i) ? 1.f : 0.f;
@@ -341,11 +419,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
           for (int k = 0; k < 3; k++) { s.cdof[6 * (da + 3 + i) + k] = a[k]; s.cdof[6 * (da + 3 + i) + 3 + k] = cr[k]; }
         }
       } else if (m->jnt_type[ji] == DIAL_JNT_HINGE) {
-        float ax[3] = {s.xaxis[3 * ji], s.xaxis[3 * ji + 1], s.xaxis[3 * ji + 2]}, cr[3];
+        float ax[3] = {jaxis[0], jaxis[1], jaxis[2]}, cr[3];
         dm::cross3(cr, ax, off);
         for (int k = 0; k < 3; k++) { s.cdof[6 * da + k] = ax[k]; s.cdof[6 * da + 3 + k] = cr[k]; }
       } else {
-        for (int k = 0; k < 3; k++) { s.cdof[6 * da + k] = 0.f; s.cdof[6 * da + 3 + k] = s.xaxis[3 * ji + k]; }
+        for (int k = 0; k < 3; k++) { s.cdof[6 * da + k] = 0.f; s.cdof[6 * da + 3 + k] = jaxis[k]; }
       }
     }
   });

@@ -27,7 +27,12 @@ def test_emulated_kernel_matches_oracle(example, N, H, path):
     nv, nu = model.nv, model.nu
     s_o, xp_o, xq_o = o32.env_reset(env._init_q, np.zeros(nv))
     s_e, xp_e, xq_e = emu.env_reset(env._init_q, np.zeros(nv), check_races=True)
-    assert np.allclose(s_o, s_e, rtol=2e-4, atol=2e-4) and np.allclose(xp_o, xp_e, atol=1e-6)
+    # (qacc_warmstart, the third block of the packed state, is a difference of forces: its absolute error scales with
+    # the largest acceleration -- the Allegro keyframe starts with |qacc| ~ 5e4)
+    nqv = model.nq + nv
+    atol = np.full(s_o.shape, 2e-4)
+    atol[nqv:nqv + nv] = 2e-4 * max(1.0, float(np.abs(s_o[nqv:nqv + nv]).max()) * 1e-2)
+    assert np.all(np.abs(s_o - s_e) <= atol + 2e-4 * np.abs(s_o)) and np.allclose(xp_o, xp_e, atol=1e-6)
     eps, sigma, Ybar = seeded_inputs(dc, nu, seed=0)
     ro = o32.reverse_once(s_o, Ybar, sigma, eps, full=True)
     re = emu.rollout_nodes(s_o, Ybar, sigma, eps, check_races=True)   # asserts: zero races
