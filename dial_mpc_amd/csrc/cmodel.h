@@ -117,7 +117,7 @@ struct CModel {
   int32_t kin_fast;                      // every body has at most one joint: parent-independent local transforms (forward())
   float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
   float body_mass[D::NB], body_inertia[D::NB][3], body_invweight0[D::NB];
-  int32_t lvl_start[D::NB + 1], lvl_body[D::NB];
+  int32_t lvl_start[D::NB + 1], lvl_body[D::NB], body_depth[D::NB];
   // root-to-leaf chains: prefix sums along a chain give every ancestor sum (cvel, cacc) in one sweep
   int32_t nchain, chain_len[D::NCHAIN];
   uint8_t chain_body[D::NCHAIN][D::CHAINLEN];

@@ -184,6 +184,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 4; k++) { o.body_quat[b][k] = m->body_quat[b][k]; o.body_iquat[b][k] = m->body_iquat[b][k]; }
     o.body_mass[b] = m->body_mass[b]; o.body_invweight0[b] = m->body_invweight0[b][0];
     o.lvl_body[b] = dv->lvl_body[b];
+    o.body_depth[b] = m->body_depth[b];
   }
   for (int b = 0; b <= m->nbody && b <= D::NB; b++) o.lvl_start[b] = dv->lvl_start[b < DIAL_MAX_BODY + 1 ? b : DIAL_MAX_BODY];
   {  // chains: one per leaf body, listed root first; models that exceed the table sizes get nchain = 0
@@ -344,7 +345,7 @@ struct Ws {
   float *cdist, *cpos, *cframe, *Jc;
   float *D, *aref, *lsign, *Jaref, *qfs, *qas, *qacc, *Ma, *rhs;
   // dynamics temporaries (dead after the contact-Jacobian phase) ...
-  float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd, *lq, *lp;
+  float *xmat, *xipos, *ximat, *xanchor, *xaxis, *gpos, *gaxis, *cinert, *cdofdot, *cacc, *crb, *cfl, *cfrc, *Fd;
   // ... aliased by solver-only arrays
   float *H, *JarefW, *JarefS, *jv, *frc, *quad, *MaW, *MaS, *grad, *search, *mv, *qfc, *ysol;
   // elliptic models (solver_cone.h): contact-on flags, per-contact cone Hessian weights, per-dof vectors that the row
@@ -382,8 +383,6 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv) WS_TAKE(ulist, ell * (nefc > 0 ? 68 : 0))
   const int u0 = o;
-  // local body transforms of the kinematics sweep: dead before the frames phase writes xipos / ximat over them
-  s.lq = base + u0; s.lp = base + u0 + 4 * nbody;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
   WS_TAKE(xaxis, njnt * 3)

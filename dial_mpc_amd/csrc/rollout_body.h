@@ -215,11 +215,15 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     // The transform of a body RELATIVE to its parent does not depend on the parent: with q_b = body_quat * q_joint,
     //   hinge:  l_q = q_b,        l_p = body_pos + R(body_quat) jnt_pos - R(q_b) jnt_pos
     //   slide:  l_q = body_quat,  l_p = body_pos + R(body_quat) jnt_axis * (q - q0)
-    // (MJX composes the same maps body by body: anchor = pos + R jnt_pos, rotate, pos = anchor - R' jnt_pos).  One
-    // fully parallel phase evaluates every joint's sin / cos and local transform; the level sweep that follows is one
-    // quaternion product and one rotation per body instead of the whole per-joint chain with its table look-ups.
-    w.items(nb, [&](int b) {
-      if (b == 0) return;
+    // (MJX composes the same maps body by body: anchor = pos + R jnt_pos, rotate, pos = anchor - R' jnt_pos).  Lane b
+    // owns body b: it evaluates its joint's sin / cos and local transform into registers (all bodies at once), then
+    // the level sweep is one fetch of the parent's pose, one quaternion product and one rotation per level -- not the
+    // per-joint chain with its table look-ups at every level.
+    vfloat L[9];   // l_q (4), l_p (3), depth, parent
+    w.per_lane_n(L, [&](int b, float* o) {
+      for (int k = 0; k < 9; k++) o[k] = 0.f;
+      o[7] = -1.f;
+      if (b == 0 || b >= nb) return;
       const int bflags = m->body_flags[b];
       float lq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
       float lp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
@@ -251,25 +255,27 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
           for (int k = 0; k < 3; k++) lp[k] += ax[k] * disp;
         }
       }
-      for (int k = 0; k < 4; k++) s.lq[4 * b + k] = lq[k];
-      for (int k = 0; k < 3; k++) s.lp[3 * b + k] = lp[k];
+      for (int k = 0; k < 4; k++) o[k] = lq[k];
+      for (int k = 0; k < 3; k++) o[4 + k] = lp[k];
+      o[7] = (bflags & 4) ? 0.f : (float)m->body_depth[b];   // free-joint bodies: "depth 0" = absolute, written below
+      o[8] = (float)m->body_parent[b];
+    });
+    w.items(nb, [&](int b) {   // free-joint bodies (and nothing else) before the sweep
+      if (b == 0 || lane_val(L[7], b) != 0.f) return;
+      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(L[4 + k], b);
+      for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = lane_val(L[k], b);
     });
     for (int d = 1; d <= m->nlevel; d++) {
-      const int b0 = m->lvl_start[d - 1];
-      w.items(m->lvl_start[d] - b0, [&](int idx) {
-        const int b = m->lvl_body[b0 + idx], p = m->body_parent[b];
-        const float lq[4] = {s.lq[4 * b], s.lq[4 * b + 1], s.lq[4 * b + 2], s.lq[4 * b + 3]};
-        const float lp[3] = {s.lp[3 * b], s.lp[3 * b + 1], s.lp[3 * b + 2]};
+      w.items(nb, [&](int b) {
+        if (lane_val(L[7], b) != (float)d) return;
+        const int p = (int)lane_val(L[8], b);
+        const float lq[4] = {lane_val(L[0], b), lane_val(L[1], b), lane_val(L[2], b), lane_val(L[3], b)};
+        const float lp[3] = {lane_val(L[4], b), lane_val(L[5], b), lane_val(L[6], b)};
+        const float pq[4] = {s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
         float pos[3], quat[4];
-        if (m->body_flags[b] & 4) {           // free joint: absolute
-          for (int k = 0; k < 3; k++) pos[k] = lp[k];
-          for (int k = 0; k < 4; k++) quat[k] = lq[k];
-        } else {
-          const float pq[4] = {s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
-          dm::rotate(pos, lp, pq);
-          for (int k = 0; k < 3; k++) pos[k] += s.xpos[3 * p + k];
-          dm::quat_mul(quat, pq, lq);
-        }
+        dm::rotate(pos, lp, pq);
+        for (int k = 0; k < 3; k++) pos[k] += s.xpos[3 * p + k];
+        dm::quat_mul(quat, pq, lq);
         for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = pos[k];
         for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = quat[k];
       });
