@@ -434,7 +434,50 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
   });
   DIAL_MARK(w, 18);
-  // ---- smooth.com_vel: cvel[b] = sum over ancestor dofs (root first), no recursion needed
+  // ---- smooth.com_vel + cdof_dot + the forward part of smooth.rne in ONE walk down every root-to-leaf chain
+  if (m->nchain > 0 && kin_fast) {
+    // cvel[b] = sum of cdof * qvel over the ancestor dofs, cdof_dot[i] = motion_cross(velocity accumulated BEFORE joint
+    // i, cdof[i]), cacc[b] = [0, -g] + sum of cdof_dot * qvel: three dependent sweeps in MJX.  One lane per chain carries
+    // the running velocity and acceleration in registers (cdof_dot is consumed on the spot and never stored); bodies
+    // shared by several chains are written by each of them with the same value.
+    w.items(m->nchain, [&](int c) {
+      float vel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float acc[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
+      if (c == 0) for (int k = 0; k < 6; k++) { s.cvel[k] = vel[k]; s.cacc[k] = acc[k]; }   // world body
+      const int len = m->chain_len[c];
+      for (int q = 0; q < len; q++) {
+        const int b = m->chain_body[c][q], d0 = m->body_dofadr[b], nd = m->body_dofnum[b];
+        if (nd == 6) {   // free joint: the translational dofs have cdof_dot = 0, the rotational ones see the velocity after them
+          float vs[6];
+          for (int k = 0; k < 6; k++) vs[k] = vel[k];
+          for (int j = 0; j < 3; j++) {
+            const float qv = s.qvel[d0 + j];
+            for (int k = 0; k < 6; k++) { const float t = s.cdof[6 * (d0 + j) + k] * qv; vs[k] += t; vel[k] += t; }
+          }
+          for (int j = 3; j < 6; j++) {
+            const float qv = s.qvel[d0 + j];
+            float cd[6], cdd[6];
+            for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * (d0 + j) + k];
+            dm::motion_cross(cdd, vs, cd);
+            for (int k = 0; k < 6; k++) { acc[k] += cdd[k] * qv; vel[k] += cd[k] * qv; }
+          }
+        } else {
+          float vpar[6];
+          for (int k = 0; k < 6; k++) vpar[k] = vel[k];
+          for (int j = 0; j < nd; j++) {
+            const float qv = s.qvel[d0 + j];
+            float cd[6], cdd[6];
+            for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * (d0 + j) + k];
+            dm::motion_cross(cdd, vpar, cd);
+            for (int k = 0; k < 6; k++) { acc[k] += cdd[k] * qv; vel[k] += cd[k] * qv; }
+          }
+        }
+        for (int k = 0; k < 6; k++) { s.cvel[6 * b + k] = vel[k]; s.cacc[6 * b + k] = acc[k]; }
+      }
+    });
+    DIAL_MARK(w, 19);
+  } else {
+  // cvel[b] = sum over ancestor dofs (root first), no recursion needed
   if (m->nchain > 0) {
     // prefix sums down every root-to-leaf chain: item = (chain, component); bodies shared by several chains
     // are written by each of them with the same value
@@ -499,6 +542,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       }
       s.cacc[6 * b + k] = acc;
     });
+  }
   }
   DIAL_MARK(w, 21);
   // ---- smooth.crb composite inertias (subtree sums) | rne local body forces
