@@ -450,9 +450,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         if (nd == 6) {   // free joint: the translational dofs have cdof_dot = 0, the rotational ones see the velocity after them
           float vs[6];
           for (int k = 0; k < 6; k++) vs[k] = vel[k];
-          for (int j = 0; j < 3; j++) {
+          for (int j = 0; j < 3; j++) {   // cdof of translational dof j is the unit vector e_(3+j) (written as such above)
             const float qv = s.qvel[d0 + j];
-            for (int k = 0; k < 6; k++) { const float t = s.cdof[6 * (d0 + j) + k] * qv; vs[k] += t; vel[k] += t; }
+            vs[3 + j] += qv;
+            vel[3 + j] += qv;
           }
           for (int j = 3; j < 6; j++) {
             const float qv = s.qvel[d0 + j];
