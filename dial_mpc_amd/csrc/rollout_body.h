@@ -445,8 +445,18 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float acc[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
       if (c == 0) for (int k = 0; k < 6; k++) { s.cvel[k] = vel[k]; s.cacc[k] = acc[k]; }   // world body
       const int len = m->chain_len[c];
-      for (int q = 0; q < len; q++) {
-        const int b = m->chain_body[c][q], d0 = m->body_dofadr[b], nd = m->body_dofnum[b];
+      // the chain's tables first (two LDS round trips for the whole chain, not two per body: the stores below would
+      // otherwise pin every look-up behind them)
+      constexpr int CL = M::D::CHAINLEN;
+      int cb[CL], cd0[CL], cnd[CL];
+#pragma unroll
+      for (int q = 0; q < CL; q++) cb[q] = q < len ? (int)m->chain_body[c][q] : 0;
+#pragma unroll
+      for (int q = 0; q < CL; q++) { cd0[q] = m->body_dofadr[cb[q]]; cnd[q] = m->body_dofnum[cb[q]]; }
+#pragma unroll
+      for (int q = 0; q < CL; q++) {
+        if (q >= len) break;
+        const int b = cb[q], d0 = cd0[q], nd = cnd[q];
         if (nd == 6) {   // free joint: the translational dofs have cdof_dot = 0, the rotational ones see the velocity after them
           float vs[6];
           for (int k = 0; k < 6; k++) vs[k] = vel[k];
