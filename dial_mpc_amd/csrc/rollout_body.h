@@ -901,6 +901,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   });
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
+  w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
   if constexpr (M::D::is_static) {
     const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });

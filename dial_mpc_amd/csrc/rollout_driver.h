@@ -91,7 +91,9 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     });
   }
   float rsum = 0.f;
+  w.set_rollout(n);
   for (int st = 0; st < T; st++) {
+    w.redraw_priority();
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {
       float u;
