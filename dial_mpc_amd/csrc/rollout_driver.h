@@ -29,6 +29,12 @@ struct RolloutIO {
   int use_rng;
   uint32_t seed_lo, seed_hi, rng_iter;
   int n_offset;              // global index of this launch's sample 0 (sample shards)
+  // mean-trajectory relay (GPU launches whose last rollout is the mean trajectory; nullptr / 0 otherwise): the extra
+  // rollout is cut into pieces of `relay_steps` control steps, each run by its own wavefront on a different SIMD
+  float* relay_buf;          // packed state + running reward sum handed from piece to piece
+  int* relay_flag;           // index of the piece that may run
+  int relay_steps;
+  int relay_base;            // index of the first relay workgroup of the launch
 };
 
 template <class W, class M>
@@ -55,16 +61,23 @@ DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
   });
 }
 
+// `relay` >= 0: this wavefront runs piece `relay` of the mean-trajectory rollout (RolloutIO::relay_*): it prepares
+// everything that does not depend on its predecessor, waits for the predecessor's state, runs its control steps at the
+// highest issue priority and hands the state on.  Every piece is a different wavefront on a different SIMD, so the
+// "+1" rollout loads no SIMD for longer than relay_steps control steps.
 template <class W, class M>
 DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_cfg* cfg, const Ws& s,
-                             const RolloutIO& io, int n) {
+                             const RolloutIO& io, int n, int relay = -1) {
   const int nq = dim_nq(m), nv = dim_nv(m), nu = dim_nu(m), nx = (dim_nb(m) - 1) * 3, T = io.T, Hn1 = io.Hn1;
 #ifdef DIAL_PROFILE
   w.tprev = __builtin_readcyclecounter();
 #endif
   init_world(w, s);
   init_square(w, m, s);
-  load_state(w, m, s, io.state);
+  const int nstate = nq + 2 * nv + DIAL_INFO_N;
+  int st_begin = 0, st_end = T;
+  if (relay >= 0) { st_begin = relay * io.relay_steps; st_end = st_begin + io.relay_steps < T ? st_begin + io.relay_steps : T; }
+  if (relay <= 0) load_state(w, m, s, io.state);
   if (!io.us) {
     // K1: candidate nodes (dial_core.py:110-115)
     w.items(Hn1 * nu, [&](int it) {
@@ -92,7 +105,22 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   }
   float rsum = 0.f;
   w.set_rollout(n);
-  for (int st = 0; st < T; st++) {
+#ifndef DIAL_EMU
+  if (relay > 0) {
+    // wait for the predecessor (it was dispatched before this wavefront: it is running or done), then take its state
+    if (w.lane == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(io.relay_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != relay && ++spins < (1u << 20))
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    load_state(w, m, s, io.relay_buf);
+    rsum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (relay >= 0) w.hold_priority(3);
+#endif
+  for (int st = st_begin; st < st_end; st++) {
     w.redraw_priority();
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {
@@ -128,6 +156,16 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   // event counters 28..31 are summed over ALL samples (28/29: Newton iterations 2 / with an unchanged active set,
   // 30/31: line-search iterations / Newton iterations)
   if (io.prof && w.lane == 0) for (int k = 28; k < DIAL_NSEC; k++) atomicAdd(&io.prof[k], w.acc[k]);
+#endif
+#ifndef DIAL_EMU
+  if (relay >= 0 && st_end < T) {   // hand over: state, running sum, then the flag (release)
+    store_state(w, m, s, io.relay_buf);
+    w.items(1, [&](int) { io.relay_buf[nstate] = rsum; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (w.lane == 0) __hip_atomic_store(io.relay_flag, relay + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (relay >= 0 && w.lane == 0) __hip_atomic_store(io.relay_flag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // last piece: re-arm
 #endif
   if (io.rews) {
     const float mean = rsum / (float)T;

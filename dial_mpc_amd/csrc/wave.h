@@ -310,9 +310,12 @@ struct Wave {
   // wavefronts of a SIMD finish together (437 ... 570 us) and the launch is 9 % shorter.
   // Results do not depend on it.  -DDIAL_FIXED_PRIORITY keeps the hardware default (measurement switch).
   unsigned prio_seed = 0, prio_ctr = 0;
-  __device__ __forceinline__ void set_rollout(int n) { prio_seed = (unsigned)n * 2654435761u; prio_ctr = 0; }
+  bool prio_held = false;
+  __device__ __forceinline__ void set_rollout(int n) { prio_seed = (unsigned)n * 2654435761u; prio_ctr = 0; prio_held = false; }
+  __device__ __forceinline__ void hold_priority(int) { prio_held = true; __builtin_amdgcn_s_setprio(3); }   // relay pieces
   __device__ __forceinline__ void redraw_priority() {
 #ifndef DIAL_FIXED_PRIORITY
+    if (prio_held) return;
     prio_ctr++;
     const unsigned h = (prio_seed + prio_ctr * 0x9E3779B1u) >> 30;
     if (h == 0) __builtin_amdgcn_s_setprio(0);

@@ -470,6 +470,35 @@ def test_rollout_queue_beyond_the_resident_batch():
     assert rep["rollouts"] == len(idx)
 
 
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 2048, 16), ("unitree_go2_seq_jump", 1024, 20), ("unitree_go2_trot", 100, 7)])
+def test_mean_trajectory_relay_is_bit_identical(example, N, H):
+    """The mean-trajectory rollout cut into pieces that different wavefronts run one after the other (state handed over
+    through global memory) must give exactly what one wavefront computes: same per-step outputs, same reward mean."""
+    import os
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    ctx = _lib.Context(model, task, cfg)
+    os.environ["DIAL_NO_RELAY"] = "1"
+    try:
+        ctx0 = _lib.Context(model, task, cfg)
+    finally:
+        del os.environ["DIAL_NO_RELAY"]
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=4, Ybar_scale=0.1)
+    for it in range(3):                                               # the turn flag re-arms itself between launches
+        out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        out = {k: v.clone() for k, v in out.items()}
+        sc = {k: np.array(v) for k, v in ctx.debug_scratch().items()}
+        out0 = ctx0.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        sc0 = ctx0.debug_scratch()
+        for k in ("Ybar", "rews", "qbar", "qdbar", "xbar"):
+            assert torch.equal(out[k], out0[k]), (it, k)
+        for k in ("rewss", "qss", "qdss", "xss", "Y0s", "weights"):
+            assert np.array_equal(sc[k], sc0[k]), (it, k)
+        Ybar = out["Ybar"].cpu().numpy()
+
+
 def test_degenerate_std_is_nan_like_the_reference():
     """All N+1 mean rewards identical => std = 0 and dial_core.py:126 divides 0 by 0: weights / Ybar are NaN in the
     reference (numpy restatement below) and, by definition (include/dial_mpc.h), here."""
