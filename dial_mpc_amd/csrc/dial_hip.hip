@@ -355,7 +355,8 @@ struct dial_ctx {
   int* next = nullptr;         // rollout queue head (batches larger than the chip keeps resident)
   float* relay_buf = nullptr;  // mean-trajectory relay: state handed from piece to piece, and the turn flag
   int* relay_flag = nullptr;
-  bool relay_ok = false;
+  bool relay_ok = false, relay_always = false;
+  int n_simd = 0;              // SIMDs of the device (4 per CU)
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
   bool timing = false;
@@ -509,6 +510,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     else if (ctx->inst == 4) DIAL_RESIDENT(DimsAllegro, DIAL_ALLEGRO_WPB);
     else DIAL_RESIDENT(DimsMax, 1);
 #undef DIAL_RESIDENT
+    ctx->n_simd = 4 * prop.multiProcessorCount;
     if (e == hipSuccess) ctx->resident_blocks = nb * prop.multiProcessorCount;
     if (e == hipSuccess && ctx->inst == 1) {
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>,
@@ -521,7 +523,8 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_buf, sizeof(float) * (DIAL_MAX_Q + 2 * DIAL_MAX_V + DIAL_INFO_N + 4)));
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_flag, sizeof(int)));
     HIP_TRY_CREATE(hipMemset(ctx->relay_flag, 0, sizeof(int)));
-    ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switch
+    ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switches
+    ctx->relay_always = getenv("DIAL_RELAY_ALWAYS") != nullptr;
     if (const char* e = getenv("DIAL_RELAY_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->relay_steps = v; }
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
@@ -602,7 +605,9 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // mean-trajectory relay (one wavefront per workgroup, the launch's last rollout is the mean trajectory, everything is
   // resident): the "+1" rollout runs as ceil(T / 2) two-step pieces on as many SIMDs instead of one more wavefront on one
   dial::RolloutIO io = io_in;
-  if (ctx->relay_ok && !large && !io.us && io.n_noise == B - 1 && B > 1 && ctx->T >= 4) {
+  // (only when the noisy rollouts fill the SIMDs evenly and the mean trajectory is the odd one out: N = k x 1024)
+  if (ctx->relay_ok && !large && !io.us && io.n_noise == B - 1 && B > 1 && ctx->T >= 4 && ctx->n_simd > 0 &&
+      ((B - 1) % ctx->n_simd == 0 || ctx->relay_always)) {
     const int pieces = (ctx->T + ctx->relay_steps - 1) / ctx->relay_steps;
     if ((B - 1) + pieces <= ctx->resident_blocks) {
       io.relay_buf = ctx->relay_buf;

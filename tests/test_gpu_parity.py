@@ -478,14 +478,25 @@ def test_mean_trajectory_relay_is_bit_identical(example, N, H):
     import torch
     from dial_mpc_amd import _lib
     dc, env, model, task, cfg = setup_case(example, N, H)
-    ctx = _lib.Context(model, task, cfg)
+    os.environ["DIAL_RELAY_ALWAYS"] = "1"                             # (the library relays only when N fills the SIMDs evenly)
+    try:
+        ctx = _lib.Context(model, task, cfg)
+        s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+        eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=4, Ybar_scale=0.1)
+        _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar)
+    finally:
+        del os.environ["DIAL_RELAY_ALWAYS"]
+
+
+def _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar):
+    import os
+    import torch
+    from dial_mpc_amd import _lib
     os.environ["DIAL_NO_RELAY"] = "1"
     try:
         ctx0 = _lib.Context(model, task, cfg)
     finally:
         del os.environ["DIAL_NO_RELAY"]
-    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
-    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=4, Ybar_scale=0.1)
     for it in range(3):                                               # the turn flag re-arms itself between launches
         out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
         out = {k: v.clone() for k, v in out.items()}
