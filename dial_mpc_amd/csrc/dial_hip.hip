@@ -35,6 +35,10 @@
 #ifndef DIAL_ALLEGRO_WPB
 #define DIAL_ALLEGRO_WPB 9
 #endif
+// ... except when the batch is exactly N + 1 = 8 x CUs + 1: then 8 wavefronts per workgroup (one workgroup per CU, every CU
+// equally loaded) and the mean-trajectory rollout as a one-wavefront workgroup of its own (26.6 KB: fits beside a 133 KB
+// workgroup), launched on a side stream so that it runs concurrently
+#define DIAL_ALLEGRO_WPB_EVEN 8
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
@@ -78,7 +82,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
   const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words);
-  int n = WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x;
+  int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
   int relay = -1;
   if constexpr (WPB == 1 && !QUEUE) {
     if (io.relay_flag && (int)blockIdx.x >= io.relay_base) { relay = (int)blockIdx.x - io.relay_base; n = B - 1; }
@@ -356,6 +360,11 @@ struct dial_ctx {
   float* relay_buf = nullptr;  // mean-trajectory relay: state handed from piece to piece, and the turn flag
   int* relay_flag = nullptr;
   bool relay_ok = false, relay_always = false;
+  // Allegro split launch (see DIAL_ALLEGRO_WPB_EVEN)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  size_t lds_even = 0, lds_one = 0;
+  bool split_ok = false;
   int n_simd = 0;              // SIMDs of the device (4 per CU)
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
@@ -398,6 +407,9 @@ void dial_destroy(dial_ctx* ctx) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   delete ctx;
 }
 
@@ -525,6 +537,24 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipMemset(ctx->relay_flag, 0, sizeof(int)));
     ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switches
     ctx->relay_always = getenv("DIAL_RELAY_ALWAYS") != nullptr;
+    if (ctx->inst == 4 && !getenv("DIAL_NO_SPLIT")) {
+      ctx->lds_even = ctx->cm_bytes + (size_t)DIAL_ALLEGRO_WPB_EVEN * ctx->ws_words * sizeof(float);
+      ctx->lds_one = ctx->cm_bytes + (size_t)ctx->ws_words * sizeof(float);
+#ifdef DIAL_PROFILE
+      ctx->lds_even += 16 + (size_t)DIAL_ALLEGRO_WPB_EVEN * 32 * sizeof(unsigned long long);
+      ctx->lds_one += 16 + 32 * sizeof(unsigned long long);
+#endif
+      // both workgroups on one CU: 160 KiB of LDS
+      if (ctx->lds_even + ctx->lds_one <= 160 * 1024) {
+        hipError_t e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+        if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+        if (e2 != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: split-launch set-up: ") + hipGetErrorString(e2)); }
+        ctx->split_ok = true;
+      }
+    }
     if (const char* e = getenv("DIAL_RELAY_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->relay_steps = v; }
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
@@ -623,6 +653,27 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
+  }
+  // Allegro, batch = 8 x CUs + 1 (N = 2048 on 256 CUs): the N noisy rollouts as one 8-wavefront workgroup per CU, the
+  // mean trajectory as a one-wavefront workgroup launched on the side stream (fork / join by events)
+  if (ctx->inst == 4 && ctx->split_ok && !next && !io.us && io.n_noise == B - 1 &&
+      (B - 1) == DIAL_ALLEGRO_WPB_EVEN * (ctx->n_simd / 4)) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    dial::RolloutIO io1 = io;
+    io1.n_first = B - 1;
+    hipLaunchKernelGGL((rollout_kernel<DimsAllegro, 1>), dim3(1), dim3(64), ctx->lds_one, ctx->side,
+                       (const CModel<DimsAllegro>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io1, B,
+                       ctx->ws_words, (int*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    hipLaunchKernelGGL((rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>), dim3((B - 1) / DIAL_ALLEGRO_WPB_EVEN),
+                       dim3(64 * DIAL_ALLEGRO_WPB_EVEN), ctx->lds_even, st, (const CModel<DimsAllegro>*)ctx->dcm,
+                       (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B - 1, ctx->ws_words, (int*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
+    return DIAL_OK;
   }
 #define DIAL_LAUNCH_ROLLOUT_Q(D, WPB, Q)                                                                    \
   hipLaunchKernelGGL((rollout_kernel<D, WPB, 3, Q>), dim3(blocks), dim3(64 * WPB), ctx->lds_rollout,        \

@@ -35,6 +35,7 @@ struct RolloutIO {
   int* relay_flag;           // index of the piece that may run
   int relay_steps;
   int relay_base;            // index of the first relay workgroup of the launch
+  int n_first;               // rollout index of the launch's first wavefront (split launches)
 };
 
 template <class W, class M>

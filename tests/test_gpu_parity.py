@@ -510,6 +510,35 @@ def _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar):
         Ybar = out["Ybar"].cpu().numpy()
 
 
+def test_allegro_split_launch_is_bit_identical():
+    """Allegro at N = 8 x CUs: the N noisy rollouts run as one 8-wavefront workgroup per CU and the mean trajectory as a
+    one-wavefront workgroup on a side stream (fork / join by events).  Same results as the single launch, bit for bit."""
+    import os
+    import torch
+    from dial_mpc_amd import _lib
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    dc, env, model, task, cfg = setup_case("allegro_reorient", 8 * ncu, 6)
+    ctx = _lib.Context(model, task, cfg)
+    os.environ["DIAL_NO_SPLIT"] = "1"
+    try:
+        ctx0 = _lib.Context(model, task, cfg)
+    finally:
+        del os.environ["DIAL_NO_SPLIT"]
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=6, Ybar_scale=0.2)
+    for it in range(2):
+        out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        out = {k: v.clone() for k, v in out.items()}
+        sc = {k: np.array(v) for k, v in ctx.debug_scratch().items()}
+        out0 = ctx0.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        sc0 = ctx0.debug_scratch()
+        for k in ("Ybar", "rews", "qbar", "qdbar", "xbar"):
+            assert torch.equal(out[k], out0[k]), (it, k)
+        for k in ("rewss", "qss", "qdss", "xss", "Y0s", "weights"):
+            assert np.array_equal(sc[k], sc0[k]), (it, k)
+        Ybar = out["Ybar"].cpu().numpy()
+
+
 def test_degenerate_std_is_nan_like_the_reference():
     """All N+1 mean rewards identical => std = 0 and dial_core.py:126 divides 0 by 0: weights / Ybar are NaN in the
     reference (numpy restatement below) and, by definition (include/dial_mpc.h), here."""
