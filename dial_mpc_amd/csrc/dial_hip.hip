@@ -39,6 +39,9 @@
 // equally loaded) and the mean-trajectory rollout as a one-wavefront workgroup of its own (26.6 KB: fits beside a 133 KB
 // workgroup), launched on a side stream so that it runs concurrently
 #define DIAL_ALLEGRO_WPB_EVEN 8
+// H1: same idea with 4-wavefront workgroups (one wavefront per SIMD), two per CU: 1.012 -> 0.971 ms.  (H1 loco's
+// two-wavefront workgroups already load every CU with 8 wavefronts; the split measured 0.7 % slower there.)
+#define DIAL_H1_WPB_EVEN 4
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
@@ -365,6 +368,7 @@ struct dial_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   size_t lds_even = 0, lds_one = 0;
   bool split_ok = false;
+  int wpb_even = 0;            // wavefronts per workgroup of the even launch (8 x CUs rollouts in all)
   int n_simd = 0;              // SIMDs of the device (4 per CU)
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
@@ -537,17 +541,22 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipMemset(ctx->relay_flag, 0, sizeof(int)));
     ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switches
     ctx->relay_always = getenv("DIAL_RELAY_ALWAYS") != nullptr;
-    if (ctx->inst == 4 && !getenv("DIAL_NO_SPLIT")) {
-      ctx->lds_even = ctx->cm_bytes + (size_t)DIAL_ALLEGRO_WPB_EVEN * ctx->ws_words * sizeof(float);
+    ctx->wpb_even = ctx->inst == 4 ? DIAL_ALLEGRO_WPB_EVEN : ctx->inst == 2 ? DIAL_H1_WPB_EVEN : 0;
+    if (const char* e = getenv("DIAL_SPLIT_MASK")) { if (!((atoi(e) >> ctx->inst) & 1)) ctx->wpb_even = 0; }   // measurement switch
+    if (ctx->wpb_even > 0 && !getenv("DIAL_NO_SPLIT")) {
+      ctx->lds_even = ctx->cm_bytes + (size_t)ctx->wpb_even * ctx->ws_words * sizeof(float);
       ctx->lds_one = ctx->cm_bytes + (size_t)ctx->ws_words * sizeof(float);
 #ifdef DIAL_PROFILE
-      ctx->lds_even += 16 + (size_t)DIAL_ALLEGRO_WPB_EVEN * 32 * sizeof(unsigned long long);
+      ctx->lds_even += 16 + (size_t)ctx->wpb_even * 32 * sizeof(unsigned long long);
       ctx->lds_one += 16 + 32 * sizeof(unsigned long long);
 #endif
-      // both workgroups on one CU: 160 KiB of LDS
-      if (ctx->lds_even + ctx->lds_one <= 160 * 1024) {
-        hipError_t e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+      // (8 / wpb_even) even workgroups and the one-wavefront workgroup on one CU: 160 KiB of LDS
+      if ((8 / ctx->wpb_even) * ctx->lds_even + ctx->lds_one <= 160 * 1024) {
+        hipError_t e2 = hipSuccess;
+        if (ctx->lds_even > 64 * 1024) {
+          if (ctx->inst == 4) e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+          else e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsH1, DIAL_H1_WPB_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+        }
         if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
@@ -654,22 +663,25 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
   }
-  // Allegro, batch = 8 x CUs + 1 (N = 2048 on 256 CUs): the N noisy rollouts as one 8-wavefront workgroup per CU, the
-  // mean trajectory as a one-wavefront workgroup launched on the side stream (fork / join by events)
-  if (ctx->inst == 4 && ctx->split_ok && !next && !io.us && io.n_noise == B - 1 &&
-      (B - 1) == DIAL_ALLEGRO_WPB_EVEN * (ctx->n_simd / 4)) {
+  // Batch = 8 x CUs + 1 (N = 2048 on 256 CUs) with multi-wavefront workgroups: the N noisy rollouts as evenly sized
+  // workgroups that load every CU with 8 wavefronts (Allegro: one workgroup of 8, H1: two of 4, one wavefront per SIMD
+  // each), the mean trajectory as a one-wavefront workgroup launched on the side stream (fork / join by events)
+  if (ctx->split_ok && !next && !io.us && io.n_noise == B - 1 && (B - 1) == 8 * (ctx->n_simd / 4)) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     dial::RolloutIO io1 = io;
     io1.n_first = B - 1;
-    hipLaunchKernelGGL((rollout_kernel<DimsAllegro, 1>), dim3(1), dim3(64), ctx->lds_one, ctx->side,
-                       (const CModel<DimsAllegro>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io1, B,
-                       ctx->ws_words, (int*)nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-    hipLaunchKernelGGL((rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>), dim3((B - 1) / DIAL_ALLEGRO_WPB_EVEN),
-                       dim3(64 * DIAL_ALLEGRO_WPB_EVEN), ctx->lds_even, st, (const CModel<DimsAllegro>*)ctx->dcm,
-                       (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B - 1, ctx->ws_words, (int*)nullptr);
+#define DIAL_SPLIT_LAUNCH(D, WPBE)                                                                                         \
+    hipLaunchKernelGGL((rollout_kernel<D, 1>), dim3(1), dim3(64), ctx->lds_one, ctx->side, (const CModel<D>*)ctx->dcm,     \
+                       (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io1, B, ctx->ws_words, (int*)nullptr);    \
+    HIP_TRY(ctx, hipGetLastError());                                                                                       \
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));                                                                 \
+    hipLaunchKernelGGL((rollout_kernel<D, WPBE>), dim3((B - 1) / WPBE), dim3(64 * WPBE), ctx->lds_even, st,                \
+                       (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B - 1,    \
+                       ctx->ws_words, (int*)nullptr)
+    if (ctx->inst == 4) { DIAL_SPLIT_LAUNCH(DimsAllegro, DIAL_ALLEGRO_WPB_EVEN); }
+    else { DIAL_SPLIT_LAUNCH(DimsH1, DIAL_H1_WPB_EVEN); }
+#undef DIAL_SPLIT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));

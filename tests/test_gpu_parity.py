@@ -510,14 +510,16 @@ def _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar):
         Ybar = out["Ybar"].cpu().numpy()
 
 
-def test_allegro_split_launch_is_bit_identical():
-    """Allegro at N = 8 x CUs: the N noisy rollouts run as one 8-wavefront workgroup per CU and the mean trajectory as a
-    one-wavefront workgroup on a side stream (fork / join by events).  Same results as the single launch, bit for bit."""
+@pytest.mark.parametrize("example,H", [("allegro_reorient", 6), ("unitree_h1_jog", 10)])
+def test_split_launch_is_bit_identical(example, H):
+    """Multi-wavefront workgroups at N = 8 x CUs: the N noisy rollouts run as evenly sized workgroups (8 wavefronts per CU)
+    and the mean trajectory as a one-wavefront workgroup on a side stream (fork / join by events).  Same results as the
+    single launch, bit for bit."""
     import os
     import torch
     from dial_mpc_amd import _lib
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    dc, env, model, task, cfg = setup_case("allegro_reorient", 8 * ncu, 6)
+    dc, env, model, task, cfg = setup_case(example, 8 * ncu, H)
     ctx = _lib.Context(model, task, cfg)
     os.environ["DIAL_NO_SPLIT"] = "1"
     try:
