@@ -1,9 +1,12 @@
 // dial_hip.hip -- gfx950 kernels and the C ABI of libdialhip.so (see include/dial_mpc.h).
 //
 // Kernels
-//   rollout_kernel   K1+K2+K3: one wavefront per sample (1-3 wavefronts per workgroup share the staged
+//   rollout_kernel   K1+K2+K3: one wavefront per sample (1-9 wavefronts per workgroup share the staged
 //                    constants); per-sample state and constants in LDS, per-step outputs streamed to HBM in
-//                    the layout of MBDPI.rollout_us_vmap.
+//                    the layout of MBDPI.rollout_us_vmap.  How the N + 1 wavefronts of a launch are put on the
+//                    chip is decided in launch_rollout(): rollout queue (batch > resident set), mean-trajectory
+//                    relay (one-wavefront workgroups, N a multiple of the SIMD count), split launch (H1 / Allegro
+//                    at N = 8 x CUs); every wavefront re-draws its issue priority (wave.h: redraw_priority).
 //   weights_kernel   K4a: rew_bar, std, softmax over all N+1 mean rewards (one workgroup, fixed
 //                    reduction order => bit-identical on every GPU of a sharded run).
 //   wsum_*_kernel    K4b: weighted means of Y0s / q / qd / x.pos, two deterministic passes.

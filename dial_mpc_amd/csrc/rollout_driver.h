@@ -1,6 +1,7 @@
 // rollout_driver.h -- what one wavefront does for one sample: stage the shared initial state in LDS,
 // build its control nodes (K1) and controls (K2), run T env.steps (K3) and stream the per-step
 // outputs of MBDPI.rollout_us_vmap to HBM.  Shared by the HIP kernels and the host wave emulator.
+// On the GPU a wavefront may also run one PIECE of the mean-trajectory rollout (relay, see rollout_sample).
 //
 // Reference: dial_mpc/core/dial_core.py:106-117 (sampling + node2u), :36-42 (rollout_us).
 #pragma once
