@@ -110,15 +110,20 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #ifndef DIAL_EMU
   if (relay > 0) {
     // wait for the predecessor (it was dispatched before this wavefront: it is running or done), then take its state
+    // (bounded: a wavefront that never gets its turn -- ~2 s -- poisons the rollout's reward instead of hanging the GPU)
+    int timed_out = 0;
     if (w.lane == 0) {
       unsigned spins = 0;
       while (__hip_atomic_load(io.relay_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != relay && ++spins < (1u << 20))
         __builtin_amdgcn_s_sleep(4);
+      timed_out = spins >= (1u << 20);
     }
+    timed_out = __builtin_amdgcn_readfirstlane(timed_out);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     load_state(w, m, s, io.relay_buf);
     rsum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (timed_out) rsum = __builtin_bit_cast(float, 0x7fc00000u);   // NaN: every weight of the iteration becomes NaN
   }
   if (relay >= 0) w.hold_priority(3);
 #endif
