@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--hsample", type=int, default=None, help="default: the example's own Hsample (Go2 trot: 16)")
     ap.add_argument("--example", default="unitree_go2_trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-cfg5", action="store_true", help="skip the N_total=65536 strong-scaling companion measurement")
     ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
     args = ap.parse_args()
 
@@ -99,11 +100,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only compute path")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL over xGMI) by
+        # re-executing this script under torch.distributed.run; rank 0's JSON line is this process's stdout
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: needs {args.gpus} visible GPUs, this box has {have}")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.dup2(stdout_fd, 1)
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -140,32 +155,39 @@ def main():
     eps_pool = [torch.randn((N_total, Hn1, nu), generator=gen, device=dev, dtype=torch.float32) for _ in range(4)] \
         if args.host_noise else [None] * 4
     sigma = mbdpi.sigma_control.clone()
-    Y = torch.zeros((Hn1, nu), dtype=torch.float32, device=dev)
 
-    def one_step(i, Y):
-        eps = eps_pool[i % len(eps_pool)] if args.host_noise else None     # None: Philox noise inside the rollout kernel
-        _, Y, info = mbdpi.reverse_once(states[i % len(states)], None, Y, sigma, eps=eps)
-        return Y
+    def timed_iterations(pl, sts, steps, warmup, host_eps=None):
+        """`warmup` untimed + exactly `steps` timed reverse_once calls of planner `pl`, bracketed by a barrier and a device
+        synchronize on both sides; returns (max over ranks of the elapsed seconds, kernel ms total, launches)."""
+        Yl = torch.zeros((pl.args.Hnode + 1, pl.nu), dtype=torch.float32, device=dev)
 
-    for i in range(args.warmup):
-        Y = one_step(i, Y)
-    mbdpi.ctx.set_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        Y = one_step(i, Y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    kernel_ms, launches = mbdpi.ctx.rollout_ms()
-    mbdpi.ctx.set_timing(False)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        def one_step(i, Yl):
+            eps = host_eps[i % len(host_eps)] if host_eps is not None else None   # None: Philox noise inside the rollout kernel
+            _, Yl, _ = pl.reverse_once(sts[i % len(sts)], None, Yl, pl.sigma_control, eps=eps)
+            return Yl
+
+        for i in range(warmup):
+            Yl = one_step(i, Yl)
+        pl.ctx.set_timing(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            Yl = one_step(i, Yl)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        k_ms, n_launch = pl.ctx.rollout_ms()
+        pl.ctx.set_timing(False)
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), k_ms, n_launch
+
+    elapsed, kernel_ms, launches = timed_iterations(mbdpi, states, args.steps, args.warmup,
+                                                    eps_pool if args.host_noise else None)
 
     # ---- plan latency: one control tick = env.step + shift + Ndiffuse x reverse_once (dial_core.py:245-264)
     lat = []
@@ -182,6 +204,23 @@ def main():
         torch.cuda.synchronize()
         if tick > 0:
             lat.append((time.perf_counter() - a) * 1e3)
+
+    # ---- BASELINE config 5 beside the headline: unitree_go2_trot, a FIXED global N = 65536 sharded over the ranks (8192 per
+    # GPU on 8 GPUs) -- the configuration of north_star's ">= 6x strong scaling at 8 GPUs"; the driver's per-N values of this
+    # object give that curve, whatever `scaling` the headline value uses
+    strong = None
+    if not args.no_strong_cfg5 and args.example == "unitree_go2_trot" and args.scaling == "weak" and not args.host_noise:
+        cfgs = dict(cfgd)
+        cfgs["Nsample"], cfgs["Hsample"] = 65536, 16
+        dcs, _, envs = load_dial_and_env(cfgs)
+        pls = MBDPI(dcs, envs, kernel_rng=True)
+        s_steps, s_warm = max(10, args.steps // 8), 3
+        s_el, s_kms, s_nl = timed_iterations(pls, states, s_steps, s_warm)
+        strong = {"workload": "unitree_go2_trot reverse_once, N_total=65536 (fixed), Hsample=16, Hnode=4 -- BASELINE config 5",
+                  "scaling": "strong", "value": 65537 * s_steps / s_el, "unit": "sample-rollouts/s", "n_gpus": world,
+                  "nsample_per_gpu": pls.n_local, "steps": s_steps, "warmup": s_warm, "ms_per_step": s_el / s_steps * 1e3,
+                  "avg_rollout_kernel_ms": s_kms / max(s_nl, 1)}
+        del pls
 
     if rank != 0:
         dist.destroy_process_group()
@@ -248,6 +287,8 @@ def main():
                             "ticks": len(lat), "tick_budget_ms": 20.0,
                             "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},
     }
+    if strong is not None:
+        out["strong_cfg5"] = strong
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.example, args.nsample_per_gpu, args.hsample)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -77,6 +77,7 @@ def load():
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
+    lib.dial_status.argtypes = [vp]
     lib.dial_set_timing.argtypes = [vp, ci]
     lib.dial_get_rollout_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci)]
     lib.dial_abi_sizes.argtypes = [ctypes.POINTER(ci)] * 3
@@ -91,7 +92,7 @@ def load():
 EXPORTED = ("dial_create", "dial_create_sharded", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
             "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset",
-            "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
+            "dial_status", "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
 def _ptr(t) -> Optional[int]:
@@ -259,6 +260,10 @@ class Context:
         Y = Y.clone()
         self._check(self.lib.dial_shift(self.h, _ptr(Y), _stream()), "dial_shift")
         return Y
+
+    def status(self):
+        """Raise if an earlier asynchronous launch gave up (sticky; costs no synchronisation)."""
+        self._check(self.lib.dial_status(self.h), "dial_status")
 
     # ---- measurement
     def set_timing(self, enable: bool):

@@ -253,6 +253,7 @@ def main():
         for i in range(n_diffuse):                          # lax.scan(reverse_scan) :262-264
             rng, Y0, info = mbdpi.reverse_once(state, rng, Y0, factors[i], want_bars=(i == n_diffuse - 1))
         torch.cuda.synchronize()
+        mbdpi.ctx.status()                                   # raises if an asynchronous launch of this tick gave up
         plan_ms.append((time.time() - t0) * 1e3)
         rews_plan.append(float(info["rews"].mean()))         # :266 mean over all N+1 sample rewards of the last iteration
         infos.append(info)

@@ -34,8 +34,13 @@ class ShardPlan:
         import torch
         self.ctx, self.rank, self.world, self.N, self.T, self.Hn1 = ctx, rank, world, N, T, Hn1
         self.per, self.n_begin, self.n_local = partition(N, rank, world)
-        if world > 1 and partition(N, 0, world)[2] != self.per:
-            raise ValueError("sample sharding needs Nsample >= world size")
+        # invariant the packing kernel relies on: rank 0's shard is always FULL (n_local == per), so its copy of the
+        # mean-trajectory reward sits in slot `per` of its send buffer.  Later ranks may hold a ragged or an EMPTY shard
+        # (N = 5 over 4 ranks: 2 + 2 + 1 + 0); such a rank rolls out the mean trajectory only.  Slots [n_local + 1, per]
+        # of a ragged rank's send buffer are never read (the packing kernel reads the first N noisy entries + rank 0's
+        # slot `per`).  Fewer samples than ranks is refused outright.
+        if N < world:
+            raise ValueError(f"sample sharding needs Nsample >= world size (Nsample = {N}, world = {world})")
         dev = ctx.torch_device
         f32 = dict(dtype=torch.float32, device=dev)
         self.send = torch.zeros(self.per + 1, **f32)               # [n_local noisy rewards ... | slot `per`: unused unless full]
@@ -65,16 +70,18 @@ def sharded_reverse_once(ctx, dist, rank: int, world: int, N: int, T: int, Hn1: 
             ctx.shard_ybar_rng(plan.rews_all, N, seed, counter, Ybar_i, noise_scale, plan.Ybar)
         else:
             ctx.shard_ybar(plan.rews_all, N, eps, Ybar_i, noise_scale, plan.Ybar)
-        return plan.Ybar, plan.rews_all, None, None, None
+        # fresh tensors: the plan's buffers are reused by the next iteration, callers keep `info` dicts across ticks
+        return plan.Ybar.clone(), plan.rews_all.clone(), None, None, None
     ctx.shard_reduce(plan.rews_all, N, n_begin, n_local, rank == 0, plan.packed)
     dist.all_reduce(plan.packed, op=dist.ReduceOp.SUM)
     nq, nv, nx, nu = ctx.nq, ctx.nv, ctx.nx, ctx.nu
+    packed = plan.packed.clone()     # fresh storage for the views handed out below (see above)
     o = 0
-    Ybar = plan.packed[o:o + Hn1 * nu].reshape(Hn1, nu)
+    Ybar = packed[o:o + Hn1 * nu].reshape(Hn1, nu)
     o += Hn1 * nu
-    qbar = plan.packed[o:o + T * nq].reshape(T, nq)
+    qbar = packed[o:o + T * nq].reshape(T, nq)
     o += T * nq
-    qdbar = plan.packed[o:o + T * nv].reshape(T, nv)
+    qdbar = packed[o:o + T * nv].reshape(T, nv)
     o += T * nv
-    xbar = plan.packed[o:o + T * nx].reshape(T, nx)
-    return Ybar, plan.rews_all, qbar, qdbar, xbar
+    xbar = packed[o:o + T * nx].reshape(T, nx)
+    return Ybar, plan.rews_all.clone(), qbar, qdbar, xbar

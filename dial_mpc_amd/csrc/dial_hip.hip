@@ -365,6 +365,8 @@ struct dial_ctx {
   int* next = nullptr;         // rollout queue head (batches larger than the chip keeps resident)
   float* relay_buf = nullptr;  // mean-trajectory relay: state handed from piece to piece, and the turn flag
   int* relay_flag = nullptr;
+  int* err_host = nullptr;     // sticky error word: pinned host memory the kernels can write (relay time-out) ...
+  int* err_dev = nullptr;      // ... and its device-side address
   bool relay_ok = false, relay_always = false;
   // Allegro split launch (see DIAL_ALLEGRO_WPB_EVEN)
   hipStream_t side = nullptr;
@@ -417,6 +419,7 @@ void dial_destroy(dial_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->err_host) (void)hipHostFree(ctx->err_host);
   delete ctx;
 }
 
@@ -542,6 +545,9 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_buf, sizeof(float) * (DIAL_MAX_Q + 2 * DIAL_MAX_V + DIAL_INFO_N + 4)));
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_flag, sizeof(int)));
     HIP_TRY_CREATE(hipMemset(ctx->relay_flag, 0, sizeof(int)));
+    HIP_TRY_CREATE(hipHostMalloc((void**)&ctx->err_host, sizeof(int), hipHostMallocMapped));
+    *ctx->err_host = 0;
+    HIP_TRY_CREATE(hipHostGetDevicePointer((void**)&ctx->err_dev, ctx->err_host, 0));
     ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switches
     ctx->relay_always = getenv("DIAL_RELAY_ALWAYS") != nullptr;
     ctx->wpb_even = ctx->inst == 4 ? DIAL_ALLEGRO_WPB_EVEN : ctx->inst == 2 ? DIAL_H1_WPB_EVEN : 0;
@@ -603,6 +609,24 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   return DIAL_OK;
 }
 
+// Sticky asynchronous error (today: a relay piece that never got its turn).  The word lives in pinned host memory, so
+// looking at it costs nothing and needs no synchronisation; once it is seen the device is drained, the relay's turn flag
+// is re-armed (a late predecessor may have left it non-zero) and the error is reported ONCE.
+static int check_sticky(dial_ctx* ctx) {
+  if (!ctx->err_host || __atomic_load_n(ctx->err_host, __ATOMIC_ACQUIRE) == 0) return DIAL_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->relay_flag) (void)hipMemset(ctx->relay_flag, 0, sizeof(int));
+  __atomic_store_n(ctx->err_host, 0, __ATOMIC_RELEASE);
+  return fail(ctx, DIAL_ERR_HIP, "an earlier rollout launch gave up: a piece of the mean-trajectory relay never got its turn "
+                                 "(results of that launch and of the launches queued behind it are invalid)");
+}
+
+int dial_status(dial_ctx* ctx) {
+  if (!ctx) return DIAL_ERR_ARG;
+  return check_sticky(ctx);
+}
+
 int dial_set_timing(dial_ctx* ctx, int enable) {
   if (!ctx) return DIAL_ERR_ARG;
   ctx->timing = enable != 0;
@@ -626,6 +650,7 @@ int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches) {
 }
 
 static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hipStream_t st) {
+  if (int rc = check_sticky(ctx)) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
     if (ctx->events_used == ctx->events.size()) {
@@ -656,6 +681,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
       io.relay_flag = ctx->relay_flag;
       io.relay_steps = ctx->relay_steps;
       io.relay_base = B - 1;
+      io.err_word = ctx->err_dev;
     }
   }
   int blocks = io.relay_flag ? io.relay_base + (ctx->T + io.relay_steps - 1) / io.relay_steps : (B + wpb - 1) / wpb;

@@ -37,6 +37,7 @@ struct RolloutIO {
   int relay_steps;
   int relay_base;            // index of the first relay workgroup of the launch
   int n_first;               // rollout index of the launch's first wavefront (split launches)
+  int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
 };
 
 template <class W, class M>
@@ -110,7 +111,9 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #ifndef DIAL_EMU
   if (relay > 0) {
     // wait for the predecessor (it was dispatched before this wavefront: it is running or done), then take its state
-    // (bounded: a wavefront that never gets its turn -- ~2 s -- poisons the rollout's reward instead of hanging the GPU)
+    // (bounded: a wavefront that never gets its turn -- ~2 s -- gives up instead of hanging the GPU: it raises the
+    // context's sticky error word, which every later API call reports (dial_status), marks the rollout's reward with a
+    // NaN bit pattern and RETURNS -- it neither runs on a stale state nor hands over, so its successors give up too)
     int timed_out = 0;
     if (w.lane == 0) {
       unsigned spins = 0;
@@ -119,11 +122,17 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       timed_out = spins >= (1u << 20);
     }
     timed_out = __builtin_amdgcn_readfirstlane(timed_out);
+    if (timed_out) {
+      if (w.lane == 0) {
+        if (io.err_word) __hip_atomic_store(io.err_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (io.rews) reinterpret_cast<uint32_t*>(io.rews)[n] = 0x7fc00000u;
+      }
+      return;
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     load_state(w, m, s, io.relay_buf);
     rsum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (timed_out) rsum = __builtin_bit_cast(float, 0x7fc00000u);   // NaN: every weight of the iteration becomes NaN
   }
   if (relay >= 0) w.hold_priority(3);
 #endif

@@ -11,8 +11,8 @@ re-evaluated at step_nodes + shift_time (:136-139, right-side extrapolation as F
 ``reverse_once`` iterations with the ASYNC noise schedule traj_diffuse_factor**i (no sigma_control, :207-209)
 -> publish joint targets, torques, plan time and body-position references.
 
-The plant side (native-MuJoCo simulator, Unitree DDS bridge) is out of scope; ``FakePlant`` below steps
-the same HIP env and is what the tests use.
+The plant side (native-MuJoCo simulator, Unitree DDS bridge) is out of scope; the tests drive this module with a
+test double that owns the segments and steps the same HIP env (``tests/fake_plant.py``).
 """
 from __future__ import annotations
 
@@ -135,14 +135,24 @@ class MBDPublisher:
             info = self.plan_once(state, self.dial_config.Ndiffuse)
             x_targets = info["xbar"]                                   # (T, nbody-1, 3)
             us = self.mbdpi.node2u_vmap(self.Y)                        # plan -> controls
-            us_np = us.cpu().numpy()
+            us_np = us.cpu().numpy()                                  # (synchronises with the planner's stream)
+            xt = x_targets.cpu().numpy()[:, 1:, :3]                    # drop the root body, as the reference does
+            # nothing non-finite ever reaches the robot: a launch that gave up (dial_status) raises, a NaN plan (the
+            # reference's 0 / 0 when every sample earns the same reward, dial_core.py:126) is dropped -- the plant keeps
+            # executing the previous plan, plan_time_shm is not advanced, the plan restarts from zero
+            self.mbdpi.ctx.status()
+            if not (np.isfinite(us_np).all() and np.isfinite(xt).all()):
+                print("[ERROR] non-finite plan, not published; control reset")
+                self.Y = self.Y * 0.0
+                last_plan_time = plan_time
+                ticks += 1
+                continue
             joint_targets = np.stack([self.env.act2joint(u) for u in us_np])
             ps = state.pipeline_state
             taus = np.stack([self.env.act2tau(u, ps) for u in us_np])
             self.acts_shared[: joint_targets.shape[0], :] = joint_targets
             self.tau_shared[: taus.shape[0], :] = taus
             self.plan_time_shared[0] = plan_time
-            xt = x_targets.cpu().numpy()[:, 1:, :3]                    # drop the root body, as the reference does
             n = min(self.refs_shared.shape[1], xt.shape[1])
             self.refs_shared[:, :n, :] = xt[: self.refs_shared.shape[0], :n, :]
             last_plan_time = plan_time
@@ -161,43 +171,6 @@ class MBDPublisher:
     def close(self):
         for shm, _ in self._seg.values():
             shm.close()
-
-
-class FakePlant:
-    """Stand-in for dial_sim / dial_real: owns the shm segments and advances the same HIP env with the
-    torques the planner publishes (tau_shm) -- enough to exercise the protocol end to end."""
-
-    def __init__(self, env, dial_config, shm_prefix: str = ""):
-        self.env = env
-        mj = env.sys.mj_model
-        self.nq, self.nv, self.nu = mj.nq, mj.nv, mj.nu
-        self.n_acts = dial_config.Hsample + 1
-        self.ctrl_dt = env._config.dt
-        self._seg = open_segments(self.nq, self.nv, self.nu, self.n_acts, create=True, prefix=shm_prefix)
-        for _, arr in self._seg.values():
-            arr[...] = 0.0
-        self._seg["plan_time_shm"][1][0] = -self.ctrl_dt
-        self.t = 0.0
-        self.state = env.reset(0)
-        self.publish()
-
-    def publish(self):
-        ps = self.state.pipeline_state
-        self._seg["time_shm"][1][0] = self.t
-        self._seg["state_shm"][1][:] = np.concatenate([ps.qpos.cpu().numpy(), ps.qvel.cpu().numpy()])
-
-    def step_with_action(self, action):
-        self.state = self.env.step(self.state, action)
-        self.t += self.ctrl_dt
-        self.publish()
-
-    def close(self):
-        for shm, _ in self._seg.values():
-            shm.close()
-            try:
-                shm.unlink()
-            except FileNotFoundError:
-                pass
 
 
 def main(args=None):

@@ -252,7 +252,10 @@ typedef struct dial_cfg {
 static inline int dial_state_size(int nq, int nv) { return nq + 2 * nv + DIAL_INFO_N; }
 
 /* =============================== product C ABI (libdialhip.so) ================= */
-typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg); not thread-safe */
+typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg).  NOT thread-safe, and ONE STREAM AT A
+                                   * TIME: a context owns one set of scratch tensors, one rollout-queue head and one relay
+                                   * turn flag, so two launches of the same context must never be in flight on different
+                                   * streams (use one context per stream / per Python thread).                          */
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for
  * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable. */
@@ -340,6 +343,13 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
  * kernel, measured with hipEvents on the launch stream (enable with dial_set_timing).   */
 int dial_set_timing(dial_ctx* ctx, int enable);
 int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches);
+
+/* Sticky status of the context's ASYNCHRONOUS work, readable without synchronising: DIAL_OK, or DIAL_ERR_HIP once if an
+ * earlier rollout launch gave up (a piece of the mean-trajectory relay that never got its turn -- bounded wait, ~2 s --
+ * marks the launch invalid instead of hanging the GPU; the mean trajectory's reward then carries a NaN bit pattern).
+ * Every compute entry point performs the same check first.  Drivers call it after their own synchronisation point,
+ * before they publish a plan (deploy/dial_plan.py, core/dial_core.py).                                              */
+int dial_status(dial_ctx* ctx);
 
 /* ABI self-description used by tests: sizeof of the three structs. */
 int dial_abi_sizes(int* model_bytes, int* task_bytes, int* cfg_bytes);

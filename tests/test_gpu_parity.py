@@ -259,7 +259,8 @@ def test_async_planner_protocol_end_to_end():
     import uuid
     import yaml
     from dial_mpc_amd.core.dial_core import load_dial_and_env
-    from dial_mpc_amd.deploy.dial_plan import FakePlant, MBDPublisher
+    from dial_mpc_amd.deploy.dial_plan import MBDPublisher
+    from fake_plant import FakePlant
     from dial_mpc_amd.utils.io_utils import get_example_path
     cfgd = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
     cfgd["Nsample"], cfgd["Ndiffuse_init"] = 256, 3
@@ -605,7 +606,8 @@ def test_async_planner_replay_matches_oracle_restatement():
     import oracle as O
     from dial_mpc_amd.core import spline
     from dial_mpc_amd.core.dial_core import load_dial_and_env, make_cfg
-    from dial_mpc_amd.deploy.dial_plan import FakePlant, MBDPublisher
+    from dial_mpc_amd.deploy.dial_plan import MBDPublisher
+    from fake_plant import FakePlant
     from dial_mpc_amd.utils.io_utils import get_example_path
     cfgd = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
     cfgd["Nsample"], cfgd["Ndiffuse_init"] = 256, 3
@@ -665,3 +667,58 @@ def test_async_planner_replay_matches_oracle_restatement():
         n = min(rec["refs"].shape[1], refs.shape[1])
         assert np.allclose(rec["refs"][:, :n], refs[:, :n], atol=3e-3), (k, float(np.abs(rec["refs"][:, :n] - refs[:, :n]).max()))
         last_plan_time = rec["t"]
+
+
+@pytest.mark.parametrize("N,world", [(2048, 2), (2048, 4), (1001, 4), (37, 4), (5, 4), (2048, 1)])
+def test_sharded_kernels_at_world_2_and_4_on_one_gpu(N, world):
+    """The HIP kernels of the sharded path at world > 1, driven on ONE GPU: one dial_create_sharded context per pseudo-rank
+    (threads, tests/local_group.py), the production `sharded_reverse_once` on each, collectives as device-side copies /
+    rank-ordered sums.  Against the fused dial_reverse_once[_rng] on the same inputs: the gathered rewards are bit-equal
+    (a rollout's result does not depend on which shard ran it), every rank holds bit-identical Ybar / bars, and they
+    agree with the fused sums to summation-order rounding (the fused K4b sums 64 row chunks over all samples, the
+    sharded one world x 64 over the shards; world = 1: bit-equal).  1001 / 37 / 5 samples: ragged and EMPTY shards."""
+    import torch
+    from dial_mpc_amd import _lib
+    from dial_mpc_amd.core.sharding import ShardPlan, partition, sharded_reverse_once
+    from local_group import LocalGroup
+    H = 16
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H)
+    full = _lib.Context(model, task, cfg)
+    s0, _, _ = full.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=9, Ybar_scale=0.2)
+    eps_d, sigma_d, Ybar_d = _dev(eps), _dev(sigma), _dev(Ybar)
+    seed, counter = 0xBEEF, 11
+    ref = {k: v.clone() for k, v in full.reverse_once(s0, Ybar_d, sigma_d, eps_d).items()}
+    ref_rng = {k: v.clone() for k, v in full.reverse_once_rng(s0, Ybar_d, sigma_d, seed, counter).items()}
+    grp = LocalGroup(world)
+    T, Hn1 = H + 1, dc.Hnode + 1
+
+    def rank_body(rank):
+        per, n_begin, n_local = partition(N, rank, world)
+        ctx = _lib.Context(model, task, cfg, n_local_cap=per)               # dial_create_sharded: scratch for `per` + 1 rollouts
+        plan = ShardPlan(ctx, rank, world, N, T, Hn1)
+        res = {}
+        for name, e, rng in (("eps", eps_d, None), ("rng", None, (seed, counter))):
+            for bars in (False, True, False):                               # the driver's pattern, then the buffers once more
+                out = sharded_reverse_once(ctx, grp, rank, world, N, T, Hn1, s0, Ybar_d, sigma_d, e, want_bars=bars,
+                                           plan=plan, rng=rng)
+                res[(name, bars)] = [None if o is None else o.clone() for o in out]
+        torch.cuda.synchronize()
+        ctx.status()
+        return res
+
+    results = grp.run(rank_body)
+    for name, r in (("eps", ref), ("rng", ref_rng)):
+        for rank in range(world):
+            Yb1, rews1, q1, qd1, x1 = results[rank][(name, False)]
+            Yb2, rews2, q2, qd2, x2 = results[rank][(name, True)]
+            assert q1 is None and x1 is None
+            assert torch.equal(rews1, r["rews"]) and torch.equal(rews2, r["rews"]), (name, rank)
+            if world == 1:
+                assert torch.equal(Yb2, r["Ybar"]) and torch.equal(q2, r["qbar"]) and torch.equal(x2, r["xbar"])
+            for got, want, atol in ((Yb1, r["Ybar"], 2e-6), (Yb2, r["Ybar"], 2e-6), (q2, r["qbar"], 5e-6),
+                                    (qd2, r["qdbar"], 1e-4), (x2, r["xbar"], 5e-6)):
+                assert torch.allclose(got, want, rtol=1e-5, atol=atol), (name, rank, float((got - want).abs().max()))
+            for a, b in zip(results[0][(name, False)] + results[0][(name, True)],
+                            results[rank][(name, False)] + results[rank][(name, True)]):
+                assert (a is None and b is None) or torch.equal(a, b), (name, rank)     # bit-identical on every rank

@@ -99,6 +99,15 @@ def _worker(rank, world, port, N, H, ret):
         Yb_single = one[0].numpy().copy()
         out = sharded_reverse_once(*args, want_bars=True, plan=plan)
         ret[rank] = [o.numpy().copy() for o in out] + [Yb_single]
+        # callers keep `info` dicts across ticks (dial_core.main appends them and reads xbar at the very end): what a call
+        # returned must survive the next call on the same plan buffers
+        args2 = args[:8] + (out[0],) + args[9:]                           # next iteration starts from the new mean plan
+        out2 = sharded_reverse_once(*args2, want_bars=True, plan=plan)
+        for a, b in zip(out, ret[rank][:5]):
+            assert np.array_equal(a.numpy(), b), "an earlier call's result was overwritten by the next call"
+        assert not np.array_equal(out2[4].numpy(), out[4].numpy())        # the second plan differs from the first
+        one2 = sharded_reverse_once(*args2, want_bars=False, plan=plan)
+        assert np.array_equal(one[0].numpy(), Yb_single) and one2[0].data_ptr() != one[0].data_ptr()
     finally:
         dist.destroy_process_group()
 
@@ -122,6 +131,9 @@ def test_sharded_reverse_once_equals_unsharded(N, world):
         assert np.allclose(rews, ref["rews"], atol=1e-3)
         assert np.allclose(Yb, ref["Ybar"], atol=2e-3) and np.allclose(qbar, ref["qbar"], atol=5e-3)
         assert np.allclose(xbar, ref["xbar"].reshape(xbar.shape), atol=5e-3)
+    with pytest.raises(ValueError):
+        from dial_mpc_amd.core.sharding import ShardPlan
+        ShardPlan(type("C", (), dict(torch_device=torch.device("cpu"), nu=12, packed_size=lambda self: 8))(), 0, 8, 5, 9, 5)
     for rank in range(1, world):                        # every rank holds bit-identical results
         for a, b in zip(ret[0], ret[rank]):
             assert np.array_equal(a, b)
