@@ -17,9 +17,7 @@ _configs: Dict[str, Any] = {
 }
 _envs: Dict[str, Callable] = {
     "unitree_h1_walk": UnitreeH1WalkEnv,
-    # the reference ships the config and the example but never registers this env with brax
-    # (unitree_h1_env.py:904-906 registers walk and push_crate only); registered here so the example runs
-    "unitree_h1_loco": UnitreeH1LocoEnv,
+    "unitree_h1_loco": UnitreeH1LocoEnv,      # unitree_h1_env.py:906
     "unitree_go2_walk": UnitreeGo2Env,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
     "allegro_reorient": AllegroReorientEnv,

@@ -584,10 +584,10 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         iterations=int(opt["iterations"]), ls_iterations=int(opt["ls_iterations"]),
         eulerdamp=0 if flags.get("eulerdamp", "enable") == "disable" else 1,
         cone=0 if opt["cone"] == "pyramidal" else 1,
-        # line-search bracket rule (include/dial_mpc.h): elliptic cones need an MJX release with `_in_bracket`
-        # (the older rule cycles on the cone cost); pyramidal models default to the older rule, which every MJX >= 3.0
-        # that can run them had at some point and under which the truncated solve is well-conditioned
-        ls_rule=1 if opt["cone"] == "elliptic" else 0,
+        # line-search bracket rule (include/dial_mpc.h): `_in_bracket`, the rule of every MJX release that can run ALL of the
+        # reference's envs (its Allegro env needs elliptic cones, i.e. MJX >= 3.1.4; tools/reference_env.txt pins 3.2.7).
+        # DIAL_LS_SWAP (MJX <= 3.1.3) stays selectable per model: the tests use it where rollouts are compared one by one
+        ls_rule=1,
         timestep=float(opt["timestep"]), gravity=_floats(str(opt["gravity"])),
         tolerance=float(opt["tolerance"]), ls_tolerance=float(opt["ls_tolerance"]),
         impratio=float(opt["impratio"]), meaninertia=0.0,

@@ -76,11 +76,12 @@ extern "C" {
 #define DIAL_CON_CAPSULE_CAPSULE 4 /* MJX capsule_capsule: closest points of the two segments */
 
 /* bracket-update rule of the Newton solver's line search (solver._linesearch of MJX).  The reference pins no MJX
- * version (setup.py:9-21); its Allegro env needs elliptic cones, i.e. a release that carries the `_in_bracket`
- * rule, so that rule is the default for every model.  The older rule is kept selectable because it is
- * well-conditioned under truncation (ls_iterations = 5): with it GPU and oracle can be compared rollout by rollout
- * at the envs' real solver settings (tests), whereas `_in_bracket` rejects zero-slope candidates and turns rounding
- * noise into different iterates.                                                                                  */
+ * version (setup.py:9-21); its Allegro env needs elliptic cones, i.e. a release (>= 3.1.4) that carries the
+ * `_in_bracket` rule, and tools/reference_env.txt pins 3.2.7 -- so DIAL_LS_IN_BRACKET is what dial_mpc_amd/mjcf.py
+ * writes into EVERY compiled model.  The older rule stays selectable per model because it is well-conditioned under
+ * truncation (ls_iterations = 5): with it GPU and oracle can be compared rollout by rollout at the envs' real solver
+ * settings (tests), whereas `_in_bracket` rejects zero-slope candidates and turns rounding noise into different
+ * iterates -- under it the product outputs are gated at the distribution level (tests/conftest.py).               */
 #define DIAL_LS_SWAP 0        /* MJX <= 3.1.3: swap_lo_next / swap_lo_mid / swap_hi_next / swap_hi_mid            */
 #define DIAL_LS_IN_BRACKET 1  /* MJX >= 3.1.4: _in_bracket(x, y), each end offered lo_next, mid, hi_next          */
 

@@ -1342,6 +1342,42 @@ int oracle_rollout_trace(const dial_model* m, const dial_task* t, const real* st
   return 0;
 }
 
+/* oracle_rollout with the rounding-level jitter of oracle_rollout_trace applied to EVERY rollout (rollout n draws from
+ * an LCG seeded with noise_seed + n): one member of the "jitter ensemble" the distribution-level parity gates are
+ * calibrated on -- how far do the aggregates of reverse_once move when nothing but <= noise_mag ulp of the state
+ * changes before each step?  (tests/conftest.py: jitter_envelope) */
+int oracle_rollout_jitter(const dial_model* m, const dial_task* t, const real* state, const real* us, int B, int T,
+                          real* rewss, real* qss, real* qdss, real* xposs, unsigned long long noise_seed,
+                          double noise_mag) {
+  int nq = m->nq, nv = m->nv, nu = m->nu, nx = (m->nbody - 1) * 3;
+  const double sc = noise_mag * 5.9604644775390625e-08;
+#pragma omp parallel
+  {
+    odata* d = (odata*)calloc(1, sizeof(odata));
+    real info[DIAL_INFO_N];
+#pragma omp for schedule(dynamic, 4)
+    for (int n = 0; n < B; n++) {
+      load_state(m, state, d, info);
+      unsigned long long lcg = (noise_seed + (unsigned long long)n) * 6364136223846793005ULL + 1442695040888963407ULL;
+      for (int s = 0; s < T; s++) {
+#define ORACLE_JITTER(x) do { lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL; \
+        double u_ = (double)(lcg >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0; (x) = (real)((double)(x) * (1.0 + sc * u_)); } while (0)
+        for (int i = 0; i < nq; i++) ORACLE_JITTER(d->qpos[i]);
+        for (int i = 0; i < nv; i++) { ORACLE_JITTER(d->qvel[i]); ORACLE_JITTER(d->qacc_warmstart[i]); }
+#undef ORACLE_JITTER
+        real rew = env_step(m, t, d, info, us + ((size_t)n * T + s) * nu);
+        size_t o = (size_t)n * T + s;
+        rewss[o] = rew;
+        if (qss) for (int i = 0; i < nq; i++) qss[o * nq + i] = d->qpos[i];
+        if (qdss) for (int i = 0; i < nv; i++) qdss[o * nv + i] = d->qvel[i];
+        if (xposs) for (int b = 1; b < m->nbody; b++) for (int k = 0; k < 3; k++) xposs[o * nx + (b - 1) * 3 + k] = d->xpos[b][k];
+      }
+    }
+    free(d);
+  }
+  return 0;
+}
+
 /* reverse_once (dial_core.py:103-145).  eps [N,Hn+1,nu]; noise_scale [ns] (ns = Hn+1 or 1).
  * Outputs: Ybar_out [Hn+1,nu], rews [N+1], qbar [T,nq], qdbar [T,nv], xbar [T,nx], and the optional
  * full intermediates us_out [N+1,T,nu], rewss_out [N+1,T], weights_out [N+1] for stage-wise parity tests. */

@@ -79,6 +79,20 @@ class Oracle:
                                 self._p(us), B, T, self._p(rewss), self._p(qss), self._p(qdss), self._p(xss))
         return rewss, qss, qdss, xss
 
+    def rollout_jitter(self, state, us, noise_seed: int, noise_mag: float = 1.0):
+        """`rollout` with qpos / qvel / qacc_warmstart of every rollout jittered by <= noise_mag ulp (fp32) before every
+        step: one member of the jitter ensemble of the distribution-level gates (conftest.jitter_envelope)."""
+        us = self._a(us)
+        B, T = us.shape[0], us.shape[1]
+        rewss = np.zeros((B, T), self.dtype)
+        qss = np.zeros((B, T, self.nq), self.dtype)
+        qdss = np.zeros((B, T, self.nv), self.dtype)
+        xss = np.zeros((B, T, self.nx), self.dtype)
+        self.lib.oracle_rollout_jitter(ctypes.byref(self.model), ctypes.byref(self.task), self._p(self._a(state)),
+                                       self._p(us), B, T, self._p(rewss), self._p(qss), self._p(qdss), self._p(xss),
+                                       ctypes.c_ulonglong(int(noise_seed)), ctypes.c_double(float(noise_mag)))
+        return rewss, qss, qdss, xss
+
     def rollout_trace(self, state, us, noise_seed: int = 0, noise_mag: float = 0.0):
         """One rollout (us [T,nu]) with the solver's decision trace per step:
         [use_warm, niter, nactive_start, nactive_end, ls_iters_total, improved_mask, ncontact_rows_on, nlimit_rows_on].

@@ -17,7 +17,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
                                               ("allegro_reorient_N64_H8", "allegro_reorient", 64, 8)])
 def test_oracle_reproduces_fixture(name, example, N, H):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    dc, env, model, task, cfg = setup_case(example, N, H)
+    dc, env, model, task, cfg = setup_case(example, N, H, per_rollout=True)   # the fixtures pin the per-rollout-comparable rule
     for dt, tol in ((np.float64, 1e-5), (np.float32, 2e-3)):
         orc = O.Oracle(model, task, cfg, dt)
         r = orc.reverse_once(g["state"], g["Ybar_in"], g["noise_scale"], g["eps"], full=True)

@@ -9,7 +9,7 @@ from conftest import setup_case
 
 @pytest.fixture(scope="module")
 def go2():
-    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 64, 8)
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 64, 8, per_rollout=True)   # fp32-vs-fp64 below is a per-rollout comparison
     return dc, env, model, task, cfg, O.Oracle(model, task, cfg, np.float64)
 
 

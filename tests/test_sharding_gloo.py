@@ -84,7 +84,7 @@ def _worker(rank, world, port, N, H, ret):
     try:
         from dial_mpc_amd.core.sharding import sharded_reverse_once
         import oracle as O
-        dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H)
+        dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H, per_rollout=True)
         ctx = FakeCtx(model, task, cfg)
         o32 = O.Oracle(model, task, cfg, np.float32)
         s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
@@ -120,7 +120,7 @@ def test_sharded_reverse_once_equals_unsharded(N, world):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, N, H, ret), nprocs=world, join=True)
-    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H)
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H, per_rollout=True)
     o32 = O.Oracle(model, task, cfg, np.float32)
     s0, _, _ = o32.env_reset(env._init_q, np.zeros(18))
     eps, sigma, Ybar = seeded_inputs(dc, 12, seed=0)

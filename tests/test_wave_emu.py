@@ -8,7 +8,8 @@ import pytest
 
 import emu_lib
 import oracle as O
-from conftest import CASES, TOL, one_step_consistency, perturbed_state, seeded_inputs, setup_case, with_solver, witness_parity
+from conftest import (CASES, TOL, distribution_parity, k4_fp64, one_step_consistency, perturbed_state, seeded_inputs, setup_case,
+                      with_solver, witness_parity)
 
 
 def _close(a, b, tol):
@@ -18,7 +19,7 @@ def _close(a, b, tol):
 @pytest.mark.parametrize("path", [0, 1], ids=["specialised", "generic"])
 @pytest.mark.parametrize("example,N,H", CASES)
 def test_emulated_kernel_matches_oracle(example, N, H, path):
-    dc, env, model, task, cfg = setup_case(example, N, H)
+    dc, env, model, task, cfg = setup_case(example, N, H, per_rollout=True)
     if example == "allegro_reorient" and path == 1:
         pytest.skip("elliptic cones run on the dimension-specialised instantiation only")
     o32 = O.Oracle(model, task, cfg, np.float32)
@@ -61,7 +62,7 @@ def test_emulated_allegro_one_step_consistency():
 @pytest.mark.parametrize("example,N,H", CASES[:2])
 def test_emulated_kernel_from_perturbed_states(example, N, H):
     """BASELINE.md synthetic states: contact-active set differs from the rest pose."""
-    dc, env, model, task, cfg = setup_case(example, 8, H)
+    dc, env, model, task, cfg = setup_case(example, 8, H, per_rollout=True)
     o32 = O.Oracle(model, task, cfg, np.float32)
     emu = emu_lib.Emu(model, task, cfg)
     rng = np.random.default_rng(11)
@@ -76,7 +77,7 @@ def test_emulated_kernel_from_perturbed_states(example, N, H):
 
 
 def test_emulated_env_step_sequence():
-    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8)
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 8, 8, per_rollout=True)
     o32 = O.Oracle(model, task, cfg, np.float32)
     emu = emu_lib.Emu(model, task, cfg)
     s_o, _, _ = o32.env_reset(env._init_q, np.zeros(18))
@@ -98,6 +99,7 @@ def test_in_bracket_rule_converged_and_truncated(example, N, H):
     iterates (a zero-slope candidate is rejected): every rollout that leaves the gate must be a branch
     the oracle itself takes under <= 64 ulp of jitter."""
     dc, env, model, task, cfg = setup_case(example, N, H)
+    assert model.ls_rule == 1                                      # the shipped default
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
     for m2, strict in ((with_solver(model, ls_rule=1, iterations=50, ls_iterations=50), True), (with_solver(model, ls_rule=1), False)):
         o32 = O.Oracle(m2, task, cfg, np.float32)
@@ -108,3 +110,22 @@ def test_in_bracket_rule_converged_and_truncated(example, N, H):
         rep = witness_parity(o32, s0, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), example,
                              model.nq + 2 * model.nv, max_frac=0.0 if strict else 0.95)
         assert not strict or rep["outside_tol"] == 0
+
+
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 192, 16), ("unitree_h1_loco", 96, 20)])
+def test_emulated_kernel_default_rule_distribution_parity(example, N, H):
+    """CPU leg of the distribution-level gate (the GPU suite runs it at the BASELINE sizes): the kernel logic under the
+    SHIPPED line-search rule against the oracle's own 1-ulp jitter envelope (conftest.distribution_parity)."""
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.2)
+    ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+    re = emu.rollout_nodes(s0, Ybar, sigma, eps, check_races=False)
+    got = (re["rewss"], re["qss"], re["qdss"], re["xss"])
+    prod = k4_fp64(got[0], re["Y0s"], got[1], got[2], got[3], cfg.temp_sample)      # (the emulator has no K4 of its own)
+    rep = distribution_parity(o32, s0, ro["us"], re["Y0s"], got, prod, cfg.temp_sample, members=6)
+    assert rep["gpu"]["outside"] > 0.05      # the lottery is real at these settings: this test is not vacuous ...
+    strict = setup_case(example, N, H, per_rollout=True)[2]
+    assert strict.ls_rule == 0               # ... and the per-rollout tests run the other rule

@@ -37,10 +37,6 @@ def main():
     cfg["Nsample"], cfg["Hsample"] = args.nsample, args.hsample
     dial_config = load_dataclass_from_dict(DialConfig, cfg)
     env_config = load_dataclass_from_dict(dial_envs.get_config(dial_config.env_name), cfg, convert_list_to_array=True)
-    if dial_config.env_name == "unitree_h1_loco":
-        # the reference ships this env's config and example but never registers it (unitree_h1_env.py:904-906)
-        from dial_mpc.envs.unitree_h1_env import UnitreeH1LocoEnv
-        brax_envs.register_environment("unitree_h1_loco", UnitreeH1LocoEnv)
     env = brax_envs.get_environment(dial_config.env_name, config=env_config)
     mbdpi = MBDPI(dial_config, env)
     state = jax.jit(env.reset)(jax.random.PRNGKey(0))

@@ -21,7 +21,7 @@ for name, example, N, H in [("go2_trot_N64_H8", "unitree_go2_trot", 64, 8),
                             ("h1_jog_N32_H16", "unitree_h1_jog", 32, 16),
                             ("h1_loco_N32_H20", "unitree_h1_loco", 32, 20),
                             ("allegro_reorient_N64_H8", "allegro_reorient", 64, 8)]:
-    dc, env, model, task, cfg = setup_case(example, N, H)
+    dc, env, model, task, cfg = setup_case(example, N, H, per_rollout=True)   # the fixtures pin the per-rollout-comparable rule
     o64 = O.Oracle(model, task, cfg, np.float64)
     s0, _, _ = o64.env_reset(env._init_q, np.zeros(model.nv))
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.2)

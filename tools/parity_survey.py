@@ -47,7 +47,7 @@ def main():
     if "allegro_reorient" in sys.argv:
         cases.append(("allegro_reorient", 4096, 24, [0]))
     for ex, N, H, seeds in cases:
-        dc, env, model, task, cfg = setup_case(ex, N, H)
+        dc, env, model, task, cfg = setup_case(ex, N, H, per_rollout=True)
         ctx = _lib.Context(model, task, cfg)
         o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
         for seed in seeds:

@@ -31,7 +31,7 @@ def dev(x):
 
 def main():
     ex, H, N = "unitree_go2_seq_jump", 20, 192
-    dc, env, model, task, cfg = setup_case(ex, N, H)
+    dc, env, model, task, cfg = setup_case(ex, N, H, per_rollout=True)
     ctx = _lib.Context(model, task, cfg)
     o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
     ct = _abi.as_numpy(task, "contact_targets")
