@@ -52,7 +52,10 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
     import oracle as O
     from conftest import seeded_inputs, setup_case
     dc, env, model, task, cfg = setup_case(example, N, H)
-    o32 = O.Oracle(model, task, cfg, np.float32)
+    try:
+        o32, build_note = O.Oracle(model, task, cfg, np.float32, native=True), "gcc -O3 -march=native, built on this host"
+    except Exception:                                           # no compiler on the box: the portable -O2 build
+        o32, build_note = O.Oracle(model, task, cfg, np.float32), "gcc -O2 (portable build)"
     s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
     o32.reverse_once(s0, Ybar, sigma, eps)                      # warm-up (thread pool, page faults)
@@ -64,9 +67,13 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
         dt = time.perf_counter() - t0
         if (dt * cores >= budget_s and dt >= min_wall_s and reps >= 3) or dt >= 30.0:
             break
+    n_frames = int(task.n_frames)
+    ns_per_step = dt * cores / ((N + 1) * reps * (H + 1)) * 1e9
     return {"value": (N + 1) * reps / dt, "unit": "sample-rollouts/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x reverse_once(N={N}, H={H}) fp32 C oracle, OpenMP over samples on {cores} threads, "
-                      f"{dt:.2f} s wall = {dt * cores:.0f} core-s; not the JAX reference (not installable)"}
+            "ns_per_env_step_per_thread": ns_per_step, "physics_steps_per_env_step": n_frames, "build": build_note,
+            "sample": f"{reps} x reverse_once(N={N}, H={H}) fp32 C oracle ({build_note}), OpenMP over samples on {cores} "
+                      f"threads, {dt:.2f} s wall = {dt * cores:.0f} core-s, {ns_per_step / 1e3:.0f} us per env.step per thread; "
+                      f"a CPU restatement, not the JAX reference (not installable) -- a reported baseline, no quality claim"}
 
 
 def main():

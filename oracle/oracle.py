@@ -34,10 +34,15 @@ class Oracle:
     """One flavour (float32 / float64) of the oracle bound to a (model, task, cfg)."""
 
     def __init__(self, model: "_abi.DialModel", task: "_abi.DialTask", cfg: Optional["_abi.DialCfg"],
-                 dtype=np.float64):
+                 dtype=np.float64, native: bool = False):
+        """native=True (fp32 only; bench.py's cpu_baseline): the -O3 -march=native build, compiled on this host."""
         build()
         self.dtype = np.dtype(dtype)
         name = "liboracle_f32.so" if self.dtype == np.float32 else "liboracle_f64.so"
+        if native:
+            assert self.dtype == np.float32
+            subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+            name = os.path.join("_native", name)
         self.lib = ctypes.CDLL(os.path.join(_HERE, name))
         assert self.lib.oracle_real_bytes() == self.dtype.itemsize
         self.model, self.task, self.cfg = model, task, cfg
