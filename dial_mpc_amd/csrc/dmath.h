@@ -15,6 +15,7 @@
 #define DM_RINT(x) std::nearbyint(x)
 #define DM_FMA(a, b, c) std::fma((float)(a), (float)(b), (float)(c))
 #define DM_OPAQUE(x) ((void)0)
+#define DM_UNIFORM_I(x) (x)
 #else
 #define DM_SQRT(x) sqrtf(x)
 #define DM_SIN(x) sinf(x)
@@ -27,6 +28,8 @@
 #define DM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 // hides a VGPR value's provenance from the optimiser (stops select chains from becoming scratch-array lookups)
 #define DM_OPAQUE(x) asm("" : "+v"(x))
+// a wave-uniform int that the compiler holds in a VGPR (loaded from LDS / computed by the VALU): move it to an SGPR
+#define DM_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 namespace dm {

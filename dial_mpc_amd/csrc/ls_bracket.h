@@ -1,0 +1,97 @@
+// ls_bracket.h -- the bracket bookkeeping of MJX's `solver._linesearch` on INTEGER keys.
+//
+// One wavefront owns the sample, so the line search's points (alpha, cost, slope) are wave-uniform.  gfx950 has no
+// scalar floating-point ALU: written with floats, every comparison of the bracket update became a VALU v_cmp into a
+// 64-bit lane mask + s_and_b64 with exec + s_cbranch -- ~20 dependent VALU->SALU->branch round trips per line-search
+// iteration (build/go2.s, round 2), the longest serial stretch of the iteration.  Floats order like sign-magnitude
+// integers, so each point is carried as four 32-bit words in SGPRs instead --
+//     alpha   raw bits                          nalpha  raw bits of the point's own Newton step alpha - d0 / d1
+//     cost    monotone key of the cost          d0      monotone key of the slope
+// -- produced LANE-WISE where the point is evaluated (the three trial points of an iteration sit in three 16-lane
+// groups) and broadcast with v_readlane.  The whole update is then s_cmp_*_i32 / s_cselect_b32 on the scalar unit, and
+// the next iteration's trial steps are already there (lo.nalpha, hi.nalpha; only the mid-point needs one VALU add).
+// fkey(a) < fkey(b)  <=>  a < b for all non-NaN floats (-0 and +0 share key 0, as they compare equal); the device code
+// does not honour NaNs anywhere (-fno-honor-nans).  Same code in the host wave emulator.
+//
+// Reference: mujoco.mjx._src.solver._linesearch (both bracket rules, see include/dial_mpc.h DIAL_LS_*); the oracle's
+// float restatement is oracle/dial_oracle.c: linesearch.
+#pragma once
+
+namespace dial {
+
+DIAL_DEV int fbits(float x) { return __builtin_bit_cast(int, x); }
+DIAL_DEV float bitsf(int b) { return __builtin_bit_cast(float, b); }
+// monotone integer key of a float
+DIAL_DEV int fkey(float x) {
+  const int b = fbits(x + 0.f);   // -0 + 0 = +0: one key for both zeros
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+// the same key carried in a float-typed register (per-lane results travel as vfloat)
+DIAL_DEV float fkeyf(float x) { return bitsf(fkey(x)); }
+
+struct LsPt { int alpha, nalpha, cost, d0; };
+
+DIAL_DEV LsPt ls_pick(bool c, const LsPt& a, const LsPt& b) {
+  LsPt r;
+  r.alpha = c ? a.alpha : b.alpha; r.nalpha = c ? a.nalpha : b.nalpha; r.cost = c ? a.cost : b.cost; r.d0 = c ? a.d0 : b.d0;
+  return r;
+}
+
+// opening bracket: p0 = point at 0, p1 = its Newton step
+DIAL_DEV void ls_open(const LsPt& p0, const LsPt& p1, LsPt& lo, LsPt& hi) {
+  const bool lesser = p1.d0 < p0.d0;
+  lo = ls_pick(lesser, p1, p0);
+  hi = ls_pick(lesser, p0, p1);
+}
+
+// done-test of an iteration (ls_iter < max_ls is checked by the caller): kg = fkey(gtol), kng = fkey(-gtol)
+DIAL_DEV bool ls_converged(const LsPt& lo, const LsPt& hi, int kg, int kng) {
+  return ((lo.d0 < 0) & (lo.d0 > kng)) | ((hi.d0 > 0) & (hi.d0 < kg));
+}
+
+// one bracket update; returns whether any end moved (`swap` of the reference)
+DIAL_DEV bool ls_update(bool rule_swap, LsPt& lo, LsPt& hi, const LsPt& lo_next, const LsPt& hi_next, const LsPt& mid) {
+  if (rule_swap) {   // MJX <= 3.1.3
+    const bool swap_lo_next = (lo.d0 > 0) | (lo.d0 < lo_next.d0);
+    lo = ls_pick(swap_lo_next, lo_next, lo);
+    const bool swap_lo_mid = (mid.d0 < 0) & (lo.d0 < mid.d0);
+    lo = ls_pick(swap_lo_mid, mid, lo);
+    const bool swap_hi_next = (hi.d0 < 0) | (hi.d0 > hi_next.d0);
+    hi = ls_pick(swap_hi_next, hi_next, hi);
+    const bool swap_hi_mid = (mid.d0 > 0) & (hi.d0 > mid.d0);
+    hi = ls_pick(swap_hi_mid, mid, hi);
+    return swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
+  }
+  // MJX >= 3.1.4 `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer
+  // to it; each end is offered its own Newton step, the mid-point and the other end's Newton step
+  const auto in_bracket = [](const LsPt& x, const LsPt& y) { return ((x.d0 < y.d0) & (y.d0 < 0)) | ((x.d0 > y.d0) & (y.d0 > 0)); };
+  const bool s1 = in_bracket(lo, lo_next);
+  lo = ls_pick(s1, lo_next, lo);
+  const bool s2 = in_bracket(lo, mid);
+  lo = ls_pick(s2, mid, lo);
+  const bool s3 = in_bracket(lo, hi_next);
+  lo = ls_pick(s3, hi_next, lo);
+  const bool s4 = in_bracket(hi, hi_next);
+  hi = ls_pick(s4, hi_next, hi);
+  const bool s5 = in_bracket(hi, mid);
+  hi = ls_pick(s5, mid, hi);
+  const bool s6 = in_bracket(hi, lo_next);
+  hi = ls_pick(s6, lo_next, hi);
+  return s1 | s2 | s3 | s4 | s5 | s6;
+}
+
+// result of the search: improved?  and the step of the better end
+DIAL_DEV bool ls_result(const LsPt& p0, const LsPt& lo, const LsPt& hi, float& alpha) {
+  alpha = bitsf(lo.cost < hi.cost ? lo.alpha : hi.alpha);
+  return (lo.cost < p0.cost) | (hi.cost < p0.cost);
+}
+
+// lane-wise: pack a point's four words from its float values (alpha, cost, slope d0, curvature d1 != 0)
+DIAL_DEV void ls_pack(float alpha, float cost, float d0, float d1, float& o_alpha, float& o_nalpha, float& o_cost, float& o_d0) {
+  o_alpha = alpha;
+  o_nalpha = alpha - d0 / d1;
+  o_cost = fkeyf(cost);
+  o_d0 = fkeyf(d0);
+}
+
+}  // namespace dial

@@ -198,6 +198,7 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 }
 
 }  // namespace dial
+#include "ls_bracket.h"
 #include "solver_reg.h"
 #include "solver_cone.h"
 namespace dial {
@@ -1049,67 +1050,39 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const vfloat vD = w.per_lane([&](int l) { return l < ne ? s.D[l] : 0.f; });
     const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
     const vfloat vzero = vsplat(0.f);
-    struct LsPoint { float alpha, cost, d0, d1; };
     auto ls_point = [&](float alpha) {
       const vbool act = vlt0(vJa + vjv * alpha);
       float q0 = w.vsum(vsel(act, vq0, vzero)), q1 = w.vsum(vsel(act, vq1, vzero)), q2 = w.vsum(vsel(act, vq2, vzero));
       q0 += qg0; q1 += qg1; q2 += qg2;
-      LsPoint p;
-      p.alpha = alpha;
-      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+      const float cost = alpha * alpha * q2 + alpha * q1 + q0;
       // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
       // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
       // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
-      p.d0 = DM_FMA(2.f * alpha, q2, q1);
-      p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      const float d0 = DM_FMA(2.f * alpha, q2, q1);
+      const float d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      float pa, pn, pc, pd;
+      ls_pack(alpha, cost, d0, d1, pa, pn, pc, pd);   // integer keys: ls_bracket.h
+      LsPt p;
+      p.alpha = fbits(pa); p.nalpha = fbits(pn); p.cost = fbits(pc); p.d0 = fbits(pd);
       return p;
     };
-    LsPoint p0 = ls_point(0.f);
-    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
-    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    const LsPt p0 = ls_point(0.f);
+    LsPt lo, hi;
+    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+    const int kg = fkey(gtol), kng = fkey(-gtol);
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
-      bool done = ls_iter >= m->ls_iterations || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
       if (done) break;
-      LsPoint lo_next = ls_point(lo.alpha - lo.d0 / lo.d1);
-      LsPoint hi_next = ls_point(hi.alpha - hi.d0 / hi.d1);
-      LsPoint mid = ls_point(0.5f * (lo.alpha + hi.alpha));
-      // MJX `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer to it;
-      // each end is offered its own Newton step, the mid-point and the other end's Newton step
-      const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
-        return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
-      };
-      if (rule_swap) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
-        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-        if (swap_lo_next) lo = lo_next;
-        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-        if (swap_lo_mid) lo = mid;
-        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-        if (swap_hi_next) hi = hi_next;
-        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-        if (swap_hi_mid) hi = mid;
-        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
-        ls_iter++;
-        continue;
-      }
-      const bool s1 = in_bracket(lo, lo_next);
-      if (s1) lo = lo_next;
-      const bool s2 = in_bracket(lo, mid);
-      if (s2) lo = mid;
-      const bool s3 = in_bracket(lo, hi_next);
-      if (s3) lo = hi_next;
-      const bool s4 = in_bracket(hi, hi_next);
-      if (s4) hi = hi_next;
-      const bool s5 = in_bracket(hi, mid);
-      if (s5) hi = mid;
-      const bool s6 = in_bracket(hi, lo_next);
-      if (s6) hi = lo_next;
-      swap = s1 || s2 || s3 || s4 || s5 || s6;
+      const LsPt lo_next = ls_point(bitsf(lo.nalpha));
+      const LsPt hi_next = ls_point(bitsf(hi.nalpha));
+      const LsPt mid = ls_point(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));
+      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
       ls_iter++;
     }
-    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    float alpha;
+    const bool improved = ls_result(p0, lo, hi, alpha);
     if (improved) {
       w.items(nv + ne, [&](int it) {
         if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }

@@ -169,7 +169,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
   const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
-  const int max_iter = m->iterations, max_ls = m->ls_iterations;
+  const int max_iter = DM_UNIFORM_I(m->iterations), max_ls = DM_UNIFORM_I(m->ls_iterations);
   const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
 
   int niter = 0;
@@ -313,7 +313,6 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       o[7] = q0; o[8] = q1; o[9] = q2;
     });
     // is the lane's unit a limit row?  (mu = L[6] is > 0 exactly for contacts)
-    struct LsPoint { float alpha, cost, d0, d1; };
     // the six sums of one unit at alpha: quadratic part (q0 q1 q2) + cone part (cost, slope, curvature)
     auto unit_terms = [&](int l, float alpha, float* o) {
       for (int k = 0; k < 6; k++) o[k] = 0.f;
@@ -344,15 +343,14 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
         o[5] = dmc * (g * g - nmt * mu * t2);
       }
     };
-    auto finish = [&](float alpha, const float* r) {
+    // cost / slope / curvature of a point from its six sums, packed into the four words of ls_bracket.h
+    auto finish = [&](float alpha, const float* r, float* o) {
       const float q0 = r[0] + qg0, q1 = r[1] + qg1, q2 = r[2] + qg2;
-      LsPoint p;
-      p.alpha = alpha;
-      p.cost = alpha * alpha * q2 + alpha * q1 + q0 + r[3];
-      p.d0 = DM_FMA(2.f * alpha, q2, q1) + r[4];   // single-rounding slope, see rollout_body.h
-      p.d1 = 2.f * q2 + r[5];
-      if (p.d1 == 0.f) p.d1 = MJ_MINVAL;
-      return p;
+      const float cost = alpha * alpha * q2 + alpha * q1 + q0 + r[3];
+      const float d0 = DM_FMA(2.f * alpha, q2, q1) + r[4];   // single-rounding slope, see rollout_body.h
+      float d1 = 2.f * q2 + r[5];
+      if (d1 == 0.f) d1 = MJ_MINVAL;
+      ls_pack(alpha, cost, d0, d1, o[0], o[1], o[2], o[3]);
     };
     auto ls_point = [&](float alpha) {
       vfloat t[6];
@@ -360,11 +358,14 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
         unit_terms(l, alpha, o);
         if (fast && l >= 16) for (int k = 0; k < 6; k++) o[k] = 0.f;   // the groups hold copies: count one
       });
-      float r[6];
+      float r[6], o[4];
       w.vsumN(t, r);
-      return finish(alpha, r);
+      finish(alpha, r, o);
+      LsPt p;
+      p.alpha = fbits(o[0]); p.nalpha = fbits(o[1]); p.cost = fbits(o[2]); p.d0 = fbits(o[3]);
+      return p;
     };
-    auto ls_eval3 = [&](float a0, float a1, float a2, LsPoint& P0, LsPoint& P1, LsPoint& P2) {
+    auto ls_eval3 = [&](float a0, float a1, float a2, LsPt& P0, LsPt& P1, LsPt& P2) {
       if (!fast) { P0 = ls_point(a0); P1 = ls_point(a1); P2 = ls_point(a2); return; }
       vfloat t[6];
       // (two opaque v_cndmask selects: left to itself the compiler stores the three trial steps to a scratch array and
@@ -379,66 +380,32 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       };
       w.per_lane_n(t, [&](int l, float* o) { unit_terms(l, group_alpha(l), o); });
       w.row16_sumN(t);
-      // cost / slope / curvature of the group's point, lane-wise (every lane of a group holds the six sums)
-      vfloat res[3];
+      // the group's point finished lane-wise (every lane of a group holds the six sums): 4 words per point to broadcast
+      vfloat res[4];
       w.per_lane_n(res, [&](int l, float* o) {
         const float r6[6] = {lane_val(t[0], l), lane_val(t[1], l), lane_val(t[2], l), lane_val(t[3], l), lane_val(t[4], l), lane_val(t[5], l)};
-        const LsPoint p = finish(group_alpha(l), r6);
-        o[0] = p.cost; o[1] = p.d0; o[2] = p.d1;
+        finish(group_alpha(l), r6, o);
       });
-      P0.alpha = a0; P0.cost = bcast(res[0], 0); P0.d0 = bcast(res[1], 0); P0.d1 = bcast(res[2], 0);
-      P1.alpha = a1; P1.cost = bcast(res[0], 16); P1.d0 = bcast(res[1], 16); P1.d1 = bcast(res[2], 16);
-      P2.alpha = a2; P2.cost = bcast(res[0], 32); P2.d0 = bcast(res[1], 32); P2.d1 = bcast(res[2], 32);
+      P0.alpha = fbits(bcast(res[0], 0)); P0.nalpha = fbits(bcast(res[1], 0)); P0.cost = fbits(bcast(res[2], 0)); P0.d0 = fbits(bcast(res[3], 0));
+      P1.alpha = fbits(bcast(res[0], 16)); P1.nalpha = fbits(bcast(res[1], 16)); P1.cost = fbits(bcast(res[2], 16)); P1.d0 = fbits(bcast(res[3], 16));
+      P2.alpha = fbits(bcast(res[0], 32)); P2.nalpha = fbits(bcast(res[1], 32)); P2.cost = fbits(bcast(res[2], 32)); P2.d0 = fbits(bcast(res[3], 32));
     };
-    LsPoint p0 = ls_point(0.f);
-    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
-    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    const LsPt p0 = ls_point(0.f);
+    LsPt lo, hi;
+    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+    const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
-      const bool ls_done = ls_iter >= max_ls || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
-      LsPoint lo_next, hi_next, mid;
-      ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
-      // (bitwise & / | on the comparison results and whole-struct selects: straight-line v_cmp + s_and / s_or +
-      // v_cndmask instead of ~20 short-circuit branches per iteration)
-      const auto pick = [](bool c, const LsPoint& a, const LsPoint& b) {
-        LsPoint r;
-        r.alpha = c ? a.alpha : b.alpha; r.cost = c ? a.cost : b.cost; r.d0 = c ? a.d0 : b.d0; r.d1 = c ? a.d1 : b.d1;
-        return r;
-      };
-      if (rule_swap) {
-        const bool swap_lo_next = (lo.d0 > 0.f) | (lo.d0 < lo_next.d0);
-        lo = pick(swap_lo_next, lo_next, lo);
-        const bool swap_lo_mid = (mid.d0 < 0.f) & (lo.d0 < mid.d0);
-        lo = pick(swap_lo_mid, mid, lo);
-        const bool swap_hi_next = (hi.d0 < 0.f) | (hi.d0 > hi_next.d0);
-        hi = pick(swap_hi_next, hi_next, hi);
-        const bool swap_hi_mid = (mid.d0 > 0.f) & (hi.d0 > mid.d0);
-        hi = pick(swap_hi_mid, mid, hi);
-        swap = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
-      } else {
-        const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
-          return ((x.d0 < y.d0) & (y.d0 < 0.f)) | ((x.d0 > y.d0) & (y.d0 > 0.f));
-        };
-        const bool s1 = in_bracket(lo, lo_next);
-        lo = pick(s1, lo_next, lo);
-        const bool s2b = in_bracket(lo, mid);
-        lo = pick(s2b, mid, lo);
-        const bool s3 = in_bracket(lo, hi_next);
-        lo = pick(s3, hi_next, lo);
-        const bool s4 = in_bracket(hi, hi_next);
-        hi = pick(s4, hi_next, hi);
-        const bool s5 = in_bracket(hi, mid);
-        hi = pick(s5, mid, hi);
-        const bool s6 = in_bracket(hi, lo_next);
-        hi = pick(s6, lo_next, hi);
-        swap = s1 | s2b | s3 | s4 | s5 | s6;
-      }
+      LsPt lo_next, hi_next, mid;
+      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)), lo_next, hi_next, mid);
+      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);   // integer keys on the scalar unit (ls_bracket.h)
       ls_iter++;
     }
-    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    float alpha;
+    const bool improved = ls_result(p0, lo, hi, alpha);
     if (improved) {
       vqacc = vqacc + vsearch * alpha;
       vMa = vMa + vmv * alpha;

@@ -237,7 +237,7 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   float prev_cost = INFINITY;
   const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
   const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;   // fetched once: the constants live in LDS
-  const int max_iter = m->iterations, max_ls = m->ls_iterations;
+  const int max_iter = DM_UNIFORM_I(m->iterations), max_ls = DM_UNIFORM_I(m->ls_iterations);
   const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
 
 #ifdef DIAL_PROFILE
@@ -389,9 +389,10 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       Q1[q] = ljv[q] * dja;
       Q2[q] = (ljv[q] * 0.5f) * djv;
     }
-    struct LsPoint { float alpha, cost, d0, d1; };
-    // evaluate the points a0, a1, a2 (group g evaluates a_g)
-    auto ls_eval3 = [&](float a0, float a1, float a2, LsPoint& p0_, LsPoint& p1_, LsPoint& p2_) {
+    // evaluate the points a0, a1, a2 (group g evaluates a_g).  Every lane of a group finishes its point -- cost, slope,
+    // the point's own Newton step, and the integer keys of ls_bracket.h -- so that what is broadcast (4 words per
+    // point) is all the scalar bracket logic needs
+    auto ls_eval3 = [&](float a0, float a1, float a2, LsPt& p0_, LsPt& p1_, LsPt& p2_) {
       const vfloat va = vsel(g0, vsplat(a0), vsel(g01, vsplat(a1), vsplat(a2)));
       vfloat s0 = vzero, s1v = vzero, s2v = vzero;
 #pragma unroll
@@ -406,60 +407,35 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       const vfloat vcost = (va * va) * q2 + va * q1 + q0;
       const vfloat vd0 = vfma(va * 2.f, q2, q1);   // single rounding: see the line search of rollout_body.h
       const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
-      p0_.alpha = a0; p0_.cost = bcast(vcost, 0); p0_.d0 = bcast(vd0, 0); p0_.d1 = bcast(vd1, 0);
-      p1_.alpha = a1; p1_.cost = bcast(vcost, 16); p1_.d0 = bcast(vd0, 16); p1_.d1 = bcast(vd1, 16);
-      p2_.alpha = a2; p2_.cost = bcast(vcost, 32); p2_.d0 = bcast(vd0, 32); p2_.d1 = bcast(vd1, 32);
+      vfloat pk[4];
+      w.per_lane_n(pk, [&](int l, float* o) {
+        ls_pack(lane_val(va, l), lane_val(vcost, l), lane_val(vd0, l), lane_val(vd1, l), o[0], o[1], o[2], o[3]);
+      });
+      p0_.alpha = fbits(bcast(pk[0], 0)); p0_.nalpha = fbits(bcast(pk[1], 0)); p0_.cost = fbits(bcast(pk[2], 0)); p0_.d0 = fbits(bcast(pk[3], 0));
+      p1_.alpha = fbits(bcast(pk[0], 16)); p1_.nalpha = fbits(bcast(pk[1], 16)); p1_.cost = fbits(bcast(pk[2], 16)); p1_.d0 = fbits(bcast(pk[3], 16));
+      p2_.alpha = fbits(bcast(pk[0], 32)); p2_.nalpha = fbits(bcast(pk[1], 32)); p2_.cost = fbits(bcast(pk[2], 32)); p2_.d0 = fbits(bcast(pk[3], 32));
     };
     auto ls_point = [&](float alpha) {   // single point (the two points that open the bracket)
-      LsPoint p, u1, u2;
+      LsPt p, u1, u2;
       ls_eval3(alpha, alpha, alpha, p, u1, u2);
       return p;
     };
-    LsPoint p0 = ls_point(0.f);
-    LsPoint lo = ls_point(p0.alpha - p0.d0 / p0.d1), hi;
-    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    const LsPt p0 = ls_point(0.f);
+    LsPt lo, hi;
+    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+    const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
-      const bool ls_done = ls_iter >= max_ls || !swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol);
+      const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
-      LsPoint lo_next, hi_next, mid;
-      ls_eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
-      // MJX `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer to it;
-      // each end is offered its own Newton step, the mid-point and the other end's Newton step
-      const auto in_bracket = [](const LsPoint& x, const LsPoint& y) {
-        return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f);
-      };
-      if (rule_swap) {   // the rule of MJX <= 3.1.3 (wave-uniform branch)
-        const bool swap_lo_next = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-        if (swap_lo_next) lo = lo_next;
-        const bool swap_lo_mid = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-        if (swap_lo_mid) lo = mid;
-        const bool swap_hi_next = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-        if (swap_hi_next) hi = hi_next;
-        const bool swap_hi_mid = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-        if (swap_hi_mid) hi = mid;
-        swap = swap_lo_next || swap_lo_mid || swap_hi_next || swap_hi_mid;
-        ls_iter++;
-        continue;
-      }
-      const bool s1 = in_bracket(lo, lo_next);
-      if (s1) lo = lo_next;
-      const bool s2 = in_bracket(lo, mid);
-      if (s2) lo = mid;
-      const bool s3 = in_bracket(lo, hi_next);
-      if (s3) lo = hi_next;
-      const bool s4 = in_bracket(hi, hi_next);
-      if (s4) hi = hi_next;
-      const bool s5 = in_bracket(hi, mid);
-      if (s5) hi = mid;
-      const bool s6 = in_bracket(hi, lo_next);
-      if (s6) hi = lo_next;
-      swap = s1 || s2 || s3 || s4 || s5 || s6;
+      LsPt lo_next, hi_next, mid;
+      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)), lo_next, hi_next, mid);
+      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);   // integer keys: scalar unit (ls_bracket.h)
       ls_iter++;
     }
-    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    float alpha;
+    const bool improved = ls_result(p0, lo, hi, alpha);
     if (improved) {
       vqacc = vqacc + vsearch * alpha;
       vMa = vMa + vmv * alpha;
