@@ -197,6 +197,7 @@ def load_dial_and_env(config_dict: Dict[str, Any]):
     dial_config = load_dataclass_from_dict(DialConfig, config_dict)
     env_config_type = dial_envs.get_config(dial_config.env_name)
     env_config = load_dataclass_from_dict(env_config_type, config_dict, convert_list_to_array=True)
+    env_config.seed = int(dial_config.seed)      # randomize_tasks draws from the run's seed (envs/base_env.py)
     env = dial_envs.get_environment(dial_config.env_name, config=env_config)
     return dial_config, env_config, env
 

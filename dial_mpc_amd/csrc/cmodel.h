@@ -165,7 +165,7 @@ struct CModel {
   int32_t act_qposadr[D::NU], act_ctrllimited[D::NU], act_isposition[D::NU];
   float act_gear[D::NU], act_kp[D::NU], act_ctrlrange[D::NU][2];
   // ---- task (dial_task; the seq-jump stage tables stay in the global dial_task)
-  int32_t kind, n_frames, position_control, torso_x, upright_x, nfeet, n_stage, feet_site[DIAL_MAX_FEET];
+  int32_t kind, n_frames, position_control, torso_x, upright_x, nfeet, n_stage, feet_site[DIAL_MAX_FEET], randomize_tasks, n_cmd;
   float dt, action_scale, foot_radius, gait_duty, gait_cadence, gait_amp, gait_phase[DIAL_MAX_FEET];
   float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3], init_ang_vel_tar[3];
   float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2], joint_offset[D::NU];

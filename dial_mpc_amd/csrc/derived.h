@@ -327,6 +327,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   }
   o.kind = t->kind; o.n_frames = t->n_frames; o.position_control = t->position_control; o.torso_x = t->torso_x;
   o.upright_x = t->upright_x; o.nfeet = t->nfeet; o.n_stage = t->n_stage;
+  o.randomize_tasks = t->randomize_tasks && t->n_cmd > 0; o.n_cmd = t->n_cmd;
   for (int f = 0; f < DIAL_MAX_FEET; f++) { o.feet_site[f] = t->feet_site[f]; o.gait_phase[f] = t->gait_phase[f]; }
   o.dt = t->dt; o.action_scale = t->action_scale; o.foot_radius = t->foot_radius; o.gait_duty = t->gait_duty;
   o.gait_cadence = t->gait_cadence; o.gait_amp = t->gait_amp; o.ramp_up_time = t->ramp_up_time;

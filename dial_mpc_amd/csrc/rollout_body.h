@@ -1096,6 +1096,23 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   DIAL_MARK(w, 8);
 }
 
+// Velocity command of one env.step (unitree_go2_env.py:142-155, unitree_h1_env.py:199-212): component k < 3 of the linear,
+// k - 3 of the angular command.  With randomize_tasks the command of a step whose (pre-increment) index is a multiple of
+// 500 is the episode's entry of dial_task::cmd_table -- and ONLY of that step: upstream does not store the sampled command,
+// every other step computes from the default again.  The table stays in the global dial_task (read once per 500 steps).
+template <class M>
+DIAL_DEV float step_cmd(const M* m, const dial_task* tg, float step, int k) {
+  float v = k < 3 ? m->cmd_vel[k] : m->cmd_ang_vel[k - 3];
+  if (m->randomize_tasks) {
+    const int is = (int)step;
+    if (is % 500 == 0) {
+      const int e = (is / 500) % m->n_cmd;
+      v = k < 2 ? tg->cmd_table[e][k] : (k == 5 ? tg->cmd_table[e][2] : 0.f);
+    }
+  }
+  return v;
+}
+
 // ================================================================ forward.euler (eulerdamp disabled)
 template <class W, class M>
 DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
@@ -1288,7 +1305,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
       const float yaw = quat_yaw(rot_t);
       if (walk) {
-        const float a2 = m->cmd_ang_vel[2];
+        const float a2 = step_cmd(m, tg, step, 5);
         const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
         const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
         // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
@@ -1309,7 +1326,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
           for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
           dm::inv_rotate(vb, vel, rot_t);
           float vt[2];
-          for (int k = 0; k < 2; k++) { const float v = m->cmd_vel[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+          for (int k = 0; k < 2; k++) { const float v = step_cmd(m, tg, step, k); vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
           const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
           out = -(e0 * e0 + e1 * e1);
         } else {
@@ -1318,13 +1335,13 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
           if (m->kind == DIAL_TASK_H1_LOCO) {   // all three components (unitree_h1_env.py:797)
             float e3 = 0.f;
             for (int k = 0; k < 3; k++) {
-              const float a = m->cmd_ang_vel[k];
+              const float a = step_cmd(m, tg, step, 3 + k);
               const float e = ab[k] - dm::fminf_(a * step * dt / m->ramp_up_time, a);
               e3 += e * e;
             }
             out = -e3;
           } else {
-            const float a2 = m->cmd_ang_vel[2];
+            const float a2 = step_cmd(m, tg, step, 5);
             const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
             out = -(ea * ea);
           }
@@ -1406,7 +1423,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     }
     if (walk) {
       for (int k = 0; k < 3; k++) {
-        const float v = m->cmd_vel[k], a = m->cmd_ang_vel[k];
+        const float v = step_cmd(m, tg, step, k), a = step_cmd(m, tg, step, 3 + k);
         info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
         info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
       }

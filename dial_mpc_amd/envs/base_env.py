@@ -81,12 +81,6 @@ class BaseEnv:
 
     def __init__(self, config: BaseEnvConfig):
         assert np.allclose(config.dt % config.timestep, 0.0), "timestep must be divisible by dt"
-        if getattr(config, "randomize_tasks", False):
-            # unitree_go2_env.py:142-155: the reference redraws (vel_tar, ang_vel_tar) from its JAX key every 500
-            # steps (`sample_command`); the kernels bake the fixed command in, so running such a config would be a
-            # different task.  No silent fallback: refuse.
-            raise NotImplementedError("randomize_tasks=True (sample_command every 500 steps) is not implemented by "
-                                      "the HIP path; set randomize_tasks: false")
         self._config = config
         self._n_frames = int(config.dt / config.timestep)
         self.sys = self.make_system(config)
@@ -101,6 +95,7 @@ class BaseEnv:
         self._nv = self.sys.nv
         self._nq = self.sys.nq
         self._ctx = None  # HIP context for env.step / env.reset, created on first use
+        self._cmd_table = None   # randomize_tasks: (n_cmd, 3) commands (vx, vy, vyaw), see command_table()
 
     # ---- reference surface
     def make_system(self, config: BaseEnvConfig) -> System:
@@ -150,7 +145,37 @@ class BaseEnv:
             kd=np.broadcast_to(np.asarray(cfg.kd, dtype=np.float64), (nu,)),
             joint_range=jr, phys_range=np.asarray(self.physical_joint_range)[:nu],
             tau_range=np.asarray(self.joint_torque_range),
+            **self._randomize_dict(),
         )
+
+    def _randomize_dict(self) -> Dict[str, Any]:
+        if not getattr(self._config, "randomize_tasks", False):
+            return dict(randomize_tasks=0, n_cmd=0)
+        tab = self.command_table()
+        full = np.zeros((int(M["DIAL_MAX_CMD"]), 3))
+        full[: tab.shape[0]] = tab
+        return dict(randomize_tasks=1, n_cmd=int(tab.shape[0]), cmd_table=full)
+
+    # ---- randomize_tasks (unitree_go2_env.py:142-155, :298-325; unitree_h1_env.py:199-212, :885-902)
+    # sample_command's ranges: lin_vel_x, lin_vel_y, ang_vel_yaw
+    COMMAND_RANGES = ((-1.5, 1.5), (-0.5, 0.5), (-1.5, 1.5))
+
+    def command_table(self) -> np.ndarray:
+        """The commands `sample_command` hands out, as DATA (include/dial_mpc.h: dial_task.cmd_table): entry e holds
+        for the step 500 e.  Drawn once per env from numpy's PCG64 seeded with the run's seed (``config.seed``, set by
+        ``load_dial_and_env`` from DialConfig.seed; 0 otherwise) -- the reference draws from its JAX key chain, whose
+        stream is version dependent; ``set_command_table`` installs exported reference values instead."""
+        if self._cmd_table is None:
+            rng = np.random.default_rng(int(getattr(self._config, "seed", 0)))
+            n = int(M["DIAL_MAX_CMD"])
+            self._cmd_table = np.stack([rng.uniform(lo, hi, n) for lo, hi in self.COMMAND_RANGES], axis=1)
+        return self._cmd_table
+
+    def set_command_table(self, table) -> None:
+        table = np.asarray(table, dtype=np.float64).reshape(-1, 3)
+        assert 1 <= table.shape[0] <= int(M["DIAL_MAX_CMD"])
+        self._cmd_table = table
+        self._ctx = None                       # contexts bake the task in
 
     def model_dict(self) -> Dict[str, Any]:
         return self.sys.model

@@ -111,7 +111,19 @@ class UnitreeGo2SeqJumpEnv(UnitreeGo2Env):
     def __init__(self, config: UnitreeGo2SeqJumpEnvConfig = None):
         config = config if config is not None else UnitreeGo2SeqJumpEnvConfig()
         super().__init__(config)
-        if config.contact_targets is None or config.contact_target_radius is None:
+        if getattr(config, "randomize_tasks", False):
+            # unitree_go2_env.py:383-392, 594-629: reset() replaces the configured sequence by `sample_command(rng)` -- a
+            # 10-jump random walk of the body position (+-0.65 m in x, y per jump) and of the heading (+-0.5 rad), turned
+            # into foot targets by generate_jumping_sequence.  Drawn here, once, from the run's seed (see
+            # BaseEnv.command_table for why the draw is data and not JAX's stream); the kernels only see the tables.
+            rng = np.random.default_rng(int(getattr(config, "seed", 0)))
+            com_pos = np.zeros((11, 3))
+            com_pos[:, 2] = 0.27
+            com_pos[1:, :2] = np.cumsum(rng.uniform(-0.65, 0.65, (10, 2)), axis=0)
+            com_yaw = np.concatenate([[0.0], np.cumsum(rng.uniform(-0.5, 0.5, 10))])
+            (self._contact_targets, self._contact_target_radius, self._pose_target_sequence,
+             self._yaw_target_sequence) = UnitreeGo2SeqJumpEnv.generate_jumping_sequence(com_pos, com_yaw, 0.1)
+        elif config.contact_targets is None or config.contact_target_radius is None:
             (self._contact_targets, self._contact_target_radius, self._pose_target_sequence,
              self._yaw_target_sequence) = UnitreeGo2SeqJumpEnv.generate_jumping_sequence(
                 np.asarray(config.pose_target_sequence, dtype=np.float64),
@@ -145,6 +157,9 @@ class UnitreeGo2SeqJumpEnv(UnitreeGo2Env):
             contact_targets.append(contact_target + offsets @ R.T)
         return (np.array(contact_targets), contact_target_radius, np.array(com_pos),
                 np.array(com_heading, dtype=np.float64))
+
+    def _randomize_dict(self) -> Dict[str, Any]:
+        return dict(randomize_tasks=0, n_cmd=0)     # seq-jump's env.step never redraws a command (:403-521)
 
     def task_dict(self) -> Dict[str, Any]:
         d = super().task_dict()

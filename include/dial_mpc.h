@@ -56,6 +56,7 @@ extern "C" {
 #define DIAL_MAX_T 36      /* Hsample+1                                          */
 #define DIAL_MAX_NODE 10   /* Hnode+1                                            */
 #define DIAL_INFO_N 48     /* floats of env info in the packed state             */
+#define DIAL_MAX_CMD 16    /* randomize_tasks: velocity commands of the episodes step / 500 = 0, 1, ... (wraps)  */
 
 /* joint types (MuJoCo numbering) */
 #define DIAL_JNT_FREE 0
@@ -236,6 +237,15 @@ typedef struct dial_task {
   float init_pos_tar[3];
   float init_ang_vel_tar[3];
   float joint_offset[DIAL_MAX_U];
+  /* BaseEnvConfig.randomize_tasks of the walking envs (unitree_go2_env.py:142-155, unitree_h1_env.py:199-212,
+   * :436-449, :718-731): on a step with info.step % 500 == 0 the command is `sample_command(rng)`, on EVERY other step
+   * the default command (upstream does not store the sampled one) -- inside planner rollouts as well, since they run
+   * env.step.  The draw crosses the boundary as DATA, like the planner's noise (JAX's key stream is version dependent):
+   * cmd_table[e] = (vx, vy, vyaw) of episode e = step / 500 (mod n_cmd), filled by the host (dial_mpc_amd/envs) from a
+   * documented generator with sample_command's ranges, or with values exported from a reference run.            */
+  int32_t randomize_tasks;
+  int32_t n_cmd;
+  float cmd_table[DIAL_MAX_CMD][3];
 } dial_task;
 
 /* Planner configuration: DialConfig + the constant spline matrices

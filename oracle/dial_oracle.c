@@ -1128,6 +1128,13 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
     /* unitree_go2_env.py:142-162 / unitree_h1_env.py:196-217: target ramp uses the PRE-increment step */
     for (int k = 0; k < 3; k++) {
       real v = t->cmd_vel[k], a = t->cmd_ang_vel[k];
+      /* :150-155: `lax.cond(randomize_target & (step % 500 == 0), randomize, dont_randomize)` -- the sampled command
+       * holds for THIS step only (it is not stored), every other step uses the default */
+      if (t->randomize_tasks && t->n_cmd > 0 && ((long)step) % 500 == 0) {
+        const float* c = t->cmd_table[(((long)step) / 500) % t->n_cmd];
+        v = k < 2 ? (real)c[k] : 0;          /* new_lin_vel_cmd = [vx, vy, 0] */
+        a = k == 2 ? (real)c[2] : 0;         /* new_ang_vel_cmd = [0, 0, vyaw] */
+      }
       info[DIAL_INFO_VEL_TAR + k] = r_min(v * step * dt / (real)t->ramp_up_time, v);
       info[DIAL_INFO_ANG_VEL_TAR + k] = r_min(a * step * dt / (real)t->ramp_up_time, a);
     }

@@ -758,3 +758,41 @@ def test_sharded_kernels_at_world_2_and_4_on_one_gpu(N, world):
             for a, b in zip(results[0][(name, False)] + results[0][(name, True)],
                             results[rank][(name, False)] + results[rank][(name, True)]):
                 assert (a is None and b is None) or torch.equal(a, b), (name, rank)     # bit-identical on every rank
+
+
+@pytest.mark.parametrize("example", ["unitree_go2_trot", "unitree_h1_jog", "unitree_h1_loco"])
+def test_randomize_tasks_across_the_500_step_boundary(example):
+    """BaseEnvConfig.randomize_tasks on the HIP path (unitree_go2_env.py:142-162, unitree_h1_env.py:199-217, :718-737):
+    planner rollouts that start at info.step = 494 cross step 500, where the velocity command is the draw of
+    dial_task.cmd_table for that ONE step.  dial_rollout == oracle rollout by rollout; the redraw changes the reward of
+    exactly that step; env.step (dial_env_step) on the true state writes the same targets into info."""
+    import yaml
+    import oracle as O
+    from dial_mpc_amd import _lib
+    from dial_mpc_amd.core.dial_core import load_dial_and_env, make_cfg
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    outs = {}
+    for rnd in (True, False):
+        d = yaml.safe_load(open(get_example_path(example + ".yaml")))
+        d.update(randomize_tasks=rnd, seed=5, Nsample=128, Hsample=12)
+        dc, ec, env = load_dial_and_env(d)
+        model, task, cfg = with_solver(env.make_model(), ls_rule=0), env.make_task(), make_cfg(dc)
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        ctx = _lib.Context(model, task, cfg)
+        s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+        istep = model.nq + 2 * model.nv
+        s0[istep] = 494.0
+        us = np.random.default_rng(1).uniform(-0.5, 0.5, (64, 13, model.nu)).astype(np.float32)
+        got = [t.cpu().numpy() for t in ctx.rollout(_dev(s0), _dev(us))]
+        witness_parity(o32, s0, us, got, example, istep)
+        outs[rnd] = got[0]
+        if rnd:   # the true-state step at 500 carries the table's command, ramp saturated (500 * dt >= ramp_up_time)
+            st = s0.copy()
+            st[istep] = 500.0
+            s_g, _, _, _ = ctx.env_step(_dev(st), _dev(np.zeros(model.nu)))
+            e = env.command_table()[1]
+            info = s_g.cpu().numpy()[istep:]
+            assert np.allclose(info[4:7], np.minimum(np.array([e[0], e[1], 0.0]) * 500 * ec.dt / ec.ramp_up_time, [e[0], e[1], 0.0]), atol=1e-6)
+            assert np.allclose(info[7:10], np.minimum(np.array([0.0, 0.0, e[2]]) * 500 * ec.dt / ec.ramp_up_time, [0.0, 0.0, e[2]]), atol=1e-6)
+    assert np.array_equal(outs[True][:, :6], outs[False][:, :6])
+    assert np.all(np.abs(outs[True][:, 6] - outs[False][:, 6]) > 1e-4)

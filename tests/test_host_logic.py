@@ -111,17 +111,66 @@ def test_result_artefact_layout():
     assert np.array_equal(preds[2], infos[2]["xbar"])
 
 
-def test_randomize_tasks_is_refused():
-    """unitree_go2_env.py:142-155 resamples the command every 500 steps; the kernels bake a fixed command in, so a
-    config that asks for it must fail loudly instead of running a different task."""
-    import pytest
+def _randomized(example, seed=3):
     import yaml
-    from dial_mpc_amd.core.dial_core import load_dial_and_env
+    from dial_mpc_amd.core.dial_core import load_dial_and_env, make_cfg
     from dial_mpc_amd.utils.io_utils import get_example_path
-    d = yaml.safe_load(open(get_example_path("unitree_go2_trot.yaml")))
-    d["randomize_tasks"] = True
-    with pytest.raises(NotImplementedError):
-        load_dial_and_env(d)
+    d = yaml.safe_load(open(get_example_path(example + ".yaml")))
+    d.update(randomize_tasks=True, seed=seed, Nsample=24, Hsample=12)
+    dc, ec, env = load_dial_and_env(d)
+    return dc, env, make_cfg(dc)
+
+
+def test_randomize_tasks_command_schedule_matches_the_reference():
+    """unitree_go2_env.py:142-162 (same code in the H1 envs): with randomize_tasks the command of a step whose index is
+    a multiple of 500 is `sample_command`'s draw and -- the draw is never stored -- the default command on every other
+    step; the ramp `min(cmd * step * dt / ramp_up_time, cmd)` applies to whichever it is.  The draw crosses the boundary
+    as data (dial_task.cmd_table).  Checked on the oracle, step by step across the 500-step boundary, against a NumPy
+    restatement of those lines; sample_command's ranges and the run-seed dependence of the table on the host side."""
+    import oracle as O
+    for example in ("unitree_go2_trot", "unitree_h1_jog", "unitree_h1_loco"):
+        dc, env, cfg = _randomized(example)
+        tab = env.command_table()
+        assert tab.shape == (16, 3) and np.all(np.abs(tab[:, 0]) <= 1.5) and np.all(np.abs(tab[:, 1]) <= 0.5) and np.all(np.abs(tab[:, 2]) <= 1.5)
+        assert not np.array_equal(tab, _randomized(example, seed=4)[1].command_table())        # drawn from the run's seed
+        assert np.array_equal(tab, _randomized(example, seed=3)[1].command_table())
+        model, task = env.make_model(), env.make_task()
+        assert task.randomize_tasks == 1 and task.n_cmd == 16
+        o64 = O.Oracle(model, task, cfg, np.float64)
+        state, _, _ = o64.env_reset(env._init_q, np.zeros(model.nv))
+        nq, nv = model.nq, model.nv
+        istep = nq + 2 * nv                                       # DIAL_INFO_STEP
+        c = env._config
+        default_v, default_a = np.array([c.default_vx, c.default_vy, 0.0]), np.array([0.0, 0.0, c.default_vyaw])
+        for start in (0, 497, 998):
+            state[istep] = start
+            for k in range(5):
+                step = start + k
+                state, _, _, _ = o64.env_step(state, np.zeros(model.nu))
+                if step % 500 == 0:
+                    e = tab[(step // 500) % 16]
+                    v, a = np.array([e[0], e[1], 0.0]), np.array([0.0, 0.0, e[2]])
+                else:
+                    v, a = default_v, default_a
+                ramp = step * c.dt / c.ramp_up_time
+                assert np.allclose(state[istep + 4:istep + 7], np.minimum(v * ramp, v), atol=1e-6), (example, step)     # vel_tar
+                assert np.allclose(state[istep + 7:istep + 10], np.minimum(a * ramp, a), atol=1e-6), (example, step)    # ang_vel_tar
+                assert state[istep] == step + 1
+
+
+def test_randomize_tasks_seq_jump_samples_its_sequence():
+    """unitree_go2_env.py:383-392, 594-629: the jump sequence is a 10-jump random walk (|dx|, |dy| <= 0.65, |dyaw| <= 0.5)
+    from (0, 0, 0.27), 11 stages, foot targets from generate_jumping_sequence; env.step itself never redraws."""
+    dc, env, cfg = _randomized("unitree_go2_seq_jump")
+    task = env.make_task()
+    assert task.n_stage == 11 and task.randomize_tasks == 0
+    pose = np.array([[task.pose_targets[s][k] for k in range(3)] for s in range(11)])
+    yaw = np.array([task.yaw_targets[s] for s in range(11)])
+    assert np.allclose(pose[0], [0, 0, 0.27]) and np.allclose(pose[:, 2], 0.27) and yaw[0] == 0
+    assert np.all(np.abs(np.diff(pose[:, :2], axis=0)) <= 0.65 + 1e-6) and np.all(np.abs(np.diff(yaw)) <= 0.5 + 1e-6)
+    ct = np.array([[[task.contact_targets[s][f][k] for k in range(3)] for f in range(4)] for s in range(11)])
+    assert np.allclose(ct.mean(1)[:, :2], pose[:, :2], atol=1e-6)            # the four feet surround the body target
+    assert np.allclose(np.linalg.norm(ct[:, 0] - ct[:, 3], axis=1), np.hypot(0.4, 0.27), atol=1e-6)
 
 
 def test_allegro_task_description_and_act2joint_override():

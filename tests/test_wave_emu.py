@@ -129,3 +129,32 @@ def test_emulated_kernel_default_rule_distribution_parity(example, N, H):
     assert rep["gpu"]["outside"] > 0.05      # the lottery is real at these settings: this test is not vacuous ...
     strict = setup_case(example, N, H, per_rollout=True)[2]
     assert strict.ls_rule == 0               # ... and the per-rollout tests run the other rule
+
+
+@pytest.mark.parametrize("example", ["unitree_go2_trot", "unitree_h1_jog", "unitree_h1_loco"])
+def test_emulated_kernel_randomize_tasks_across_the_500_step_boundary(example):
+    """randomize_tasks inside planner rollouts (unitree_go2_env.py:142-162): rollouts that start at info.step = 494 cross
+    step 500, where the command is the table's draw for ONE step.  Kernel logic == oracle step by step, and the redraw is
+    visible: the reward of that step differs from the same rollout without randomisation, the steps before it do not."""
+    import yaml
+    from dial_mpc_amd.core.dial_core import load_dial_and_env, make_cfg
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    outs = {}
+    for rnd in (True, False):
+        d = yaml.safe_load(open(get_example_path(example + ".yaml")))
+        d.update(randomize_tasks=rnd, seed=5, Nsample=12, Hsample=12)
+        dc, ec, env = load_dial_and_env(d)
+        model, task, cfg = with_solver(env.make_model(), ls_rule=0), env.make_task(), make_cfg(dc)
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        emu = emu_lib.Emu(model, task, cfg)
+        s0, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+        s0[model.nq + 2 * model.nv] = 494.0                       # info.step
+        us = np.random.default_rng(1).uniform(-0.5, 0.5, (6, 13, model.nu)).astype(np.float32)
+        r_o = o32.rollout(s0, us)
+        r_e = emu.rollout(s0, us, check_races=False)
+        for name, a, b in zip(("rewss", "q", "qd", "x"), r_o, r_e):
+            assert _close(b, a, TOL[name]), (example, rnd, name, np.abs(a - b).max())
+        outs[rnd] = r_e[0]
+    # steps 494 .. 499 use the default command in both runs; step 500 (index 6) is the redraw
+    assert np.array_equal(outs[True][:, :6], outs[False][:, :6])
+    assert np.all(np.abs(outs[True][:, 6] - outs[False][:, 6]) > 1e-4)
