@@ -156,7 +156,7 @@ struct CModel {
   int32_t cone, eulerdamp;
   int32_t con_dim[D::NCE], con_adr[D::NCE];      // condim and first constraint row
   int32_t con_ndof[D::NCE], con_joff[D::NCE];    // dofs that move body1 or body2; word offset of J_c (dim x ndof, row-major)
-  uint8_t con_dof[D::NCE][D::NCD];
+  uint8_t con_dof[D::NCE][(D::NCD + 3) & ~3];   // rows padded to whole words: the row products fetch them as 32-bit words
   int32_t dof_ncon[D::NVE];
   uint16_t dof_con[D::NVE][D::NDC];              // contact | (index of the dof in the contact's dof list) << 8
   uint8_t con_dofpos[D::NCE][(D::NVE + 3) & ~3]; // index of dof i in the contact's dof list, 255 = the dof does not move it

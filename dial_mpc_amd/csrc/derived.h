@@ -140,9 +140,17 @@ static inline bool ell_fits(const dial_model* m, const dial_derived* dv) {
       const uint32_t mask = dv->body_ancmask[m->con_body1[c]] | dv->body_ancmask[m->con_body2[c]];
       int nd = 0;
       for (int i = 0; i < m->nv; i++) if ((mask >> i) & 1u) { nd++; if (++dofc[i] > D::NDC) return false; }
-      if (nd > D::NCD) return false;
+      if (nd > D::NCD || (nd & 1)) return false;   // (even: the row products fetch the compact Jacobian in 8-byte pairs)
       ne += m->con_dim[c];
       jcw += m->con_dim[c] * nd;
+    }
+    for (int i = 0; i < m->nv; i++) {   // solver_cone.h: NBLK = 6 -- rows of M at most 6 wide (a free body; four-joint finger chains)
+      uint32_t mask = dv->dof_ancmask[i] | (1u << i);
+      for (int j = 0; j < m->nv; j++) if ((dv->dof_ancmask[j] >> i) & 1u) mask |= 1u << j;
+      int lo = 0, hi = m->nv;
+      while (!((mask >> lo) & 1u)) lo++;
+      while (!((mask >> (hi - 1)) & 1u)) hi--;
+      if (hi - lo > 6) return false;
     }
     return ne == D::NE && ne == m->nefc && jcw == D::JCW;
   }
@@ -245,11 +253,12 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int j = 0; j < m->nv; j++) if ((dv->dof_ancmask[j] >> i) & 1u) o.dof_descmask[i] |= (1u << j);
     o.dof_armature[i] = m->dof_armature[i]; o.dof_damping[i] = m->dof_damping[i]; o.dof_invweight0[i] = m->dof_invweight0[i];
   }
-  for (int i = 0; i < m->nv; i++) {   // dof range of the kinematic tree that holds dof i (dofs of a tree are contiguous)
-    const int root = m->body_rootid[m->dof_bodyid[i]];
-    int lo = i, hi = i + 1;
-    while (lo > 0 && m->body_rootid[m->dof_bodyid[lo - 1]] == root) lo--;
-    while (hi < m->nv && m->body_rootid[m->dof_bodyid[hi]] == root) hi++;
+  for (int i = 0; i < m->nv; i++) {   // column range of row i of M that can be non-zero: from its first ancestor dof to its last
+    // descendant dof (depth-first numbering).  Entries of that range that belong to a sibling branch are exact zeros.
+    const uint32_t mask = o.dof_ancmask[i] | o.dof_descmask[i] | (1u << i);
+    int lo = 0, hi = m->nv;
+    while (!((mask >> lo) & 1u)) lo++;
+    while (!((mask >> (hi - 1)) & 1u)) hi--;
     o.dof_blk0[i] = lo; o.dof_blk1[i] = hi;
   }
   for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];

@@ -13,8 +13,8 @@
 // fkey(a) < fkey(b)  <=>  a < b for all non-NaN floats (-0 and +0 share key 0, as they compare equal); the device code
 // does not honour NaNs anywhere (-fno-honor-nans).  Same code in the host wave emulator.
 //
-// Reference: mujoco.mjx._src.solver._linesearch (both bracket rules, see include/dial_mpc.h DIAL_LS_*); the oracle's
-// float restatement is oracle/dial_oracle.c: linesearch.
+// Reference: mujoco.mjx._src.solver._linesearch (both bracket rules, see include/dial_mpc.h DIAL_LS_*); the
+// CPU checker restates the same rules with plain float comparisons.
 #pragma once
 
 namespace dial {

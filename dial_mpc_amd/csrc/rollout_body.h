@@ -1101,16 +1101,16 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 // 500 is the episode's entry of dial_task::cmd_table -- and ONLY of that step: upstream does not store the sampled command,
 // every other step computes from the default again.  The table stays in the global dial_task (read once per 500 steps).
 template <class M>
-DIAL_DEV float step_cmd(const M* m, const dial_task* tg, float step, int k) {
-  float v = k < 3 ? m->cmd_vel[k] : m->cmd_ang_vel[k - 3];
+DIAL_DEV void step_cmd(const M* m, const dial_task* tg, float step, float* cmd /* [vx vy vz | wx wy wz] */) {
+  for (int k = 0; k < 3; k++) { cmd[k] = m->cmd_vel[k]; cmd[3 + k] = m->cmd_ang_vel[k]; }
   if (m->randomize_tasks) {
     const int is = (int)step;
     if (is % 500 == 0) {
       const int e = (is / 500) % m->n_cmd;
-      v = k < 2 ? tg->cmd_table[e][k] : (k == 5 ? tg->cmd_table[e][2] : 0.f);
+      cmd[0] = tg->cmd_table[e][0]; cmd[1] = tg->cmd_table[e][1]; cmd[2] = 0.f;
+      cmd[3] = 0.f; cmd[4] = 0.f; cmd[5] = tg->cmd_table[e][2];
     }
   }
-  return v;
 }
 
 // ================================================================ forward.euler (eulerdamp disabled)
@@ -1251,6 +1251,8 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     const float tcom[3] = {cmr[0], cmr[1], cmr[2]};
     const float tv[6] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2], s.cvel[6 * tb + 3], s.cvel[6 * tb + 4], s.cvel[6 * tb + 5]};
     const float yaw_tar0 = info[DIAL_INFO_YAW_TAR], pos_tar_z = info[DIAL_INFO_POS_TAR + 2];
+    float cmd[6];
+    if (walk) step_cmd(m, tg, step, cmd);   // this step's velocity command (randomize_tasks: the episode's draw)
     float out = 0.f;
     if (it == 0) {
       if (walk) {
@@ -1305,7 +1307,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
       const float yaw = quat_yaw(rot_t);
       if (walk) {
-        const float a2 = step_cmd(m, tg, step, 5);
+        const float a2 = cmd[5];
         const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
         const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
         // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
@@ -1326,7 +1328,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
           for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
           dm::inv_rotate(vb, vel, rot_t);
           float vt[2];
-          for (int k = 0; k < 2; k++) { const float v = step_cmd(m, tg, step, k); vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+          for (int k = 0; k < 2; k++) { const float v = cmd[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
           const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
           out = -(e0 * e0 + e1 * e1);
         } else {
@@ -1335,13 +1337,13 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
           if (m->kind == DIAL_TASK_H1_LOCO) {   // all three components (unitree_h1_env.py:797)
             float e3 = 0.f;
             for (int k = 0; k < 3; k++) {
-              const float a = step_cmd(m, tg, step, 3 + k);
+              const float a = cmd[3 + k];
               const float e = ab[k] - dm::fminf_(a * step * dt / m->ramp_up_time, a);
               e3 += e * e;
             }
             out = -e3;
           } else {
-            const float a2 = step_cmd(m, tg, step, 5);
+            const float a2 = cmd[5];
             const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
             out = -(ea * ea);
           }
@@ -1422,8 +1424,10 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
     }
     if (walk) {
+      float cmd[6];
+      step_cmd(m, tg, step, cmd);
       for (int k = 0; k < 3; k++) {
-        const float v = step_cmd(m, tg, step, k), a = step_cmd(m, tg, step, 3 + k);
+        const float v = cmd[k], a = cmd[3 + k];
         info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
         info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
       }

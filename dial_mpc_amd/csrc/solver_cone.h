@@ -33,6 +33,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   using D = typename M::D;
   constexpr int NV = D::NV, NC = D::NC, NL = D::NL, S = D::S, NCD = D::NCD, NU_ = NL + NC;
   static_assert(D::ell && D::square && NU_ <= 64 && NV <= 32, "unit lanes / dof lanes must fit one wavefront");
+  constexpr int NBLK = 6;   // widest diagonal block of M: a free body (checked on the host: ell_fits)
   w.begin_region();
   const vfloat vzero = vsplat(0.f);
   const vbool isdof = w.lane_lt(NV);
@@ -55,11 +56,23 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (k >= m->con_dim[c]) return;
       const int r = m->con_adr[c] + k, nd = m->con_ndof[c];
       const float* J = s.Jc + m->con_joff[c] + k * nd;
+      // The row of the compact Jacobian in 8-byte pairs (dim * nd and nd are even: rows start 8-byte aligned) and the
+      // contact's dof list as three 32-bit words, with a FIXED trip count (pairs >= nd masked): ~18 independent LDS
+      // fetches issued up front instead of two dependent round trips per column of a loop of unknown length
+      const uint32_t* dw = reinterpret_cast<const uint32_t*>(m->con_dof[c]);
+      const uint32_t dws[3] = {dw[0], dw[1], dw[2]};
       float a = 0.f, b = 0.f;
-      for (int q = 0; q < nd; q++) {
-        const int i = m->con_dof[c][q];
-        a += J[q] * vecA[i];
-        if (vecB) b += J[q] * vecB[i];
+#pragma unroll
+      for (int t = 0; t < (NCD + 1) / 2; t++) {
+        const bool on = 2 * t < nd;
+        float j0, j1;
+        load2(J + (on ? 2 * t : 0), j0, j1);
+        const int i0 = (int)((dws[(2 * t) >> 2] >> (8 * ((2 * t) & 3))) & 255u), i1 = (int)((dws[(2 * t + 1) >> 2] >> (8 * ((2 * t + 1) & 3))) & 255u);
+        const int g0 = on ? i0 : 0, g1 = on ? i1 : 0;
+        float ta = a + j0 * vecA[g0];
+        ta = ta + j1 * vecA[g1];
+        a = on ? ta : a;
+        if (vecB) { float tb = b + j0 * vecB[g0]; tb = tb + j1 * vecB[g1]; b = on ? tb : b; }
       }
       outA[r] = a;
       if (vecB) outB[r] = b;
@@ -89,22 +102,35 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     }
     const int c = u - NL, r0 = m->con_adr[c], dim = m->con_dim[c];
     if (s.con_on[c] == 0.f) {
-      if (store) { s.lsign[r0] = 0.f; for (int k = 0; k < dim; k++) s.frc[r0 + k] = 0.f; }
+      if (store) {
+        s.lsign[r0] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < dim) s.frc[r0 + k] = 0.f;
+      }
       return 0.f;
     }
     const float mu = m->con_friction[c][0] * mu_scale;
-    float U[6], jr[6], fr[6], tsqr = 0.f;
-    jr[0] = val(r0);
-    fr[0] = mu;
-    U[0] = jr[0] * mu;
-    for (int k = 1; k < dim; k++) { jr[k] = val(r0 + k); fr[k] = m->con_friction[c][k - 1]; U[k] = jr[k] * fr[k]; tsqr += U[k] * U[k]; }
+    // all (<= 6) rows of the contact with a fixed trip count, rows >= dim masked (they re-read row 0): the loads issue
+    // back to back and jr / fr / U stay in registers -- the dim-bounded loops paid a dependent LDS round trip per row
+    float U[6], jr[6], fr[6], Dk[6], tsqr = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int rk = r0 + (k < dim ? k : 0);
+      jr[k] = val(rk);
+      Dk[k] = s.D[rk];
+      fr[k] = k == 0 ? mu : m->con_friction[c][k - 1];
+      U[k] = jr[k] * fr[k];
+    }
+#pragma unroll
+    for (int k = 1; k < 6; k++) { const float t2 = tsqr + U[k] * U[k]; tsqr = k < dim ? t2 : tsqr; }
     const float N = U[0], T = DM_SQRT(tsqr);
     const bool bottom = (tsqr <= 0.f && N < 0.f) || (tsqr > 0.f && mu * N + T <= 0.f);
     const bool middle = tsqr > 0.f && N < mu * T && mu * N + T > 0.f;
-    const float Dm = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL);
+    const float Dm = Dk[0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL);
     float cost = 0.f;
     if (bottom) {
-      for (int k = 0; k < dim; k++) cost += 0.5f * s.D[r0 + k] * jr[k] * jr[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { const float t2 = cost + 0.5f * Dk[k] * jr[k] * jr[k]; cost = k < dim ? t2 : cost; }
     } else if (middle) {
       const float nmt = N - mu * T;
       cost = 0.5f * Dm * nmt * nmt;
@@ -112,19 +138,23 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     if (store) {
       s.lsign[r0] = bottom ? 2.f : (middle ? 1.f : 0.f);
       if (bottom) {
-        for (int k = 0; k < dim; k++) { s.frc[r0 + k] = -s.D[r0 + k] * jr[k]; s.cwd[6 * c + k] = s.D[r0 + k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < dim) { s.frc[r0 + k] = -Dk[k] * jr[k]; s.cwd[6 * c + k] = Dk[k]; }
       } else if (middle) {
         const float nmt = N - mu * T, fn = -Dm * nmt * mu;
         s.frc[r0] = fn;
-        for (int k = 1; k < dim; k++) s.frc[r0 + k] = -fn / T * U[k] * fr[k];
+#pragma unroll
+        for (int k = 1; k < 6; k++) if (k < dim) s.frc[r0 + k] = -fn / T * U[k] * fr[k];
         const float Tg = dm::fmaxf_(T, MJ_MINVAL), TTT = dm::fmaxf_(Tg * Tg * Tg, MJ_MINVAL);
-        for (int k = 0; k < dim; k++) { s.cwa[6 * c + k] = fr[k]; s.cwb[6 * c + k] = U[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < dim) { s.cwa[6 * c + k] = fr[k]; s.cwb[6 * c + k] = U[k]; }
         s.ccf[4 * c] = Dm;
         s.ccf[4 * c + 1] = -mu / Tg;             // c0
         s.ccf[4 * c + 2] = mu * mu - mu * N / Tg;  // c1
         s.ccf[4 * c + 3] = mu * N / TTT;         // c2
       } else {
-        for (int k = 0; k < dim; k++) s.frc[r0 + k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < dim) s.frc[r0 + k] = 0.f;
       }
     }
     return cost;
@@ -138,8 +168,15 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   auto mul_m = [&](const float* vec) {
     return w.per_lane([&](int l) {
       if (l >= NV) return 0.f;
-      float acc = 0.f;   // M is block diagonal: the columns of the dof's own kinematic tree
-      for (int j = m->dof_blk0[l]; j < m->dof_blk1[l]; j++) acc += s.M[l * S + j] * vec[j];
+      float acc = 0.f;   // M is block diagonal: the columns of the dof's own kinematic tree (<= NBLK, fixed trip count)
+      const int j0 = m->dof_blk0[l], j1 = m->dof_blk1[l];
+#pragma unroll
+      for (int t = 0; t < NBLK; t++) {
+        const bool on = j0 + t < j1;
+        const int j = on ? j0 + t : j0;
+        const float t2 = acc + s.M[l * S + j] * vec[j];
+        acc = on ? t2 : acc;
+      }
       return acc;
     });
   };
@@ -172,11 +209,13 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   const int max_iter = DM_UNIFORM_I(m->iterations), max_ls = DM_UNIFORM_I(m->ls_iterations);
   const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
 
+  DIAL_MARK(w, 14);
   int niter = 0;
   for (;;) {
     // ---- _update_constraint: zones, forces, Hessian weights (unit lanes); cost
     const vfloat ucost = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, nullptr, true) : 0.f; });
     w.fence();
+    DIAL_MARK(w, 12);
     // ---- J^T f per dof lane: own limit row + the contacts that move the dof
     const vfloat qfc = w.per_lane([&](int l) {
       if (l >= NV) return 0.f;
@@ -196,6 +235,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       return acc;
     });
     const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
+    DIAL_MARK(w, 13);
     float gn;
     {
       vfloat t[3] = {ucost, (vMa - vqfs) * (vqacc - vqas), vgrad * vgrad};
@@ -229,8 +269,11 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     w.items(NL, [&](int r) {
       if (s.D[r] > 0.f && s.Jaref[r] < 0.f) { const int i = m->jnt_dofadr[m->lim_jnt[r]]; s.H[i * S + i] += s.D[r]; }
     });
-    for (int c = 0; c < NC; c++) {
-      if (s.con_on[c] == 0.f) continue;            // wave-uniform
+    DIAL_MARK(w, 24);
+    for (int idx = 0; idx < n_on; idx++) {           // the contributing units (compacted once per solve), not all NC contacts
+      const int u = DM_UNIFORM_I((int)s.ulist[idx]);
+      if (u < NL) continue;                          // limit row: added above (wave-uniform)
+      const int c = u - NL;
       const float zone = s.lsign[m->con_adr[c]];
       if (zone == 0.f) continue;                    // top zone: no curvature
       const int nd = m->con_ndof[c], dim = m->con_dim[c];
@@ -241,16 +284,24 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
         float acc;
         if (zone == 2.f) {                          // bottom zone: plain quadratic rows
           acc = 0.f;
-          for (int k = 0; k < dim; k++) acc += (J[k * nd + a] * s.cwd[6 * c + k]) * J[k * nd + b];
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            const int kk = k < dim ? k : 0;
+            const float t2 = acc + (J[kk * nd + a] * s.cwd[6 * c + kk]) * J[kk * nd + b];
+            acc = k < dim ? t2 : acc;
+          }
         } else {                                    // middle zone: cone Hessian
           const float Dm = s.ccf[4 * c], c0 = s.ccf[4 * c + 1], c1 = s.ccf[4 * c + 2], c2 = s.ccf[4 * c + 3];
           const float x0 = s.cwa[6 * c] * J[a], y0 = s.cwa[6 * c] * J[b];
           float ux = 0.f, uy = 0.f, xty = 0.f;
-          for (int k = 1; k < dim; k++) {
-            const float xk = s.cwa[6 * c + k] * J[k * nd + a], yk = s.cwa[6 * c + k] * J[k * nd + b], uk = s.cwb[6 * c + k];
-            ux += uk * xk;
-            uy += uk * yk;
-            xty += xk * yk;
+#pragma unroll
+          for (int k = 1; k < 6; k++) {
+            const int kk = k < dim ? k : 0;
+            const float xk = s.cwa[6 * c + kk] * J[kk * nd + a], yk = s.cwa[6 * c + kk] * J[kk * nd + b], uk = s.cwb[6 * c + kk];
+            const float t_ux = ux + uk * xk, t_uy = uy + uk * yk, t_xy = xty + xk * yk;
+            ux = k < dim ? t_ux : ux;
+            uy = k < dim ? t_uy : uy;
+            xty = k < dim ? t_xy : xty;
           }
           acc = Dm * (x0 * y0 + c0 * (x0 * uy + ux * y0) + c2 * (ux * uy) + c1 * xty);
         }
@@ -303,24 +354,31 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       const int r0 = m->con_adr[c], dim = m->con_dim[c];
       const float mu = m->con_friction[c][0] * mu_scale;
       float uu = 0.f, uv = 0.f, vv = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
-      for (int k = 0; k < dim; k++) {
-        const float ja = s.Jaref[r0 + k], jv = s.jv[r0 + k], d = s.D[r0 + k];
-        q0 += 0.5f * ja * ja * d; q1 += jv * ja * d; q2 += 0.5f * jv * jv * d;
-        if (k > 0) { const float f = m->con_friction[c][k - 1], a = ja * f, b = jv * f; uu += a * a; uv += a * b; vv += b * b; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {                 // fixed trip count, rows >= dim masked (see unit_cost)
+        const bool on = k < dim;
+        const int rk = r0 + (on ? k : 0);
+        const float ja = s.Jaref[rk], jv = s.jv[rk], d = s.D[rk];
+        const float t0 = q0 + 0.5f * ja * ja * d, t1 = q1 + jv * ja * d, t2 = q2 + 0.5f * jv * jv * d;
+        q0 = on ? t0 : q0; q1 = on ? t1 : q1; q2 = on ? t2 : q2;
+        if (k > 0) {
+          const float f = m->con_friction[c][k - 1], a = ja * f, b = jv * f;
+          const float tuu = uu + a * a, tuv = uv + a * b, tvv = vv + b * b;
+          uu = on ? tuu : uu; uv = on ? tuv : uv; vv = on ? tvv : vv;
+        }
       }
       o[0] = s.Jaref[r0] * mu; o[1] = s.jv[r0] * mu; o[2] = uu; o[3] = uv; o[4] = vv;
       o[5] = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL); o[6] = mu;
       o[7] = q0; o[8] = q1; o[9] = q2;
     });
+    DIAL_MARK(w, 25);
     // is the lane's unit a limit row?  (mu = L[6] is > 0 exactly for contacts)
     // the six sums of one unit at alpha: quadratic part (q0 q1 q2) + cone part (cost, slope, curvature)
+    // Straight-line code for every lane: a limit row is the degenerate contact mu = 0, uu = uv = vv = 0 (tsqr = 0, so the
+    // "bottom" test reduces to Jaref + alpha jv < 0 and "middle" is never true), an idle lane holds zeros everywhere.
+    // Three divergent branches per evaluation (limit / bottom / middle lanes ran one after the other) become selects.
     auto unit_terms = [&](int l, float alpha, float* o) {
-      for (int k = 0; k < 6; k++) o[k] = 0.f;
       const float mu = lane_val(L[6], l);
-      if (mu == 0.f) {   // limit row (or an idle lane: all registers 0)
-        if (lane_val(L[0], l) + alpha * lane_val(L[1], l) < 0.f) { o[0] = lane_val(L[7], l); o[1] = lane_val(L[8], l); o[2] = lane_val(L[9], l); }
-        return;
-      }
       const float u0 = lane_val(L[0], l), v0 = lane_val(L[1], l), uu = lane_val(L[2], l), uv = lane_val(L[3], l), vv = lane_val(L[4], l);
       const float dmc = lane_val(L[5], l);
       const float n = u0 + alpha * v0;
@@ -333,15 +391,15 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       const float rt = DM_FMA(rt0, DM_FMA(-tt, rt0, 1.f), rt0);
       const bool bottom = (tsqr <= 0.f && n < 0.f) || (tsqr > 0.f && mu * n + tt <= 0.f);
       const bool middle = tsqr > 0.f && n < mu * tt && mu * n + tt > 0.f;
-      if (bottom) { o[0] = lane_val(L[7], l); o[1] = lane_val(L[8], l); o[2] = lane_val(L[9], l); }
-      if (middle) {
-        const float w1 = uv + alpha * vv;
-        const float n1 = v0, t1 = w1 * rt, t2 = vv * rt - w1 * t1 * (rt * rt);
-        const float nmt = n - mu * tt, g = n1 - mu * t1;
-        o[3] = 0.5f * dmc * nmt * nmt;
-        o[4] = dmc * nmt * g;
-        o[5] = dmc * (g * g - nmt * mu * t2);
-      }
+      o[0] = bottom ? lane_val(L[7], l) : 0.f;
+      o[1] = bottom ? lane_val(L[8], l) : 0.f;
+      o[2] = bottom ? lane_val(L[9], l) : 0.f;
+      const float w1 = uv + alpha * vv;
+      const float n1 = v0, t1 = w1 * rt, t2 = vv * rt - w1 * t1 * (rt * rt);
+      const float nmt = n - mu * tt, g = n1 - mu * t1;
+      o[3] = middle ? 0.5f * dmc * nmt * nmt : 0.f;
+      o[4] = middle ? dmc * nmt * g : 0.f;
+      o[5] = middle ? dmc * (g * g - nmt * mu * t2) : 0.f;
     };
     // cost / slope / curvature of a point from its six sums, packed into the four words of ls_bracket.h
     auto finish = [&](float alpha, const float* r, float* o) {
@@ -394,6 +452,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     LsPt lo, hi;
     ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
     const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
+    DIAL_MARK(w, 26);
     bool swap = true;
     int ls_iter = 0;
     for (;;) {

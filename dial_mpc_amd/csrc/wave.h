@@ -52,6 +52,8 @@ inline vbool vlt0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l
 inline vbool veq0(const vfloat& a) { vbool r; for (int l = 0; l < 64; l++) r.x[l] = a.x[l] == 0.f; return r; }
 inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
 inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
+// two consecutive floats from an 8-byte aligned address (one ds_read_b64 on the GPU)
+inline void load2(const float* p, float& a, float& b) { a = p[0]; b = p[1]; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
@@ -213,6 +215,7 @@ __device__ __forceinline__ float bcast(vfloat v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 __device__ __forceinline__ float lane_val(vfloat v, int) { return v; }
+__device__ __forceinline__ void load2(const float* p, float& a, float& b) { const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y; }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

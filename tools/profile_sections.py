@@ -23,7 +23,10 @@ NAMES = {0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies
          30: "  line-search iterations", 31: "  Newton iterations"}
 if len(sys.argv) > 1 and sys.argv[1] == "allegro_reorient":
     NAMES.update({27: "EVENTS (all samples): contributing units (sum over solves)", 28: "  constraint solves (physics sub-steps)",
-                  29: "  Newton iterations on the 3-points-per-pass line search (<= 16 units)"})
+                  29: "  Newton iterations on the 3-points-per-pass line search (<= 16 units)",
+                  14: "  solver: warm-start selection (per solve)", 12: "  solver: unit zones / forces / weights (per Newton it)", 13: "  solver: J^T f + gradient", 4: "  solver: sums + convergence test (+ warm start)",
+                  24: "  solver: H = M copy + limit rows", 5: "  solver: H contact blocks", 25: "  solver: LS set-up (J v, M v, sums, unit registers)",
+                  26: "  solver: LS opening points p0, p1", 7: "  solver: LS bracketing iterations + update"})
 
 example = sys.argv[1] if len(sys.argv) > 1 else "unitree_go2_trot"
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
