@@ -204,16 +204,25 @@ def k4_fp64(rewss, Y0s, qss, qdss, xss, temp):
     w /= w.sum()
     B = rews.shape[0]
     f = lambda a: np.einsum("n,nc->c", w, np.asarray(a, np.float64).reshape(B, -1))  # noqa: E731
+    # the same weighted mean at 8 x the temperature: a smooth functional of the whole reward distribution, where the
+    # planner's own softmax (temp_sample ~ 0.1: effective sample size 1 .. 40 of thousands) hangs on the best few rollouts
+    wt = np.exp((logp - logp.max()) / 8.0)
+    wt /= wt.sum()
     return dict(rews=rews, weights=w, Ybar=f(Y0s), qbar=f(qss), qdbar=f(qdss), xbar=f(xss), ess=1.0 / np.sum(w * w),
+                Ybar_t8=np.einsum("n,nc->c", wt, np.asarray(Y0s, np.float64).reshape(B, -1)), ess_t8=1.0 / np.sum(wt * wt),
                 quantiles=np.quantile(rews, [0.01, 0.05, 0.25, 0.5, 0.75, 0.95, 0.99]), mean=rews.mean(), std=rews.std())
 
 
 # floors of the distribution-level gate = the per-entry aggregate tolerances above (a GPU result inside them passes
 # whatever the ensemble says); beyond them the jitter envelope decides
-DIST_FLOOR = dict(Ybar=3e-4, qbar=3e-4, qdbar=5e-3, xbar=3e-4, quantiles=5e-4, mean=2e-4, std=2e-4, ess_rel=5e-3)
+DIST_FLOOR = dict(Ybar=3e-4, qbar=3e-4, qdbar=5e-3, xbar=3e-4, Ybar_t8=3e-4, quantiles=5e-4, mean=2e-4, std=2e-4, ess_rel=5e-3)
+# statistics that hang on the planner's sharply peaked softmax are heavy-tailed under jitter (one flipped top rollout moves
+# them by more than all the others together: measured envelopes of the same config range from 0.005 to 0.29 between
+# seeds): they get the wider factor; the smooth ones (reward distribution, tempered mean) the narrow one
+DIST_PEAKED = ("Ybar", "qbar", "qdbar", "xbar", "ess_rel")
 
 
-def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_mag=1.0, scale=2.5):
+def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_mag=1.0, scale=2.5, scale_peaked=4.0):
     """Distribution-level parity of one reverse_once at full size under a solver rule that is a rounding lottery rollout
     by rollout (`_in_bracket` truncated; Allegro's 100 impact-rich sub-steps).
 
@@ -221,8 +230,9 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
     `Y0s` the shared controls / nodes.  The yardstick is the ORACLE'S OWN sensitivity: an ensemble of `members` oracle
     runs whose state is jittered by <= `noise_mag` ulp (fp32) before every step (oracle_rollout_jitter).  For every
     aggregate a caller consumes -- Ybar, qbar, qdbar, xbar -- and for the reward distribution (mean, std, seven quantiles,
-    softmax effective sample size), the GPU's distance from the unperturbed oracle must not exceed `scale` x the
-    LARGEST distance any ensemble member shows (or the plain fp32 floor DIST_FLOOR, whichever is larger).  A kernel
+    softmax effective sample size, the weighted mean action at 8 x the temperature), the GPU's distance from the
+    unperturbed oracle must not exceed `scale` x the LARGEST distance any ensemble member shows (`scale_peaked` for the
+    statistics in DIST_PEAKED; or the plain fp32 floor DIST_FLOOR, whichever is larger).  A kernel
     that computes something else than the oracle -- a wrong force, a missed contact -- moves the aggregates far outside
     an envelope that 1 ulp of jitter spans; a kernel that differs by rounding stays inside.  Also reported / bounded: the
     share of rollouts outside the per-step gate, GPU vs ensemble."""
@@ -238,7 +248,7 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
             ok &= wv if wv.ndim == 2 else wv.reshape(B, T, -1).all(-1)
         return float((~ok.all(1)).mean())
 
-    names = ("Ybar", "qbar", "qdbar", "xbar", "quantiles", "mean", "std")
+    names = ("Ybar", "qbar", "qdbar", "xbar", "Ybar_t8", "quantiles", "mean", "std")
     env_d = {k: 0.0 for k in names + ("ess_rel", "outside")}
     for k in range(members):
         roll = o32.rollout_jitter(s0, us, noise_seed=7919 * (k + 1), noise_mag=noise_mag)
@@ -257,7 +267,7 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
         assert np.allclose(np.asarray(product[nme], np.float64).reshape(-1), g[nme], atol=atol), nme
     # ... and sit inside the oracle's jitter envelope
     for nme in names + ("ess_rel",):
-        bound = max(DIST_FLOOR[nme], scale * env_d[nme])
+        bound = max(DIST_FLOOR[nme], (scale_peaked if nme in DIST_PEAKED else scale) * env_d[nme])
         assert rep["gpu"][nme] <= bound, (nme, rep)
     assert rep["gpu"]["outside"] <= max(0.01, 1.5 * env_d["outside"] + 0.02), rep
     return rep

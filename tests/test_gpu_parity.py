@@ -343,7 +343,7 @@ def test_full_size_oracle_parity(example, N, H):
             # product outputs of the chaotic env: Ybar / qbar / qdbar / xbar and the reward distribution against the oracle's
             # own <= 1 ulp jitter envelope (conftest.distribution_parity) instead of no aggregate check at all
             prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-            drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample, members=6)
+            drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample, members=8)
             print(f"   distribution level: GPU {drep['gpu']}\n   jitter envelope: {drep['envelope']}")
         if not chaotic:
             # product outputs: the few knife-edge rollouts carry softmax weight ~1/N each, so the aggregates stay comparable
@@ -601,7 +601,8 @@ def test_in_bracket_rule_converged_at_full_size(example, N, H):
 def test_default_rule_distribution_parity_full_size(example, N, H):
     """What a caller gets from the SHIPPED models (line-search rule `_in_bracket`, the envs' own truncated solver settings)
     at the BASELINE sizes, bounded against the oracle: Ybar, qbar, qdbar, xbar, the reward distribution (mean, std,
-    quantiles) and the softmax's effective sample size must lie within 2.5 x the envelope that <= 1 ulp of per-step state
+    quantiles, the weighted mean action at 8 x the temperature) within 2.5 x, and the sharply peaked statistics (Ybar, qbar, qdbar,
+    xbar, the softmax's effective sample size: ESS is 1 .. 40 here) within 4 x the envelope that <= 1 ulp of per-step state
     jitter spans in the fp32 oracle itself (conftest.distribution_parity; floors = the plain fp32 aggregate tolerances).
     Per rollout the rule is a rounding lottery -- a third to two thirds of the rollouts leave the per-step
     gate under that jitter, in the oracle as on the GPU -- so THIS is the gate of the default configuration; the
@@ -623,7 +624,7 @@ def test_default_rule_distribution_parity_full_size(example, N, H):
         us = np.einsum("tk,nka->nta", W, sc["Y0s"]).astype(np.float32)
         prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
         rep = distribution_parity(o32, s0, us, sc["Y0s"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), prod,
-                                  cfg.temp_sample, members=6 if example == "allegro_reorient" else 8)
+                                  cfg.temp_sample, members=8)
         print(f"{example} N={N} seed={seed} default rule: ESS oracle {rep['ess_oracle']:.1f} / GPU {rep['ess_gpu']:.1f}\n"
               f"   GPU vs oracle   {rep['gpu']}\n   jitter envelope {rep['envelope']}")
 
