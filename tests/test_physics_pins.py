@@ -117,6 +117,71 @@ def test_bias_forces_satisfy_lagranges_equations_on_the_hinges(example, _n):
     assert np.allclose(bias[6:], c, rtol=1e-5, atol=2e-5), (example, np.abs(bias[6:] - c).max())
 
 
+@pytest.mark.parametrize("example,_n", ROBOTS)
+def test_bias_forces_satisfy_the_hamel_equations_on_every_dof(example, _n):
+    """ALL dofs, moving base included.  The free joint's velocity is a quasi-velocity (world-frame linear, BODY-frame
+    angular), so Lagrange's equations take Hamel's form: with p = M v, D_k the derivative along generator k (a step of
+    mj_integratePos along the unit velocity e_k) and the so(3) structure constants of the body-frame rates,
+        c_k = (d/dt M) v |_k  -  D_k (1/2 v^T M v)  +  D_k V  +  [w x p_rot]_k   (last term: rotational base dofs only).
+    M is taken as the Hessian of the kinetic energy of plain forward kinematics (no cdof / CRB / RNE anywhere)."""
+    env, md, model, task, cfg, q, qd = _case(example, 7)
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    nv = md["nv"]
+    v = np.array(qd)
+    bias = o64.forward_dump(q, v)["qfrc_bias"]
+    g = np.asarray(md["gravity"], np.float64)
+    arm = np.asarray(md["dof_armature"], np.float64)
+    E = np.eye(nv)
+
+    def Mv(qq):          # M(qq) v from the kinetic energy's bilinear form (body velocities by finite differences)
+        return np.array([_kinetic_bilinear(md, qq, E[i], v) for i in range(nv)]) + arm * v
+
+    def T(qq):
+        return 0.5 * (_kinetic_bilinear(md, qq, v, v) + v @ (arm * v))
+
+    def V(qq):
+        k = mjcf.host_kinematics(md, qq)
+        return -sum(md["body_mass"][b] * g @ k["xipos"][b] for b in range(1, md["nbody"]))
+
+    h = 2e-4
+    Mdot_v = (Mv(_integrate(md, q, v, h)) - Mv(_integrate(md, q, v, -h))) / (2 * h)
+    c = np.array(Mdot_v)
+    for k in range(nv):
+        qp, qm = _integrate(md, q, E[k], h), _integrate(md, q, E[k], -h)
+        c[k] += -(T(qp) - T(qm)) / (2 * h) + (V(qp) - V(qm)) / (2 * h)
+    p = Mv(q)
+    c[3:6] += np.cross(v[3:6], p[3:6])
+    scale = max(1.0, float(np.abs(bias).max()))
+    assert np.allclose(bias, c, rtol=0, atol=2e-4 * scale), (example, np.abs(bias - c).max(), scale)
+
+
+@pytest.mark.parametrize("example,_n", ROBOTS + [("allegro_reorient", 8)])
+def test_invweight0_and_meaninertia_follow_their_definitions(example, _n):
+    """What MuJoCo's mj_setConst derives at qpos0, checked from the DEFINITIONS with independent ingredients -- M as the
+    Hessian of the kinetic energy, body Jacobians as finite differences of forward kinematics:
+    meaninertia = mean diag M;  dof_invweight0 = diag M^-1 (free joint: mean over its 3 translational / 3 rotational dofs);
+    body_invweight0 = (tr(Jp M^-1 Jp^T) / 3, tr(Jr M^-1 Jr^T) / 3) at the body's centre of mass."""
+    dc, env, model, task, cfg = setup_case(example, 8, 8)
+    md = env.sys.model
+    nv, nb = md["nv"], md["nbody"]
+    q0 = np.asarray(md["qpos0"], np.float64)
+    E = np.eye(nv)
+    M = np.array([[_kinetic_bilinear(md, q0, E[i], E[j]) for j in range(nv)] for i in range(nv)]) + np.diag(md["dof_armature"])
+    Minv = np.linalg.inv(M)
+    assert abs(md["meaninertia"] - np.mean(np.diag(M))) < 1e-6 * np.mean(np.diag(M))
+    diw = np.diag(Minv).copy()
+    for j in range(md["njnt"]):
+        if md["jnt_type"][j] == mjcf.JNT_FREE:
+            da = int(md["jnt_dofadr"][j])
+            diw[da:da + 3], diw[da + 3:da + 6] = diw[da:da + 3].mean(), diw[da + 3:da + 6].mean()
+    assert np.allclose(md["dof_invweight0"], diw, rtol=2e-5), np.abs(np.asarray(md["dof_invweight0"]) / diw - 1).max()
+    vc, om = zip(*[_body_velocities(md, q0, E[i]) for i in range(nv)])       # columns of Jp (at the COM) and Jr
+    for b in range(1, nb):
+        Jp, Jr = np.stack([vc[i][b] for i in range(nv)], 1), np.stack([om[i][b] for i in range(nv)], 1)
+        ref = np.array([np.trace(Jp @ Minv @ Jp.T) / 3, np.trace(Jr @ Minv @ Jr.T) / 3])
+        assert np.allclose(md["body_invweight0"][b], ref, rtol=2e-5, atol=1e-9), (example, b, md["body_invweight0"][b], ref)
+
+
 @pytest.mark.parametrize("example,_n", ROBOTS[:2])
 def test_contact_jacobian_is_the_velocity_of_the_material_contact_point(example, _n):
     env, md, model, task, cfg, _, _ = _case(example, 0)
