@@ -69,8 +69,23 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
             break
     n_frames = int(task.n_frames)
     ns_per_step = dt * cores / ((N + 1) * reps * (H + 1)) * 1e9
+    # the same code on ONE thread (64 rollouts): what a core does when it is not waiting for the others
+    single_us = None
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        us1 = np.zeros((64, H + 1, model.nu), np.float32)
+        o32.rollout(s0, us1)
+        t1 = time.perf_counter()
+        o32.rollout(s0, us1)
+        single_us = (time.perf_counter() - t1) / (64 * (H + 1)) * 1e6
+        gomp.omp_set_num_threads(cores)
+    except Exception:
+        pass
     return {"value": (N + 1) * reps / dt, "unit": "sample-rollouts/s", "cores": cores, "kind": "port",
-            "ns_per_env_step_per_thread": ns_per_step, "physics_steps_per_env_step": n_frames, "build": build_note,
+            "ns_per_env_step_per_thread": ns_per_step, "single_thread_us_per_env_step": single_us,
+            "physics_steps_per_env_step": n_frames, "build": build_note,
             "sample": f"{reps} x reverse_once(N={N}, H={H}) fp32 C oracle ({build_note}), OpenMP over samples on {cores} "
                       f"threads, {dt:.2f} s wall = {dt * cores:.0f} core-s, {ns_per_step / 1e3:.0f} us per env.step per thread; "
                       f"a CPU restatement, not the JAX reference (not installable) -- a reported baseline, no quality claim"}
@@ -249,17 +264,18 @@ def main():
     alg_bytes = bytes_per_step * n_local * T
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     valu_tflops = flop_per_step * n_local * T / avg_kernel_s / 1e12 if (avg_kernel_s > 0 and flop_per_step) else None
-    traffic, traffic_src, valu_busy, valu_per_step, lane_util = None, None, None, None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_rollout_kernel.json")
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_rollout_kernel.json")
-    if os.path.exists(pmc_path) and args.example == "unitree_go2_trot" and args.nsample_per_gpu == 2048 and world == 1:
+    # HBM traffic / instruction counters of THIS configuration from the committed PMC passes (separate rocprofv3 --pmc runs of
+    # the same command, tools/pmc_passes.sh -> tools/pmc_to_json.py); null when the batch measured there is not the one run here
+    traffic, traffic_src, valu_per_step, lane_util, stall = None, None, None, None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.example}.json")
+    if os.path.exists(pmc_path) and world == 1:
         pmc = json.load(open(pmc_path))
-        traffic = pmc["hbm_bytes_per_launch"]
-        traffic_src = pmc["source"]
-        valu_busy = pmc.get("valu_pipe_busy_frac")              # SQ_ACTIVE_INST_VALU / SIMD cycles (PMC pass)
-        valu_per_step = pmc.get("valu_insts_per_wave_env_step")
-        lane_util = pmc.get("valu_active_lanes_per_inst")
+        if pmc.get("Nsample") == args.nsample_per_gpu and pmc.get("Hsample") == args.hsample:
+            traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/r03_pmc_{args.example}.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, per reverse_once)"
+            valu_per_step = pmc.get("valu_insts_per_wave_env_step")
+            lane_util = pmc.get("valu_active_lanes_per_inst")
+            stall = pmc.get("wave_time_breakdown")
     out = {
         "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"
         else f"sample-rollouts/sec (N x H env.steps), {args.example}", "value": value,
@@ -274,9 +290,10 @@ def main():
                    "env_steps_per_s": value * T, "parallelism": f"samples sharded over {world} rank(s)" +
                    (" (sharded code path forced: 1-rank RCCL all-gather + all-reduce per iteration)" if args.force_sharded else "")},
         # `achieved / peak / frac / traffic` are the HBM figures the bench contract defines (algorithmic bytes per launch /
-        # kernel time vs 8 TB/s).  They are NOT what bounds this kernel: `bound` names that -- dependent VALU issue latency
-        # (one sample = one dependence chain of ~5 k VALU instructions per env.step, ~10.6 cycles each) -- and the
-        # counted-FLOP and PMC figures next to it quantify it.
+        # kernel time vs 8 TB/s).  They are NOT what bounds this kernel: `bound` names that -- dependent issue latency (one
+        # sample = one dependence chain of ~4.9 k VALU + 0.7 k LDS instructions per env.step; PMC: a wavefront issues half
+        # of its time, is parked at s_waitcnt a third and stalled at issue a tenth) -- and the counted-FLOP and PMC figures
+        # next to it quantify it.
         "roofline": {"bound": "valu-latency",
                      "bound_note": "neither hbm nor mfma: 176 counted FLOP per algorithmic byte vs a machine balance of 20 FLOP/B; "
                                    "achieved/peak/frac/traffic below are the HBM figures of the bench contract",
@@ -288,8 +305,8 @@ def main():
                      "flop_per_env_step_counted": flop_per_step, "flop_source": flop_src,
                      "valu_tflops_counted": valu_tflops,
                      "valu_frac_counted": (valu_tflops / VALU_PEAK_TFLOPS) if valu_tflops is not None else None,
-                     "valu_pipe_busy_frac_pmc": valu_busy, "valu_insts_per_wave_env_step_pmc": valu_per_step,
-                     "valu_active_lanes_per_inst_pmc": lane_util},
+                     "valu_insts_per_wave_env_step_pmc": valu_per_step, "valu_active_lanes_per_inst_pmc": lane_util,
+                     "wave_time_breakdown_pmc": stall},
         "plan_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
                             "ticks": len(lat), "tick_budget_ms": 20.0,
                             "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},

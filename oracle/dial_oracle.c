@@ -1401,6 +1401,7 @@ int oracle_reverse_once(const dial_model* m, const dial_task* t, const dial_cfg*
   real* qdss = (real*)malloc(sizeof(real) * (size_t)B * T * nv);
   real* xss = (real*)malloc(sizeof(real) * (size_t)B * T * nx);
   real* w = (real*)malloc(sizeof(real) * (size_t)B);
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < B; n++)
     for (int k = 0; k < Hn1; k++)
       for (int a = 0; a < nu; a++) {
@@ -1414,6 +1415,7 @@ int oracle_reverse_once(const dial_model* m, const dial_task* t, const dial_cfg*
         }
         Y0s[((size_t)n * Hn1 + k) * nu + a] = r_clip(v, -1, 1);               /* :115 */
       }
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < B; n++) /* node2u (:117): us = W @ Y0s */
     for (int s = 0; s < T; s++)
       for (int a = 0; a < nu; a++) {
@@ -1444,10 +1446,22 @@ int oracle_reverse_once(const dial_model* m, const dial_task* t, const dial_cfg*
   real den = 0;
   for (int n = 0; n < B; n++) { w[n] = (real)exp((double)(w[n] - mx)); den += w[n]; } /* :128 softmax */
   for (int n = 0; n < B; n++) w[n] /= den;
+  /* weighted means (:132-135): every output entry sums over the samples in index order (one thread per entry: the
+   * OpenMP split does not touch the summation order) */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < Hn1 * nu; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * Y0s[(size_t)n * Hn1 * nu + i]; Ybar_out[i] = s_; }
-  if (qbar) for (int i = 0; i < T * nq; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * qss[(size_t)n * T * nq + i]; qbar[i] = s_; }
-  if (qdbar) for (int i = 0; i < T * nv; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * qdss[(size_t)n * T * nv + i]; qdbar[i] = s_; }
-  if (xbar) for (int i = 0; i < T * nx; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * xss[(size_t)n * T * nx + i]; xbar[i] = s_; }
+  if (qbar) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < T * nq; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * qss[(size_t)n * T * nq + i]; qbar[i] = s_; }
+  }
+  if (qdbar) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < T * nv; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * qdss[(size_t)n * T * nv + i]; qdbar[i] = s_; }
+  }
+  if (xbar) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < T * nx; i++) { real s_ = 0; for (int n = 0; n < B; n++) s_ += w[n] * xss[(size_t)n * T * nx + i]; xbar[i] = s_; }
+  }
   if (us_out) memcpy(us_out, us, sizeof(real) * (size_t)B * T * nu);
   if (rewss_out) memcpy(rewss_out, rewss, sizeof(real) * (size_t)B * T);
   if (weights_out) memcpy(weights_out, w, sizeof(real) * (size_t)B);
