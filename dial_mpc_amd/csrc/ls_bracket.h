@@ -80,6 +80,55 @@ DIAL_DEV bool ls_update(bool rule_swap, LsPt& lo, LsPt& hi, const LsPt& lo_next,
   return s1 | s2 | s3 | s4 | s5 | s6;
 }
 
+// One bracket update with LAZY fetches; returns whether any end moved (`swap` of the reference).  The three trial points
+// of the iteration stay where they were evaluated -- `pk[4]` holds (alpha, nalpha, cost key, d0 key) of group g's point
+// in the lanes of group g (lane_of: lo_next / hi_next / mid -> first lane of its group) -- and only their three slope keys
+// are broadcast up front.  The update runs on the slope keys alone and yields, per bracket end, WHICH point it ends up
+// with; the winner's other three words are fetched afterwards with a lane-indexed v_readlane.  (Carrying all 12 words
+// of the three candidates through the select chain cost ~28 live SGPRs and four s_cselect per pick: the kernels sit at
+// the SGPR limit, and every SGPR spilled to a VGPR lane is a v_writelane / v_readlane pair on the VALU.)
+template <class BC>
+DIAL_DEV bool ls_update_lazy(bool rule_swap, LsPt& lo, LsPt& hi, int k_lo_next, int k_hi_next, int k_mid, int lane_lo_next,
+                             int lane_hi_next, int lane_mid, BC&& fetch /* (word 0..2, lane) -> int */) {
+  int lo_d0 = lo.d0, hi_d0 = hi.d0, lo_sel = -1, hi_sel = -1;
+  bool any;
+  if (rule_swap) {   // MJX <= 3.1.3
+    const bool swap_lo_next = (lo_d0 > 0) | (lo_d0 < k_lo_next);
+    lo_sel = swap_lo_next ? lane_lo_next : lo_sel; lo_d0 = swap_lo_next ? k_lo_next : lo_d0;
+    const bool swap_lo_mid = (k_mid < 0) & (lo_d0 < k_mid);
+    lo_sel = swap_lo_mid ? lane_mid : lo_sel; lo_d0 = swap_lo_mid ? k_mid : lo_d0;
+    const bool swap_hi_next = (hi_d0 < 0) | (hi_d0 > k_hi_next);
+    hi_sel = swap_hi_next ? lane_hi_next : hi_sel; hi_d0 = swap_hi_next ? k_hi_next : hi_d0;
+    const bool swap_hi_mid = (k_mid > 0) & (hi_d0 > k_mid);
+    hi_sel = swap_hi_mid ? lane_mid : hi_sel; hi_d0 = swap_hi_mid ? k_mid : hi_d0;
+    any = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
+  } else {
+    // MJX >= 3.1.4 `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer
+    // to it; each end is offered its own Newton step, the mid-point and the other end's Newton step
+    const auto in_bracket = [](int x, int y) { return ((x < y) & (y < 0)) | ((x > y) & (y > 0)); };
+    const bool s1 = in_bracket(lo_d0, k_lo_next);
+    lo_sel = s1 ? lane_lo_next : lo_sel; lo_d0 = s1 ? k_lo_next : lo_d0;
+    const bool s2 = in_bracket(lo_d0, k_mid);
+    lo_sel = s2 ? lane_mid : lo_sel; lo_d0 = s2 ? k_mid : lo_d0;
+    const bool s3 = in_bracket(lo_d0, k_hi_next);
+    lo_sel = s3 ? lane_hi_next : lo_sel; lo_d0 = s3 ? k_hi_next : lo_d0;
+    const bool s4 = in_bracket(hi_d0, k_hi_next);
+    hi_sel = s4 ? lane_hi_next : hi_sel; hi_d0 = s4 ? k_hi_next : hi_d0;
+    const bool s5 = in_bracket(hi_d0, k_mid);
+    hi_sel = s5 ? lane_mid : hi_sel; hi_d0 = s5 ? k_mid : hi_d0;
+    const bool s6 = in_bracket(hi_d0, k_lo_next);
+    hi_sel = s6 ? lane_lo_next : hi_sel; hi_d0 = s6 ? k_lo_next : hi_d0;
+    any = s1 | s2 | s3 | s4 | s5 | s6;
+  }
+  const bool lo_new = lo_sel >= 0, hi_new = hi_sel >= 0;
+  const int ll = lo_new ? lo_sel : 0, hl = hi_new ? hi_sel : 0;
+  const int la = fetch(0, ll), ln = fetch(1, ll), lc = fetch(2, ll);
+  const int ha = fetch(0, hl), hn = fetch(1, hl), hc = fetch(2, hl);
+  lo.alpha = lo_new ? la : lo.alpha; lo.nalpha = lo_new ? ln : lo.nalpha; lo.cost = lo_new ? lc : lo.cost; lo.d0 = lo_d0;
+  hi.alpha = hi_new ? ha : hi.alpha; hi.nalpha = hi_new ? hn : hi.nalpha; hi.cost = hi_new ? hc : hi.cost; hi.d0 = hi_d0;
+  return any;
+}
+
 // result of the search: improved?  and the step of the better end
 DIAL_DEV bool ls_result(const LsPt& p0, const LsPt& lo, const LsPt& hi, float& alpha) {
   alpha = bitsf(lo.cost < hi.cost ? lo.alpha : hi.alpha);

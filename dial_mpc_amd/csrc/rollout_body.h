@@ -1200,7 +1200,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       }
     }
   });
-  DIAL_MARK(w, 10);
+  DIAL_MARK(w, 25);
   for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
     forward(w, m, s);
     euler(w, m, s);

@@ -165,6 +165,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
       if (rrow && i == 0) rrow[0] = rew;
     });
+    DIAL_MARK(w, 24);
   }
 #ifdef DIAL_PROFILE
   DIAL_MARK(w, 11);

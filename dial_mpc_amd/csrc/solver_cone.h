@@ -423,8 +423,18 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       p.alpha = fbits(o[0]); p.nalpha = fbits(o[1]); p.cost = fbits(o[2]); p.d0 = fbits(o[3]);
       return p;
     };
-    auto ls_eval3 = [&](float a0, float a1, float a2, LsPt& P0, LsPt& P1, LsPt& P2) {
-      if (!fast) { P0 = ls_point(a0); P1 = ls_point(a1); P2 = ls_point(a2); return; }
+    // res: the packed words (alpha, nalpha, cost key, d0 key) of the three points of an iteration, each in the lanes of its
+    // 16-lane group; ls_update_lazy broadcasts the slope keys and fetches the rest of the winners only (ls_bracket.h)
+    vfloat res[4];
+    auto ls_eval3 = [&](float a0, float a1, float a2) {
+      if (!fast) {   // > 16 contributing units: three full-wave passes, results parked in the groups' lanes
+        const LsPt P0 = ls_point(a0), P1 = ls_point(a1), P2 = ls_point(a2);
+        w.per_lane_n(res, [&](int l, float* o) {
+          const LsPt& P = l < 16 ? P0 : (l < 32 ? P1 : P2);
+          o[0] = bitsf(P.alpha); o[1] = bitsf(P.nalpha); o[2] = bitsf(P.cost); o[3] = bitsf(P.d0);
+        });
+        return;
+      }
       vfloat t[6];
       // (two opaque v_cndmask selects: left to itself the compiler stores the three trial steps to a scratch array and
       // loads a[lane >> 4] back -- a memory round trip in every line-search iteration)
@@ -438,15 +448,11 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       };
       w.per_lane_n(t, [&](int l, float* o) { unit_terms(l, group_alpha(l), o); });
       w.row16_sumN(t);
-      // the group's point finished lane-wise (every lane of a group holds the six sums): 4 words per point to broadcast
-      vfloat res[4];
+      // the group's point finished lane-wise (every lane of a group holds the six sums)
       w.per_lane_n(res, [&](int l, float* o) {
         const float r6[6] = {lane_val(t[0], l), lane_val(t[1], l), lane_val(t[2], l), lane_val(t[3], l), lane_val(t[4], l), lane_val(t[5], l)};
         finish(group_alpha(l), r6, o);
       });
-      P0.alpha = fbits(bcast(res[0], 0)); P0.nalpha = fbits(bcast(res[1], 0)); P0.cost = fbits(bcast(res[2], 0)); P0.d0 = fbits(bcast(res[3], 0));
-      P1.alpha = fbits(bcast(res[0], 16)); P1.nalpha = fbits(bcast(res[1], 16)); P1.cost = fbits(bcast(res[2], 16)); P1.d0 = fbits(bcast(res[3], 16));
-      P2.alpha = fbits(bcast(res[0], 32)); P2.nalpha = fbits(bcast(res[1], 32)); P2.cost = fbits(bcast(res[2], 32)); P2.d0 = fbits(bcast(res[3], 32));
     };
     const LsPt p0 = ls_point(0.f);
     LsPt lo, hi;
@@ -458,9 +464,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     for (;;) {
       const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
-      LsPt lo_next, hi_next, mid;
-      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)), lo_next, hi_next, mid);
-      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);   // integer keys on the scalar unit (ls_bracket.h)
+      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
+      swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(res[3], 0)), fbits(bcast(res[3], 16)), fbits(bcast(res[3], 32)), 0, 16, 32,
+                            [&](int word, int lane) { return fbits(bcast(res[word], lane)); });
       ls_iter++;
     }
     float alpha;

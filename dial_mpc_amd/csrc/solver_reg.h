@@ -392,7 +392,9 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     // evaluate the points a0, a1, a2 (group g evaluates a_g).  Every lane of a group finishes its point -- cost, slope,
     // the point's own Newton step, and the integer keys of ls_bracket.h -- so that what is broadcast (4 words per
     // point) is all the scalar bracket logic needs
-    auto ls_eval3 = [&](float a0, float a1, float a2, LsPt& p0_, LsPt& p1_, LsPt& p2_) {
+    // pk: the packed words of the three points, each in the lanes of its group (see ls_bracket.h)
+    vfloat pk[4];
+    auto ls_eval3 = [&](float a0, float a1, float a2) {
       const vfloat va = vsel(g0, vsplat(a0), vsel(g01, vsplat(a1), vsplat(a2)));
       vfloat s0 = vzero, s1v = vzero, s2v = vzero;
 #pragma unroll
@@ -407,31 +409,29 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       const vfloat vcost = (va * va) * q2 + va * q1 + q0;
       const vfloat vd0 = vfma(va * 2.f, q2, q1);   // single rounding: see the line search of rollout_body.h
       const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
-      vfloat pk[4];
       w.per_lane_n(pk, [&](int l, float* o) {
         ls_pack(lane_val(va, l), lane_val(vcost, l), lane_val(vd0, l), lane_val(vd1, l), o[0], o[1], o[2], o[3]);
       });
-      p0_.alpha = fbits(bcast(pk[0], 0)); p0_.nalpha = fbits(bcast(pk[1], 0)); p0_.cost = fbits(bcast(pk[2], 0)); p0_.d0 = fbits(bcast(pk[3], 0));
-      p1_.alpha = fbits(bcast(pk[0], 16)); p1_.nalpha = fbits(bcast(pk[1], 16)); p1_.cost = fbits(bcast(pk[2], 16)); p1_.d0 = fbits(bcast(pk[3], 16));
-      p2_.alpha = fbits(bcast(pk[0], 32)); p2_.nalpha = fbits(bcast(pk[1], 32)); p2_.cost = fbits(bcast(pk[2], 32)); p2_.d0 = fbits(bcast(pk[3], 32));
     };
-    auto ls_point = [&](float alpha) {   // single point (the two points that open the bracket)
-      LsPt p, u1, u2;
-      ls_eval3(alpha, alpha, alpha, p, u1, u2);
+    auto point_at = [&](int lane) {   // all four words of the point held by the group that starts at `lane`
+      LsPt p;
+      p.alpha = fbits(bcast(pk[0], lane)); p.nalpha = fbits(bcast(pk[1], lane)); p.cost = fbits(bcast(pk[2], lane)); p.d0 = fbits(bcast(pk[3], lane));
       return p;
     };
-    const LsPt p0 = ls_point(0.f);
+    ls_eval3(0.f, 0.f, 0.f);
+    const LsPt p0 = point_at(0);
+    ls_eval3(bitsf(p0.nalpha), bitsf(p0.nalpha), bitsf(p0.nalpha));
     LsPt lo, hi;
-    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+    ls_open(p0, point_at(0), lo, hi);
     const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
     bool swap = true;
     int ls_iter = 0;
     for (;;) {
       const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
-      LsPt lo_next, hi_next, mid;
-      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)), lo_next, hi_next, mid);
-      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);   // integer keys: scalar unit (ls_bracket.h)
+      ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
+      swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+                            [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
       ls_iter++;
     }
     float alpha;

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import seeded_inputs, setup_case  # noqa: E402
 from dial_mpc_amd import _lib  # noqa: E402
 
-NAMES = {0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies, geoms, sites)", 17: "subtree COM", 18: "cinert + cdof", 19: "cvel", 20: "cdof_dot", 21: "cacc", 22: "crb + local forces", 23: "F_i + cfrc", 2: "Jc + efc rows", 3: "chol(M)+solve",
+NAMES = {24: "per-step output stores", 25: "ctrl (act2tau) + gait clock", 0: "kinematics (levels)", 1: "M + qfs + collision", 16: "frames (bodies, geoms, sites)", 17: "subtree COM", 18: "cinert + cdof", 19: "cvel", 20: "cdof_dot", 21: "cacc", 22: "crb + local forces", 23: "F_i + cfrc", 2: "Jc + efc rows", 3: "chol(M)+solve",
          4: "warmstart select + constraint_grad", 5: "H build", 6: "chol(H)+solve", 7: "linesearch", 8: "post-ls update/sums",
          9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)",
          28: "EVENTS (all samples, cumulative): 2nd Newton iterations", 29: "  ... with an unchanged active set",
@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "allegro_reorient":
     NAMES.update({27: "EVENTS (all samples): contributing units (sum over solves)", 28: "  constraint solves (physics sub-steps)",
                   29: "  Newton iterations on the 3-points-per-pass line search (<= 16 units)",
                   14: "  solver: warm-start selection (per solve)", 12: "  solver: unit zones / forces / weights (per Newton it)", 13: "  solver: J^T f + gradient", 4: "  solver: sums + convergence test (+ warm start)",
-                  24: "  solver: H = M copy + limit rows", 5: "  solver: H contact blocks", 25: "  solver: LS set-up (J v, M v, sums, unit registers)",
+                  24: "  solver: H = M copy + limit rows (+ per-step output stores)", 5: "  solver: H contact blocks", 25: "  solver: LS set-up (J v, M v, sums, unit registers) (+ ctrl)",
                   26: "  solver: LS opening points p0, p1", 7: "  solver: LS bracketing iterations + update"})
 
 example = sys.argv[1] if len(sys.argv) > 1 else "unitree_go2_trot"
