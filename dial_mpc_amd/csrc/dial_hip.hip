@@ -438,6 +438,12 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
   if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_ALLEGRO)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
+  {   // the reward phase unrolls over the feet of the task's robot (rollout_body.h: reward_phase)
+    const bool go2 = task->kind == DIAL_TASK_GO2_WALK || task->kind == DIAL_TASK_GO2_SEQ_JUMP;
+    const bool h1 = task->kind == DIAL_TASK_H1_WALK || task->kind == DIAL_TASK_H1_LOCO;
+    if ((go2 && task->nfeet != 4) || (h1 && task->nfeet != 2))
+      return fail(nullptr, DIAL_ERR_ARG, "dial_create: task.nfeet must be 4 for the Go2 tasks and 2 for the H1 tasks");
+  }
   if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
   if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)
@@ -492,9 +498,10 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;
     };
     int urc;
-    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd)) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd)) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
+    const auto kind_ok = [&](uint32_t mask) { return ((mask >> task->kind) & 1u) != 0; };   // the robot's own task kinds only
+    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>())) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1>())) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
+    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1Loco>())) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else if (model->cone == DIAL_CONE_ELLIPTIC) {
       if (!(dims_match<DimsAllegro>(model) && ell_fits<DimsAllegro>(model, &ctx->hd))) {
         dial_destroy(ctx);

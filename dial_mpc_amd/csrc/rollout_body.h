@@ -1096,6 +1096,15 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   DIAL_MARK(w, 8);
 }
 
+// Task kinds a kernel instantiation can be asked to run (the dimension-specialised ones are per robot; dial_create checks).
+template <class D>
+constexpr uint32_t task_kind_mask() {
+  if (std::is_same<typename D::Topo, TopoGo2>::value) return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP);
+  if (std::is_same<typename D::Topo, TopoH1>::value) return 1u << DIAL_TASK_H1_WALK;
+  if (std::is_same<typename D::Topo, TopoH1Loco>::value) return 1u << DIAL_TASK_H1_LOCO;
+  return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP) | (1u << DIAL_TASK_H1_WALK) | (1u << DIAL_TASK_H1_LOCO);
+}
+
 // Velocity command of one env.step (unitree_go2_env.py:142-155, unitree_h1_env.py:199-212): component k < 3 of the linear,
 // k - 3 of the angular command.  With randomize_tasks the command of a step whose (pre-increment) index is a multiple of
 // 500 is the episode's entry of dial_task::cmd_table -- and ONLY of that step: upstream does not store the sampled command,
@@ -1235,211 +1244,229 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   // The terms are independent scalar chains.  One term per lane sounds parallel but is not: lanes that take different
   // branches are SERIALISED by the SIMD, each chain paying the ~10-cycle dependent-issue latency on its own.  Instead ONE
   // lane evaluates all of them in straight-line code (term index = compile-time constant): the scheduler interleaves the
-  // independent chains, which then issue back to back.
-  auto term = [&](auto IT) -> float {
-    constexpr int it = decltype(IT)::value;
-    const float dt = m->dt;
-    const int tb = m->torso_x + 1, ub = m->upright_x + 1;
-    float* info = s.info;
-    const float step = info[DIAL_INFO_STEP];
-    // torso / upright-body state, fetched once up front by every term lane (same addresses: LDS broadcasts, one
-    // round trip) instead of inside the divergent branches, where each term would pay its own dependent fetch
-    const float tq[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
-    const float uq[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
-    const float tp[3] = {s.xpos[3 * tb], s.xpos[3 * tb + 1], s.xpos[3 * tb + 2]};
-    const float* cmr = s.com + 3 * m->body_rootid[tb];
-    const float tcom[3] = {cmr[0], cmr[1], cmr[2]};
-    const float tv[6] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2], s.cvel[6 * tb + 3], s.cvel[6 * tb + 4], s.cvel[6 * tb + 5]};
-    const float yaw_tar0 = info[DIAL_INFO_YAW_TAR], pos_tar_z = info[DIAL_INFO_POS_TAR + 2];
-    float cmd[6];
-    if (walk) step_cmd(m, tg, step, cmd);   // this step's velocity command (randomize_tasks: the episode's draw)
-    float out = 0.f;
-    if (it == 0) {
-      if (walk) {
-        float reward_gaits = 0.f;
-        for (int f = 0; f < m->nfeet; f++) {
-          const float z_tar = s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
-          float fz;
-          if (m->kind == DIAL_TASK_GO2_WALK) {
-            float e = (z_tar - zs) / 0.05f;
-            reward_gaits += e * e;
-            fz = zs - m->foot_radius;
-          } else if (m->kind == DIAL_TASK_H1_WALK) {
-            float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
-            reward_gaits += (z_tar - zf) * (z_tar - zf);
-            fz = zs;
-          } else {  // H1 loco: four contacts per foot (unitree_h1_env.py:746-752)
-            float zf = dm::fminf_(dm::fminf_(s.cdist[4 * f], s.cdist[4 * f + 1]), dm::fminf_(s.cdist[4 * f + 2], s.cdist[4 * f + 3]));
-            reward_gaits += (z_tar - zf) * (z_tar - zf);
-            fz = zs;
-          }
-          if (FULL_INFO) {
-            const bool contact = fz < 1e-3f;
-            const bool filt = contact || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
-            info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
-            info[DIAL_INFO_LAST_CONTACT + f] = contact ? 1.f : 0.f;
-          }
-        }
-        out = -reward_gaits;
-      } else {
-        const int stage = (int)info[DIAL_INFO_STAGE];
-        float reward_contact = 0.f, penalty_contact = 0.f;
-        for (int i = 0; i < 4; i++) {
-          bool pen = s.cdist[i] <= 0.001f;
-          for (int j = 0; j < m->n_stage; j++) {
-            float dx = s.cpos[3 * i] - tg->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - tg->contact_targets[j][i][1];
-            bool cond = (dx * dx + dy * dy) <= tg->contact_radius[j][i] * tg->contact_radius[j][i];
-            float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
-            reward_contact += cond ? val : 0.f;
-            pen = pen && !cond;
-          }
-          penalty_contact += pen ? 1.f : 0.f;
-        }
-        out = reward_contact;
-        s.rpart[4] = penalty_contact;
-      }
-    } else if (it == 1) {
-      float rot_u[4] = {uq[0], uq[1], uq[2], uq[3]};
-      float up[3] = {0.f, 0.f, 1.f}, vec[3];
-      dm::rotate(vec, up, rot_u);
-      out = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
-    } else if (it == 2) {
-      float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
-      const float yaw = quat_yaw(rot_t);
-      if (walk) {
-        const float a2 = cmd[5];
-        const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
-        const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
-        // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
-        const float wy = d_yaw - 6.283185307179586f * DM_RINT(d_yaw * 0.15915494309189535f);
-        out = -(wy * wy);
-      } else {
-        const float ey = yaw - tg->yaw_targets[(int)info[DIAL_INFO_STAGE]];
-        out = -(ey * ey);
-      }
-    } else if (it == 3 || it == 4) {
-      if (walk) {
-        float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
-        float off[3] = {tp[0] - tcom[0], tp[1] - tcom[1], tp[2] - tcom[2]};
-        float ang[3] = {tv[0], tv[1], tv[2]};
-        if (it == 3) {
-          float cr[3], vel[3], vb[3];
-          dm::cross3(cr, off, ang);
-          for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
-          dm::inv_rotate(vb, vel, rot_t);
-          float vt[2];
-          for (int k = 0; k < 2; k++) { const float v = cmd[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
-          const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
-          out = -(e0 * e0 + e1 * e1);
-        } else {
-          float ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
-          dm::inv_rotate(ab, angs, rot_t);
-          if (m->kind == DIAL_TASK_H1_LOCO) {   // all three components (unitree_h1_env.py:797)
-            float e3 = 0.f;
-            for (int k = 0; k < 3; k++) {
-              const float a = cmd[3 + k];
-              const float e = ab[k] - dm::fminf_(a * step * dt / m->ramp_up_time, a);
-              e3 += e * e;
+  // independent chains, which then issue back to back.  For that the whole phase has to be ONE basic block: the task kind
+  // is therefore a compile-time constant inside (`reward_phase(KIND)`, dispatched once, wave-uniformly, below) -- with the
+  // kind tested at run time inside every term, each term was its own chain of blocks and the ~400 instructions issued one
+  // dependent instruction after the other (4.7 k cycles per step, round 3 section profile).
+  auto reward_phase = [&](auto KIND) {
+    constexpr int kind = decltype(KIND)::value;
+    constexpr bool walk = kind == DIAL_TASK_GO2_WALK || kind == DIAL_TASK_H1_WALK || kind == DIAL_TASK_H1_LOCO;
+    constexpr int NF = (kind == DIAL_TASK_GO2_WALK || kind == DIAL_TASK_GO2_SEQ_JUMP) ? 4 : 2;   // feet (dial_create checks task.nfeet)
+    auto term = [&](auto IT, const float* cmd) -> float {
+      constexpr int it = decltype(IT)::value;
+      const float dt = m->dt;
+      const int tb = m->torso_x + 1, ub = m->upright_x + 1;
+      float* info = s.info;
+      const float step = info[DIAL_INFO_STEP];
+      // torso / upright-body state, fetched once up front by every term lane (same addresses: LDS broadcasts, one
+      // round trip) instead of inside the divergent branches, where each term would pay its own dependent fetch
+      const float tq[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+      const float uq[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+      const float tp[3] = {s.xpos[3 * tb], s.xpos[3 * tb + 1], s.xpos[3 * tb + 2]};
+      const float* cmr = s.com + 3 * m->body_rootid[tb];
+      const float tcom[3] = {cmr[0], cmr[1], cmr[2]};
+      const float tv[6] = {s.cvel[6 * tb], s.cvel[6 * tb + 1], s.cvel[6 * tb + 2], s.cvel[6 * tb + 3], s.cvel[6 * tb + 4], s.cvel[6 * tb + 5]};
+      const float yaw_tar0 = info[DIAL_INFO_YAW_TAR], pos_tar_z = info[DIAL_INFO_POS_TAR + 2];
+      float out = 0.f;
+      if (it == 0) {
+        if (walk) {
+          float reward_gaits = 0.f;
+  #pragma unroll
+          for (int f = 0; f < NF; f++) {
+            const float z_tar = s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
+            float fz;
+            if (kind == DIAL_TASK_GO2_WALK) {
+              float e = (z_tar - zs) / 0.05f;
+              reward_gaits += e * e;
+              fz = zs - m->foot_radius;
+            } else if (kind == DIAL_TASK_H1_WALK) {
+              float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
+              reward_gaits += (z_tar - zf) * (z_tar - zf);
+              fz = zs;
+            } else {  // H1 loco: four contacts per foot (unitree_h1_env.py:746-752)
+              float zf = dm::fminf_(dm::fminf_(s.cdist[4 * f], s.cdist[4 * f + 1]), dm::fminf_(s.cdist[4 * f + 2], s.cdist[4 * f + 3]));
+              reward_gaits += (z_tar - zf) * (z_tar - zf);
+              fz = zs;
             }
-            out = -e3;
-          } else {
-            const float a2 = cmd[5];
-            const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
-            out = -(ea * ea);
+            if (FULL_INFO) {
+              const bool contact = fz < 1e-3f;
+              const bool filt = contact || (info[DIAL_INFO_LAST_CONTACT + f] != 0.f);
+              info[DIAL_INFO_AIR_TIME + f] = (info[DIAL_INFO_AIR_TIME + f] + dt) * (filt ? 0.f : 1.f);
+              info[DIAL_INFO_LAST_CONTACT + f] = contact ? 1.f : 0.f;
+            }
           }
+          out = -reward_gaits;
+        } else {
+          const int stage = (int)info[DIAL_INFO_STAGE];
+          float reward_contact = 0.f, penalty_contact = 0.f;
+          for (int i = 0; i < 4; i++) {
+            bool pen = s.cdist[i] <= 0.001f;
+            for (int j = 0; j < m->n_stage; j++) {
+              float dx = s.cpos[3 * i] - tg->contact_targets[j][i][0], dy = s.cpos[3 * i + 1] - tg->contact_targets[j][i][1];
+              bool cond = (dx * dx + dy * dy) <= tg->contact_radius[j][i] * tg->contact_radius[j][i];
+              float val = (j == stage ? 1.f : 0.f) * dm::clip(s.cdist[i] * -1.0f + 1.0f, 0.f, 1.f);
+              reward_contact += cond ? val : 0.f;
+              pen = pen && !cond;
+            }
+            penalty_contact += pen ? 1.f : 0.f;
+          }
+          out = reward_contact;
+          s.rpart[4] = penalty_contact;
         }
-      } else if (it == 3) {
-        const int stage = (int)info[DIAL_INFO_STAGE];
-        float rp = 0.f;
-        for (int k = 0; k < 3; k++) { float e = tp[k] - tg->pose_targets[stage][k]; rp += e * e; }
-        out = -rp;
-      } else {
-        return s.rpart[4];  // seq-jump: the penalty count, written by term 0
-      }
-    } else if (it == 5) {
-      const float dh = tp[2] - pos_tar_z;
-      out = -(dh * dh);
-    } else if (it == 6) {
-      float reward_energy = 0.f;
-      if (m->kind == DIAL_TASK_H1_WALK)
-        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
-      if (m->kind == DIAL_TASK_H1_LOCO) {   // energy uses the post-step qvel; foot-level term shares this lane
-        for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1] * s.qvel[6 + a] / 160.0f; reward_energy += e * e; }
-        float lvl = 0.f;
-        for (int f = 0; f < 2; f++) {
-          const int si = m->feet_site[f], sb = m->site_bodyid[si];
-          float bq[4] = {s.xquat[4 * sb], s.xquat[4 * sb + 1], s.xquat[4 * sb + 2], s.xquat[4 * sb + 3]};
-          float sq[4] = {m->site_quat[si][0], m->site_quat[si][1], m->site_quat[si][2], m->site_quat[si][3]};
-          float q[4], mat[9];
-          dm::quat_mul(q, bq, sq);
-          dm::quat_to_mat(mat, q);
-          lvl += (mat[2] - 0.f) * (mat[2] - 0.f) + (mat[5] - 0.f) * (mat[5] - 0.f) + (mat[8] - 1.f) * (mat[8] - 1.f);
+      } else if (it == 1) {
+        float rot_u[4] = {uq[0], uq[1], uq[2], uq[3]};
+        float up[3] = {0.f, 0.f, 1.f}, vec[3];
+        dm::rotate(vec, up, rot_u);
+        out = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
+      } else if (it == 2) {
+        float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
+        const float yaw = quat_yaw(rot_t);
+        if (walk) {
+          const float a2 = cmd[5];
+          const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+          const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
+          // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
+          const float wy = d_yaw - 6.283185307179586f * DM_RINT(d_yaw * 0.15915494309189535f);
+          out = -(wy * wy);
+        } else {
+          const float ey = yaw - tg->yaw_targets[(int)info[DIAL_INFO_STAGE]];
+          out = -(ey * ey);
         }
-        out = -reward_energy;
-        s.rpart[8] = -lvl;                                 // foot-level term (slot 8)
+      } else if (it == 3 || it == 4) {
+        if (walk) {
+          float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
+          float off[3] = {tp[0] - tcom[0], tp[1] - tcom[1], tp[2] - tcom[2]};
+          float ang[3] = {tv[0], tv[1], tv[2]};
+          if (it == 3) {
+            float cr[3], vel[3], vb[3];
+            dm::cross3(cr, off, ang);
+            for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
+            dm::inv_rotate(vb, vel, rot_t);
+            float vt[2];
+            for (int k = 0; k < 2; k++) { const float v = cmd[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+            const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
+            out = -(e0 * e0 + e1 * e1);
+          } else {
+            float ab[3], angs[3] = {ang[0] * DIAL_PI / 180.0f, ang[1] * DIAL_PI / 180.0f, ang[2] * DIAL_PI / 180.0f};
+            dm::inv_rotate(ab, angs, rot_t);
+            if (kind == DIAL_TASK_H1_LOCO) {   // all three components (unitree_h1_env.py:797)
+              float e3 = 0.f;
+              for (int k = 0; k < 3; k++) {
+                const float a = cmd[3 + k];
+                const float e = ab[k] - dm::fminf_(a * step * dt / m->ramp_up_time, a);
+                e3 += e * e;
+              }
+              out = -e3;
+            } else {
+              const float a2 = cmd[5];
+              const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+              out = -(ea * ea);
+            }
+          }
+        } else if (it == 3) {
+          const int stage = (int)info[DIAL_INFO_STAGE];
+          float rp = 0.f;
+          for (int k = 0; k < 3; k++) { float e = tp[k] - tg->pose_targets[stage][k]; rp += e * e; }
+          out = -rp;
+        } else {
+          return s.rpart[4];  // seq-jump: the penalty count, written by term 0
+        }
+      } else if (it == 5) {
+        const float dh = tp[2] - pos_tar_z;
+        out = -(dh * dh);
+      } else if (it == 6) {
+        float reward_energy = 0.f;
+        if (kind == DIAL_TASK_H1_WALK)
+          for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
+        if (kind == DIAL_TASK_H1_LOCO) {   // energy uses the post-step qvel; foot-level term shares this lane
+          for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1] * s.qvel[6 + a] / 160.0f; reward_energy += e * e; }
+          float lvl = 0.f;
+          for (int f = 0; f < 2; f++) {
+            const int si = m->feet_site[f], sb = m->site_bodyid[si];
+            float bq[4] = {s.xquat[4 * sb], s.xquat[4 * sb + 1], s.xquat[4 * sb + 2], s.xquat[4 * sb + 3]};
+            float sq[4] = {m->site_quat[si][0], m->site_quat[si][1], m->site_quat[si][2], m->site_quat[si][3]};
+            float q[4], mat[9];
+            dm::quat_mul(q, bq, sq);
+            dm::quat_to_mat(mat, q);
+            lvl += (mat[2] - 0.f) * (mat[2] - 0.f) + (mat[5] - 0.f) * (mat[5] - 0.f) + (mat[8] - 1.f) * (mat[8] - 1.f);
+          }
+          out = -reward_energy;
+          s.rpart[8] = -lvl;                                 // foot-level term (slot 8)
+        } else {
+          out = -reward_energy;
+        }
       } else {
-        out = -reward_energy;
+        float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
+        float up[3] = {0.f, 0.f, 1.f}, upv[3];
+        dm::rotate(upv, up, rot_t);
+        bool done = upv[2] < 0.f;
+        for (int a = 0; a < nu; a++) {
+          float q = s.qpos[7 + a];
+          done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
+        }
+        done = done || tp[2] < m->done_height;
+        out = done ? 1.f : 0.f;
       }
-    } else {
-      float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
-      float up[3] = {0.f, 0.f, 1.f}, upv[3];
-      dm::rotate(upv, up, rot_t);
-      bool done = upv[2] < 0.f;
-      for (int a = 0; a < nu; a++) {
-        float q = s.qpos[7 + a];
-        done = done || q < m->joint_range[a][0] || q > m->joint_range[a][1];
+      return out;
+    };
+    // ---- terms, total in the reference's summation order and info update (one lane; last_ctrl by nu lanes)
+    w.items(1 + nu, [&](int it) {
+      float* info = s.info;
+      if (it > 0) {
+        if (!walk) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
+        return;
       }
-      done = done || tp[2] < m->done_height;
-      out = done ? 1.f : 0.f;
-    }
-    return out;
+      // this step's velocity command, once for all terms (randomize_tasks: the episode's draw -- the only branch left
+      // between here and the end of the phase)
+      float cmd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (walk) step_cmd(m, tg, info[DIAL_INFO_STEP], cmd);
+      float r[9];
+      r[0] = term(std::integral_constant<int, 0>{}, cmd);
+      r[1] = term(std::integral_constant<int, 1>{}, cmd);
+      r[2] = term(std::integral_constant<int, 2>{}, cmd);
+      r[3] = term(std::integral_constant<int, 3>{}, cmd);
+      r[4] = term(std::integral_constant<int, 4>{}, cmd);
+      r[5] = term(std::integral_constant<int, 5>{}, cmd);
+      r[6] = term(std::integral_constant<int, 6>{}, cmd);
+      r[7] = FULL_INFO ? term(std::integral_constant<int, 7>{}, cmd) : 0.f;
+      r[8] = kind == DIAL_TASK_H1_LOCO ? s.rpart[8] : 0.f;      // foot-level term, written by term 6
+      const float dt = m->dt, step = info[DIAL_INFO_STEP];
+      float reward;
+      if (kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239
+        reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;
+      } else if (kind == DIAL_TASK_H1_WALK) {    // unitree_h1_env.py:286-298
+        reward = r[0] * 5.0f + r[1] * 0.5f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f;
+      } else if (kind == DIAL_TASK_H1_LOCO) {    // unitree_h1_env.py:812-827
+        reward = r[0] * 10.0f + r[1] * 0.5f + r[2] * 0.5f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f +
+                 r[8] * 0.02f + r[6] * 0.01f;
+      } else {                                      // unitree_go2_env.py:485-496
+        reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
+      }
+      if (walk) {
+        for (int k = 0; k < 3; k++) {
+          const float v = cmd[k], a = cmd[3 + k];
+          info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
+          info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
+        }
+      }
+      if (FULL_INFO) info[DIAL_INFO_DONE] = r[7];
+      info[DIAL_INFO_STEP] = step + 1.f;
+      if (kind == DIAL_TASK_GO2_SEQ_JUMP) {
+        float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / m->jump_dt);
+        info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(m->n_stage - 1));
+      }
+      info[DIAL_INFO_REWARD] = reward;
+    });
   };
-  // ---- terms, total in the reference's summation order and info update (one lane; last_ctrl by nu lanes)
-  w.items(1 + nu, [&](int it) {
-    float* info = s.info;
-    if (it > 0) {
-      if (!walk) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
-      return;
-    }
-    float r[9];
-    r[0] = term(std::integral_constant<int, 0>{});
-    r[1] = term(std::integral_constant<int, 1>{});
-    r[2] = term(std::integral_constant<int, 2>{});
-    r[3] = term(std::integral_constant<int, 3>{});
-    r[4] = term(std::integral_constant<int, 4>{});
-    r[5] = term(std::integral_constant<int, 5>{});
-    r[6] = term(std::integral_constant<int, 6>{});
-    r[7] = FULL_INFO ? term(std::integral_constant<int, 7>{}) : 0.f;
-    r[8] = m->kind == DIAL_TASK_H1_LOCO ? s.rpart[8] : 0.f;      // foot-level term, written by term 6
-    const float dt = m->dt, step = info[DIAL_INFO_STEP];
-    float reward;
-    if (m->kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239
-      reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;
-    } else if (m->kind == DIAL_TASK_H1_WALK) {    // unitree_h1_env.py:286-298
-      reward = r[0] * 5.0f + r[1] * 0.5f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f;
-    } else if (m->kind == DIAL_TASK_H1_LOCO) {    // unitree_h1_env.py:812-827
-      reward = r[0] * 10.0f + r[1] * 0.5f + r[2] * 0.5f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f +
-               r[8] * 0.02f + r[6] * 0.01f;
-    } else {                                      // unitree_go2_env.py:485-496
-      reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
-    }
-    if (walk) {
-      float cmd[6];
-      step_cmd(m, tg, step, cmd);
-      for (int k = 0; k < 3; k++) {
-        const float v = cmd[k], a = cmd[3 + k];
-        info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);
-        info[DIAL_INFO_ANG_VEL_TAR + k] = dm::fminf_(a * step * dt / m->ramp_up_time, a);
-      }
-    }
-    if (FULL_INFO) info[DIAL_INFO_DONE] = r[7];
-    info[DIAL_INFO_STEP] = step + 1.f;
-    if (m->kind == DIAL_TASK_GO2_SEQ_JUMP) {
-      float st = DM_FLOOR(info[DIAL_INFO_STEP] * dt / m->jump_dt);
-      info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(m->n_stage - 1));
-    }
-    info[DIAL_INFO_REWARD] = reward;
-  });
+  // wave-uniform dispatch on the task kind; a dimension-specialised instantiation only carries its robot's kinds
+  {
+    constexpr uint32_t kmask = task_kind_mask<typename M::D>();
+    const int kind_u = DM_UNIFORM_I(m->kind);
+    if ((kmask >> DIAL_TASK_GO2_WALK & 1u) && kind_u == DIAL_TASK_GO2_WALK) reward_phase(std::integral_constant<int, DIAL_TASK_GO2_WALK>{});
+    else if ((kmask >> DIAL_TASK_GO2_SEQ_JUMP & 1u) && kind_u == DIAL_TASK_GO2_SEQ_JUMP) reward_phase(std::integral_constant<int, DIAL_TASK_GO2_SEQ_JUMP>{});
+    else if ((kmask >> DIAL_TASK_H1_WALK & 1u) && kind_u == DIAL_TASK_H1_WALK) reward_phase(std::integral_constant<int, DIAL_TASK_H1_WALK>{});
+    else if ((kmask >> DIAL_TASK_H1_LOCO & 1u) && kind_u == DIAL_TASK_H1_LOCO) reward_phase(std::integral_constant<int, DIAL_TASK_H1_LOCO>{});
+  }
   DIAL_MARK(w, 10);
   return s.info[DIAL_INFO_REWARD];
 }
