@@ -23,10 +23,27 @@ class DialHipError(RuntimeError):
     pass
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/dial_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+IEEE_LIB_PATH = os.path.join(_CSRC, "libdialhip_ieee.so")
+
+
+def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str:
+    """Compile csrc/dial_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    ieee=True builds the MEASUREMENT variant libdialhip_ieee.so: the same source without the device fast-math flags below
+    (correctly rounded divide / sqrt, no reciprocal-math, no approximate functions, NaNs honoured).  It is never the product
+    path; the GPU suite loads it next to the product library to show how much of the knife-edge witness traffic is the
+    fast-math rounding (tests/test_gpu_parity.py: test_ieee_build_needs_no_more_witnesses)."""
     # every source of the library takes part in the staleness check (a stale .so must never ship silently)
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip"))) + [_abi.HEADER]
+    if ieee:
+        if not force and os.path.exists(IEEE_LIB_PATH) and all(os.path.getmtime(IEEE_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return IEEE_LIB_PATH
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Xarch_device", "-fno-slp-vectorize", "-o", IEEE_LIB_PATH, os.path.join(_CSRC, "dial_hip.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return IEEE_LIB_PATH
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -48,14 +65,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-def load():
+def load(path: Optional[str] = None):
+    """The product library (cached), or -- path given -- another build of it (measurement variants; not cached)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DialHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    lib_path = LIB_PATH if path is None else path
+    if not os.path.exists(lib_path):
+        raise DialHipError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is the only compute path; there is no CPU fallback)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(lib_path)
     vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
     lib.dial_create.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci]
     lib.dial_create_sharded.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci, ci]
@@ -85,7 +104,8 @@ def load():
     lib.dial_debug_scratch.argtypes = [vp] + [ctypes.POINTER(vp)] * 6
     lib.dial_lds_bytes.argtypes = [vp]
     lib.dial_debug_resident_rollouts.argtypes = [vp, ctypes.c_int]
-    _lib = lib
+    if path is None:
+        _lib = lib
     return lib
 
 
@@ -111,10 +131,11 @@ class Context:
     """One dial_ctx: (device, model, task, cfg).  Not thread-safe (C ABI contract)."""
 
     def __init__(self, model: "_abi.DialModel", task: "_abi.DialTask", cfg: Optional["_abi.DialCfg"],
-                 device: Optional[int] = None, n_local_cap: Optional[int] = None):
-        """n_local_cap: size the rollout scratch for that many local samples (one rank of a sharded run)."""
+                 device: Optional[int] = None, n_local_cap: Optional[int] = None, lib_path: Optional[str] = None):
+        """n_local_cap: size the rollout scratch for that many local samples (one rank of a sharded run).
+        lib_path: another build of the library (measurement variants, e.g. libdialhip_ieee.so)."""
         import torch
-        self.lib = load()
+        self.lib = load(lib_path)
         if not torch.cuda.is_available():
             raise DialHipError("no HIP device visible to PyTorch: the DIAL-MPC kernels only run on a GPU")
         self.device = torch.cuda.current_device() if device is None else int(device)

@@ -797,3 +797,36 @@ def test_randomize_tasks_across_the_500_step_boundary(example):
             assert np.allclose(info[7:10], np.minimum(np.array([0.0, 0.0, e[2]]) * 500 * ec.dt / ec.ramp_up_time, [0.0, 0.0, e[2]]), atol=1e-6)
     assert np.array_equal(outs[True][:, :6], outs[False][:, :6])
     assert np.all(np.abs(outs[True][:, 6] - outs[False][:, 6]) > 1e-4)
+
+
+@pytest.mark.parametrize("example,H", [("unitree_go2_seq_jump", 20), ("unitree_h1_loco", 20)])
+def test_ieee_build_needs_no_more_witnesses(example, H):
+    """How much of the knife-edge traffic is the device's fast-math rounding (v_rcp / v_rsq divide and sqrt, approximate
+    functions)?  The same source built WITHOUT those flags (libdialhip_ieee.so, a measurement variant) runs the stress
+    cases of the two envs with the most witnesses next to the product library: the IEEE build must not need more, and
+    both counts are printed (the product's flags are a rounding choice inside the type the reference computes in, not a
+    source of additional branches)."""
+    import os
+    import oracle as O
+    from dial_mpc_amd import _lib
+    if not os.path.exists(_lib.IEEE_LIB_PATH):
+        pytest.skip("libdialhip_ieee.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    dc, env, model, task, cfg = setup_case(example, 192, H, per_rollout=True)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    counts = {}
+    for name, path in (("fast-math (product)", None), ("IEEE", _lib.IEEE_LIB_PATH)):
+        ctx = _lib.Context(model, task, cfg, lib_path=path)
+        outside = 0
+        for seed in range(4):
+            q, qd = (env._init_q, np.zeros(model.nv)) if seed == 0 else perturbed_state(env, seed)
+            s0, _, _ = o32.env_reset(q, qd)
+            eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=seed, Ybar_scale=0.3)
+            ro = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+            ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+            sc = ctx.debug_scratch()
+            rep = witness_parity(o32, s0, ro["us"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), example,
+                                 model.nq + 2 * model.nv, max_frac=0.1)
+            outside += rep["outside_tol"]
+        counts[name] = outside
+    print(f"{example}: rollouts outside the per-step gate (all witnessed), of {4 * 193}: {counts}")
+    assert counts["IEEE"] <= counts["fast-math (product)"] + 3
