@@ -202,34 +202,33 @@ class Context:
         return rewss, qss, qdss, xss
 
     # ---- K1..K4
-    def reverse_once(self, state, Ybar, noise_scale, eps, out=None):
+    def _out(self, want_bars: bool):
         import torch
         cfg, dev = self.cfg, self.torch_device
         N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        return dict(Ybar=torch.empty((Hn1, self.nu), **f32), rews=torch.empty(N + 1, **f32),
+                    qbar=torch.empty((T, self.nq), **f32) if want_bars else None,
+                    qdbar=torch.empty((T, self.nv), **f32) if want_bars else None,
+                    xbar=torch.empty((T, self.nx), **f32) if want_bars else None)
+
+    def reverse_once(self, state, Ybar, noise_scale, eps, out=None, want_bars: bool = True):
+        """want_bars=False: qbar / qdbar / xbar are None and the rollouts do not write their per-step states."""
+        cfg = self.cfg
+        N, Hn1 = cfg.Nsample, cfg.Hnode + 1
         assert tuple(eps.shape) == (N, Hn1, self.nu) and tuple(Ybar.shape) == (Hn1, self.nu)
         ns = int(noise_scale.numel())
         if out is None:
-            out = dict(Ybar=torch.empty((Hn1, self.nu), dtype=torch.float32, device=dev),
-                       rews=torch.empty(N + 1, dtype=torch.float32, device=dev),
-                       qbar=torch.empty((T, self.nq), dtype=torch.float32, device=dev),
-                       qdbar=torch.empty((T, self.nv), dtype=torch.float32, device=dev),
-                       xbar=torch.empty((T, self.nx), dtype=torch.float32, device=dev))
+            out = self._out(want_bars)
         self._check(self.lib.dial_reverse_once(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale), ns, _ptr(eps),
                                                _ptr(out["Ybar"]), _ptr(out["rews"]), _ptr(out["qbar"]),
                                                _ptr(out["qdbar"]), _ptr(out["xbar"]), _stream()), "dial_reverse_once")
         return out
 
-    def reverse_once_rng(self, state, Ybar, noise_scale, seed: int, counter: int, out=None):
+    def reverse_once_rng(self, state, Ybar, noise_scale, seed: int, counter: int, out=None, want_bars: bool = True):
         """reverse_once with the noise generated inside the rollout kernel (Philox keyed by seed / counter)."""
-        import torch
-        cfg, dev = self.cfg, self.torch_device
-        N, Hn1, T = cfg.Nsample, cfg.Hnode + 1, cfg.Hsample + 1
         if out is None:
-            out = dict(Ybar=torch.empty((Hn1, self.nu), dtype=torch.float32, device=dev),
-                       rews=torch.empty(N + 1, dtype=torch.float32, device=dev),
-                       qbar=torch.empty((T, self.nq), dtype=torch.float32, device=dev),
-                       qdbar=torch.empty((T, self.nv), dtype=torch.float32, device=dev),
-                       xbar=torch.empty((T, self.nx), dtype=torch.float32, device=dev))
+            out = self._out(want_bars)
         self._check(self.lib.dial_reverse_once_rng(self.h, _ptr(state), _ptr(Ybar), _ptr(noise_scale),
                                                    int(noise_scale.numel()), int(seed), int(counter), _ptr(out["Ybar"]),
                                                    _ptr(out["rews"]), _ptr(out["qbar"]), _ptr(out["qdbar"]),

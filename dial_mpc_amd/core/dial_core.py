@@ -122,8 +122,10 @@ class MBDPI:
         return gen, eps
 
     def reverse_once(self, state, rng, Ybar_i, noise_scale, eps=None, want_bars: bool = True):
-        """want_bars=False skips qbar/qdbar/xbar (None in info); in a sharded run this also drops the
-        all-reduce, leaving one collective per annealing iteration (core/sharding.py)."""
+        """want_bars=False skips qbar/qdbar/xbar (None in info): the rollouts then do not write their per-step states and K4b
+        sums the candidate nodes only; in a sharded run this also drops the all-reduce, leaving one collective per annealing
+        iteration (core/sharding.py).  The drivers ask for the bars on the last iteration of a plan only, as upstream reads
+        them (dial_core.py:262-264, dial_plan.py:214-215)."""
         import torch
         packed = _packed(state)
         if eps is None and self.kernel_rng:
@@ -133,7 +135,7 @@ class MBDPI:
             counter = self._rng_counter
             self._rng_counter += 1
             if self.world == 1 and not self._force_sharded:
-                out = self.ctx.reverse_once_rng(packed, Yb, nsc, int(self.args.seed), counter)
+                out = self.ctx.reverse_once_rng(packed, Yb, nsc, int(self.args.seed), counter, want_bars=want_bars)
                 Ybar, rews, qbar, qdbar, xbar = out["Ybar"], out["rews"], out["qbar"], out["qdbar"], out["xbar"]
             else:   # sharded: every rank draws its own shard's noise (and, for the mean action, everybody's) in-kernel
                 Ybar, rews, qbar, qdbar, xbar = self._reverse_once_sharded(packed, Yb, nsc, None, want_bars,
@@ -146,7 +148,7 @@ class MBDPI:
         noise_scale = torch.as_tensor(noise_scale, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
         T, nb1 = self.args.Hsample + 1, self.ctx.nbody - 1
         if self.world == 1 and not self._force_sharded:
-            out = self.ctx.reverse_once(packed, Ybar_i, noise_scale, eps.contiguous())
+            out = self.ctx.reverse_once(packed, Ybar_i, noise_scale, eps.contiguous(), want_bars=want_bars)
             Ybar, rews = out["Ybar"], out["rews"]
             qbar, qdbar, xbar = out["qbar"], out["qdbar"], out["xbar"]
         else:

@@ -759,7 +759,8 @@ int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, floa
 
 static int shard_rollout_impl(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale,
                               int ns, const float* eps, int use_rng, uint64_t seed, uint32_t counter, int n_begin,
-                              int n_local, int with_mean, float* rews_local, void* stream, const char* who) {
+                              int n_local, int with_mean, float* rews_local, void* stream, const char* who,
+                              bool store_states = true) {
   if (!ctx || !state || !Ybar_in || !noise_scale || (!eps && !use_rng && n_local > 0) || !rews_local)
     return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
   if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": context was created without a dial_cfg");
@@ -768,7 +769,8 @@ static int shard_rollout_impl(dial_ctx* ctx, const float* state, const float* Yb
   if (n_local < 0 || B < 1 || B > ctx->B_cap || n_begin < 0) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": shard larger than Nsample+1");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
-                     ctx->Y0s, ctx->rewss, rews_local, ctx->qss, ctx->qdss, ctx->xss, ctx->prof,
+                     ctx->Y0s, ctx->rewss, rews_local, store_states ? ctx->qss : nullptr, store_states ? ctx->qdss : nullptr,
+                     store_states ? ctx->xss : nullptr, ctx->prof,
                      use_rng, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter, n_begin};
   return launch_rollout(ctx, io, B, (hipStream_t)stream);
 }
@@ -801,16 +803,16 @@ int dial_rng_fill(dial_ctx* ctx, uint64_t seed, uint32_t counter, int n_begin, i
 }
 
 static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_begin, int mean_row, int mean_widx,
-                       float* Yo, float* qo, float* qdo, float* xo, hipStream_t st) {
+                       float* Yo, float* qo, float* qdo, float* xo, hipStream_t st, bool nodes_only = false) {
   const dial_model& m = ctx->hm;
   WsumArgs a;
   const int T = ctx->T;
-  a.nseg = 4;
+  a.nseg = nodes_only ? 1 : 4;   // nodes_only: the weighted mean action alone (the per-step states were not materialised)
   a.seg[0] = {ctx->Y0s, Yo, ctx->Hn1 * m.nu, 0};
   a.seg[1] = {ctx->qss, qo, T * m.nq, a.seg[0].C};
   a.seg[2] = {ctx->qdss, qdo, T * m.nv, a.seg[1].c0 + a.seg[1].C};
   a.seg[3] = {ctx->xss, xo, T * ctx->nx, a.seg[2].c0 + a.seg[2].C};
-  a.Ctot = a.seg[3].c0 + a.seg[3].C;
+  a.Ctot = nodes_only ? a.seg[0].C : a.seg[3].c0 + a.seg[3].C;
   a.n_rows = n_rows; a.w_begin = w_begin; a.mean_row = mean_row; a.mean_widx = mean_widx;
   const int gx = (a.Ctot + 255) / 256;
   hipLaunchKernelGGL(wsum_partial_kernel, dim3((a.Ctot + 63) / 64, WSUM_CHUNKS), dim3(256), 0, st, a, weights, ctx->partial);
@@ -890,12 +892,16 @@ static int reverse_once_impl(dial_ctx* ctx, const float* state, const float* Yba
   if (!ctx || !Ybar_out || !rews) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
   if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": context was created without a dial_cfg");
   const int N = ctx->hc.Nsample;
-  int rc = shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, eps, use_rng, seed, counter, 0, N, 1, rews, stream, who);
+  // qbar == qdbar == xbar == NULL: the caller wants the mean action only (every annealing iteration of a plan but the last,
+  // dial_core.py:262-264 / dial_plan.py:214-215 read the bars of the LAST one) -- the rollouts then do not write their
+  // per-step q / qd / x.pos rows at all (11 MB per launch for Go2) and K4b sums the candidate nodes only
+  const bool bars = qbar || qdbar || xbar;
+  int rc = shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, eps, use_rng, seed, counter, 0, N, 1, rews, stream, who, bars);
   if (rc != DIAL_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
   HIP_TRY(ctx, hipGetLastError());
-  return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st);
+  return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st, !bars);
 }
 
 int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in, const float* noise_scale, int ns,

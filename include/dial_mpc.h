@@ -293,6 +293,8 @@ int dial_rollout(dial_ctx* ctx, const float* state, const float* us, int B, floa
  * Outputs: Ybar_out:[Hnode+1,nu], rews:[n_local+1] (last = mean trajectory), qbar:[T,nq],
  * qdbar:[T,nv], xbar:[T,(nbody-1)*3]; with n_local < Nsample the *_out tensors hold this
  * shard's partial (un-normalised) sums -- see dial_shard_reduce.
+ * qbar, qdbar and xbar may ALL be NULL: the mean action alone is formed and the rollouts do not materialise their per-step
+ * states (what the drivers need from every annealing iteration of a plan but the last, dial_core.py:262-264).
  * Degenerate case, bug-compatible with the reference: when all N+1 mean rewards are identical, std(rews) = 0 and
  * dial_core.py:126 divides 0 by 0 -- every weight and with it Ybar_out / qbar / qdbar / xbar is NaN.             */
 int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in,

@@ -830,3 +830,69 @@ def test_ieee_build_needs_no_more_witnesses(example, H):
         counts[name] = outside
     print(f"{example}: rollouts outside the per-step gate (all witnessed), of {4 * 193}: {counts}")
     assert counts["IEEE"] <= counts["fast-math (product)"] + 3
+
+
+@pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 2048, 16), ("unitree_h1_jog", 300, 12), ("allegro_reorient", 100, 6)])
+def test_mean_action_only_iteration_is_bit_identical(example, N, H):
+    """want_bars=False (qbar = qdbar = xbar = NULL at the C ABI): the rollouts do not write their per-step q / qd / x.pos
+    rows and K4b sums the candidate nodes only -- what every annealing iteration of a plan but the last needs.  Ybar and the
+    rewards must be bit-identical to the full iteration (eps and in-kernel-noise variants), and a following full iteration
+    must be unaffected."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(example, N, H)
+    ctx = _lib.Context(model, task, cfg)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=8, Ybar_scale=0.2)
+    full = {k: v.clone() for k, v in ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps)).items()}
+    lean = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps), want_bars=False)
+    assert lean["qbar"] is None and lean["qdbar"] is None and lean["xbar"] is None
+    assert torch.equal(lean["Ybar"], full["Ybar"]) and torch.equal(lean["rews"], full["rews"])
+    full_r = {k: v.clone() for k, v in ctx.reverse_once_rng(s0, _dev(Ybar), _dev(sigma), 77, 5).items()}
+    lean_r = ctx.reverse_once_rng(s0, _dev(Ybar), _dev(sigma), 77, 5, want_bars=False)
+    assert torch.equal(lean_r["Ybar"], full_r["Ybar"]) and torch.equal(lean_r["rews"], full_r["rews"])
+    again = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    for k in ("Ybar", "rews", "qbar", "qdbar", "xbar"):
+        assert torch.equal(again[k], full[k]), k
+
+
+def test_config5_batch_on_one_gpu_matches_small_batch_kernel_and_oracle():
+    """BASELINE config 5's batch (unitree_go2_trot N = 65536, H = 16) on ONE GPU: the large-batch instantiation (4 wavefronts
+    per workgroup, rollout queue) against (1) the small-batch kernel -- three 2048-sample slices of the same noise rows
+    give bit-identical mean rewards, (2) the oracle -- 96 rollouts drawn from the whole batch, per step, witness gate,
+    (3) K4 in fp64 on the device's own rewards / nodes.  (The 8-GPU run shards this batch 8192 per rank.)"""
+    import torch
+    import oracle as O
+    from dial_mpc_amd import _lib
+    N, H = 65536, 16
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, H, per_rollout=True)
+    ctx = _lib.Context(model, task, cfg)
+    assert 0 < ctx.lib.dial_debug_resident_rollouts(ctx.h, N + 1) < N + 1          # the queue runs
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    s0n, _, _ = o32.env_reset(*perturbed_state(env, 2))
+    s0 = _dev(s0n)
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=11, Ybar_scale=0.2)
+    out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    sc = ctx.debug_scratch()
+    rews = out["rews"].cpu().numpy()
+    # (1) slices through the small-batch kernel
+    dc2, _, model2, task2, cfg2 = setup_case("unitree_go2_trot", 2048, H, per_rollout=True)
+    small = _lib.Context(model2, task2, cfg2)
+    for a in (0, 30000, N - 2048):
+        r2 = small.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps[a:a + 2048]))["rews"].cpu().numpy()
+        assert np.array_equal(r2[:-1], rews[a:a + 2048]) and r2[-1] == rews[-1], a
+    # (2) oracle parity of a sample of rollouts from all over the batch
+    idx = np.concatenate([np.random.default_rng(0).choice(N, 88, replace=False), np.arange(N - 7, N + 1)])
+    W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(H + 1)], np.float32)
+    us = np.einsum("tk,nka->nta", W, sc["Y0s"][idx]).astype(np.float32)
+    rep = witness_parity(o32, s0n, us, tuple(sc[k][idx] for k in ("rewss", "qss", "qdss", "xss")), "unitree_go2_trot",
+                         model.nq + 2 * model.nv, max_frac=0.05)
+    assert rep["rollouts"] == 96
+    # (3) K4 on the device == fp64 K4 of the device's own rollouts
+    r64 = rews.astype(np.float64)
+    logp = (r64 - r64[-1]) / r64.std() / float(cfg.temp_sample)
+    w_ref = np.exp(logp - logp.max())
+    w_ref /= w_ref.sum()
+    assert np.allclose(sc["weights"], w_ref, rtol=5e-3, atol=1e-9)
+    assert np.allclose(out["Ybar"].cpu().numpy(), np.einsum("n,nka->ka", w_ref, sc["Y0s"].astype(np.float64)), atol=1e-4)
+    assert np.allclose(out["xbar"].cpu().numpy(), np.einsum("n,nti->ti", w_ref, sc["xss"].astype(np.float64)), atol=1e-4)
