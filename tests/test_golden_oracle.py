@@ -22,6 +22,8 @@ def test_oracle_reproduces_fixture(name, example, N, H):
         orc = O.Oracle(model, task, cfg, dt)
         r = orc.reverse_once(g["state"], g["Ybar_in"], g["noise_scale"], g["eps"], full=True)
         ok = (np.abs(r["rewss"] - g["rewss"]) <= tol + tol * np.abs(g["rewss"])).all(1)
-        # fp32 vs the fp64 fixture: a rollout through an impact / solver knife edge may leave the fp64 branch
-        assert ok.all() if dt == np.float64 else ok.mean() >= 0.9, (name, dt, float(ok.mean()))
+        # fp32 vs the fp64 fixture: every rollout on the fp64 branch for the legged robots (measured: all of them, Ybar within
+        # 3e-6); ONLY Allegro -- 32 impact-rich physics sub-steps per rollout -- may lose a rollout to another branch
+        chaotic = example == "allegro_reorient"
+        assert ok.all() if (dt == np.float64 or not chaotic) else ok.mean() >= 0.9, (name, dt, float(ok.mean()))
         assert np.allclose(r["Ybar"], g["Ybar"], atol=max(tol, 1e-4) if ok.all() else 2e-2)

@@ -143,8 +143,10 @@ def test_golden_fixtures(name, example, N, H):
     got = ctx.debug_scratch()["rewss"]
     ok = (np.abs(got - g["rewss"]) <= TOL["rewss"]["atol"] + TOL["rewss"]["rtol"] * np.abs(g["rewss"])).all(1)
     # stored fp64-oracle outputs: rollouts through a knife edge / an impact may follow another branch (the per-rollout
-    # witness test is test_reverse_once_matches_oracle_stagewise); the bulk must agree with the stored numbers
-    assert ok.mean() >= 0.9, (name, float(ok.mean()))
+    # witness test is test_reverse_once_matches_oracle_stagewise); the bulk must agree with the stored numbers -- all but one
+    # rollout for the legged robots, 90 % for Allegro's impact-rich rollouts (a self-generated regression net, not parity
+    # evidence: the fixtures are this repo's own fp64 oracle)
+    assert ok.mean() >= (0.9 if example == "allegro_reorient" else 1.0 - 1.5 / ok.size), (name, float(ok.mean()))
     assert _close(out["Ybar"].cpu().numpy(), g["Ybar"], TOL["Ybar"] if ok.all() else dict(rtol=0, atol=2e-2))
 
 

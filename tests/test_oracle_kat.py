@@ -123,9 +123,9 @@ def test_fp32_matches_fp64(go2):
     s0, _, _ = o64.env_reset(env._init_q, np.zeros(18))
     r64 = o64.rollout(s0, us)
     r32 = o32.rollout(s0.astype(np.float32), us.astype(np.float32))
-    # per rollout; a truncated-solver knife edge (conftest.witness_parity) may take one of the eight off the fp64 branch
+    # per rollout (measured: 1.4e-6 in the rewards, 3.7e-6 in q over all eight -- no knife edge in this case)
     dr, dq = np.abs(r64[0] - r32[0]).max(1), np.abs(r64[1] - r32[1]).reshape(8, -1).max(1)
-    assert np.sort(dr)[-2] < 1e-4 and np.sort(dq)[-2] < 1e-4 and dr.max() < 2e-2 and dq.max() < 2e-2, (dr, dq)
+    assert dr.max() < 5e-5 and dq.max() < 5e-5, (dr, dq)
 
 
 def test_reward_lags_action_by_one_step(go2):
