@@ -13,7 +13,7 @@ available everywhere.  The softmax couples all samples through the global std / 
   2b. want_bars=True (last iteration of a plan, whose qbar/qdbar/xbar the drivers read): all-reduce (sum) of the
      packed partial weighted sums [Ybar | qbar | qdbar | xbar] (5.4 KB for Go2).
 
-Both messages are KB-sized, i.e. latency-bound on xGMI.  Every buffer is allocated once (``ShardPlan``); an iteration
+Both messages are KB-sized, i.e. latency-bound on xGMI.  The collective staging buffers are allocated once (``ShardPlan``), results are fresh tensors; an iteration
 is 1 rollout launch + the all-gather + 1 packing launch + 3 K4 launches (+ the all-reduce).  The compute backend is
 passed in as ``ctx`` (``dial_mpc_amd._lib.Context`` in production) so that the partition / collective logic is
 testable with gloo on CPU against a stand-in context.
@@ -64,18 +64,23 @@ def sharded_reverse_once(ctx, dist, rank: int, world: int, N: int, T: int, Hn1: 
     else:
         ctx.shard_rollout(packed_state, Ybar_i, noise_scale, eps[n_begin:n_begin + n_local], n_local, True, plan.send)
     dist.all_gather_into_tensor(plan.gathered, plan.send)
-    ctx.shard_pack_rewards(plan.gathered, world, per, N, plan.rews_all)
+    # Results go into FRESH tensors (allocator bookkeeping, no kernel): callers keep `info` dicts across ticks
+    # (dial_core.main reads xbar of every tick at the very end), so nothing handed out may alias a buffer the next call
+    # writes.  Only the collective's own staging buffers (send / gathered) are reused.
+    import torch
+    rews_all = torch.empty_like(plan.rews_all)
+    ctx.shard_pack_rewards(plan.gathered, world, per, N, rews_all)
     if not want_bars:
+        Ybar = torch.empty_like(plan.Ybar)
         if eps is None:
-            ctx.shard_ybar_rng(plan.rews_all, N, seed, counter, Ybar_i, noise_scale, plan.Ybar)
+            ctx.shard_ybar_rng(rews_all, N, seed, counter, Ybar_i, noise_scale, Ybar)
         else:
-            ctx.shard_ybar(plan.rews_all, N, eps, Ybar_i, noise_scale, plan.Ybar)
-        # fresh tensors: the plan's buffers are reused by the next iteration, callers keep `info` dicts across ticks
-        return plan.Ybar.clone(), plan.rews_all.clone(), None, None, None
-    ctx.shard_reduce(plan.rews_all, N, n_begin, n_local, rank == 0, plan.packed)
-    dist.all_reduce(plan.packed, op=dist.ReduceOp.SUM)
+            ctx.shard_ybar(rews_all, N, eps, Ybar_i, noise_scale, Ybar)
+        return Ybar, rews_all, None, None, None
+    packed = torch.empty_like(plan.packed)
+    ctx.shard_reduce(rews_all, N, n_begin, n_local, rank == 0, packed)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     nq, nv, nx, nu = ctx.nq, ctx.nv, ctx.nx, ctx.nu
-    packed = plan.packed.clone()     # fresh storage for the views handed out below (see above)
     o = 0
     Ybar = packed[o:o + Hn1 * nu].reshape(Hn1, nu)
     o += Hn1 * nu
@@ -84,4 +89,4 @@ def sharded_reverse_once(ctx, dist, rank: int, world: int, N: int, T: int, Hn1: 
     qdbar = packed[o:o + T * nv].reshape(T, nv)
     o += T * nv
     xbar = packed[o:o + T * nx].reshape(T, nx)
-    return Ybar, plan.rews_all.clone(), qbar, qdbar, xbar
+    return Ybar, rews_all, qbar, qdbar, xbar
