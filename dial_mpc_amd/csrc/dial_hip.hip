@@ -45,6 +45,14 @@
 // H1: same idea with 4-wavefront workgroups (one wavefront per SIMD), two per CU: 1.012 -> 0.971 ms.  (H1 loco's
 // two-wavefront workgroups already load every CU with 8 wavefronts; the split measured 0.7 % slower there.)
 #define DIAL_H1_WPB_EVEN 4
+// The even launch keeps exactly 2 wavefronts on every SIMD.  Allegro's 8-wavefront kernel is compiled for that occupancy
+// (more than 168 VGPRs allowed: -3.3 % in the A/B, 7.70 -> 7.45 ms; the one-wavefront mean-trajectory workgroup still finds
+// room).  H1's must stay at the 3-wavefront budget: at 2 its registers leave no SIMD for the mean-trajectory workgroup, which
+// then runs AFTER the even launch (+50 %).
+#ifndef DIAL_EVEN_OCC_ALLEGRO
+#define DIAL_EVEN_OCC_ALLEGRO 2
+#endif
+#define DIAL_EVEN_OCC_H1 3
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
@@ -570,8 +578,8 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       if ((8 / ctx->wpb_even) * ctx->lds_even + ctx->lds_one <= 160 * 1024) {
         hipError_t e2 = hipSuccess;
         if (ctx->lds_even > 64 * 1024) {
-          if (ctx->inst == 4) e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
-          else e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsH1, DIAL_H1_WPB_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+          if (ctx->inst == 4) e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB_EVEN, DIAL_EVEN_OCC_ALLEGRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
+          else e2 = hipFuncSetAttribute((const void*)rollout_kernel<DimsH1, DIAL_H1_WPB_EVEN, DIAL_EVEN_OCC_H1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_even);
         }
         if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
         if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
@@ -707,16 +715,16 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     dial::RolloutIO io1 = io;
     io1.n_first = B - 1;
-#define DIAL_SPLIT_LAUNCH(D, WPBE)                                                                                         \
+#define DIAL_SPLIT_LAUNCH(D, WPBE, OCCE)                                                                                       \
     hipLaunchKernelGGL((rollout_kernel<D, 1>), dim3(1), dim3(64), ctx->lds_one, ctx->side, (const CModel<D>*)ctx->dcm,     \
                        (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io1, B, ctx->ws_words, (int*)nullptr);    \
     HIP_TRY(ctx, hipGetLastError());                                                                                       \
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));                                                                 \
-    hipLaunchKernelGGL((rollout_kernel<D, WPBE>), dim3((B - 1) / WPBE), dim3(64 * WPBE), ctx->lds_even, st,                \
+    hipLaunchKernelGGL((rollout_kernel<D, WPBE, OCCE>), dim3((B - 1) / WPBE), dim3(64 * WPBE), ctx->lds_even, st,                \
                        (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B - 1,    \
                        ctx->ws_words, (int*)nullptr)
-    if (ctx->inst == 4) { DIAL_SPLIT_LAUNCH(DimsAllegro, DIAL_ALLEGRO_WPB_EVEN); }
-    else { DIAL_SPLIT_LAUNCH(DimsH1, DIAL_H1_WPB_EVEN); }
+    if (ctx->inst == 4) { DIAL_SPLIT_LAUNCH(DimsAllegro, DIAL_ALLEGRO_WPB_EVEN, DIAL_EVEN_OCC_ALLEGRO); }
+    else { DIAL_SPLIT_LAUNCH(DimsH1, DIAL_H1_WPB_EVEN, DIAL_EVEN_OCC_H1); }
 #undef DIAL_SPLIT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
