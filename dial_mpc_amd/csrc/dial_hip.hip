@@ -46,8 +46,8 @@
 // two-wavefront workgroups already load every CU with 8 wavefronts; the split measured 0.7 % slower there.)
 #define DIAL_H1_WPB_EVEN 4
 // The even launch keeps exactly 2 wavefronts on every SIMD.  Allegro's 8-wavefront kernel is compiled for that occupancy
-// (more than 168 VGPRs allowed: -3.3 % in the A/B, 7.70 -> 7.45 ms; the one-wavefront mean-trajectory workgroup still finds
-// room).  H1's must stay at the 3-wavefront budget: at 2 its registers leave no SIMD for the mean-trajectory workgroup, which
+// (-3.3 % in the A/B, 7.70 -> 7.45 ms: the scheduler orders for latency at the lower occupancy target; the kernel still uses
+// 150 VGPRs, so the one-wavefront mean-trajectory workgroup finds room beside two of its wavefronts).  H1's must stay at the 3-wavefront budget: at 2 its registers leave no SIMD for the mean-trajectory workgroup, which
 // then runs AFTER the even launch (+50 %).
 #ifndef DIAL_EVEN_OCC_ALLEGRO
 #define DIAL_EVEN_OCC_ALLEGRO 2
