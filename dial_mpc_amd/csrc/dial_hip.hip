@@ -383,6 +383,7 @@ struct dial_ctx {
   bool split_ok = false;
   int wpb_even = 0;            // wavefronts per workgroup of the even launch (8 x CUs rollouts in all)
   int n_simd = 0;              // SIMDs of the device (4 per CU)
+  int debug_stall_piece1 = 0;  // DIAL_DEBUG_RELAY_STALL=k (tests): relay piece k - 1 never hands over
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
   bool timing = false;
@@ -589,6 +590,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       }
     }
     if (const char* e = getenv("DIAL_RELAY_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->relay_steps = v; }
+    if (const char* e = getenv("DIAL_DEBUG_RELAY_STALL")) ctx->debug_stall_piece1 = atoi(e);
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
   HIP_TRY_CREATE(hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
@@ -697,6 +699,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
       io.relay_steps = ctx->relay_steps;
       io.relay_base = B - 1;
       io.err_word = ctx->err_dev;
+      io.debug_stall_piece1 = ctx->debug_stall_piece1;
     }
   }
   int blocks = io.relay_flag ? io.relay_base + (ctx->T + io.relay_steps - 1) / io.relay_steps : (B + wpb - 1) / wpb;
@@ -991,6 +994,8 @@ int dial_debug_scratch(dial_ctx* ctx, float** Y0s, float** rewss, float** qss, f
   return DIAL_OK;
 }
 int dial_lds_bytes(dial_ctx* ctx) { return ctx ? (int)ctx->lds_rollout : -1; }
+// tests: switch the relay-stall hook of DIAL_DEBUG_RELAY_STALL on (k >= 1: piece k - 1 never hands over) or off (0)
+int dial_debug_set_stall(dial_ctx* ctx, int piece1) { if (!ctx) return DIAL_ERR_ARG; ctx->debug_stall_piece1 = piece1; return DIAL_OK; }
 // wavefront slots of the rollout kernel on the whole chip for a batch of B rollouts (B > slots: the rollout queue runs)
 int dial_debug_resident_rollouts(dial_ctx* ctx, int B) {
   if (!ctx) return -1;

@@ -38,6 +38,7 @@ struct RolloutIO {
   int relay_base;            // index of the first relay workgroup of the launch
   int n_first;               // rollout index of the launch's first wavefront (split launches)
   int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
+  int debug_stall_piece1;    // test hook (DIAL_DEBUG_RELAY_STALL=k): relay piece k - 1 never hands over; 0 = off
 };
 
 template <class W, class M>
@@ -111,7 +112,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #ifndef DIAL_EMU
   if (relay > 0) {
     // wait for the predecessor (it was dispatched before this wavefront: it is running or done), then take its state
-    // (bounded: a wavefront that never gets its turn -- ~2 s -- gives up instead of hanging the GPU: it raises the
+    // (bounded: a wavefront that never gets its turn -- ~0.2 s -- gives up instead of hanging the GPU: it raises the
     // context's sticky error word, which every later API call reports (dial_status), marks the rollout's reward with a
     // NaN bit pattern and RETURNS -- it neither runs on a stale state nor hands over, so its successors give up too)
     int timed_out = 0;
@@ -175,6 +176,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   if (io.prof && w.lane == 0) for (int k = 28; k < DIAL_NSEC; k++) atomicAdd(&io.prof[k], w.acc[k]);
 #endif
 #ifndef DIAL_EMU
+  if (relay >= 0 && relay + 1 == io.debug_stall_piece1) return;   // test hook: a piece that never hands over (its successors time out)
   if (relay >= 0 && st_end < T) {   // hand over: state, running sum, then the flag (release)
     store_state(w, m, s, io.relay_buf);
     w.items(1, [&](int) { io.relay_buf[nstate] = rsum; });

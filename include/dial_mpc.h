@@ -358,7 +358,7 @@ int dial_set_timing(dial_ctx* ctx, int enable);
 int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches);
 
 /* Sticky status of the context's ASYNCHRONOUS work, readable without synchronising: DIAL_OK, or DIAL_ERR_HIP once if an
- * earlier rollout launch gave up (a piece of the mean-trajectory relay that never got its turn -- bounded wait, ~2 s --
+ * earlier rollout launch gave up (a piece of the mean-trajectory relay that never got its turn -- bounded wait, ~0.2 s --
  * marks the launch invalid instead of hanging the GPU; the mean trajectory's reward then carries a NaN bit pattern).
  * Every compute entry point performs the same check first.  Drivers call it after their own synchronisation point,
  * before they publish a plan (deploy/dial_plan.py, core/dial_core.py).                                              */

@@ -941,3 +941,40 @@ def test_closed_loop_behaviour(example, ticks, N):
     else:
         print(f"allegro: ball height {zs[-1]:.3f} m after {ticks} ticks, mean reward {np.mean(rews[-10:]):.3f}")
         assert zs[-1] > 0.08
+
+
+def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():
+    """The mean-trajectory relay waits for its predecessor with a BOUNDED spin.  With the test hook DIAL_DEBUG_RELAY_STALL
+    (piece 1 never hands over) the later pieces give up after ~2 s: the launch completes, the context's sticky error word is
+    set, the next API call -- and dial_status -- report DIAL_ERR_HIP once, the turn flag is re-armed, and the context works
+    again afterwards (bit-identical to a context that never stalled)."""
+    import os
+    import time
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", 2048, 16)
+    eps, sigma, Ybar = seeded_inputs(dc, 12, seed=1, Ybar_scale=0.1)
+    good = _lib.Context(model, task, cfg)
+    s0, _, _ = good.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
+    ref = {k: v.clone() for k, v in good.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps)).items()}
+    os.environ["DIAL_DEBUG_RELAY_STALL"] = "2"
+    try:
+        ctx = _lib.Context(model, task, cfg)
+    finally:
+        del os.environ["DIAL_DEBUG_RELAY_STALL"]
+    t0 = time.time()
+    ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))        # enqueues fine; the relay stalls on the device
+    torch.cuda.synchronize()
+    waited = time.time() - t0
+    assert waited < 30.0, waited                                    # bounded, no hang
+    with pytest.raises(_lib.DialHipError, match="gave up"):
+        ctx.status()
+    ctx.status()                                                    # reported once; the context is usable again ...
+    ctx.lib.dial_debug_set_stall.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ctx.lib.dial_debug_set_stall(ctx.h, 0)                          # ... (hook off)
+    out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+    torch.cuda.synchronize()
+    ctx.status()
+    for k in ("Ybar", "rews", "qbar", "xbar"):
+        assert torch.equal(out[k], ref[k]), k
+    print(f"relay stall: the launch gave up after {waited:.1f} s, error reported once, context recovered")
