@@ -1,0 +1,247 @@
+// box_collide.h -- narrow phases of box geoms (the crate scenes: include/dial_mpc.h DIAL_CON_*_BOX).
+//
+// MJX sends boxes through collision_convex.py -- third-party code that is not part of the reference checkout and whose
+// manifold selection changed between releases.  What is implemented here is the GEOMETRY of each pair (unique wherever
+// the contact is unique) with a fixed number of candidate contacts per pair, in MJX's conventions: the normal points
+// from geom1 into geom2, dist < 0 is penetration, pos lies midway between the two surfaces.  One lane evaluates one
+// candidate; the candidates of one pair recompute the pair (a box pair is <= 4 lanes of the contact phase).
+// Only the generic instantiation carries this code (rollout_body.h: `if constexpr (!is_static)`).
+#pragma once
+
+namespace dial {
+
+struct BoxG {
+  float c[3], q[4], h[3];   // centre, orientation (world-from-box quaternion), half sizes
+};
+
+DIAL_DEV void box_axes(const BoxG& b, float ax[3][3]) {   // ax[k] = world direction of the box's k-th axis
+  float mat[9];
+  dm::quat_to_mat(mat, b.q);
+  for (int k = 0; k < 3; k++) { ax[k][0] = mat[k]; ax[k][1] = mat[3 + k]; ax[k][2] = mat[6 + k]; }
+}
+
+// sphere (centre sc, radius r) against a box
+DIAL_DEV void sphere_box(const float* sc, float r, const BoxG& b, float& dist, float* pos, float* fr) {
+  const float rel[3] = {sc[0] - b.c[0], sc[1] - b.c[1], sc[2] - b.c[2]};
+  float p[3], nl[3];
+  dm::inv_rotate(p, rel, b.q);
+  float len2 = 0.f, slack = 0.f;
+  int kn = 0;
+  for (int k = 0; k < 3; k++) {
+    const float over = dm::absf(p[k]) - b.h[k];          // > 0: outside the slab of axis k
+    const float o = over > 0.f ? over : 0.f;
+    nl[k] = p[k] > 0.f ? -o : o;                         // from the centre towards the box
+    len2 += o * o;
+    if (k == 0 || over > slack) { slack = over; kn = k; }   // inside: the face that is nearest (largest negative `over`)
+  }
+  if (len2 > 0.f) {
+    const float len = DM_SQRT(len2);
+    for (int k = 0; k < 3; k++) nl[k] /= len;
+    dist = len - r;
+  } else {
+    for (int k = 0; k < 3; k++) nl[k] = 0.f;
+    nl[kn] = p[kn] >= 0.f ? -1.f : 1.f;
+    dist = slack - r;                                    // slack = -(depth below the nearest face)
+  }
+  float n[3];
+  dm::rotate(n, nl, b.q);
+  for (int k = 0; k < 3; k++) pos[k] = sc[k] + n[k] * (r + dist * 0.5f);
+  make_frame(fr, n);
+}
+
+// plane (normal n through ppos) against a box: the sub-th lowest vertex.  With e_k = h_k |n . axis_k| the vertex heights
+// are base -+ e_0 -+ e_1 -+ e_2; sorted: all minus, then the smallest e flipped, ... -- ranked by counting, ties by index
+DIAL_DEV void plane_box(const float* n, const float* ppos, const BoxG& b, int sub, float& dist, float* pos, float* fr) {
+  float ax[3][3], e[3];
+  box_axes(b, ax);
+  const float rel[3] = {b.c[0] - ppos[0], b.c[1] - ppos[1], b.c[2] - ppos[2]};
+  const float base = dm::dot3(rel, n);
+  for (int k = 0; k < 3; k++) e[k] = b.h[k] * dm::dot3(n, ax[k]);
+  float hv[8];
+  for (int i = 0; i < 8; i++) hv[i] = base + ((i & 1) ? e[0] : -e[0]) + ((i & 2) ? e[1] : -e[1]) + ((i & 4) ? e[2] : -e[2]);
+  int pick = 0;
+  for (int i = 0; i < 8; i++) {
+    int rank = 0;
+    for (int j = 0; j < 8; j++) rank += (hv[j] < hv[i] || (hv[j] == hv[i] && j < i)) ? 1 : 0;
+    pick = rank == sub ? i : pick;
+  }
+  float v[3];
+  for (int k = 0; k < 3; k++)
+    v[k] = b.c[k] + ((pick & 1) ? b.h[0] : -b.h[0]) * ax[0][k] + ((pick & 2) ? b.h[1] : -b.h[1]) * ax[1][k] + ((pick & 4) ? b.h[2] : -b.h[2]) * ax[2][k];
+  const float d[3] = {v[0] - ppos[0], v[1] - ppos[1], v[2] - ppos[2]};
+  dist = dm::dot3(d, n);
+  for (int k = 0; k < 3; k++) pos[k] = v[k] - n[k] * (dist * 0.5f);
+  make_frame(fr, n);
+}
+
+// parameter t in [0, 1] of the segment point l0 + t (l1 - l0) (box frame) closest to the box: the squared distance is convex
+// and piecewise quadratic in t; its pieces end where the point crosses one of the six slab planes.  A later piece replaces
+// an earlier one only if it is better by more than rounding (a capsule parallel to a face keeps its first end)
+DIAL_DEV float segment_box_t(const float* l0, const float* l1, const float* h) {
+  float cut[8];
+  int nc = 0;
+  cut[nc++] = 0.f;
+  for (int k = 0; k < 3; k++) {
+    const float dk = l1[k] - l0[k];
+    if (dk == 0.f) continue;
+    const float ta = (h[k] - l0[k]) / dk, tb = (-h[k] - l0[k]) / dk;
+    const float tlo = ta < tb ? ta : tb, thi = ta < tb ? tb : ta;
+    if (tlo > 0.f && tlo < 1.f) cut[nc++] = tlo;
+    if (thi > 0.f && thi < 1.f) cut[nc++] = thi;
+  }
+  cut[nc++] = 1.f;
+  for (int i = 1; i < nc; i++)            // sort (<= 8 entries)
+    for (int j = i; j > 0 && cut[j - 1] > cut[j]; j--) { const float x = cut[j]; cut[j] = cut[j - 1]; cut[j - 1] = x; }
+  float best_t = 0.f, best_f = -1.f;
+  for (int i = 0; i + 1 < nc; i++) {
+    const float t0 = cut[i], t1 = cut[i + 1], tm = 0.5f * (t0 + t1);
+    float A = 0.f, B = 0.f, C = 0.f;    // f(t) = A t^2 + 2 B t + C over this piece
+    for (int k = 0; k < 3; k++) {
+      const float dk = l1[k] - l0[k], x = l0[k] + tm * dk;
+      const float wall = x > h[k] ? h[k] : (x < -h[k] ? -h[k] : x);
+      if (wall != x) { const float o = l0[k] - wall; A += dk * dk; B += dk * o; C += o * o; }
+    }
+    const float t = A > 0.f ? dm::clip(-B / A, t0, t1) : t0;
+    const float f = (A * t + 2.f * B) * t + C;
+    if (best_f < 0.f || f < best_f * (1.f - 1e-6f) - 1e-12f) { best_f = f > 0.f ? f : 0.f; best_t = t; }
+  }
+  return best_t;
+}
+
+// capsule against a box: sub 0 = sphere at the segment point closest to the box, sub 1 = sphere at the end farther from it
+DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r, const BoxG& b, int sub, float& dist, float* pos, float* fr) {
+  float e0[3], e1[3], r0[3], r1[3], l0[3], l1[3];
+  for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; r0[k] = e0[k] - b.c[k]; r1[k] = e1[k] - b.c[k]; }
+  dm::inv_rotate(l0, r0, b.q);
+  dm::inv_rotate(l1, r1, b.q);
+  const float t = segment_box_t(l0, l1, b.h);
+  float sc[3];
+  for (int k = 0; k < 3; k++) sc[k] = sub == 0 ? e0[k] + t * (e1[k] - e0[k]) : (t <= 0.5f ? e1[k] : e0[k]);
+  sphere_box(sc, r, b, dist, pos, fr);
+}
+
+// box against box (separating-axis test; see the description at DIAL_CON_BOX_BOX and oracle-independent notes in DESIGN.md).
+// Everything is done in A's frame: C = RA^T RB, t = RA^T (cB - cA).
+DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float* pos, float* fr) {
+  float axA[3][3], axB[3][3], C[3][3], Q[3][3], t[3];
+  box_axes(A, axA);
+  box_axes(B, axB);
+  const float tw[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
+  for (int i = 0; i < 3; i++) {
+    t[i] = dm::dot3(tw, axA[i]);
+    for (int j = 0; j < 3; j++) { C[i][j] = dm::dot3(axA[i], axB[j]); Q[i][j] = dm::absf(C[i][j]); }
+  }
+  int best = -1;
+  float sbest = 0.f;
+  for (int i = 0; i < 3; i++) {          // faces of A
+    const float sep = dm::absf(t[i]) - (A.h[i] + B.h[0] * Q[i][0] + B.h[1] * Q[i][1] + B.h[2] * Q[i][2]);
+    if (best < 0 || sep > sbest) { best = i; sbest = sep; }
+  }
+  for (int j = 0; j < 3; j++) {          // faces of B
+    const float tb = t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j];
+    const float sep = dm::absf(tb) - (B.h[j] + A.h[0] * Q[0][j] + A.h[1] * Q[1][j] + A.h[2] * Q[2][j]);
+    if (sep > sbest) { best = 3 + j; sbest = sep; }
+  }
+  float nedge[3] = {0.f, 0.f, 0.f};       // world direction of the winning edge axis
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float L[3];
+      dm::cross3(L, axA[i], axB[j]);
+      const float len = DM_SQRT(dm::dot3(L, L));
+      if (len < 1e-4f) continue;
+      for (int k = 0; k < 3; k++) L[k] /= len;
+      float ra = 0.f, rb = 0.f;
+      for (int k = 0; k < 3; k++) { ra += A.h[k] * dm::absf(dm::dot3(L, axA[k])); rb += B.h[k] * dm::absf(dm::dot3(L, axB[k])); }
+      const float sep = dm::absf(dm::dot3(tw, L)) - (ra + rb);
+      if (sep > sbest + 0.05f * dm::absf(sbest) + 1e-5f) { best = 6 + 3 * i + j; sbest = sep; for (int k = 0; k < 3; k++) nedge[k] = L[k]; }
+    }
+  const float mid[3] = {0.5f * (A.c[0] + B.c[0]), 0.5f * (A.c[1] + B.c[1]), 0.5f * (A.c[2] + B.c[2])};
+  float n[3];
+  if (best < 3) { const float sg = t[best] >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = axA[best][k] * sg; }
+  else if (best < 6) { const float sg = dm::dot3(tw, axB[best - 3]) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = axB[best - 3][k] * sg; }
+  else { const float sg = dm::dot3(tw, nedge) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = nedge[k] * sg; }
+  make_frame(fr, n);
+  if (sbest > 0.01f) {                    // clearly apart
+    dist = sub == 0 ? sbest : 1.f;
+    for (int k = 0; k < 3; k++) pos[k] = mid[k];
+    return;
+  }
+  if (best >= 6) {                        // edge - edge: closest points of the two supporting edges
+    const int i = (best - 6) / 3, j = (best - 6) - 3 * i;
+    float pa[3] = {A.c[0], A.c[1], A.c[2]}, pb[3] = {B.c[0], B.c[1], B.c[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != i) { const float sk = dm::dot3(n, axA[k]) >= 0.f ? A.h[k] : -A.h[k]; for (int q = 0; q < 3; q++) pa[q] += sk * axA[k][q]; }
+      if (k != j) { const float sk = dm::dot3(n, axB[k]) >= 0.f ? B.h[k] : -B.h[k]; for (int q = 0; q < 3; q++) pb[q] -= sk * axB[k][q]; }
+    }
+    const float wv[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const float uu = dm::dot3(axA[i], axB[j]), q1 = dm::dot3(axA[i], wv), q2 = -dm::dot3(axB[j], wv), den = 1.f - uu * uu;
+    const float al = dm::clip((q1 + uu * q2) / den, -A.h[i], A.h[i]), be = dm::clip((uu * q1 + q2) / den, -B.h[j], B.h[j]);
+    float gap = 0.f;
+    for (int k = 0; k < 3; k++) {
+      const float ca = pa[k] + al * axA[i][k], cb = pb[k] + be * axB[j][k];
+      gap += (cb - ca) * n[k];
+      pos[k] = 0.5f * (ca + cb);
+    }
+    dist = sub == 0 ? gap : 1.f;
+    return;
+  }
+  // face contact: reference box X (face axis kx, outward normal nref towards Y), incident box Y
+  const bool a_ref = best < 3;
+  const BoxG& X = a_ref ? A : B;
+  const BoxG& Y = a_ref ? B : A;
+  const float (*aX)[3] = a_ref ? axA : axB;
+  const float (*aY)[3] = a_ref ? axB : axA;
+  const int kx = a_ref ? best : best - 3, ux = (kx + 1) % 3, vx = (kx + 2) % 3;
+  float nref[3];
+  for (int k = 0; k < 3; k++) nref[k] = a_ref ? n[k] : -n[k];
+  int my = 0;
+  float amax = -1.f;
+  for (int k = 0; k < 3; k++) { const float a = dm::absf(dm::dot3(nref, aY[k])); if (a > amax) { amax = a; my = k; } }
+  const int uy = (my + 1) % 3, vy = (my + 2) % 3;
+  const float sgy = dm::dot3(nref, aY[my]) >= 0.f ? -Y.h[my] : Y.h[my];   // the incident face looks back at X
+  // incident face in reference-face coordinates (a, b) and signed distance d to the reference face
+  float fc[3], cu[3], cv[3];   // face centre, half edges
+  {
+    float cw[3];
+    for (int k = 0; k < 3; k++) cw[k] = Y.c[k] + sgy * aY[my][k] - X.c[k];
+    fc[0] = dm::dot3(cw, aX[ux]); fc[1] = dm::dot3(cw, aX[vx]); fc[2] = dm::dot3(cw, nref) - X.h[kx];
+    cu[0] = Y.h[uy] * dm::dot3(aY[uy], aX[ux]); cu[1] = Y.h[uy] * dm::dot3(aY[uy], aX[vx]); cu[2] = Y.h[uy] * dm::dot3(aY[uy], nref);
+    cv[0] = Y.h[vy] * dm::dot3(aY[vy], aX[ux]); cv[1] = Y.h[vy] * dm::dot3(aY[vy], aX[vx]); cv[2] = Y.h[vy] * dm::dot3(aY[vy], nref);
+  }
+  float pa_[10][3], pb_[10][3];
+  int np_ = 4;
+  for (int k = 0; k < 3; k++) {
+    pa_[0][k] = fc[k] + cu[k] + cv[k]; pa_[1][k] = fc[k] - cu[k] + cv[k];
+    pa_[2][k] = fc[k] - cu[k] - cv[k]; pa_[3][k] = fc[k] + cu[k] - cv[k];
+  }
+  for (int pl = 0; pl < 4 && np_ > 0; pl++) {   // clip against a <= hu, -a <= hu, b <= hv, -b <= hv
+    const int co = pl >> 1;
+    const float sg = (pl & 1) ? -1.f : 1.f, lim = co == 0 ? X.h[ux] : X.h[vx];
+    float (*src)[3] = (pl & 1) ? pb_ : pa_;
+    float (*dst)[3] = (pl & 1) ? pa_ : pb_;
+    int no = 0;
+    for (int q = 0; q < np_; q++) {
+      const int q2 = q + 1 < np_ ? q + 1 : 0;
+      const float fp = sg * src[q][co] - lim, fq = sg * src[q2][co] - lim;
+      if (fp <= 0.f) { for (int k = 0; k < 3; k++) dst[no][k] = src[q][k]; no++; }
+      if ((fp <= 0.f) != (fq <= 0.f)) {
+        const float wgt = fp / (fp - fq);
+        for (int k = 0; k < 3; k++) dst[no][k] = src[q][k] + wgt * (src[q2][k] - src[q][k]);
+        no++;
+      }
+    }
+    np_ = no;
+  }
+  // after the four passes the polygon is back in pa_ (each pass ping-pongs)
+  int pick = -1;
+  for (int q = 0; q < np_; q++) {
+    int rank = 0;
+    for (int o = 0; o < np_; o++) rank += (pa_[o][2] < pa_[q][2] || (pa_[o][2] == pa_[q][2] && o < q)) ? 1 : 0;
+    pick = rank == sub ? q : pick;
+  }
+  if (pick < 0) { dist = 1.f; for (int k = 0; k < 3; k++) pos[k] = mid[k]; return; }
+  dist = pa_[pick][2];
+  for (int k = 0; k < 3; k++) pos[k] = X.c[k] + pa_[pick][0] * aX[ux][k] + pa_[pick][1] * aX[vx][k] + (X.h[kx] + pa_[pick][2] * 0.5f) * nref[k];
+}
+
+}  // namespace dial

@@ -99,9 +99,20 @@ void static_for(F&& f) {
   }
 }
 
+// What only the generic instantiation carries (box narrow phases and the crate task: include/dial_mpc.h).  An EMPTY base for
+// the dimension-specialised instantiations: their constants live in LDS, which is on the residency edge.
+template <class D, bool GENERIC = !D::is_static>
+struct CModelGeneric {};
+template <class D>
+struct CModelGeneric<D, true> {
+  int32_t con_sub[D::NC];
+  int32_t crate_contact[DIAL_MAX_FEET];
+  float crate_region[6], head_vec[3];
+};
+
 // Everything one env.step reads that is constant across samples and steps.
 template <class D_>
-struct CModel {
+struct CModel : CModelGeneric<D_> {
   using D = D_;
   // ---- scalars
   int32_t nq, nv, nu, nbody, njnt, ngeom, nsite, ncon, nlim, nefc;

@@ -298,6 +298,12 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 2; k++) o.con_solref[cidx][k] = m->con_solref[cidx][k];
   }
   o.cone = m->cone; o.eulerdamp = m->eulerdamp;
+  if constexpr (!D::is_static) {
+    for (int cidx = 0; cidx < m->ncon; cidx++) o.con_sub[cidx] = m->con_sub[cidx];
+    for (int f = 0; f < DIAL_MAX_FEET; f++) o.crate_contact[f] = t->crate_contact[f];
+    for (int k = 0; k < 6; k++) o.crate_region[k] = t->crate_region[k];
+    for (int k = 0; k < 3; k++) o.head_vec[k] = t->head_vec[k];
+  }
   if constexpr (D::ell) {
     int adr = m->nlim, joff = 0;
     for (int i = 0; i < m->nv; i++) o.dof_ncon[i] = 0;

@@ -445,23 +445,27 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, DIAL_ERR_HIP, "dial_create: no HIP device available (the HIP path has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
-  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_ALLEGRO)
+  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_GO2_CRATE)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
   {   // the reward phase unrolls over the feet of the task's robot (rollout_body.h: reward_phase)
-    const bool go2 = task->kind == DIAL_TASK_GO2_WALK || task->kind == DIAL_TASK_GO2_SEQ_JUMP;
+    const bool go2 = task->kind == DIAL_TASK_GO2_WALK || task->kind == DIAL_TASK_GO2_SEQ_JUMP || task->kind == DIAL_TASK_GO2_CRATE;
     const bool h1 = task->kind == DIAL_TASK_H1_WALK || task->kind == DIAL_TASK_H1_LOCO;
     if ((go2 && task->nfeet != 4) || (h1 && task->nfeet != 2))
       return fail(nullptr, DIAL_ERR_ARG, "dial_create: task.nfeet must be 4 for the Go2 tasks and 2 for the H1 tasks");
   }
+  if (task->kind == DIAL_TASK_GO2_CRATE)
+    for (int f = 0; f < 4; f++)
+      if (task->crate_contact[f] < 0 || task->crate_contact[f] >= model->ncon)
+        return fail(nullptr, DIAL_ERR_ARG, "dial_create: task.crate_contact must index the model's contact list");
   if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
   if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: unknown line-search rule");
-  // pyramidal models: <= 64 constraint rows (one row per lane), explicit Euler damping off;
-  // elliptic models run on their dimension-specialised instantiation only (checked below)
+  // pyramidal models: explicit Euler damping off; elliptic models run on their dimension-specialised instantiation only
+  // (checked below)
   if (model->cone == DIAL_CONE_PYRAMIDAL && model->eulerdamp)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: eulerdamp is only supported on the elliptic-cone instantiations");
-  if ((model->cone == DIAL_CONE_PYRAMIDAL && model->nefc > 64) || model->nefc > DIAL_MAX_EFC || model->nv > DIAL_MAX_V ||
+  if (model->nefc > DIAL_MAX_EFC || model->nv > DIAL_MAX_V ||
       model->nq + 2 * model->nv + DIAL_INFO_N > 4096)
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: model exceeds kernel capacities");
   dial_ctx* ctx = new dial_ctx();

@@ -198,6 +198,7 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 }
 
 }  // namespace dial
+#include "box_collide.h"
 #include "ls_bracket.h"
 #include "solver_reg.h"
 #include "solver_cone.h"
@@ -694,6 +695,32 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
       float radius = m->geom_size[g2][0];
       float* fr = s.cframe + 9 * c;
+      if constexpr (!M::D::is_static) {
+        if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) {   // box narrow phases (box_collide.h); geom2 is the box
+          const auto box_of = [&](int g, BoxG& b) {
+            const int bd = m->geom_bodyid[g];
+            const float bq[4] = {s.xquat[4 * bd], s.xquat[4 * bd + 1], s.xquat[4 * bd + 2], s.xquat[4 * bd + 3]};
+            const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
+            dm::quat_mul(b.q, bq, gq);
+            for (int k = 0; k < 3; k++) { b.c[k] = s.gpos[3 * g + k]; b.h[k] = m->geom_size[g][k]; }
+          };
+          BoxG b2;
+          box_of(g2, b2);
+          const float p1[3] = {s.gpos[3 * g1], s.gpos[3 * g1 + 1], s.gpos[3 * g1 + 2]};
+          float dist, cp[3];
+          if (m->con_kind[c] == DIAL_CON_PLANE_BOX) plane_box(n, p1, b2, m->con_sub[c], dist, cp, fr);
+          else if (m->con_kind[c] == DIAL_CON_SPHERE_BOX) sphere_box(p1, m->geom_size[g1][0], b2, dist, cp, fr);
+          else if (m->con_kind[c] == DIAL_CON_CAPSULE_BOX) capsule_box(p1, n, m->geom_size[g1][1], m->geom_size[g1][0], b2, m->con_sub[c], dist, cp, fr);
+          else {
+            BoxG b1;
+            box_of(g1, b1);
+            box_box(b1, b2, m->con_sub[c], dist, cp, fr);
+          }
+          s.cdist[c] = dist;
+          for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = cp[k];
+          return;
+        }
+      }
       if constexpr (M::D::ell) {
         if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
           // MJX sphere_capsule / capsule_capsule: closest points on the capsule segment(s), then _sphere_sphere
@@ -796,6 +823,14 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   w.items(nc * nv, [&](int it) {
     const int c = it / nv, i = it - c * nv;
     const int b1 = m->con_body1[c], b2 = m->con_body2[c];
+    if constexpr (!M::D::is_static) {
+      // a candidate that does not touch (dist >= margin) gets D = 0 rows: its Jacobian is never multiplied by anything but 0
+      // (the crate scene carries 52 candidates, 4-6 of which touch)
+      if (!(s.cdist[c] - m->con_margin[c] < 0.f)) {
+        for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = 0.f;
+        return;
+      }
+    }
     float cd[6];
     for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
     float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
@@ -982,6 +1017,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
       }
       for (int c = 0; c < nc; c++) {
+        if (s.D[nl + 4 * c] == 0.f) continue;   // candidate that does not touch: all four rows are off (wave-uniform)
         const float* jn = s.Jc + (c * 3) * nv;
         float jni = jn[i], jnj = jn[j];
         float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
@@ -1044,15 +1080,30 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r)
+    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r); models with more
+    // than 64 rows (the crate scene: 220) keep them in LDS and sum over the rows lane-strided
+    const bool wide = ne > 64;
     const vfloat vJa = w.per_lane([&](int l) { return l < ne ? s.Jaref[l] : 0.f; });
     const vfloat vjv = w.per_lane([&](int l) { return l < ne ? s.jv[l] : 0.f; });
     const vfloat vD = w.per_lane([&](int l) { return l < ne ? s.D[l] : 0.f; });
     const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
     const vfloat vzero = vsplat(0.f);
+    if (wide)
+      w.items(ne, [&](int r) {
+        const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
+        s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
+      });
     auto ls_point = [&](float alpha) {
-      const vbool act = vlt0(vJa + vjv * alpha);
-      float q0 = w.vsum(vsel(act, vq0, vzero)), q1 = w.vsum(vsel(act, vq1, vzero)), q2 = w.vsum(vsel(act, vq2, vzero));
+      float q0, q1, q2;
+      if (!wide) {
+        const vbool act = vlt0(vJa + vjv * alpha);
+        q0 = w.vsum(vsel(act, vq0, vzero)); q1 = w.vsum(vsel(act, vq1, vzero)); q2 = w.vsum(vsel(act, vq2, vzero));
+      } else {
+        w.sum3(ne, [&](int r, float& a, float& b, float& c) {
+          const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;
+          a = act ? s.quad[3 * r] : 0.f; b = act ? s.quad[3 * r + 1] : 0.f; c = act ? s.quad[3 * r + 2] : 0.f;
+        }, q0, q1, q2);
+      }
       q0 += qg0; q1 += qg1; q2 += qg2;
       const float cost = alpha * alpha * q2 + alpha * q1 + q0;
       // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
@@ -1238,6 +1289,47 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     });
     DIAL_MARK(w, 10);
     return s.info[DIAL_INFO_REWARD];
+  }
+  if constexpr (!M::D::is_static) {
+    if (m->kind == DIAL_TASK_GO2_CRATE) {
+      // UnitreeGo2CrateEnv.step (unitree_go2_env.py:679-795).  Of its eleven terms only four carry a non-zero weight:
+      // head position (:711-719), upright (:720-723), yaw (:724-727) and the feet-on-the-crate count (:741-766); the
+      // others are multiplied by 0.0 and add an exact zero.  done = 0; vel_tar / yaw_tar are not updated by the step.
+      w.items(1, [&](int) {
+        float* info = s.info;
+        const int tb = m->torso_x + 1, ub = m->upright_x + 1;
+        const float step = info[DIAL_INFO_STEP], dt = m->dt;
+        const float tq[4] = {s.xquat[4 * tb], s.xquat[4 * tb + 1], s.xquat[4 * tb + 2], s.xquat[4 * tb + 3]};
+        const float uq[4] = {s.xquat[4 * ub], s.xquat[4 * ub + 1], s.xquat[4 * ub + 2], s.xquat[4 * ub + 3]};
+        const float hv[3] = {m->head_vec[0], m->head_vec[1], m->head_vec[2]};
+        float mat[9], head[3];
+        dm::quat_to_mat(mat, tq);   // head_pos = pos + R head_vec (math.quat_to_3x3, jnp.dot)
+        float reward_pos = 0.f;
+        for (int k = 0; k < 3; k++) {
+          head[k] = s.xpos[3 * tb + k] + (mat[3 * k] * hv[0] + mat[3 * k + 1] * hv[1] + mat[3 * k + 2] * hv[2]);
+          const float e = head[k] - (info[DIAL_INFO_POS_TAR + k] + info[DIAL_INFO_VEL_TAR + k] * dt * step);
+          reward_pos += e * e;
+        }
+        const float up[3] = {0.f, 0.f, 1.f};
+        float vec[3];
+        dm::rotate(vec, up, uq);
+        const float reward_upright = -((vec[0] - 0.f) * (vec[0] - 0.f) + (vec[1] - 0.f) * (vec[1] - 0.f) + (vec[2] - 1.f) * (vec[2] - 1.f));
+        const float ey = quat_yaw(tq) - info[DIAL_INFO_YAW_TAR];
+        float reward_contact = 0.f;
+        for (int i = 0; i < 4; i++) {
+          const float* cp = s.cpos + 3 * m->crate_contact[i];
+          const bool cond = cp[0] > m->crate_region[0] && cp[0] < m->crate_region[1] && cp[1] > m->crate_region[2] &&
+                            cp[1] < m->crate_region[3] && cp[2] > m->crate_region[4] && cp[2] < m->crate_region[5];
+          reward_contact += cond ? 1.f : 0.f;
+        }
+        const float reward = -reward_pos * 1.0f + reward_upright * 0.01f + -(ey * ey) * 0.3f + reward_contact * 0.02f;
+        if (FULL_INFO) info[DIAL_INFO_DONE] = 0.f;
+        info[DIAL_INFO_STEP] = step + 1.f;
+        info[DIAL_INFO_REWARD] = reward;
+      });
+      DIAL_MARK(w, 10);
+      return s.info[DIAL_INFO_REWARD];
+    }
   }
   // ---- reward terms (all read the PRE-integration forward quantities)
   //   0 gaits | contact   1 upright   2 yaw   3 vel (walk) | pos (jump)   4 ang_vel | penalty   5 height   6 energy   7 done

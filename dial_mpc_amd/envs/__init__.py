@@ -3,7 +3,8 @@
 from typing import Any, Callable, Dict
 
 from dial_mpc_amd.envs.unitree_go2_env import (
-    UnitreeGo2Env, UnitreeGo2EnvConfig, UnitreeGo2SeqJumpEnv, UnitreeGo2SeqJumpEnvConfig)
+    UnitreeGo2CrateEnv, UnitreeGo2CrateEnvConfig, UnitreeGo2Env, UnitreeGo2EnvConfig, UnitreeGo2SeqJumpEnv,
+    UnitreeGo2SeqJumpEnvConfig)
 from dial_mpc_amd.envs.manipulation import AllegroReorientEnv, AllegroReorientEnvConfig
 from dial_mpc_amd.envs.unitree_h1_env import (
     UnitreeH1LocoEnv, UnitreeH1LocoEnvConfig, UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig)
@@ -13,6 +14,7 @@ _configs: Dict[str, Any] = {
     "unitree_h1_loco": UnitreeH1LocoEnvConfig,
     "unitree_go2_walk": UnitreeGo2EnvConfig,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnvConfig,
+    "unitree_go2_crate_climb": UnitreeGo2CrateEnvConfig,
     "allegro_reorient": AllegroReorientEnvConfig,
 }
 _envs: Dict[str, Callable] = {
@@ -20,10 +22,11 @@ _envs: Dict[str, Callable] = {
     "unitree_h1_loco": UnitreeH1LocoEnv,      # unitree_h1_env.py:906
     "unitree_go2_walk": UnitreeGo2Env,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
+    "unitree_go2_crate_climb": UnitreeGo2CrateEnv,   # unitree_go2_env.py:808 (generic kernel instantiation)
     "allegro_reorient": AllegroReorientEnv,
 }
 # reference envs that are NEXT rows and not built yet
-_NOT_BUILT = ("unitree_h1_push_crate", "unitree_go2_crate_climb")
+_NOT_BUILT = ("unitree_h1_push_crate",)
 
 
 def register_config(name: str, config: Any):

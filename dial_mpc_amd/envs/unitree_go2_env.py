@@ -2,7 +2,7 @@
 constants (dial_mpc/envs/unitree_go2_env.py:25-124 walk/trot, :319-401,559-592 seq_jump).
 
 ``reset`` / ``step`` execute in libdialhip.so; the reward formulas are in csrc/rollout_body.h
-(product); the CPU checker restates them independently.  Crate-climb is a NEXT row."""
+(product); the CPU checker restates them independently.  Crate climb: :649-803 (generic kernel instantiation)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -15,6 +15,7 @@ from dial_mpc_amd.envs.base_env import BaseEnv, BaseEnvConfig, System, load_mode
 
 TASK_GO2_WALK = _abi.MACROS["DIAL_TASK_GO2_WALK"]
 TASK_GO2_SEQ_JUMP = _abi.MACROS["DIAL_TASK_GO2_SEQ_JUMP"]
+TASK_GO2_CRATE = _abi.MACROS["DIAL_TASK_GO2_CRATE"]
 
 
 @dataclass
@@ -167,4 +168,52 @@ class UnitreeGo2SeqJumpEnv(UnitreeGo2Env):
         d.update(n_stage=S, jump_dt=self._config.jump_dt, contact_targets=self._contact_targets,
                  contact_radius=self._contact_target_radius, pose_targets=self._pose_target_sequence,
                  yaw_targets=self._yaw_target_sequence)
+        return d
+
+
+@dataclass
+class UnitreeGo2CrateEnvConfig(UnitreeGo2EnvConfig):
+    pass
+
+
+class UnitreeGo2CrateEnv(UnitreeGo2Env):
+    """unitree_go2_env.py:653-803: the Go2 with its collision model (trunk box, calf capsules, foot spheres) in front of
+    a 0.6 m crate.  Reward = head position towards (1.45, 0, 0.87) + upright + yaw + 0.02 per foot standing on the crate."""
+    task_kind = TASK_GO2_CRATE
+
+    def __init__(self, config: UnitreeGo2CrateEnvConfig = None):
+        super().__init__(config if config is not None else UnitreeGo2CrateEnvConfig())
+        self.joint_range = np.array(  # :656-671
+            [[-0.25, 0.25], [-1.0, 1.4], [-2.7, -1.0],
+             [-0.25, 0.25], [-1.0, 1.4], [-2.7, -1.0],
+             [-0.25, 0.25], [0.0, 1.8], [-2.7, -1.0],
+             [-0.25, 0.25], [0.0, 1.8], [-2.7, -1.0]])
+        self._init_pos_tar = np.array([1.45, 0.0, 0.87])  # reset(), :797-803 (vel_tar = ang_vel_tar = yaw_tar = 0)
+        # reward_contact (:741-766) reads contact.pos[contact_indices[i]] with contact_indices = [16, 17, 18, 19]: positions
+        # in the contact array of the MJX release upstream ran, which depend on that release's grouping of geom pairs.  The
+        # condition that follows (a point on the crate's top face) and the commented-out index formulas above it say what is
+        # meant: the contacts of the four FOOT spheres with the crate.  They are looked up here by geom identity, in upstream's
+        # loop order i = 0..3 = geom order FR, FL, RR, RL.
+        m = self.sys.model
+        names = m["names"]["geom"]
+        box = names.index("static_box")
+        self._crate_contact = []
+        for foot in ("FR", "FL", "RR", "RL"):
+            g = names.index(foot)
+            hits = [c for c in range(int(m["ncon"])) if int(m["con_geom1"][c]) == g and int(m["con_geom2"][c]) == box]
+            assert len(hits) == 1, f"foot geom {foot!r} has no contact with the crate in the compiled model"
+            self._crate_contact.append(hits[0])
+        self._crate_region = np.array([1.0, 1.6, -0.45, 0.45, 0.59, 0.61])   # :753-760
+        self._head_vec = np.array([0.285, 0.0, 0.0])                         # :717
+
+    def make_system(self, config: UnitreeGo2EnvConfig) -> System:
+        model = load_model("unitree_go2", "mjx_scene_force_crate.xml")
+        return System(model).tree_replace({"opt.timestep": config.timestep})
+
+    def _randomize_dict(self) -> Dict[str, Any]:
+        return dict(randomize_tasks=0, n_cmd=0)     # this env's step has no command to redraw (:679-795)
+
+    def task_dict(self) -> Dict[str, Any]:
+        d = super().task_dict()
+        d.update(crate_contact=np.array(self._crate_contact), crate_region=self._crate_region, head_vec=self._head_vec)
         return d

@@ -25,8 +25,9 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE = 0, 2, 3
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
 CON_PLANE_SPHERE, CON_PLANE_CAPSULE_P, CON_PLANE_CAPSULE_N, CON_SPHERE_CAPSULE, CON_CAPSULE_CAPSULE = 0, 1, 2, 3, 4
+CON_PLANE_BOX, CON_SPHERE_BOX, CON_CAPSULE_BOX, CON_BOX_BOX = 5, 6, 7, 8
 MJ_MINVAL = 1e-15
 
 _GEOM_TYPES = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4,
@@ -393,11 +394,16 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
                 continue
             if g["mass"] is not None and g["mass"] == 0.0:
                 continue                      # e.g. the Allegro collision primitives (`mass="0"`)
-            if g["type"] != _GEOM_TYPES["mesh"] or g["mesh"] not in meshes:
+            if g["type"] == GEOM_BOX:
+                hx, hy, hz = g["size"]
+                vol, com = 8.0 * hx * hy * hz, np.zeros(3)
+                I = vol / 3.0 * np.diag([hy * hy + hz * hz, hx * hx + hz * hz, hx * hx + hy * hy])
+            elif g["type"] != _GEOM_TYPES["mesh"] or g["mesh"] not in meshes:
                 raise NotImplementedError(
-                    f"body {b['name']!r}: inertia-from-geom is only implemented for mesh geoms")
-            me = meshes[g["mesh"]]
-            vol, com, I = _mesh_mass_props(me["file"], me["scale"], me["inertia"])
+                    f"body {b['name']!r}: inertia-from-geom is only implemented for mesh and box geoms")
+            else:
+                me = meshes[g["mesh"]]
+                vol, com, I = _mesh_mass_props(me["file"], me["scale"], me["inertia"])
             gm = g["mass"] if g["mass"] is not None else g["density"] * vol
             if gm <= 0:
                 continue
@@ -490,13 +496,17 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
     cgeoms = [g for g in geoms_all if (g["contype"] | g["conaffinity"]) != 0 and g["type"] != 7]
     contacts: List[Dict[str, Any]] = []
     pairs = []
+    # bodies welded to the world (no joint between them and the world): MuJoCo never collides two of those
+    static_body = [True] * nbody
+    for b in range(1, nbody):
+        static_body[b] = static_body[bodies[b]["parent"]] and body_jntnum[b] == 0
     for i in range(len(cgeoms)):
         for k in range(i + 1, len(cgeoms)):
             g1, g2 = cgeoms[i], cgeoms[k]
             if not ((g1["contype"] & g2["conaffinity"]) | (g2["contype"] & g1["conaffinity"])):
                 continue
             b1, b2 = g1["body"], g2["body"]
-            if b1 == b2:
+            if b1 == b2 or (static_body[b1] and static_body[b2]):
                 continue
             if b1 != 0 and b2 != 0 and (bodies[b1]["parent"] == b2 or bodies[b2]["parent"] == b1):
                 continue
@@ -520,8 +530,14 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
             return (pair_condim(p), g1["type"], g2["type"])
         return (g1["type"], g2["type"], pair_condim(p))
     pairs.sort(key=pair_key)
-    kinds = {(GEOM_PLANE, GEOM_SPHERE): (CON_PLANE_SPHERE,), (GEOM_PLANE, GEOM_CAPSULE): (CON_PLANE_CAPSULE_P, CON_PLANE_CAPSULE_N),
-             (GEOM_SPHERE, GEOM_CAPSULE): (CON_SPHERE_CAPSULE,), (GEOM_CAPSULE, GEOM_CAPSULE): (CON_CAPSULE_CAPSULE,)}
+    # (kind, sub) of the candidate contacts one geom pair yields (a fixed number, like MJX's collision functions)
+    kinds = {(GEOM_PLANE, GEOM_SPHERE): ((CON_PLANE_SPHERE, 0),),
+             (GEOM_PLANE, GEOM_CAPSULE): ((CON_PLANE_CAPSULE_P, 0), (CON_PLANE_CAPSULE_N, 0)),
+             (GEOM_SPHERE, GEOM_CAPSULE): ((CON_SPHERE_CAPSULE, 0),), (GEOM_CAPSULE, GEOM_CAPSULE): ((CON_CAPSULE_CAPSULE, 0),),
+             (GEOM_PLANE, GEOM_BOX): tuple((CON_PLANE_BOX, k) for k in range(4)),
+             (GEOM_SPHERE, GEOM_BOX): ((CON_SPHERE_BOX, 0),),
+             (GEOM_CAPSULE, GEOM_BOX): ((CON_CAPSULE_BOX, 0), (CON_CAPSULE_BOX, 1)),
+             (GEOM_BOX, GEOM_BOX): tuple((CON_BOX_BOX, k) for k in range(4))}
     for (i1, i2) in pairs:
         g1, g2 = cgeoms[i1], cgeoms[i2]
         if (g1["type"], g2["type"]) not in kinds:
@@ -546,8 +562,8 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         base = dict(geom1=i1, geom2=i2, body1=g1["body"], body2=g2["body"], dim=condim,
                     friction=np.array([fr[0], fr[0], fr[1], fr[2], fr[2]]), solref=solref,
                     solimp=solimp, margin=margin - gap)
-        for kind in kinds[(g1["type"], g2["type"])]:
-            contacts.append(dict(base, kind=kind))
+        for kind, sub in kinds[(g1["type"], g2["type"])]:
+            contacts.append(dict(base, kind=kind, sub=sub))
 
     lim_jnt = [ji for ji, j in enumerate(joints) if j["limited"]]
 
@@ -632,6 +648,7 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         con_body1=np.array([c["body1"] for c in contacts], dtype=np.int64),
         con_body2=np.array([c["body2"] for c in contacts], dtype=np.int64),
         con_dim=np.array([c["dim"] for c in contacts], dtype=np.int64),
+        con_sub=np.array([c["sub"] for c in contacts], dtype=np.int64),
         con_friction=np.array([c["friction"] for c in contacts]).reshape(-1, 5),
         con_solref=np.array([c["solref"] for c in contacts]).reshape(-1, 2),
         con_solimp=np.array([c["solimp"] for c in contacts]).reshape(-1, 5),

@@ -46,10 +46,10 @@ extern "C" {
 #define DIAL_MAX_Q 32
 #define DIAL_MAX_V 28      /* H1 walk: 25                                        */
 #define DIAL_MAX_U 20      /* H1 walk: 19                                        */
-#define DIAL_MAX_GEOM 8    /* collision geoms only                               */
+#define DIAL_MAX_GEOM 20   /* collision geoms only (Go2 crate scene: 15 robot geoms + floor + crate) */
 #define DIAL_MAX_SITE 8
-#define DIAL_MAX_CON 24    /* static contact list (Go2: 4, H1 walk: 4, Allegro: 19) */
-#define DIAL_MAX_EFC 160   /* constraint rows: limits + 4 per pyramidal / condim per elliptic contact (Allegro: 88) */
+#define DIAL_MAX_CON 56    /* static contact list (Go2: 4, H1 walk: 4, Allegro: 19, Go2 crate scene: 52) */
+#define DIAL_MAX_EFC 240   /* constraint rows: limits + 4 per pyramidal / condim per elliptic contact (Allegro: 88, crate scene: 220) */
 #define DIAL_MAX_LIM 24    /* limited hinge joints                               */
 #define DIAL_MAX_FEET 4
 #define DIAL_MAX_STAGE 12  /* seq-jump stages                                    */
@@ -68,6 +68,7 @@ extern "C" {
 #define DIAL_GEOM_PLANE 0
 #define DIAL_GEOM_SPHERE 2
 #define DIAL_GEOM_CAPSULE 3
+#define DIAL_GEOM_BOX 6
 
 /* static contact kinds */
 #define DIAL_CON_PLANE_SPHERE 0
@@ -75,6 +76,17 @@ extern "C" {
 #define DIAL_CON_PLANE_CAPSULE_N 2 /* capsule end  -axis*halflen */
 #define DIAL_CON_SPHERE_CAPSULE 3  /* geom1 sphere, geom2 capsule (MJX sphere_capsule)        */
 #define DIAL_CON_CAPSULE_CAPSULE 4 /* MJX capsule_capsule: closest points of the two segments */
+/* Box narrow phases (the crate scenes).  MJX routes boxes through collision_convex.py, which is NOT in
+ * /root/reference (third-party, un-vendored) and whose manifold selection differs between releases; what follows is a
+ * restatement of the GEOMETRY (unique wherever the contact is unique), not of MJX's vertex bookkeeping -- see DESIGN.md
+ * section 1 "crate scenes".  A pair yields a FIXED number of candidate contacts (con_sub = 0, 1, ...), as MJX's do:
+ * candidates that do not touch carry dist >= margin and produce zero rows.                                          */
+#define DIAL_CON_PLANE_BOX 5    /* geom1 plane, geom2 box: con_sub = k-th lowest of the 8 vertices (k < 4)              */
+#define DIAL_CON_SPHERE_BOX 6   /* geom1 sphere, geom2 box: closest point of the box to the centre                      */
+#define DIAL_CON_CAPSULE_BOX 7  /* geom1 capsule, geom2 box: con_sub 0 = the segment point closest to the box, 1 = the
+                                   segment end farther from that point (both as spheres of the capsule's radius)       */
+#define DIAL_CON_BOX_BOX 8      /* separating-axis test; face contact: incident face clipped against the reference face,
+                                   con_sub = k-th deepest point (k < 4); edge contact: one point (con_sub 0)            */
 
 /* bracket-update rule of the Newton solver's line search (solver._linesearch of MJX).  The reference pins no MJX
  * version (setup.py:9-21); its Allegro env needs elliptic cones, i.e. a release (>= 3.1.4) that carries the
@@ -96,6 +108,7 @@ extern "C" {
 #define DIAL_TASK_H1_WALK 2
 #define DIAL_TASK_H1_LOCO 3
 #define DIAL_TASK_ALLEGRO 4
+#define DIAL_TASK_GO2_CRATE 5  /* UnitreeGo2CrateEnv.step (unitree_go2_env.py:679-795) */
 
 /* packed-state info slots (floats; integers are stored as exactly representable floats) */
 #define DIAL_INFO_STEP 0
@@ -188,6 +201,7 @@ typedef struct dial_model {
   int32_t con_body1[DIAL_MAX_CON];
   int32_t con_body2[DIAL_MAX_CON];
   int32_t con_dim[DIAL_MAX_CON];
+  int32_t con_sub[DIAL_MAX_CON];   /* which of the pair's candidate contacts (box kinds), 0 elsewhere */
   float con_friction[DIAL_MAX_CON][5];
   float con_solref[DIAL_MAX_CON][2];
   float con_solimp[DIAL_MAX_CON][5];
@@ -246,6 +260,13 @@ typedef struct dial_task {
   int32_t randomize_tasks;
   int32_t n_cmd;
   float cmd_table[DIAL_MAX_CMD][3];
+  /* crate climb (unitree_go2_env.py:741-766): reward_contact counts the feet whose contact with the crate lies inside
+   * the box `crate_region` = (x0, x1, y0, y1, z0, z1) -- upstream's cond on contact.pos[contact_indices[i]].  Upstream
+   * hard-codes the indices [16, 17, 18, 19] of ITS MJX release's contact array; here the env class looks the four
+   * foot-sphere / crate contacts up by geom identity (`crate_contact`, indices into this model's static contact list). */
+  int32_t crate_contact[DIAL_MAX_FEET];
+  float crate_region[6];
+  float head_vec[3];           /* head_pos = torso pos + R head_vec (:717-718)                                         */
 } dial_task;
 
 /* Planner configuration: DialConfig + the constant spline matrices

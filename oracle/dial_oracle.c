@@ -385,9 +385,262 @@ static void sphere_sphere(const real* p1, real r1, const real* p2, real r2, real
   for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + *dist * (real)0.5);
   make_frame(frame, n);
 }
+/* ---- box narrow phases (the crate scenes).  MJX sends boxes through collision_convex.py, which is third-party code that
+ * is not under /root/reference; these functions restate the GEOMETRY of each pair (unique wherever the contact is), with a
+ * fixed number of candidate contacts per pair -- include/dial_mpc.h DIAL_CON_*_BOX, DESIGN.md section 1.  Conventions are
+ * MJX's: the normal points from geom1 into geom2, dist < 0 is penetration, pos lies midway between the two surfaces. */
+typedef struct { real c[3], R[9], h[3]; } obox;   /* centre, world-from-local rotation (row-major), half sizes */
+static void obox_of(const dial_model* m, const odata* d, int g, obox* b) {
+  for (int k = 0; k < 3; k++) { b->c[k] = d->geom_xpos[g][k]; b->h[k] = (real)m->geom_size[g][k]; }
+  for (int k = 0; k < 9; k++) b->R[k] = d->geom_xmat[g][k];
+}
+static void obox_axis(const obox* b, int k, real* a) { a[0] = b->R[k]; a[1] = b->R[3 + k]; a[2] = b->R[6 + k]; }
+static void obox_local(const obox* b, const real* p, real* o) {
+  real r[3] = {p[0] - b->c[0], p[1] - b->c[1], p[2] - b->c[2]};
+  for (int k = 0; k < 3; k++) o[k] = b->R[k] * r[0] + b->R[3 + k] * r[1] + b->R[6 + k] * r[2];
+}
+static void obox_world_dir(const obox* b, const real* v, real* o) {
+  for (int k = 0; k < 3; k++) o[k] = b->R[3 * k] * v[0] + b->R[3 * k + 1] * v[1] + b->R[3 * k + 2] * v[2];
+}
+/* a sphere against a box: the point of the box closest to the centre; a centre inside the box leaves through the nearest face */
+static void sphere_box(const real* sc, real r, const obox* b, real* dist, real* pos, real* frame) {
+  real p[3], nl[3], len2 = 0;
+  obox_local(b, sc, p);
+  for (int k = 0; k < 3; k++) { nl[k] = r_clip(p[k], -b->h[k], b->h[k]) - p[k]; len2 += nl[k] * nl[k]; }
+  if (len2 > 0) {
+    real len = r_sqrt(len2);
+    for (int k = 0; k < 3; k++) nl[k] /= len;
+    *dist = len - r;
+  } else {
+    int kb = 0;
+    real best = b->h[0] - r_abs(p[0]);
+    for (int k = 1; k < 3; k++) { real e = b->h[k] - r_abs(p[k]); if (e < best) { best = e; kb = k; } }
+    nl[0] = nl[1] = nl[2] = 0;
+    nl[kb] = p[kb] >= 0 ? -1 : 1;
+    *dist = -best - r;
+  }
+  real n[3];
+  obox_world_dir(b, nl, n);
+  for (int k = 0; k < 3; k++) pos[k] = sc[k] + n[k] * (r + *dist * (real)0.5);
+  make_frame(frame, n);
+}
+/* plane against a box: the sub-th lowest vertex (ties: lower vertex index first) */
+static void plane_box(const real* n, const real* ppos, const obox* b, int sub, real* dist, real* pos, real* frame) {
+  real v[8][3], dv[8];
+  for (int i = 0; i < 8; i++) {
+    real l[3] = {(i & 1) ? b->h[0] : -b->h[0], (i & 2) ? b->h[1] : -b->h[1], (i & 4) ? b->h[2] : -b->h[2]}, w[3];
+    obox_world_dir(b, l, w);
+    for (int k = 0; k < 3; k++) v[i][k] = b->c[k] + w[k];
+    real df[3] = {v[i][0] - ppos[0], v[i][1] - ppos[1], v[i][2] - ppos[2]};
+    dv[i] = dot3(df, n);
+  }
+  int pick = 0;
+  for (int i = 0; i < 8; i++) {
+    int rank = 0;
+    for (int j = 0; j < 8; j++) rank += (dv[j] < dv[i] || (dv[j] == dv[i] && j < i)) ? 1 : 0;
+    if (rank == sub) pick = i;
+  }
+  *dist = dv[pick];
+  for (int k = 0; k < 3; k++) pos[k] = v[pick][k] - n[k] * (dv[pick] * (real)0.5);
+  make_frame(frame, n);
+}
+/* squared distance from the segment point a0 + t (a1 - a0) (box frame) to the box, minimised over t in [0, 1]: the
+ * function is convex and piecewise quadratic, its pieces end where the point crosses one of the six slab planes */
+static real segment_box_closest_t(const real* a0, const real* a1, const real* h) {
+  real bp[8];
+  int nb = 0;
+  bp[nb++] = 0;
+  for (int k = 0; k < 3; k++) {
+    real dk = a1[k] - a0[k];
+    if (dk == 0) continue;
+    for (int sg = -1; sg <= 1; sg += 2) {
+      real t = ((real)sg * h[k] - a0[k]) / dk;
+      if (t > 0 && t < 1) bp[nb++] = t;
+    }
+  }
+  bp[nb++] = 1;
+  for (int i = 1; i < nb; i++) {   /* insertion sort */
+    real x = bp[i];
+    int j = i - 1;
+    while (j >= 0 && bp[j] > x) { bp[j + 1] = bp[j]; j--; }
+    bp[j + 1] = x;
+  }
+  real best_t = 0, best_f = -1;
+  for (int i = 0; i + 1 < nb; i++) {
+    real t0 = bp[i], t1 = bp[i + 1], tm = (real)0.5 * (t0 + t1), A = 0, B = 0;
+    real off[3];
+    int st[3];
+    for (int k = 0; k < 3; k++) {
+      real x = a0[k] + tm * (a1[k] - a0[k]);
+      st[k] = x > h[k] ? 1 : (x < -h[k] ? -1 : 0);
+      off[k] = a0[k] - (real)st[k] * h[k];
+      if (st[k]) { real dk = a1[k] - a0[k]; A += dk * dk; B += dk * off[k]; }
+    }
+    real t = A > 0 ? r_clip(-B / A, t0, t1) : t0, f = 0;
+    for (int k = 0; k < 3; k++) if (st[k]) { real x = off[k] + t * (a1[k] - a0[k]); f += x * x; }
+    if (best_f < 0 || f < best_f) { best_f = f; best_t = t; }
+  }
+  return best_t;
+}
+/* capsule against a box: sub 0 = the sphere at the segment point closest to the box, sub 1 = the sphere at the segment end
+ * farther from that point (a capsule lying on a face touches with both, one standing on an end or crossing an edge with one) */
+static void capsule_box(const real* ctr, const real* axis, real hl, real r, const obox* b, int sub, real* dist, real* pos, real* frame) {
+  real e0[3], e1[3], l0[3], l1[3];
+  for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; }
+  obox_local(b, e0, l0);
+  obox_local(b, e1, l1);
+  real t = segment_box_closest_t(l0, l1, b->h);
+  real sc[3];
+  if (sub == 0) for (int k = 0; k < 3; k++) sc[k] = e0[k] + t * (e1[k] - e0[k]);
+  else for (int k = 0; k < 3; k++) sc[k] = t <= (real)0.5 ? e1[k] : e0[k];
+  sphere_box(sc, r, b, dist, pos, frame);
+}
+/* box against box: separating-axis test over the 6 face normals and the 9 edge-edge directions.  Face axis: the incident
+ * face of the other box is clipped against the side planes of the reference face, the sub-th deepest point is the
+ * contact; edge axis: the closest points of the two edges (sub 0).  Candidates that do not exist are parked at dist = 1. */
+static void box_box(const obox* A, const obox* B, int sub, real* dist, real* pos, real* frame) {
+  real ax[2][3][3];
+  for (int k = 0; k < 3; k++) { obox_axis(A, k, ax[0][k]); obox_axis(B, k, ax[1][k]); }
+  real tw[3] = {B->c[0] - A->c[0], B->c[1] - A->c[1], B->c[2] - A->c[2]};
+  real Rr[3][3], Q[3][3], t[3];
+  for (int i = 0; i < 3; i++) {
+    t[i] = dot3(tw, ax[0][i]);
+    for (int j = 0; j < 3; j++) { Rr[i][j] = dot3(ax[0][i], ax[1][j]); Q[i][j] = r_abs(Rr[i][j]); }
+  }
+  /* face axes */
+  int best = -1;
+  real sbest = 0;
+  for (int i = 0; i < 3; i++) {
+    real s = r_abs(t[i]) - (A->h[i] + B->h[0] * Q[i][0] + B->h[1] * Q[i][1] + B->h[2] * Q[i][2]);
+    if (best < 0 || s > sbest) { best = i; sbest = s; }
+  }
+  for (int j = 0; j < 3; j++) {
+    real tb = t[0] * Rr[0][j] + t[1] * Rr[1][j] + t[2] * Rr[2][j];
+    real s = r_abs(tb) - (B->h[j] + A->h[0] * Q[0][j] + A->h[1] * Q[1][j] + A->h[2] * Q[2][j]);
+    if (s > sbest) { best = 3 + j; sbest = s; }
+  }
+  /* edge axes: an edge pair wins only if it separates clearly better than the best face (no jitter between the two kinds) */
+  real nbest[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      real L[3];
+      cross3(L, ax[0][i], ax[1][j]);
+      real len = r_sqrt(dot3(L, L));
+      if (len < (real)1e-4) continue;
+      for (int k = 0; k < 3; k++) L[k] /= len;
+      real ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += A->h[k] * r_abs(dot3(L, ax[0][k])); rb += B->h[k] * r_abs(dot3(L, ax[1][k])); }
+      real s = r_abs(dot3(tw, L)) - (ra + rb);
+      if (s > sbest + (real)0.05 * r_abs(sbest) + (real)1e-5) { best = 6 + 3 * i + j; sbest = s; for (int k = 0; k < 3; k++) nbest[k] = L[k]; }
+    }
+  real mid[3] = {(real)0.5 * (A->c[0] + B->c[0]), (real)0.5 * (A->c[1] + B->c[1]), (real)0.5 * (A->c[2] + B->c[2])};
+  if (sbest > (real)0.01) {   /* clearly apart */
+    real n[3];
+    if (best < 3) for (int k = 0; k < 3; k++) n[k] = ax[0][best][k] * (t[best] >= 0 ? 1 : -1);
+    else if (best < 6) { real sg = dot3(tw, ax[1][best - 3]) >= 0 ? 1 : -1; for (int k = 0; k < 3; k++) n[k] = ax[1][best - 3][k] * sg; }
+    else { real sg = dot3(tw, nbest) >= 0 ? 1 : -1; for (int k = 0; k < 3; k++) n[k] = nbest[k] * sg; }
+    *dist = sub == 0 ? sbest : 1;
+    for (int k = 0; k < 3; k++) pos[k] = mid[k];
+    make_frame(frame, n);
+    return;
+  }
+  if (best >= 6) {   /* edge - edge */
+    int i = (best - 6) / 3, j = (best - 6) % 3;
+    real n[3], sg = dot3(tw, nbest) >= 0 ? 1 : -1;
+    for (int k = 0; k < 3; k++) n[k] = nbest[k] * sg;
+    real pa[3] = {A->c[0], A->c[1], A->c[2]}, pb[3] = {B->c[0], B->c[1], B->c[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != i) { real sk = dot3(n, ax[0][k]) >= 0 ? 1 : -1; for (int q = 0; q < 3; q++) pa[q] += sk * A->h[k] * ax[0][k][q]; }
+      if (k != j) { real sk = dot3(n, ax[1][k]) >= 0 ? 1 : -1; for (int q = 0; q < 3; q++) pb[q] -= sk * B->h[k] * ax[1][k][q]; }
+    }
+    const real *ua = ax[0][i], *ub = ax[1][j];
+    real w[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    real uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub * uaub;
+    real al = (q1 + uaub * q2) / den, be = (uaub * q1 + q2) / den;
+    al = r_clip(al, -A->h[i], A->h[i]);
+    be = r_clip(be, -B->h[j], B->h[j]);
+    real ca[3], cb[3], df[3];
+    for (int k = 0; k < 3; k++) { ca[k] = pa[k] + al * ua[k]; cb[k] = pb[k] + be * ub[k]; df[k] = cb[k] - ca[k]; }
+    *dist = sub == 0 ? dot3(df, n) : 1;
+    for (int k = 0; k < 3; k++) pos[k] = (real)0.5 * (ca[k] + cb[k]);
+    make_frame(frame, n);
+    return;
+  }
+  /* face: reference box X (axis kx), incident box Y */
+  const obox *X = best < 3 ? A : B, *Y = best < 3 ? B : A;
+  const int xi = best < 3 ? 0 : 1, yi = 1 - xi, kx = best < 3 ? best : best - 3;
+  real xy[3] = {Y->c[0] - X->c[0], Y->c[1] - X->c[1], Y->c[2] - X->c[2]};
+  real nref[3], sgx = dot3(xy, ax[xi][kx]) >= 0 ? 1 : -1;
+  for (int k = 0; k < 3; k++) nref[k] = ax[xi][kx][k] * sgx;
+  int my = 0;
+  real amax = -1;
+  for (int k = 0; k < 3; k++) { real a = r_abs(dot3(nref, ax[yi][k])); if (a > amax) { amax = a; my = k; } }
+  const int uy = (my + 1) % 3, vy = (my + 2) % 3, ux = (kx + 1) % 3, vx = (kx + 2) % 3;
+  real sgy = dot3(nref, ax[yi][my]) >= 0 ? -1 : 1;   /* the incident face looks back at the reference box */
+  real poly[2][10][3];   /* (a, b, d): reference-face coordinates and signed distance to the reference face */
+  int np_ = 4;
+  for (int q = 0; q < 4; q++) {
+    real su = (q == 0 || q == 3) ? 1 : -1, sv = (q < 2) ? 1 : -1, pw[3];
+    for (int k = 0; k < 3; k++) pw[k] = Y->c[k] + sgy * Y->h[my] * ax[yi][my][k] + su * Y->h[uy] * ax[yi][uy][k] + sv * Y->h[vy] * ax[yi][vy][k] - X->c[k];
+    poly[0][q][0] = dot3(pw, ax[xi][ux]);
+    poly[0][q][1] = dot3(pw, ax[xi][vx]);
+    poly[0][q][2] = dot3(pw, nref) - X->h[kx];
+  }
+  int cur = 0;
+  for (int pl = 0; pl < 4; pl++) {   /* Sutherland-Hodgman against  +-a <= h_u,  +-b <= h_v */
+    const int co = pl >> 1;
+    const real sg = (pl & 1) ? -1 : 1, lim = co == 0 ? X->h[ux] : X->h[vx];
+    int no = 0;
+    for (int q = 0; q < np_; q++) {
+      const real* P = poly[cur][q];
+      const real* Qn = poly[cur][(q + 1) % np_];
+      real fp = sg * P[co] - lim, fq = sg * Qn[co] - lim;
+      if (fp <= 0) { for (int k = 0; k < 3; k++) poly[1 - cur][no][k] = P[k]; no++; }
+      if ((fp <= 0) != (fq <= 0)) {
+        real w = fp / (fp - fq);
+        for (int k = 0; k < 3; k++) poly[1 - cur][no][k] = P[k] + w * (Qn[k] - P[k]);
+        no++;
+      }
+    }
+    np_ = no;
+    cur = 1 - cur;
+    if (np_ == 0) break;
+  }
+  real n[3];
+  for (int k = 0; k < 3; k++) n[k] = xi == 0 ? nref[k] : -nref[k];
+  make_frame(frame, n);
+  int pick = -1;
+  for (int q = 0; q < np_; q++) {
+    int rank = 0;
+    for (int o = 0; o < np_; o++) rank += (poly[cur][o][2] < poly[cur][q][2] || (poly[cur][o][2] == poly[cur][q][2] && o < q)) ? 1 : 0;
+    if (rank == sub) pick = q;
+  }
+  if (pick < 0) { *dist = 1; for (int k = 0; k < 3; k++) pos[k] = mid[k]; return; }
+  const real* P = poly[cur][pick];
+  *dist = P[2];
+  for (int k = 0; k < 3; k++) pos[k] = X->c[k] + P[0] * ax[xi][ux][k] + P[1] * ax[xi][vx][k] + (X->h[kx] + P[2] * (real)0.5) * nref[k];
+}
 static void collision(const dial_model* m, odata* d) {
   for (int c = 0; c < m->ncon; c++) {
     int g1 = m->con_geom1[c], g2 = m->con_geom2[c];
+    if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) {
+      obox b2;
+      obox_of(m, d, g2, &b2);
+      if (m->con_kind[c] == DIAL_CON_PLANE_BOX) {
+        real n[3] = {d->geom_xmat[g1][2], d->geom_xmat[g1][5], d->geom_xmat[g1][8]};
+        plane_box(n, d->geom_xpos[g1], &b2, m->con_sub[c], &d->con_dist[c], d->con_pos[c], d->con_frame[c]);
+      } else if (m->con_kind[c] == DIAL_CON_SPHERE_BOX) {
+        sphere_box(d->geom_xpos[g1], (real)m->geom_size[g1][0], &b2, &d->con_dist[c], d->con_pos[c], d->con_frame[c]);
+      } else if (m->con_kind[c] == DIAL_CON_CAPSULE_BOX) {
+        real ax1[3] = {d->geom_xmat[g1][2], d->geom_xmat[g1][5], d->geom_xmat[g1][8]};
+        capsule_box(d->geom_xpos[g1], ax1, (real)m->geom_size[g1][1], (real)m->geom_size[g1][0], &b2, m->con_sub[c], &d->con_dist[c], d->con_pos[c], d->con_frame[c]);
+      } else {
+        obox b1;
+        obox_of(m, d, g1, &b1);
+        box_box(&b1, &b2, m->con_sub[c], &d->con_dist[c], d->con_pos[c], d->con_frame[c]);
+      }
+      continue;
+    }
     if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
       real ax2[3] = {d->geom_xmat[g2][2], d->geom_xmat[g2][5], d->geom_xmat[g2][8]}, hl2 = m->geom_size[g2][1];
       real b0[3], b1[3], p1[3], p2[3];
@@ -1124,6 +1377,54 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
     info[DIAL_INFO_REWARD] = reward;
     return reward;
   }
+  if (t->kind == DIAL_TASK_GO2_CRATE) { /* UnitreeGo2CrateEnv.step, unitree_go2_env.py:679-795 */
+    real z_tar[DIAL_MAX_FEET], reward_gaits = 0;
+    get_foot_step(t, step * dt, z_tar);                                             /* :697-703 */
+    for (int f = 0; f < t->nfeet; f++) { real e = (z_tar[f] - d->site_xpos[t->feet_site[f]][2]) / (real)0.05; reward_gaits += e * e; }
+    reward_gaits = -reward_gaits;
+    real R[9], head[3], reward_pos = 0;                                             /* :705-719 */
+    quat_to_mat(R, rot_t);
+    for (int k = 0; k < 3; k++) {
+      real pos_tar = info[DIAL_INFO_POS_TAR + k] + info[DIAL_INFO_VEL_TAR + k] * dt * step;
+      head[k] = d->xpos[tb][k] + (R[3 * k] * (real)t->head_vec[0] + R[3 * k + 1] * (real)t->head_vec[1] + R[3 * k + 2] * (real)t->head_vec[2]);
+      reward_pos += (head[k] - pos_tar) * (head[k] - pos_tar);
+    }
+    reward_pos = -reward_pos;
+    real reward_yaw = -(yaw - info[DIAL_INFO_YAW_TAR]) * (yaw - info[DIAL_INFO_YAW_TAR]);   /* :724-727 */
+    real reward_vel = 0, reward_height, reward_energy = 0;                          /* :730-740 */
+    for (int k = 0; k < 3; k++) { real e = vel[k] - info[DIAL_INFO_VEL_TAR + k]; reward_vel += e * e; }
+    reward_vel = -reward_vel;
+    reward_height = -(d->xpos[tb][2] - info[DIAL_INFO_POS_TAR + 2]) * (d->xpos[tb][2] - info[DIAL_INFO_POS_TAR + 2]);
+    for (int a = 0; a < m->nu; a++) { real e = r_max(ctrl[a] * d->qvel[6 + a] / (real)160.0, 0); reward_energy += e * e; }
+    reward_energy = -reward_energy;
+    /* pitch / roll (:741-746) are multiplied by 0.0 below; quat_to_euler is finite for every unit quaternion, so they are
+     * left out (an exact zero is added either way) */
+    real reward_contact = 0, penalty_contact = 0;                                   /* :748-767 */
+    for (int c2 = 0; c2 < m->ncon; c2++) {
+      int pen = d->con_dist[c2] <= (real)0.001;
+      for (int i = 0; i < 4; i++)
+        if (c2 == i) {   /* `penalty_contact.at[i]`: upstream indexes the penalty mask by the FOOT number, not by the contact */
+          const real* cp = d->con_pos[t->crate_contact[i]];
+          int cond = cp[0] > (real)t->crate_region[0] && cp[0] < (real)t->crate_region[1] && cp[1] > (real)t->crate_region[2] &&
+                     cp[1] < (real)t->crate_region[3] && cp[2] > (real)t->crate_region[4] && cp[2] < (real)t->crate_region[5];
+          pen = pen && !cond;
+        }
+      penalty_contact += pen ? 1 : 0;
+    }
+    for (int i = 0; i < 4; i++) {
+      const real* cp = d->con_pos[t->crate_contact[i]];
+      int cond = cp[0] > (real)t->crate_region[0] && cp[0] < (real)t->crate_region[1] && cp[1] > (real)t->crate_region[2] &&
+                 cp[1] < (real)t->crate_region[3] && cp[2] > (real)t->crate_region[4] && cp[2] < (real)t->crate_region[5];
+      reward_contact += cond ? 1 : 0;
+    }
+    reward = reward_gaits * (real)0.0 + reward_pos * (real)1.0 + reward_upright * (real)0.01 + reward_yaw * (real)0.3 +
+             reward_vel * (real)0.0 + reward_height * (real)0.0 + reward_energy * (real)0.0000 + (real)0.0 + (real)0.0 +
+             reward_contact * (real)0.02 - penalty_contact * (real)0.0;             /* :770-783 */
+    info[DIAL_INFO_DONE] = 0;
+    info[DIAL_INFO_STEP] = step + 1;
+    info[DIAL_INFO_REWARD] = reward;
+    return reward;
+  }
   if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK || t->kind == DIAL_TASK_H1_LOCO) {
     /* unitree_go2_env.py:142-162 / unitree_h1_env.py:196-217: target ramp uses the PRE-increment step */
     for (int k = 0; k < 3; k++) {
@@ -1518,6 +1819,20 @@ int oracle_forward_dump(const dial_model* m, const real* qpos, const real* qvel,
   if (efc_D) for (int r = 0; r < m->nefc; r++) efc_D[r] = d->efc_D[r];
   if (niter) *niter = d->solver_niter;
   free(d);
+  return 0;
+}
+
+/* box narrow-phase hook (tests/test_box_collisions.py): geoms as (pos[3], mat[9] row-major, size[3]) */
+int oracle_box_contact(int kind, int sub, const real* g1, const real* g2, real* dist, real* pos, real* frame) {
+  obox b1, b2;
+  for (int k = 0; k < 3; k++) { b1.c[k] = g1[k]; b1.h[k] = g1[12 + k]; b2.c[k] = g2[k]; b2.h[k] = g2[12 + k]; }
+  for (int k = 0; k < 9; k++) { b1.R[k] = g1[3 + k]; b2.R[k] = g2[3 + k]; }
+  real ax1[3] = {g1[5], g1[8], g1[11]};
+  if (kind == DIAL_CON_PLANE_BOX) plane_box(ax1, g1, &b2, sub, dist, pos, frame);
+  else if (kind == DIAL_CON_SPHERE_BOX) sphere_box(g1, g1[12], &b2, dist, pos, frame);
+  else if (kind == DIAL_CON_CAPSULE_BOX) capsule_box(g1, ax1, g1[13], g1[12], &b2, sub, dist, pos, frame);
+  else if (kind == DIAL_CON_BOX_BOX) box_box(&b1, &b2, sub, dist, pos, frame);
+  else return -1;
   return 0;
 }
 

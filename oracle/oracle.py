@@ -163,6 +163,17 @@ class Oracle:
         o["niter"] = niter.value
         return o
 
+    def box_contact(self, kind: int, sub: int, g1, g2):
+        """One candidate contact of a box pair; g = (pos[3], mat[3, 3], size[3]).  Returns (dist, pos, frame[3, 3])."""
+        pack = lambda g: self._a(np.concatenate([np.asarray(g[0], float).ravel(), np.asarray(g[1], float).ravel(),
+                                                 np.asarray(g[2], float).ravel()]))
+        a, b = pack(g1), pack(g2)
+        dist, pos, frame = np.zeros(1, self.dtype), np.zeros(3, self.dtype), np.zeros(9, self.dtype)
+        rc = self.lib.oracle_box_contact(int(kind), int(sub), self._p(a), self._p(b), self._p(dist), self._p(pos), self._p(frame))
+        if rc:
+            raise ValueError(f"oracle_box_contact: kind {kind}")
+        return float(dist[0]), pos.astype(np.float64), frame.reshape(3, 3).astype(np.float64)
+
     def foot_step(self, time: float) -> np.ndarray:
         h = np.zeros(self.task.nfeet, self.dtype)
         t = ctypes.c_float(time) if self.dtype == np.float32 else ctypes.c_double(time)

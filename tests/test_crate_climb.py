@@ -1,0 +1,184 @@
+"""Crate climb (UnitreeGo2CrateEnv) on the CPU: compiled scene, the oracle's physics on the crate,
+and the kernel body (generic instantiation, host wave emulator) against the fp32 oracle from states that TOUCH the crate
+with every kind of geom -- foot and base spheres, calf capsules, the trunk box.
+
+The box narrow phases are restated geometry, not MJX's collision_convex (tests/test_box_collisions.py pins them to brute
+force; DESIGN.md section 1 says what that does and does not establish)."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle as O
+from conftest import TOL, _within, seeded_inputs, setup_case, witness_parity
+
+EX = "unitree_go2_crate_climb"
+
+
+def _quat(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    return np.array([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy])
+
+
+def touching_state(env, o64, seed, depth=0.002):
+    """A random pose over the crate, lowered until its deepest candidate contact penetrates by `depth`."""
+    rng = np.random.default_rng(seed)
+    q = np.array(env._init_q, dtype=np.float64)
+    q[0:2] = [rng.uniform(0.95, 1.6), rng.uniform(-0.4, 0.4)]
+    q[3:7] = _quat(rng.uniform(-0.5, 0.5), rng.uniform(-0.7, 0.5), rng.uniform(-0.6, 0.6))
+    q[7:] += rng.uniform(-0.3, 0.3, 12)
+    q[2] = 1.2
+    nv = env.sys.nv
+    for _ in range(40):
+        dmin = float(o64.forward_dump(q, np.zeros(nv))["con_dist"].min())
+        if abs(dmin + depth) < 1e-5:
+            break
+        q[2] -= (dmin + depth) * 0.9
+    qd = rng.normal(0, 0.3, nv)
+    return q, qd
+
+
+@pytest.fixture(scope="module")
+def case():
+    dc, env, model, task, cfg = setup_case(EX, 12, 5, per_rollout=True)
+    return dc, env, model, task, cfg
+
+
+def test_compiled_scene(case):
+    dc, env, model, task, cfg = case
+    md = env.sys.model
+    assert (md["nq"], md["nv"], md["nu"], md["nbody"], md["ngeom"], md["ncon"], md["nefc"]) == (19, 18, 12, 15, 17, 52, 220)
+    names = md["names"]["geom"]
+    kinds = {}
+    for c in range(md["ncon"]):
+        kinds.setdefault(int(md["con_kind"][c]), []).append(c)
+    # 6 spheres + 8 capsules (2 ends) + the trunk box (4 vertices) against the floor; the same 15 geoms against the crate
+    assert {k: len(v) for k, v in kinds.items()} == {0: 6, 1: 8, 2: 8, 5: 4, 6: 6, 7: 16, 8: 4}
+    floor, box = names.index("floor"), names.index("static_box")
+    assert not any({int(md["con_geom1"][c]), int(md["con_geom2"][c])} == {floor, box} for c in range(md["ncon"]))   # both welded to the world
+    # the four contacts reward_contact reads: FR, FL, RR, RL foot spheres against the crate
+    assert [names[int(md["con_geom1"][c])] for c in env._crate_contact] == ["FR", "FL", "RR", "RL"]
+    assert all(int(md["con_geom2"][c]) == box and int(md["con_kind"][c]) == 6 for c in env._crate_contact)
+    assert task.kind == 5 and list(task.crate_contact) == env._crate_contact
+    assert md["iterations"] == 2 and md["ls_iterations"] == 5 and md["cone"] == 0 and md["eulerdamp"] == 0
+
+
+def test_oracle_robot_stands_on_the_crate_and_the_contact_reward_counts_its_feet(case):
+    dc, env, model, task, cfg = case
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    q = np.array(env._init_q, dtype=np.float64)
+    q[0:3] = [1.3, 0.0, 0.87]
+    s, _, _ = o64.env_reset(q, np.zeros(model.nv))
+    # hold the home pose with the PD law: the action that maps to the home joint angles
+    jr = np.asarray(env.joint_range)
+    act = (2 * (q[7:] - jr[:, 0]) / (jr[:, 1] - jr[:, 0]) - 1.0)
+    zs, rews = [], []
+    for _ in range(40):
+        s, xp, xq, _c = o64.env_step(s, act)
+        zs.append(s[2])
+        rews.append(s[model.nq + 2 * model.nv + 21])
+    assert 0.80 < zs[-1] < 0.88 and abs(zs[-1] - zs[-10]) < 2e-3            # settled on the crate's top face
+    f = o64.forward_dump(s[:model.nq], s[model.nq:model.nq + model.nv], ctrl=np.zeros(model.nu))
+    live = np.flatnonzero(f["con_dist"] < 0.001)
+    assert set(live) == set(env._crate_contact)                               # exactly the four feet touch, and they touch the crate
+    # reward = -|head - target|^2 - 0.01 |up - z|^2 - 0.3 yaw^2 + 0.02 * 4
+    head = s[0:3] + np.array([0.285, 0, 0])
+    want = -np.sum((head - np.array([1.45, 0, 0.87])) ** 2) + 0.08
+    assert abs(rews[-1] - want) < 5e-3
+    # on the floor in front of the crate no foot counts
+    s0, _, _ = o64.env_reset(env._init_q, np.zeros(model.nv))
+    s0, *_ = o64.env_step(s0, act)
+    head0 = s0[0:3] + np.array([0.285, 0, 0])
+    assert abs(s0[model.nq + 2 * model.nv + 21] + np.sum((head0 - np.array([1.45, 0, 0.87])) ** 2)) < 5e-3
+
+
+def test_oracle_contact_forces_carry_the_weight(case):
+    dc, env, model, task, cfg = case
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    md = env.sys.model
+    q = np.array(env._init_q, dtype=np.float64)
+    q[0:3] = [1.3, 0.0, 0.87]
+    s, _, _ = o64.env_reset(q, np.zeros(model.nv))
+    jr = np.asarray(env.joint_range)
+    act = (2 * (q[7:] - jr[:, 0]) / (jr[:, 1] - jr[:, 0]) - 1.0)
+    for _ in range(60):
+        s, xp, xq, ctrl = o64.env_step(s, act)
+    f = o64.forward_dump(s[:model.nq], s[model.nq:model.nq + model.nv], ctrl=ctrl, warm=s[model.nq + model.nv:model.nq + 2 * model.nv])
+    # generalised constraint force on the base's z translation = the robot's weight (quasi-static)
+    fz = (f["efc_J"].T @ f["efc_force"])[2]
+    weight = 9.81 * float(np.sum(md["body_mass"][1:14]))
+    assert abs(fz - weight) < 0.05 * weight, (fz, weight)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emulated_generic_kernel_matches_oracle_on_the_crate(case, seed):
+    dc, env, model, task, cfg = case
+    o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
+    emu = emu_lib.Emu(model, task, cfg)
+    nv, nu = model.nv, model.nu
+    q, qd = touching_state(env, o64, seed)
+    live = np.flatnonzero(o64.forward_dump(q, np.zeros(nv))["con_dist"] < 0.001)
+    assert live.size >= 1
+    s_o, xp_o, xq_o = o32.env_reset(q, qd)
+    s_e, xp_e, xq_e = emu.env_reset(q, qd, check_races=(seed == 0))
+    nqv = model.nq + nv
+    atol = np.full(s_o.shape, 2e-4)
+    atol[nqv:nqv + nv] = 2e-4 * max(1.0, float(np.abs(s_o[nqv:nqv + nv]).max()) * 1e-2)
+    assert np.all(np.abs(s_o - s_e) <= atol + 2e-4 * np.abs(s_o)), np.abs(s_o - s_e).max()
+    assert np.allclose(xp_o, xp_e, atol=1e-6)
+    rng = np.random.default_rng(100 + seed)
+    us = rng.uniform(-1, 1, (dc.Nsample, dc.Hsample + 1, nu)).astype(np.float32)
+    r_e = emu.rollout(s_o, us, check_races=(seed == 0))
+    rep = witness_parity(o32, s_o, us, (r_e[0], r_e[2], r_e[3], r_e[4]), EX, model.nq + 2 * nv)
+    assert rep["rollouts"] == dc.Nsample
+
+
+def test_emulated_kernel_touches_with_every_geom_kind(case):
+    """Coverage of the states the parity test draws: spheres, capsules and the trunk box all touch the crate in some of them."""
+    dc, env, model, task, cfg = case
+    o64 = O.Oracle(model, task, cfg, np.float64)
+    md = env.sys.model
+    seen = set()
+    for seed in range(6):
+        q, _ = touching_state(env, o64, seed)
+        d = o64.forward_dump(q, np.zeros(model.nv))["con_dist"]
+        seen |= {int(md["con_kind"][c]) for c in np.flatnonzero(d < 0.001)}
+    assert {6, 7} <= seen, seen            # sphere-box and capsule-box
+    # the trunk box needs a pose of its own: belly across the crate's front edge, legs stretched back
+    q = np.array(env._init_q, dtype=np.float64)
+    q[3:7] = _quat(0.0, -0.5, 0.0)
+    q[7:] = [0.0, 1.4, -0.9, 0.0, 1.4, -0.9, 0.0, 2.5, -0.9, 0.0, 2.5, -0.9]
+    Rp = np.array([[np.cos(-0.5), 0, np.sin(-0.5)], [0, 1, 0], [-np.sin(-0.5), 0, np.cos(-0.5)]])
+    q[0:3] = np.array([0.99, 0.0, 0.6]) + Rp @ np.array([0.0, 0.0, 0.057 - 0.003])
+    d = o64.forward_dump(q, np.zeros(model.nv))["con_dist"]
+    assert any(int(md["con_kind"][c]) == 8 for c in np.flatnonzero(d < 0.001))
+
+
+def test_emulated_kernel_matches_oracle_with_the_trunk_on_the_crate_edge(case):
+    dc, env, model, task, cfg = case
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    nv, nu = model.nv, model.nu
+    q = np.array(env._init_q, dtype=np.float64)
+    q[3:7] = _quat(0.0, -0.5, 0.0)
+    q[7:] = [0.0, 1.4, -0.9, 0.0, 1.4, -0.9, 0.0, 2.5, -0.9, 0.0, 2.5, -0.9]
+    Rp = np.array([[np.cos(-0.5), 0, np.sin(-0.5)], [0, 1, 0], [-np.sin(-0.5), 0, np.cos(-0.5)]])
+    q[0:3] = np.array([0.99, 0.0, 0.6]) + Rp @ np.array([0.0, 0.0, 0.057 - 0.003])
+    s_o, _, _ = o32.env_reset(q, np.zeros(nv))
+    rng = np.random.default_rng(7)
+    us = rng.uniform(-1, 1, (dc.Nsample, dc.Hsample + 1, nu)).astype(np.float32)
+    r_e = emu.rollout(s_o, us, check_races=False)
+    witness_parity(o32, s_o, us, (r_e[0], r_e[2], r_e[3], r_e[4]), EX, model.nq + 2 * nv)
+
+
+def test_emulated_reverse_once_on_the_crate(case):
+    dc, env, model, task, cfg = case
+    o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
+    emu = emu_lib.Emu(model, task, cfg)
+    q, qd = touching_state(env, o64, 1)
+    s_o, _, _ = o32.env_reset(q, qd)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+    ro = o32.reverse_once(s_o, Ybar, sigma, eps, full=True)
+    re = emu.rollout_nodes(s_o, Ybar, sigma, eps, check_races=False)
+    rep = witness_parity(o32, s_o, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), EX, model.nq + 2 * model.nv)
+    if rep["witnessed"] == 0:
+        assert _within(re["rews"], ro["rews"], TOL["rewss"]).all()

@@ -14,6 +14,7 @@ from dial_mpc_amd import mjcf  # noqa: E402
 
 MODELS = [
     ("unitree_go2", "mjx_scene_force.xml"),
+    ("unitree_go2", "mjx_scene_force_crate.xml"),
     ("unitree_h1", "mjx_scene_h1_walk.xml"),
     ("unitree_h1", "mjx_scene_h1_loco.xml"),
     ("wonik_allegro", "scene_left.xml"),
