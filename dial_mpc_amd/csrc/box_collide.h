@@ -102,8 +102,8 @@ DIAL_DEV float segment_box_t(const float* l0, const float* l1, const float* h) {
       if (wall != x) { const float o = l0[k] - wall; A += dk * dk; B += dk * o; C += o * o; }
     }
     const float t = A > 0.f ? dm::clip(-B / A, t0, t1) : t0;
-    const float f = (A * t + 2.f * B) * t + C;
-    if (best_f < 0.f || f < best_f * (1.f - 1e-6f) - 1e-12f) { best_f = f > 0.f ? f : 0.f; best_t = t; }
+    const float fr = (A * t + 2.f * B) * t + C, f = fr > 0.f ? fr : 0.f;   // (cancellation can leave a tiny negative value)
+    if (best_f < 0.f || f < best_f * (1.f - 1e-6f) - 1e-12f) { best_f = f; best_t = t; }
   }
   return best_t;
 }

@@ -74,15 +74,16 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
   dv->nhitem = 0;
   for (int p = 0; p < 8; p++) dv->hpass_n[p] = 0;
   if (m->cone == DIAL_CONE_ELLIPTIC) { dv->nhitem = 0; return DIAL_OK; }   // solver_cone.h assembles H per contact
-  for (int c = 0; c < m->ncon; c++)
-    if (m->con_body1[c] != 0) return DIAL_ERR_UNSUPPORTED;   // body-body contacts would fill H between branches
+  for (int c = 0; c < m->ncon; c++)   // contacts between two MOVING bodies would fill H between branches (a body welded to
+                                      // the world -- the crate -- has no dofs and counts as the world)
+    if (dv->body_ancmask[m->con_body1[c]] != 0 && dv->body_ancmask[m->con_body2[c]] != 0) return DIAL_ERR_UNSUPPORTED;
   // ---- H work list.  Contact c (world vs body2) touches dof i iff i moves body2; j is an ancestor of i, so
   // entry (i, j) is touched by exactly the contacts that touch i.
   if (m->ncon <= 8) {
     int chunk = 4;
     for (int i = 0; i < m->nv; i++) {
       int n = 0;
-      for (int c = 0; c < m->ncon; c++) n += (dv->body_ancmask[m->con_body2[c]] >> i) & 1u;
+      for (int c = 0; c < m->ncon; c++) n += ((dv->body_ancmask[m->con_body1[c]] | dv->body_ancmask[m->con_body2[c]]) >> i) & 1u;
       if (n > 0 && n < chunk) chunk = n;
     }
     int nh = 0;
@@ -93,7 +94,7 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
         const int i = dv->tri[e] >> 8, j = dv->tri[e] & 0xff;
         int cl[8], n = 0;
         for (int c = 0; c < m->ncon; c++)
-          if ((dv->body_ancmask[m->con_body2[c]] >> i) & 1u) cl[n++] = c;
+          if (((dv->body_ancmask[m->con_body1[c]] | dv->body_ancmask[m->con_body2[c]]) >> i) & 1u) cl[n++] = c;
         const int parts = n == 0 ? 1 : (n + chunk - 1) / chunk;
         if (parts > 4) { fits = false; break; }
         const int P = parts == 1 ? 1 : (parts == 2 ? 2 : 4);

@@ -478,7 +478,9 @@ static real segment_box_closest_t(const real* a0, const real* a1, const real* h)
     }
     real t = A > 0 ? r_clip(-B / A, t0, t1) : t0, f = 0;
     for (int k = 0; k < 3; k++) if (st[k]) { real x = off[k] + t * (a1[k] - a0[k]); f += x * x; }
-    if (best_f < 0 || f < best_f) { best_f = f; best_t = t; }
+    /* a later piece replaces an earlier one only if it is better by more than rounding (a capsule parallel to a face keeps
+     * its first end, a segment that passes through the box the point where it enters) */
+    if (best_f < 0 || f < best_f * (1 - (real)1e-6) - (real)1e-12) { best_f = f; best_t = t; }
   }
   return best_t;
 }

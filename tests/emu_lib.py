@@ -99,6 +99,15 @@ class Emu:
         assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
         return dict(Y0s=Y0s, rewss=rewss, rews=rews, qss=qss, qdss=qdss, xss=xss)
 
+    def box_contact(self, kind, sub, g1, g2):
+        """The kernel's box narrow phase on one pair; g = (pos[3], quat[4], size[3]).  Returns (dist, pos, frame[3, 3])."""
+        pack = lambda g: self._a(np.concatenate([np.asarray(x, float).ravel() for x in g]))
+        a, b = pack(g1), pack(g2)
+        dist, pos, frame = np.zeros(1, np.float32), np.zeros(3, np.float32), np.zeros(9, np.float32)
+        rc = self.lib.emu_box_contact(int(kind), int(sub), self._p(a), self._p(b), self._p(dist), self._p(pos), self._p(frame))
+        assert rc == 0
+        return float(dist[0]), pos.astype(np.float64), frame.reshape(3, 3).astype(np.float64)
+
     def sizes(self):
         """(which instantiation: 0 generic / 1 Go2 / 2 H1, sizeof(CModel), workspace words)."""
         a, b = ctypes.c_int(), ctypes.c_int()

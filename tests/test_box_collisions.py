@@ -210,3 +210,48 @@ def test_trunk_box_resting_on_the_crate_edge_gets_face_contacts(orc):
     for dist, pos, frame in live:
         assert -0.004 < dist < 0.001
         assert abs(pos[0] - 0.99) < 0.01 and abs(pos[2] - 0.6) < 0.01
+
+
+# ---------------------------------------------------------------- the kernel's copy (csrc/box_collide.h, host emulator build)
+def _rand_quat(rng):
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
+def _q2m(q):
+    from dial_mpc_amd import mjcf
+    return mjcf.quat_to_mat(q)
+
+
+@pytest.mark.parametrize("kind,nsub", [(KIND_PLANE_BOX, 4), (KIND_SPHERE_BOX, 1), (KIND_CAPSULE_BOX, 2), (KIND_BOX_BOX, 4)])
+def test_kernel_narrow_phase_matches_the_oracle(kind, nsub):
+    """Same pairs through the kernel's fp32 code and the fp32 oracle.  Both restate the same geometry in different
+    code; where the geometry has a discrete choice (which vertex is k-th lowest, which axis separates, which end of a
+    capsule is nearer) a pair sitting within rounding of a tie may legitimately come out differently: such pairs are
+    counted and capped, everything else must agree to fp32 accuracy."""
+    import emu_lib
+    _dc, _env, model, task, cfg = setup_case("unitree_go2_trot", 8, 4)
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    rng = np.random.default_rng(10 + kind)
+    n, ties = 400, 0
+    for _ in range(n):
+        c2, q2, h2 = rng.normal(size=3) * 0.2, _rand_quat(rng), rng.uniform(0.05, 0.5, 3)
+        q1 = _rand_quat(rng)
+        R2 = _q2m(q2)
+        if kind == KIND_PLANE_BOX:
+            c1, size1 = c2 - _q2m(q1)[:, 2] * rng.uniform(0.0, 0.6), np.array([0, 0, 0.05])
+        elif kind == KIND_SPHERE_BOX:
+            c1, size1 = c2 + R2 @ (rng.normal(size=3) * h2 * 1.2), np.array([rng.uniform(0.01, 0.1), 0, 0])
+        elif kind == KIND_CAPSULE_BOX:
+            c1, size1 = c2 + R2 @ (rng.normal(size=3) * h2 * 1.3), np.array([rng.uniform(0.01, 0.03), rng.uniform(0.03, 0.2), 0])
+        else:
+            size1 = rng.uniform(0.04, 0.3, 3)
+            c1 = c2 + _q2m(_rand_quat(rng))[:, 0] * rng.uniform(0.05, 0.7)
+        for sub in range(nsub):
+            do, po, fo = o32.box_contact(kind, sub, (c1, _q2m(q1), size1), (c2, R2, h2))
+            de, pe, fe = emu.box_contact(kind, sub, (c1, q1, size1), (c2, q2, h2))
+            same = abs(do - de) < 2e-5 and np.allclose(fo[0], fe[0], atol=2e-4) and (do > 0.5 or np.allclose(po, pe, atol=2e-5))
+            if not same:
+                ties += 1
+    assert ties <= n * nsub * 0.01, (kind, ties)

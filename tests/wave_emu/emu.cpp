@@ -134,4 +134,19 @@ int emu_sizes(const dial_model* m, int* cmodel_bytes, int* ws_words) {
   *ws_words = r.ws_words;
   return 0;
 }
+// the kernel's box narrow phases (csrc/box_collide.h) on one pair: geoms as (pos[3], quat[4], size[3])
+int emu_box_contact(int kind, int sub, const float* g1, const float* g2, float* dist, float* pos, float* frame) {
+  dial::BoxG b1, b2;
+  for (int k = 0; k < 3; k++) { b1.c[k] = g1[k]; b1.h[k] = g1[7 + k]; b2.c[k] = g2[k]; b2.h[k] = g2[7 + k]; }
+  for (int k = 0; k < 4; k++) { b1.q[k] = g1[3 + k]; b2.q[k] = g2[3 + k]; }
+  float mat[9];
+  dm::quat_to_mat(mat, b1.q);
+  const float ax1[3] = {mat[2], mat[5], mat[8]};
+  if (kind == DIAL_CON_PLANE_BOX) dial::plane_box(ax1, g1, b2, sub, *dist, pos, frame);
+  else if (kind == DIAL_CON_SPHERE_BOX) dial::sphere_box(g1, g1[7], b2, *dist, pos, frame);
+  else if (kind == DIAL_CON_CAPSULE_BOX) dial::capsule_box(g1, ax1, g1[8], g1[7], b2, sub, *dist, pos, frame);
+  else if (kind == DIAL_CON_BOX_BOX) dial::box_box(b1, b2, sub, *dist, pos, frame);
+  else return -1;
+  return 0;
+}
 }
