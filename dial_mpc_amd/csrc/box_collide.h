@@ -108,13 +108,39 @@ DIAL_DEV float segment_box_t(const float* l0, const float* l1, const float* h) {
   return best_t;
 }
 
-// capsule against a box: sub 0 = sphere at the segment point closest to the box, sub 1 = sphere at the end farther from it
+// capsule against a box: sub 0 = sphere at the segment point closest to the box, sub 1 = sphere at the end farther from it.
+// When the capsule's AXIS enters the box (penetration deeper than the radius) "closest" degenerates to a stretch of distance
+// 0: the contact is then where the axis crosses the surface, with the normal of the face it crosses and dist = -radius --
+// the continuation of the shallow case (closest point -> surface point, same face normal).
 DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r, const BoxG& b, int sub, float& dist, float* pos, float* fr) {
   float e0[3], e1[3], r0[3], r1[3], l0[3], l1[3];
   for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; r0[k] = e0[k] - b.c[k]; r1[k] = e1[k] - b.c[k]; }
   dm::inv_rotate(l0, r0, b.q);
   dm::inv_rotate(l1, r1, b.q);
-  const float t = segment_box_t(l0, l1, b.h);
+  // interior stretch [ta, tb] of the axis (intersection of the three slabs) and the slabs that bound it
+  float ta = 0.f, tb = 1.f;
+  int ka = -1, kb = -1;
+  bool hit = true;
+  for (int k = 0; k < 3; k++) {
+    const float dk = l1[k] - l0[k];
+    if (dk == 0.f) { hit = hit && !(dm::absf(l0[k]) > b.h[k]); continue; }
+    const float t1 = (-b.h[k] - l0[k]) / dk, t2 = (b.h[k] - l0[k]) / dk;
+    const float lo = dm::fminf_(t1, t2), hi = dm::fmaxf_(t1, t2);
+    if (lo > ta) { ta = lo; ka = k; }
+    if (hi < tb) { tb = hi; kb = k; }
+  }
+  const bool through = hit && ta <= tb;
+  const int kface = through ? (ka >= 0 ? ka : kb) : -1;          // enters through face ka, else (first end inside) leaves through kb
+  const float t = through ? (ka >= 0 ? ta : (kb >= 0 ? tb : 0.f)) : segment_box_t(l0, l1, b.h);
+  if (sub == 0 && kface >= 0) {
+    float nl[3] = {0.f, 0.f, 0.f}, n[3];
+    nl[kface] = l0[kface] + t * (l1[kface] - l0[kface]) >= 0.f ? -1.f : 1.f;
+    dm::rotate(n, nl, b.q);
+    dist = -r;
+    for (int k = 0; k < 3; k++) pos[k] = e0[k] + t * (e1[k] - e0[k]) + n[k] * (r + dist * 0.5f);
+    make_frame(fr, n);
+    return;
+  }
   float sc[3];
   for (int k = 0; k < 3; k++) sc[k] = sub == 0 ? e0[k] + t * (e1[k] - e0[k]) : (t <= 0.5f ? e1[k] : e0[k]);
   sphere_box(sc, r, b, dist, pos, fr);

@@ -257,15 +257,22 @@ struct Wave {
     for (int i = lane; i < count; i += 64) f(i);
     sync();
   }
+  // (count may exceed the wavefront: the crate scene sums over 220 constraint rows -- lane-strided partial sums first)
   template <class F>
   __device__ __forceinline__ float sum(int count, F f) {
     float v = lane < count ? f(lane) : 0.f;
+    for (int i = lane + 64; i < count; i += 64) v += f(i);
     return dialwave::wave_sum(v);
   }
   template <class F>
   __device__ __forceinline__ void sum3(int count, F f, float& a, float& b, float& c) {
     float x = 0.f, y = 0.f, z = 0.f;
     if (lane < count) f(lane, x, y, z);
+    for (int i = lane + 64; i < count; i += 64) {
+      float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+      f(i, x2, y2, z2);
+      x += x2; y += y2; z += z2;
+    }
     a = dialwave::wave_sum(x);
     b = dialwave::wave_sum(y);
     c = dialwave::wave_sum(z);
@@ -273,6 +280,7 @@ struct Wave {
   template <class F>
   __device__ __forceinline__ float maxv(int count, F f) {
     float v = lane < count ? f(lane) : -INFINITY;
+    for (int i = lane + 64; i < count; i += 64) { const float u = f(i); v = u > v ? u : v; }
     return dialwave::wave_max_shfl(v);
   }
   template <class F>

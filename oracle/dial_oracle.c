@@ -485,13 +485,44 @@ static real segment_box_closest_t(const real* a0, const real* a1, const real* h)
   return best_t;
 }
 /* capsule against a box: sub 0 = the sphere at the segment point closest to the box, sub 1 = the sphere at the segment end
- * farther from that point (a capsule lying on a face touches with both, one standing on an end or crossing an edge with one) */
+ * farther from that point (a capsule lying on a face touches with both, one standing on an end or crossing an edge with one).
+ * When the capsule's AXIS itself enters the box (penetration deeper than the radius) the closest point degenerates to a whole
+ * stretch of distance 0; the contact is then the point where the axis crosses the surface, with the normal of the face it
+ * crosses and dist = -radius -- the continuation of the shallow case (closest point -> surface point, same face normal). */
 static void capsule_box(const real* ctr, const real* axis, real hl, real r, const obox* b, int sub, real* dist, real* pos, real* frame) {
   real e0[3], e1[3], l0[3], l1[3];
   for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; }
   obox_local(b, e0, l0);
   obox_local(b, e1, l1);
-  real t = segment_box_closest_t(l0, l1, b->h);
+  /* interior stretch [ta, tb] of the axis: intersection of the three slabs; ka / kb = the slab that bounds it */
+  real ta = 0, tb = 1, t;
+  int hit = 1, ka = -1, kb = -1, kface = -1;
+  for (int k = 0; k < 3 && hit; k++) {
+    real dk = l1[k] - l0[k];
+    if (dk == 0) { if (r_abs(l0[k]) > b->h[k]) hit = 0; continue; }
+    real t1 = (-b->h[k] - l0[k]) / dk, t2 = (b->h[k] - l0[k]) / dk;
+    real lo = r_min(t1, t2), hi = r_max(t1, t2);
+    if (lo > ta) { ta = lo; ka = k; }
+    if (hi < tb) { tb = hi; kb = k; }
+  }
+  if (hit && ta <= tb) {
+    if (ka >= 0) { t = ta; kface = ka; }          /* the axis enters through face ka */
+    else if (kb >= 0) { t = tb; kface = kb; }     /* first end inside: where it leaves */
+    else t = 0;                                   /* the whole axis is inside: plain end spheres */
+  } else {
+    t = segment_box_closest_t(l0, l1, b->h);
+  }
+  if (sub == 0 && kface >= 0) {
+    real pl[3], nl[3] = {0, 0, 0}, n[3], pw[3];
+    for (int k = 0; k < 3; k++) pl[k] = l0[k] + t * (l1[k] - l0[k]);
+    nl[kface] = pl[kface] >= 0 ? -1 : 1;
+    obox_world_dir(b, nl, n);
+    for (int k = 0; k < 3; k++) pw[k] = e0[k] + t * (e1[k] - e0[k]);
+    *dist = -r;
+    for (int k = 0; k < 3; k++) pos[k] = pw[k] + n[k] * (r + *dist * (real)0.5);
+    make_frame(frame, n);
+    return;
+  }
   real sc[3];
   if (sub == 0) for (int k = 0; k < 3; k++) sc[k] = e0[k] + t * (e1[k] - e0[k]);
   else for (int k = 0; k < 3; k++) sc[k] = t <= (real)0.5 ? e1[k] : e0[k];

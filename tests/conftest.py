@@ -113,7 +113,8 @@ def one_step_consistency(o32, s0, us, got, rollouts, nq, nv, tol_scale=1.0, max_
     return report
 
 
-def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed_ok=0, max_frac=None, tail_scale=20.0):
+def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed_ok=0, max_frac=None, tail_scale=20.0,
+                   restart_ok=False):
     """Per-rollout parity of `got` = (rewss, qss, qdss, xss) [B,T,...] against the fp32 oracle `o32` run on the same
     controls `us` [B,T,nu] from the packed start state `s0`.  Returns a report dict; raises AssertionError when a
     rollout neither matches within TOL nor has a knife-edge witness (beyond `unwitnessed_ok` of them: chaotic long
@@ -126,7 +127,14 @@ def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed
     run at `tail_scale` x TOL: a witness that also tracks the GPU's tail is preferred (the search keeps going for a
     quarter of the draws to find one), the number of rollouts whose witness only covers the prefix -- a SECOND knife
     edge later in the same rollout, where the jittered run and the GPU part again -- is reported as `prefix_only` and
-    capped at a quarter of the witnessed rollouts (+2)."""
+    capped at a quarter of the witnessed rollouts (+2).
+
+    restart_ok (contact-rich scenes with a TRUNCATED solver -- the crate climb: 52 candidate contacts, long horizons): by
+    the step where a rollout leaves the gate the GPU's state may already differ from the oracle's by up to TOL (1e-4,
+    where the jitter above is 4e-6), so a knife edge the GPU crosses can be out of the jitter's reach.  For such a rollout
+    the oracle is restarted at step t* from the GPU'S OWN q / qd (warm start and info from its own run, which matched
+    through t* - 1) and must land on the GPU's state after step t* within TOL, again under <= 64 ulp of jitter; these are
+    reported as `restart_witnessed` and count towards the knife-edge cap like the others."""
     ref = o32.rollout(s0, us)
     B, T = us.shape[:2]
     ok_t = np.ones((B, T), bool)
@@ -155,6 +163,24 @@ def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed
                 if follows(n, rw, qp, qdp, slice(t_star + 1, T), tail_scale):
                     found, full = (k, mag), True
                     break
+        if found is None and restart_ok and t_star > 0:
+            nq_, nv_ = got[1].shape[2], got[2].shape[2]
+            st = np.array(s0, dtype=np.float32)
+            for tt in range(t_star):
+                st, _, _, _ = o32.env_step(st, us[n, tt])
+            st[:nq_], st[nq_:nq_ + nv_] = got[1][n, t_star - 1], got[2][n, t_star - 1]
+            rng_r = np.random.default_rng(5000 + int(n))
+            for k in range(max_draws // 2):
+                stj = st.copy()
+                if k > 0:
+                    mag = 2.0 ** rng_r.integers(0, 7)
+                    stj[:nq_ + nv_] += (rng_r.integers(-1, 2, size=nq_ + nv_) * mag * np.spacing(np.abs(st[:nq_ + nv_]))).astype(np.float32)
+                st2, _, _, _ = o32.env_step(stj, us[n, t_star])
+                if (_within(st2[nstate + 21], got[0][n, t_star], TOL["rewss"]).all() and _within(st2[:nq_], got[1][n, t_star], TOL["q"]).all()
+                        and _within(st2[nq_:nq_ + nv_], got[2][n, t_star], TOL["qd"]).all()):
+                    found, full = ("restart", k), False
+                    report["restart_witnessed"] = report.get("restart_witnessed", 0) + 1
+                    break
         report["details"].append(dict(sample=int(n), first_step=t_star, witness=found, tail=full))
         if found is None:
             report["unwitnessed"] = report.get("unwitnessed", 0) + 1
@@ -162,7 +188,7 @@ def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed
                 f"{example}: rollout {n} leaves the oracle's trajectory at step {t_star} and no <= 64 ulp "
                 f"per-step jitter of the oracle's state reproduces the GPU's branch")
         report["witnessed"] += 1
-        report["prefix_only"] += 0 if (full or found is None) else 1
+        report["prefix_only"] += 0 if (full or found is None or found[0] == "restart") else 1
     frac = report["witnessed"] / B
     cap = KNIFE_EDGE_FRAC[example] if max_frac is None else max_frac
     assert frac <= max(cap, 4.5 / B), (example, report)       # small batches: at most 4 rollouts

@@ -114,8 +114,20 @@ def test_capsule_box_first_candidate_is_the_closest_point_of_the_segment(orc):
         assert_frame(f0)
         assert_frame(f1)
         if through:
+            # the capsule's axis enters the box: the contact is where the axis crosses the surface (unless it is inside with
+            # both ends), normal = the face it crosses, dist = -radius
             n_inside += 1
-            assert d0 <= -r + 1e-9
+            inside = np.all(np.abs((pts - c) @ R) <= h, axis=1)
+            if inside.all():
+                continue
+            assert np.isclose(d0, -r, atol=1e-12)
+            surf = p0 - f0[0] * (r * 0.5)                       # pos = crossing point + n (r + dist / 2)
+            loc = R.T @ (surf - c)
+            assert np.max(np.abs(loc) - h) < 1e-9 and np.min(np.abs(np.abs(loc) - h)) < 1e-9       # on the surface
+            k = int(np.argmin(np.abs(np.abs(loc) - h)))
+            assert np.allclose(R.T @ f0[0], -np.sign(loc[k]) * np.eye(3)[k], atol=1e-9)            # into the box through that face
+            first = int(np.argmax(inside)) if not inside[0] else int(len(ts) - 1 - np.argmax(inside[::-1]))
+            assert np.linalg.norm(pts[first] - surf) < 2.0 * np.linalg.norm(e1 - e0) / 2000 + 1e-9  # where the axis crosses
             continue
         want = _segment_box_distance(c, R, h, e0, e1)
         assert np.isclose(d0 + r, want, atol=2e-6), (d0 + r, want)
