@@ -368,6 +368,8 @@ struct Ws {
   // elliptic models (solver_cone.h): contact-on flags, per-contact cone Hessian weights, per-dof vectors that the row
   // products gather from
   float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1, *ulist;
+  // generic instantiation: the contacts that touch, compacted (rollout_body.h: con_of)
+  float *clist, *sq;   // sq: DIAL_MAX_V x DIAL_MAX_V square the register Cholesky reads (rollout_body.h: solve_spd_reg)
 };
 
 #if defined(__HIPCC__)
@@ -399,6 +401,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv) WS_TAKE(ulist, ell * (nefc > 0 ? 68 : 0))
+  WS_TAKE(clist, with_L ? ncon : 0)
   const int u0 = o;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
@@ -426,6 +429,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   if (!ell) { WS_TAKE(qfc, ls * nv) }
   WS_TAKE(ysol, ls * nv)
   WS_TAKE(L, with_L ? ntri : 0)   // packed Cholesky factor of the LDS solver (the register solver writes its factor over H)
+  WS_TAKE(sq, with_L ? DIAL_MAX_V * ((DIAL_MAX_V + 3) & ~3) : 0)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE

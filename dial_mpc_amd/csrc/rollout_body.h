@@ -34,9 +34,19 @@ inline constexpr bool kNeedL = !D::is_static;
 // ---------------------------------------------------------------- constraint rows (implicit J)
 // Row r < nlim is a joint-limit row (J = lsign * e_dof); the other rows are pyramid edges of contact
 // c = (r - nlim) / 4: J = Jn + f * Jt with f = +-friction (constraint._instantiate_contact).
+//
+// Generic instantiation: the constraint section works on the COMPACTED list of contacts that touch (dist < margin):
+// compact index c' -> model contact s.clist[c'] (forward(): after the narrow phase).  A contact that does not touch
+// contributes rows with D = 0, aref = 0 -- exact zeros in every sum of the dense formulation -- so dropping it changes
+// nothing but the order of the additions; the crate scene carries 52 candidates of which 4-8 touch.
 struct RowRef { int is_lim, dof, c, tan; float f; };
 template <class M>
-DIAL_DEV RowRef row_ref(const M* m, int r) {
+DIAL_DEV int con_of(const M*, const Ws& s, int c) {   // model contact of compact contact c
+  if constexpr (M::D::is_static) return c;
+  else return (int)s.clist[c];
+}
+template <class M>
+DIAL_DEV RowRef row_ref(const M* m, const Ws& s, int r) {
   RowRef rr;
   const int nl = dim_nl(m);
   rr.is_lim = r < nl;
@@ -47,7 +57,7 @@ DIAL_DEV RowRef row_ref(const M* m, int r) {
     int e = (r - nl) & 3;
     rr.c = (r - nl) >> 2;
     rr.tan = 1 + (e >> 1);
-    float mu = m->con_friction[rr.c][rr.tan - 1];
+    float mu = m->con_friction[con_of(m, s, rr.c)][rr.tan - 1];
     rr.f = (e & 1) ? -mu : mu;
     rr.dof = 0;
   }
@@ -55,7 +65,7 @@ DIAL_DEV RowRef row_ref(const M* m, int r) {
 }
 template <class M>
 DIAL_DEV float row_dot(const M* m, const Ws& s, int r, const float* v) {
-  RowRef rr = row_ref(m, r);
+  RowRef rr = row_ref(m, s, r);
   if (rr.is_lim) return s.lsign[r] * v[rr.dof];
   const int nv = dim_nv(m);
   const float* jn = s.Jc + (rr.c * 3) * nv;
@@ -64,16 +74,17 @@ DIAL_DEV float row_dot(const M* m, const Ws& s, int r, const float* v) {
   for (int i = 0; i < nv; i++) acc += (jn[i] + jt[i] * rr.f) * v[i];
   return acc;
 }
-// (J^T f)_i
+// (J^T f)_i over the first nca (compact) contacts
 template <class M>
-DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f) {
+DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f, int nca) {
   const int nv = dim_nv(m), nl = dim_nl(m);
   float acc = 0.f;
   int lr = m->dof_limrow[i];
   if (lr >= 0) acc += s.lsign[lr] * f[lr];
-  for (int c = 0; c < dim_nc(m); c++) {
+  for (int c = 0; c < nca; c++) {
     float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
-    float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+    const int co = con_of(m, s, c);
+    float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
     const float* fc = f + nl + 4 * c;
     acc += (jn + j1 * mu1) * fc[0];
     acc += (jn - j1 * mu1) * fc[1];
@@ -204,11 +215,36 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 #include "solver_cone.h"
 namespace dial {
 
+// Generic instantiation: x = A^-1 rhs for the packed SPD matrix A (M or H) with the register-resident L D L^T of
+// solver_reg.h, instantiated ONCE for the capacity dimension (DIAL_MAX_V, dense elimination order): A is copied into a
+// square with an identity block for the dofs the model does not have.  The LDS Cholesky above (one phase per column,
+// ~35 k cycles for 18 dofs) stays as the reference implementation the emulator tests compare against (-DDIAL_LDS_CHOL).
+struct DimsPadV {
+  static constexpr int NV = DIAL_MAX_V;
+  static constexpr bool square = true;
+  using Topo = TopoDense;
+};
+template <class W, class M>
+DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const float* rhs, float* x) {
+  constexpr int NP = DIAL_MAX_V, S = kCholStride<NP>;
+  const int nv = dim_nv(m);
+  w.items(NP * S, [&](int e) {
+    const int i = e / S, j = e - i * S;
+    float v = i == j ? 1.f : 0.f;
+    if (i < nv && j < nv) v = A[i >= j ? tri_idx(i, j) : tri_idx(j, i)];
+    s.sq[e] = v;
+  });
+  const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
+  const vfloat xv = reg_chol_solve_v<DimsPadV, TopoDense>(w, m, s.sq, b, s.sq);
+  w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
+}
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   const int nb = dim_nb(m), nv = dim_nv(m), nj = dim_nj(m), ng = dim_ng(m), nsite = dim_ns(m), nc = dim_nc(m);
   const int ne = dim_ne(m), nl = dim_nl(m), ntri = m->ntri;   // ntri: structurally non-zero entries of M / H
+  int nca = nc, nea = ne;   // contacts / rows the constraint section works on (generic instantiation: the touching ones)
 
   DIAL_MARK(w, 15);
   // ---- smooth.kinematics
@@ -775,6 +811,15 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
     }
   });
+  if constexpr (!M::D::is_static) {
+    // compact the contacts that touch (see con_of above); with more than 64 candidates the list would need a second pass
+    if (nc <= 64) {
+      nca = w.compact(nc, [&](int c) { return s.cdist[c] - m->con_margin[c] < 0.f; }, s.clist);
+    } else {
+      w.items(nc, [&](int c) { s.clist[c] = (float)c; });
+    }
+    nea = nl + 4 * nca;
+  }
   // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
   DIAL_MARK(w, 1);
   if constexpr (M::D::ell) {
@@ -820,20 +865,13 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.jv[m->con_adr[c] + k] = vel;
     });
   } else
-  w.items(nc * nv, [&](int it) {
+  w.items(nca * nv, [&](int it) {
     const int c = it / nv, i = it - c * nv;
-    const int b1 = m->con_body1[c], b2 = m->con_body2[c];
-    if constexpr (!M::D::is_static) {
-      // a candidate that does not touch (dist >= margin) gets D = 0 rows: its Jacobian is never multiplied by anything but 0
-      // (the crate scene carries 52 candidates, 4-6 of which touch)
-      if (!(s.cdist[c] - m->con_margin[c] < 0.f)) {
-        for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = 0.f;
-        return;
-      }
-    }
+    const int co = con_of(m, s, c);   // model contact (positions, frames and constants are indexed by it; Jc by the compact c)
+    const int b1 = m->con_body1[co], b2 = m->con_body2[co];
     float cd[6];
     for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
-    float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
+    float p[3] = {s.cpos[3 * co], s.cpos[3 * co + 1], s.cpos[3 * co + 2]};
     float diff[3] = {0.f, 0.f, 0.f};
     if ((m->body_ancmask[b2] >> i) & 1u) {
       const float* cm = s.com + 3 * m->body_rootid[b2];
@@ -853,7 +891,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float* jt = s.Jc + i * M::D::T + 4 * c;
       jt[0] = jn + t1; jt[1] = jn - t1; jt[2] = jn + t2; jt[3] = jn - t2;
     } else {
-      for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * c + 3 * a, diff);
+      for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * co + 3 * a, diff);
     }
   });
   // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
@@ -897,7 +935,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       }
     });
   } else
-  w.items(ne, [&](int r) {
+  w.items(nea, [&](int r) {
     if (r < nl) {
       const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
       float q = s.qpos[qa];
@@ -913,7 +951,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.aref[r] = -b_ * vel - k_ * imp * pos;
       s.D[r] = 1.f / R;
     } else {
-      const int c = (r - nl) >> 2;
+      const int c = con_of(m, s, (r - nl) >> 2);
       s.lsign[r] = 0.f;
       float pos = s.cdist[c] - m->con_margin[c];
       if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
@@ -942,10 +980,14 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
+#ifdef DIAL_LDS_CHOL
     solve_spd(w, m, s, s.M, s.rhs, s.qas);
+#else
+    solve_spd_reg(w, m, s, s.M, s.rhs, s.qas);
+#endif
   }
   DIAL_MARK(w, 3);
-  if (ne == 0) {
+  if (nea == 0) {
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
     return;
   }
@@ -959,31 +1001,31 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 
   // ================================================================ solver.solve (Newton)
   // warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
-  w.items(2 * ne + 2 * nv, [&](int it) {
-    if (it < ne) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
-    else if (it < 2 * ne) s.JarefS[it - ne] = row_dot(m, s, it - ne, s.qas) - s.aref[it - ne];
-    else if (it < 2 * ne + nv) {
-      const int i = it - 2 * ne;
+  w.items(2 * nea + 2 * nv, [&](int it) {
+    if (it < nea) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
+    else if (it < 2 * nea) s.JarefS[it - nea] = row_dot(m, s, it - nea, s.qas) - s.aref[it - nea];
+    else if (it < 2 * nea + nv) {
+      const int i = it - 2 * nea;
       float acc = 0.f;
       for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.warm[j];
       s.MaW[i] = acc;
     } else {
-      const int i = it - 2 * ne - nv;
+      const int i = it - 2 * nea - nv;
       float acc = 0.f;
       for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.qas[j];
       s.MaS[i] = acc;
     }
   });
-  float cw = w.sum(ne, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+  float cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
   float gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
-  float cs = w.sum(ne, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+  float cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
   float gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
   const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
   const bool use_warm = cost_w < cost_s;
-  w.items(ne + nv, [&](int it) {
-    if (it < ne) s.Jaref[it] = use_warm ? s.JarefW[it] : s.JarefS[it];
+  w.items(nea + nv, [&](int it) {
+    if (it < nea) s.Jaref[it] = use_warm ? s.JarefW[it] : s.JarefS[it];
     else {
-      const int i = it - ne;
+      const int i = it - nea;
       s.qacc[i] = use_warm ? s.warm[i] : s.qas[i];
       s.Ma[i] = use_warm ? s.MaW[i] : s.MaS[i];
     }
@@ -996,9 +1038,9 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 
   // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
   auto constraint_grad = [&]() {
-    w.items(ne, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
+    w.items(nea, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
     w.items(nv, [&](int i) {
-      float qc = jt_dot(m, s, i, s.frc);
+      float qc = jt_dot(m, s, i, s.frc, nca);
       s.qfc[i] = qc;
       float g = s.Ma[i] - s.qfs[i] - qc;
       s.grad[i] = g;
@@ -1016,12 +1058,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         int lr = m->dof_limrow[i];
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
       }
-      for (int c = 0; c < nc; c++) {
-        if (s.D[nl + 4 * c] == 0.f) continue;   // candidate that does not touch: all four rows are off (wave-uniform)
+      for (int c = 0; c < nca; c++) {
         const float* jn = s.Jc + (c * 3) * nv;
         float jni = jn[i], jnj = jn[j];
         float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
-        float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+        const int co = con_of(m, s, c);
+        float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
         const int r0 = nl + 4 * c;
         float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
         float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
@@ -1033,7 +1075,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
     });
     DIAL_MARK(w, 5);
+#ifdef DIAL_LDS_CHOL
     solve_spd(w, m, s, s.H, s.rhs, s.search);
+#else
+    solve_spd_reg(w, m, s, s.H, s.rhs, s.search);
+#endif
     w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
   };
 
@@ -1043,7 +1089,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   for (;;) {
     constraint_grad();
     if (niter > 0) {
-      float c2 = w.sum(ne, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+      float c2 = w.sum(nea, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
       float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
       gauss = 0.5f * g2;
       prev_cost = cost;
@@ -1063,7 +1109,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     DIAL_MARK(w, 6);
     // ---------------- solver._linesearch
     DIAL_MARK(w, 8);
-    w.items(nv + ne, [&](int it) {
+    w.items(nv + nea, [&](int it) {
       if (it < nv) {
         float acc = 0.f;
         for (int j = 0; j < nv; j++) acc += msym(s, it, j) * s.search[j];
@@ -1082,14 +1128,14 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
     // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r); models with more
     // than 64 rows (the crate scene: 220) keep them in LDS and sum over the rows lane-strided
-    const bool wide = ne > 64;
-    const vfloat vJa = w.per_lane([&](int l) { return l < ne ? s.Jaref[l] : 0.f; });
-    const vfloat vjv = w.per_lane([&](int l) { return l < ne ? s.jv[l] : 0.f; });
-    const vfloat vD = w.per_lane([&](int l) { return l < ne ? s.D[l] : 0.f; });
+    const bool wide = nea > 64;
+    const vfloat vJa = w.per_lane([&](int l) { return l < nea ? s.Jaref[l] : 0.f; });
+    const vfloat vjv = w.per_lane([&](int l) { return l < nea ? s.jv[l] : 0.f; });
+    const vfloat vD = w.per_lane([&](int l) { return l < nea ? s.D[l] : 0.f; });
     const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
     const vfloat vzero = vsplat(0.f);
     if (wide)
-      w.items(ne, [&](int r) {
+      w.items(nea, [&](int r) {
         const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
         s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
       });
@@ -1099,7 +1145,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         const vbool act = vlt0(vJa + vjv * alpha);
         q0 = w.vsum(vsel(act, vq0, vzero)); q1 = w.vsum(vsel(act, vq1, vzero)); q2 = w.vsum(vsel(act, vq2, vzero));
       } else {
-        w.sum3(ne, [&](int r, float& a, float& b, float& c) {
+        w.sum3(nea, [&](int r, float& a, float& b, float& c) {
           const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;
           a = act ? s.quad[3 * r] : 0.f; b = act ? s.quad[3 * r + 1] : 0.f; c = act ? s.quad[3 * r + 2] : 0.f;
         }, q0, q1, q2);
@@ -1135,7 +1181,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     float alpha;
     const bool improved = ls_result(p0, lo, hi, alpha);
     if (improved) {
-      w.items(nv + ne, [&](int it) {
+      w.items(nv + nea, [&](int it) {
         if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }
         else s.Jaref[it - nv] += s.jv[it - nv] * alpha;
       });
