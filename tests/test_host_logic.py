@@ -24,8 +24,10 @@ def test_example_yaml_loads_into_both_dataclasses():
 
 def test_registry_names_and_errors():
     assert "unitree_go2_trot" in examples and "unitree_go2_trot_deploy" in deploy_examples
+    assert "unitree_go2_crate_climb" in examples
+    assert dial_envs.get_config("unitree_go2_crate_climb") is dial_envs.UnitreeGo2CrateEnvConfig
     with pytest.raises(NotImplementedError):
-        dial_envs.get_environment("unitree_go2_crate_climb")
+        dial_envs.get_environment("unitree_h1_push_crate")     # exists upstream, not built here
     with pytest.raises(KeyError):
         dial_envs.get_environment("my_custom_jax_env")     # user JAX envs cannot run on the HIP path
 
