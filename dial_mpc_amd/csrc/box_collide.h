@@ -149,10 +149,19 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
 // box against box (separating-axis test; see the description at DIAL_CON_BOX_BOX and oracle-independent notes in DESIGN.md).
 // Everything is done in A's frame: C = RA^T RB, t = RA^T (cB - cA).
 DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float* pos, float* fr) {
+  const float tw[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
+  {   // bounding spheres more than 1 cm apart: nothing to do (all candidates parked; the normal is the centre line)
+    const float gap = DM_SQRT(dm::dot3(tw, tw)) - DM_SQRT(dm::dot3(A.h, A.h)) - DM_SQRT(dm::dot3(B.h, B.h));
+    if (gap > 0.01f) {
+      dist = sub == 0 ? gap : 1.f;
+      for (int k = 0; k < 3; k++) pos[k] = 0.5f * (A.c[k] + B.c[k]);
+      make_frame(fr, tw);
+      return;
+    }
+  }
   float axA[3][3], axB[3][3], C[3][3], Q[3][3], t[3];
   box_axes(A, axA);
   box_axes(B, axB);
-  const float tw[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
   for (int i = 0; i < 3; i++) {
     t[i] = dm::dot3(tw, axA[i]);
     for (int j = 0; j < 3; j++) { C[i][j] = dm::dot3(axA[i], axB[j]); Q[i][j] = dm::absf(C[i][j]); }

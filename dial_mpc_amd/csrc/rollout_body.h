@@ -1016,10 +1016,22 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.MaS[i] = acc;
     }
   });
-  float cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-  float gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
-  float cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-  float gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
+  float cw, gw, cs, gs;
+  if (nea <= 64) {   // one row per lane: the four sums as one batch of stage-interleaved reductions
+    vfloat t4[4];
+    t4[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefW[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[1] = w.per_lane([&](int l) { return l < nv ? (s.MaW[l] - s.qfs[l]) * (s.warm[l] - s.qas[l]) : 0.f; });
+    t4[2] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefS[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[3] = w.per_lane([&](int l) { return l < nv ? (s.MaS[l] - s.qfs[l]) * (s.qas[l] - s.qas[l]) : 0.f; });
+    float r4[4];
+    w.vsumN(t4, r4);
+    cw = r4[0]; gw = r4[1]; cs = r4[2]; gs = r4[3];
+  } else {
+    cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
+    cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
+  }
   const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
   const bool use_warm = cost_w < cost_s;
   w.items(nea + nv, [&](int it) {
@@ -1088,7 +1100,22 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   int niter = 0;
   for (;;) {
     constraint_grad();
-    if (niter > 0) {
+    float gn_b = 0.f;
+    const bool batched = nea <= 64;   // one row per lane: cost, Gauss term and |grad|^2 as one batch of reductions
+    if (batched) {
+      vfloat t3[3];
+      t3[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.Jaref[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+      t3[1] = w.per_lane([&](int l) { return l < nv ? (s.Ma[l] - s.qfs[l]) * (s.qacc[l] - s.qas[l]) : 0.f; });
+      t3[2] = w.per_lane([&](int l) { return l < nv ? s.grad[l] * s.grad[l] : 0.f; });
+      float r3[3];
+      w.vsumN(t3, r3);
+      if (niter > 0) {
+        gauss = 0.5f * r3[1];
+        prev_cost = cost;
+        cost = 0.5f * r3[0] + gauss;
+      }
+      gn_b = r3[2];
+    } else if (niter > 0) {
       float c2 = w.sum(nea, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
       float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
       gauss = 0.5f * g2;
@@ -1098,7 +1125,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     DIAL_MARK(w, 4);
     bool done;
     if (m->iterations != 1) {
-      float gn = w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
+      float gn = batched ? gn_b : w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
       float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
       done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
     } else {
@@ -1143,7 +1170,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float q0, q1, q2;
       if (!wide) {
         const vbool act = vlt0(vJa + vjv * alpha);
-        q0 = w.vsum(vsel(act, vq0, vzero)); q1 = w.vsum(vsel(act, vq1, vzero)); q2 = w.vsum(vsel(act, vq2, vzero));
+        vfloat t3[3] = {vsel(act, vq0, vzero), vsel(act, vq1, vzero), vsel(act, vq2, vzero)};
+        float r3[3];
+        w.vsumN(t3, r3);   // three reductions with interleaved stages (one latency chain instead of three)
+        q0 = r3[0]; q1 = r3[1]; q2 = r3[2];
       } else {
         w.sum3(nea, [&](int r, float& a, float& b, float& c) {
           const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;

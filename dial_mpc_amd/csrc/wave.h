@@ -273,9 +273,10 @@ struct Wave {
       f(i, x2, y2, z2);
       x += x2; y += y2; z += z2;
     }
-    a = dialwave::wave_sum(x);
-    b = dialwave::wave_sum(y);
-    c = dialwave::wave_sum(z);
+    vfloat t3[3] = {x, y, z};
+    float r3[3];
+    vsumN(t3, r3);   // the three reductions with their DPP stages interleaved
+    a = r3[0]; b = r3[1]; c = r3[2];
   }
   template <class F>
   __device__ __forceinline__ float maxv(int count, F f) {

@@ -532,9 +532,18 @@ static void capsule_box(const real* ctr, const real* axis, real hl, real r, cons
  * face of the other box is clipped against the side planes of the reference face, the sub-th deepest point is the
  * contact; edge axis: the closest points of the two edges (sub 0).  Candidates that do not exist are parked at dist = 1. */
 static void box_box(const obox* A, const obox* B, int sub, real* dist, real* pos, real* frame) {
+  real tw[3] = {B->c[0] - A->c[0], B->c[1] - A->c[1], B->c[2] - A->c[2]};
+  {   /* bounding spheres more than 1 cm apart: every candidate is parked, the normal is the centre line */
+    real gap = r_sqrt(dot3(tw, tw)) - r_sqrt(dot3(A->h, A->h)) - r_sqrt(dot3(B->h, B->h));
+    if (gap > (real)0.01) {
+      *dist = sub == 0 ? gap : 1;
+      for (int k = 0; k < 3; k++) pos[k] = (real)0.5 * (A->c[k] + B->c[k]);
+      make_frame(frame, tw);
+      return;
+    }
+  }
   real ax[2][3][3];
   for (int k = 0; k < 3; k++) { obox_axis(A, k, ax[0][k]); obox_axis(B, k, ax[1][k]); }
-  real tw[3] = {B->c[0] - A->c[0], B->c[1] - A->c[1], B->c[2] - A->c[2]};
   real Rr[3][3], Q[3][3], t[3];
   for (int i = 0; i < 3; i++) {
     t[i] = dot3(tw, ax[0][i]);
