@@ -370,6 +370,10 @@ struct Ws {
   float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1, *ulist;
   // generic instantiation: the contacts that touch, compacted (rollout_body.h: con_of)
   float *clist, *sq;   // sq: DIAL_MAX_V x DIAL_MAX_V square the register Cholesky reads (rollout_body.h: solve_spd_reg)
+  // generic instantiation, rollout kernel: the Jacobian and the per-row arrays above are sized for con_cap touching contacts
+  // (0 = for all ncon); `ovf` = this sample's full-size copy of them in global memory (ws_overflow), used when more touch
+  float* ovf;
+  int con_cap;
 };
 
 #if defined(__HIPCC__)
@@ -385,11 +389,19 @@ WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 // `square`: the register solver's square layout (Dims::square): M and H are nv x S squares, Jc holds the dof-major
 // pyramid rows J^T[i][4c + e], the transpose scratch L aliases H, frc is padded so that the contact weights start
 // 16-byte aligned.
+// `con_cap` (generic pyramidal layout only, 0 = off): size the contact Jacobian and the per-row arrays for that many TOUCHING
+// contacts instead of all ncon candidates (crate scene: 52 candidates, 4-8 touch; 31.6 KB -> 17.4 KB per wavefront at a cap of
+// 14, i.e. 9 instead of 5 wavefronts per CU); a sample that touches with more runs on ws_overflow's arrays.
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
-                   int ncon, int nefc, int nnode, bool with_L, bool square = false, int ell_jcw = 0) {
+                   int ncon_all, int nefc_all, int nnode, bool with_L, bool square = false, int ell_jcw = 0, int con_cap = 0) {
   int o = 0;
+  const bool capped = con_cap > 0 && con_cap < ncon_all && !square && ell_jcw == 0;
+  const int ncon = ncon_all;                                            // arrays indexed by the model's contact index
+  const int nefc = capped ? nefc_all - 4 * (ncon_all - con_cap) : nefc_all;   // arrays indexed by (compact) row
+  s.con_cap = capped ? con_cap : 0;
+  s.ovf = nullptr;
   const int ntri = square ? nv * ((nv + 3) & ~3) : (nv * (nv + 1)) / 2;
-  const int njc = ell_jcw > 0 ? ell_jcw : (square ? nv * 4 * ncon : ncon * 3 * nv);
+  const int njc = ell_jcw > 0 ? ell_jcw : (square ? nv * 4 * ncon : (capped ? con_cap : ncon) * 3 * nv);
   const int ell = ell_jcw > 0 ? 1 : 0;
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(qpos, nq) WS_TAKE(qvel, nv) WS_TAKE(warm, nv) WS_TAKE(info, DIAL_INFO_N) WS_TAKE(ctrl, nu)
@@ -432,6 +444,17 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(sq, with_L ? DIAL_MAX_V * ((DIAL_MAX_V + 3) & ~3) : 0)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
+#undef WS_TAKE
+  return o;
+}
+
+// Full-size copies (all ncon candidates, all nefc rows) of the arrays ws_carve sizes by con_cap; returns the words used.
+WS_HD int ws_overflow(Ws& s, float* base, int nv, int ncon, int nefc) {
+  int o = 0;
+#define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
+  WS_TAKE(Jc, ncon * 3 * nv)
+  WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
+  WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(quad, nefc * 3)
 #undef WS_TAKE
   return o;
 }

@@ -66,7 +66,7 @@
 // wavefront-scope fences, wave.h).
 template <class D, int WPB = 1>
 __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
-                                                        int ws_words) {
+                                                        int ws_words, int con_cap = 0) {
   const CModel<D>* m = gm;
   float* wsbase = smem;
   if constexpr (D::is_static) {
@@ -82,7 +82,7 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
   if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
+           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, D::is_static ? 0 : con_cap);
   return m;
 }
 
@@ -95,7 +95,9 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
                const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words);
+  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap);
+  if constexpr (!D::is_static)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
+    s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
   int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
   int relay = -1;
   if constexpr (WPB == 1 && !QUEUE) {
@@ -362,6 +364,8 @@ struct dial_ctx {
   void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
+  int con_cap = 0, ovf_words = 0;   // generic instantiation: contact cap of the rollout kernel's LDS workspace, words of one overflow area
+  float* ovf = nullptr;            // B_cap overflow areas
   int B_cap = 0, W_cap = 0, T = 0, Hn1 = 0, nx = 0;   // B_cap: rollouts this context can hold (local shard + mean), W_cap: global N + 1
   float *Y0s = nullptr, *rewss = nullptr, *rews = nullptr, *qss = nullptr, *qdss = nullptr, *xss = nullptr;
   float *weights = nullptr, *partial = nullptr;
@@ -421,7 +425,7 @@ void dial_destroy(dial_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->next, ctx->relay_buf, ctx->relay_flag, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
-                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial};
+                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial, ctx->ovf};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -496,9 +500,22 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       const int ws0 = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>, D::square,
                                D::ell ? D::JCW : 0);
+      if constexpr (!D::is_static) {
+        // many candidate contacts, few of which touch (crate scene: 52 / 4-8): the rollout kernel's LDS workspace is sized for
+        // DIAL_CON_CAP touching contacts, samples beyond run on an overflow area in global memory.  Default 14: for the crate
+        // scene that is 17.4 KB per wavefront -- NINE per CU, so that the 2049 rollouts of its example are resident at once
+        // (at 16 the workspace is 18.3 KB, eight per CU = 2048 slots, and the 2049th rollout waits for a whole round)
+        int cap = 14;
+        if (const char* e = getenv("DIAL_CON_CAP")) cap = atoi(e);
+        if (cfg && model->cone == DIAL_CONE_PYRAMIDAL && cap > 0 && model->ncon > cap) {
+          ctx->con_cap = cap;
+          Ws so;
+          ctx->ovf_words = ws_overflow(so, (float*)0, model->nv, model->ncon, model->nefc);
+        }
+      }
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square,
-                               D::ell ? D::JCW : 0);
+                               D::ell ? D::JCW : 0, ctx->con_cap);
       ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
@@ -607,6 +624,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     ctx->has_cfg = true;
     ctx->B_cap = n_local_cap + 1;
     ctx->W_cap = cfg->Nsample + 1;
+    if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->B_cap * ctx->ovf_words * sizeof(float)));
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
     const size_t B = ctx->B_cap, T = ctx->T;
@@ -693,6 +711,9 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // mean-trajectory relay (one wavefront per workgroup, the launch's last rollout is the mean trajectory, everything is
   // resident): the "+1" rollout runs as ceil(T / 2) two-step pieces on as many SIMDs instead of one more wavefront on one
   dial::RolloutIO io = io_in;
+  io.con_cap = ctx->ovf ? ctx->con_cap : 0;
+  io.ovf = ctx->ovf;
+  io.ovf_words = ctx->ovf_words;
   // (only when the noisy rollouts fill the SIMDs evenly and the mean trajectory is the odd one out: N = k x 1024)
   if (ctx->relay_ok && !large && !io.us && io.n_noise == B - 1 && B > 1 && ctx->T >= 4 && ctx->n_simd > 0 &&
       ((B - 1) % ctx->n_simd == 0 || ctx->relay_always)) {

@@ -239,6 +239,415 @@ DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const
   w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
 }
 
+// ================================================================ mjx.forward, second half: contact Jacobians, constraint rows,
+// qacc_smooth, Newton solver.  A function of its own so that the generic instantiation can run it on two workspaces (see the
+// end of forward()).
+template <class W, class M>
+DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int nea) {
+  const int nv = dim_nv(m), nl = dim_nl(m), ntri = m->ntri;
+  // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
+  DIAL_MARK(w, 1);
+  if constexpr (M::D::ell) {
+    // compact rows: J_c is dim x ndof over the dofs that move body1 or body2 (support.jac of both bodies at the contact
+    // point, translational rows in the contact frame, then -- condim 6 -- the rotational ones); one item per (contact, dof)
+    // -- over the list of contacts that are on (2-4 of the 19 with the ball in the hand: one pass instead of three)
+    const int n_con = w.compact(M::D::NC, [&](int c) { return s.con_on[c] != 0.f; }, s.ulist);
+    w.items(n_con * M::D::NCD, [&](int it) {
+      const int idx = it / M::D::NCD, a = it - idx * M::D::NCD, c = (int)s.ulist[idx];
+      const int nd = m->con_ndof[c];
+      if (a >= nd) return;
+      const int i = m->con_dof[c][a], b1 = m->con_body1[c], b2 = m->con_body2[c], dim = m->con_dim[c];
+      float cd[6];
+      for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+      const float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
+      float dp[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f};
+      if ((m->body_ancmask[b2] >> i) & 1u) {
+        const float* cm = s.com + 3 * m->body_rootid[b2];
+        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
+        float cr[3];
+        dm::cross3(cr, cd, off);
+        for (int k = 0; k < 3; k++) { dp[k] += cd[3 + k] + cr[k]; dr[k] += cd[k]; }
+      }
+      if ((m->body_ancmask[b1] >> i) & 1u) {
+        const float* cm = s.com + 3 * m->body_rootid[b1];
+        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
+        float cr[3];
+        dm::cross3(cr, cd, off);
+        for (int k = 0; k < 3; k++) { dp[k] -= cd[3 + k] + cr[k]; dr[k] -= cd[k]; }
+      }
+      float* J = s.Jc + m->con_joff[c] + a;
+      for (int k = 0; k < 3; k++) J[k * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dp);
+      if (dim == 6) for (int k = 0; k < 3; k++) J[(3 + k) * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dr);
+    });
+    // row velocities J_c qvel, one item per (contact, row) -- not a dim x ndof double loop inside the contact's lane
+    w.items(6 * n_con, [&](int it) {
+      const int idx = it / 6, k = it - 6 * idx, c = (int)s.ulist[idx];
+      if (k >= m->con_dim[c]) return;
+      const int nd = m->con_ndof[c];
+      const float* J = s.Jc + m->con_joff[c] + k * nd;
+      float vel = 0.f;
+      for (int a = 0; a < nd; a++) vel += J[a] * s.qvel[m->con_dof[c][a]];
+      s.jv[m->con_adr[c] + k] = vel;
+    });
+  } else
+  w.items(nca * nv, [&](int it) {
+    const int c = it / nv, i = it - c * nv;
+    const int co = con_of(m, s, c);   // model contact (positions, frames and constants are indexed by it; Jc by the compact c)
+    const int b1 = m->con_body1[co], b2 = m->con_body2[co];
+    float cd[6];
+    for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
+    float p[3] = {s.cpos[3 * co], s.cpos[3 * co + 1], s.cpos[3 * co + 2]};
+    float diff[3] = {0.f, 0.f, 0.f};
+    if ((m->body_ancmask[b2] >> i) & 1u) {
+      const float* cm = s.com + 3 * m->body_rootid[b2];
+      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
+      dm::cross3(cr, cd, off);
+      for (int k = 0; k < 3; k++) diff[k] += cd[3 + k] + cr[k];
+    }
+    if ((m->body_ancmask[b1] >> i) & 1u) {
+      const float* cm = s.com + 3 * m->body_rootid[b1];
+      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
+      dm::cross3(cr, cd, off);
+      for (int k = 0; k < 3; k++) diff[k] -= cd[3 + k] + cr[k];
+    }
+    if constexpr (M::D::square) {   // dof-major pyramid rows J^T[i][4c + e] = Jn +- mu * Jt (one 16-byte store)
+      const float jn = dm::dot3(s.cframe + 9 * c, diff), t1 = dm::dot3(s.cframe + 9 * c + 3, diff) * m->con_friction[c][0];
+      const float t2 = dm::dot3(s.cframe + 9 * c + 6, diff) * m->con_friction[c][1];
+      float* jt = s.Jc + i * M::D::T + 4 * c;
+      jt[0] = jn + t1; jt[1] = jn - t1; jt[2] = jn + t2; jt[3] = jn - t2;
+    } else {
+      for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * co + 3 * a, diff);
+    }
+  });
+  // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
+  if constexpr (M::D::ell) {
+    // elliptic cones (_efc_contact_elliptic): one item per limit row and per contact; the friction rows' R follows
+    // from the normal row (impratio, friction ratios) and their reference acceleration has no position term
+    w.items(nl + M::D::NC, [&](int it) {
+      if (it < nl) {
+        const int r = it, ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+        const float q = s.qpos[qa];
+        const float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+        const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+        const float sgn = dist_min < dist_max ? 1.f : -1.f;
+        s.lsign[r] = sgn;
+        if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+        float k_, b_, imp;
+        kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+        const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
+        s.aref[r] = -b_ * (sgn * s.qvel[da]) - k_ * imp * pos;
+        s.D[r] = 1.f / R;
+        return;
+      }
+      const int c = it - nl, r0 = m->con_adr[c], dim = m->con_dim[c];
+      if (s.con_on[c] == 0.f) {
+        for (int j = 0; j < dim; j++) { s.D[r0 + j] = 0.f; s.aref[r0 + j] = 0.f; }
+        return;
+      }
+      const float pos = s.cdist[c] - m->con_margin[c];
+      const float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
+      const float f0 = m->con_friction[c][0];
+      float k_, b_, imp;
+      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
+      const float iw1 = t / m->impratio;
+      for (int j = 0; j < dim; j++) {
+        float invw = j == 0 ? t : iw1;
+        if (j >= 2) { const float fj = m->con_friction[c][j - 1]; invw = iw1 * (f0 * f0) / (fj * fj); }
+        const float vel = s.jv[r0 + j];
+        const float R = dm::fmaxf_(invw * (1.f - imp) / imp, MJ_MINVAL);
+        s.aref[r0 + j] = -b_ * vel - k_ * imp * (j == 0 ? pos : 0.f);
+        s.D[r0 + j] = 1.f / R;
+      }
+    });
+  } else
+  w.items(nea, [&](int r) {
+    if (r < nl) {
+      const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+      float q = s.qpos[qa];
+      float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+      float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+      float sgn = dist_min < dist_max ? 1.f : -1.f;
+      s.lsign[r] = sgn;
+      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+      float k_, b_, imp;
+      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
+      float vel = sgn * s.qvel[da];
+      s.aref[r] = -b_ * vel - k_ * imp * pos;
+      s.D[r] = 1.f / R;
+    } else {
+      const int c = con_of(m, s, (r - nl) >> 2);
+      s.lsign[r] = 0.f;
+      float pos = s.cdist[c] - m->con_margin[c];
+      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
+      float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
+      float mu = m->con_friction[c][0];
+      float invweight = t + mu * mu * t;
+      invweight = invweight * 2.f * mu * mu / m->impratio;
+      float k_, b_, imp;
+      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
+      float R = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
+      float vel;
+      if constexpr (M::D::square) {
+        vel = 0.f;
+        for (int i = 0; i < M::D::NV; i++) vel += s.Jc[i * M::D::T + (r - nl)] * s.qvel[i];
+      } else {
+        vel = row_dot(m, s, r, s.qvel);
+      }
+      s.aref[r] = -b_ * vel - k_ * imp * pos;
+      s.D[r] = 1.f / R;
+    }
+  });
+  // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
+  DIAL_MARK(w, 2);
+  w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
+  if constexpr (M::D::is_static) {
+    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
+    w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
+  } else {
+#ifdef DIAL_LDS_CHOL
+    solve_spd(w, m, s, s.M, s.rhs, s.qas);
+#else
+    solve_spd_reg(w, m, s, s.M, s.rhs, s.qas);
+#endif
+  }
+  DIAL_MARK(w, 3);
+  if (nea == 0) {
+    w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
+    return;
+  }
+  if constexpr (M::D::ell) {
+    solver_cone(w, m, s);  // elliptic cones: per-contact Newton solver (solver_cone.h)
+    return;
+  } else if constexpr (M::D::is_static) {
+    solver_reg(w, m, s);   // register-resident Newton solver (solver_reg.h)
+    return;
+  }
+
+  // ================================================================ solver.solve (Newton)
+  // warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
+  w.items(2 * nea + 2 * nv, [&](int it) {
+    if (it < nea) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
+    else if (it < 2 * nea) s.JarefS[it - nea] = row_dot(m, s, it - nea, s.qas) - s.aref[it - nea];
+    else if (it < 2 * nea + nv) {
+      const int i = it - 2 * nea;
+      float acc = 0.f;
+      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.warm[j];
+      s.MaW[i] = acc;
+    } else {
+      const int i = it - 2 * nea - nv;
+      float acc = 0.f;
+      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.qas[j];
+      s.MaS[i] = acc;
+    }
+  });
+  float cw, gw, cs, gs;
+  if (nea <= 64) {   // one row per lane: the four sums as one batch of stage-interleaved reductions
+    vfloat t4[4];
+    t4[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefW[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[1] = w.per_lane([&](int l) { return l < nv ? (s.MaW[l] - s.qfs[l]) * (s.warm[l] - s.qas[l]) : 0.f; });
+    t4[2] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefS[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[3] = w.per_lane([&](int l) { return l < nv ? (s.MaS[l] - s.qfs[l]) * (s.qas[l] - s.qas[l]) : 0.f; });
+    float r4[4];
+    w.vsumN(t4, r4);
+    cw = r4[0]; gw = r4[1]; cs = r4[2]; gs = r4[3];
+  } else {
+    cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
+    cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
+  }
+  const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
+  const bool use_warm = cost_w < cost_s;
+  w.items(nea + nv, [&](int it) {
+    if (it < nea) s.Jaref[it] = use_warm ? s.JarefW[it] : s.JarefS[it];
+    else {
+      const int i = it - nea;
+      s.qacc[i] = use_warm ? s.warm[i] : s.qas[i];
+      s.Ma[i] = use_warm ? s.MaW[i] : s.MaS[i];
+    }
+  });
+  float cost = use_warm ? cost_w : cost_s;
+  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
+  float prev_cost = INFINITY;
+  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
+
+  // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
+  auto constraint_grad = [&]() {
+    w.items(nea, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
+    w.items(nv, [&](int i) {
+      float qc = jt_dot(m, s, i, s.frc, nca);
+      s.qfc[i] = qc;
+      float g = s.Ma[i] - s.qfs[i] - qc;
+      s.grad[i] = g;
+      s.rhs[i] = g;
+    });
+  };
+  // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
+  auto newton_dir = [&]() {
+    w.items((nv * (nv + 1)) / 2, [&](int e) { s.H[e] = 0.f; });   // generic path only (see solver_reg.h for the other)
+    DIAL_MARK(w, 14);
+    w.items(ntri, [&](int it) {
+      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
+      float acc = 0.f;
+      if (i == j) {
+        int lr = m->dof_limrow[i];
+        if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
+      }
+      for (int c = 0; c < nca; c++) {
+        const float* jn = s.Jc + (c * 3) * nv;
+        float jni = jn[i], jnj = jn[j];
+        float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
+        const int co = con_of(m, s, c);
+        float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
+        const int r0 = nl + 4 * c;
+        float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
+        float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
+        acc += ((jni + t1i * mu1) * d0) * (jnj + t1j * mu1);
+        acc += ((jni - t1i * mu1) * d1) * (jnj - t1j * mu1);
+        acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
+        acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
+      }
+      s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
+    });
+    DIAL_MARK(w, 5);
+#ifdef DIAL_LDS_CHOL
+    solve_spd(w, m, s, s.H, s.rhs, s.search);
+#else
+    solve_spd_reg(w, m, s, s.H, s.rhs, s.search);
+#endif
+    w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
+  };
+
+  // Newton iterations.  Each stage appears once in the instruction stream (the kernel is instruction-cache
+  // sensitive): [forces + gradient] -> convergence test -> [H, Cholesky, search] -> [line search].
+  int niter = 0;
+  for (;;) {
+    constraint_grad();
+    float gn_b = 0.f;
+    const bool batched = nea <= 64;   // one row per lane: cost, Gauss term and |grad|^2 as one batch of reductions
+    if (batched) {
+      vfloat t3[3];
+      t3[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.Jaref[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+      t3[1] = w.per_lane([&](int l) { return l < nv ? (s.Ma[l] - s.qfs[l]) * (s.qacc[l] - s.qas[l]) : 0.f; });
+      t3[2] = w.per_lane([&](int l) { return l < nv ? s.grad[l] * s.grad[l] : 0.f; });
+      float r3[3];
+      w.vsumN(t3, r3);
+      if (niter > 0) {
+        gauss = 0.5f * r3[1];
+        prev_cost = cost;
+        cost = 0.5f * r3[0] + gauss;
+      }
+      gn_b = r3[2];
+    } else if (niter > 0) {
+      float c2 = w.sum(nea, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+      float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
+      gauss = 0.5f * g2;
+      prev_cost = cost;
+      cost = 0.5f * c2 + gauss;
+    }
+    DIAL_MARK(w, 4);
+    bool done;
+    if (m->iterations != 1) {
+      float gn = batched ? gn_b : w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
+      float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
+    } else {
+      done = niter >= 1;
+    }
+    if (done) break;
+    newton_dir();
+    DIAL_MARK(w, 6);
+    // ---------------- solver._linesearch
+    DIAL_MARK(w, 8);
+    w.items(nv + nea, [&](int it) {
+      if (it < nv) {
+        float acc = 0.f;
+        for (int j = 0; j < nv; j++) acc += msym(s, it, j) * s.search[j];
+        s.mv[it] = acc;
+      } else {
+        s.jv[it - nv] = row_dot(m, s, it - nv, s.search);
+      }
+    });
+    float sn2, s1, s2;
+    w.sum3(nv, [&](int i, float& a, float& b, float& c) {
+      float sv = s.search[i];
+      a = sv * sv; b = sv * s.Ma[i] - sv * s.qfs[i]; c = sv * s.mv[i];
+    }, sn2, s1, s2);
+    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
+    const float gtol = m->tolerance * m->ls_tolerance * smag;
+    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
+    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r); models with more
+    // than 64 rows (the crate scene: 220) keep them in LDS and sum over the rows lane-strided
+    const bool wide = nea > 64;
+    const vfloat vJa = w.per_lane([&](int l) { return l < nea ? s.Jaref[l] : 0.f; });
+    const vfloat vjv = w.per_lane([&](int l) { return l < nea ? s.jv[l] : 0.f; });
+    const vfloat vD = w.per_lane([&](int l) { return l < nea ? s.D[l] : 0.f; });
+    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
+    const vfloat vzero = vsplat(0.f);
+    if (wide)
+      w.items(nea, [&](int r) {
+        const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
+        s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
+      });
+    auto ls_point = [&](float alpha) {
+      float q0, q1, q2;
+      if (!wide) {
+        const vbool act = vlt0(vJa + vjv * alpha);
+        vfloat t3[3] = {vsel(act, vq0, vzero), vsel(act, vq1, vzero), vsel(act, vq2, vzero)};
+        float r3[3];
+        w.vsumN(t3, r3);   // three reductions with interleaved stages (one latency chain instead of three)
+        q0 = r3[0]; q1 = r3[1]; q2 = r3[2];
+      } else {
+        w.sum3(nea, [&](int r, float& a, float& b, float& c) {
+          const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;
+          a = act ? s.quad[3 * r] : 0.f; b = act ? s.quad[3 * r + 1] : 0.f; c = act ? s.quad[3 * r + 2] : 0.f;
+        }, q0, q1, q2);
+      }
+      q0 += qg0; q1 += qg1; q2 += qg2;
+      const float cost = alpha * alpha * q2 + alpha * q1 + q0;
+      // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
+      // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
+      // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
+      const float d0 = DM_FMA(2.f * alpha, q2, q1);
+      const float d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+      float pa, pn, pc, pd;
+      ls_pack(alpha, cost, d0, d1, pa, pn, pc, pd);   // integer keys: ls_bracket.h
+      LsPt p;
+      p.alpha = fbits(pa); p.nalpha = fbits(pn); p.cost = fbits(pc); p.d0 = fbits(pd);
+      return p;
+    };
+    const LsPt p0 = ls_point(0.f);
+    LsPt lo, hi;
+    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+    const int kg = fkey(gtol), kng = fkey(-gtol);
+    bool swap = true;
+    int ls_iter = 0;
+    for (;;) {
+      const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
+      if (done) break;
+      const LsPt lo_next = ls_point(bitsf(lo.nalpha));
+      const LsPt hi_next = ls_point(bitsf(hi.nalpha));
+      const LsPt mid = ls_point(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));
+      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
+      ls_iter++;
+    }
+    float alpha;
+    const bool improved = ls_result(p0, lo, hi, alpha);
+    if (improved) {
+      w.items(nv + nea, [&](int it) {
+        if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }
+        else s.Jaref[it - nv] += s.jv[it - nv] * alpha;
+      });
+    }
+    niter++;
+    DIAL_MARK(w, 7);
+  }
+  w.items(nv, [&](int i) { s.warm[i] = s.qacc[i]; });
+  DIAL_MARK(w, 8);
+}
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
@@ -820,407 +1229,18 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
     nea = nl + 4 * nca;
   }
-  // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
-  DIAL_MARK(w, 1);
-  if constexpr (M::D::ell) {
-    // compact rows: J_c is dim x ndof over the dofs that move body1 or body2 (support.jac of both bodies at the contact
-    // point, translational rows in the contact frame, then -- condim 6 -- the rotational ones); one item per (contact, dof)
-    // -- over the list of contacts that are on (2-4 of the 19 with the ball in the hand: one pass instead of three)
-    const int n_con = w.compact(M::D::NC, [&](int c) { return s.con_on[c] != 0.f; }, s.ulist);
-    w.items(n_con * M::D::NCD, [&](int it) {
-      const int idx = it / M::D::NCD, a = it - idx * M::D::NCD, c = (int)s.ulist[idx];
-      const int nd = m->con_ndof[c];
-      if (a >= nd) return;
-      const int i = m->con_dof[c][a], b1 = m->con_body1[c], b2 = m->con_body2[c], dim = m->con_dim[c];
-      float cd[6];
-      for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
-      const float p[3] = {s.cpos[3 * c], s.cpos[3 * c + 1], s.cpos[3 * c + 2]};
-      float dp[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f};
-      if ((m->body_ancmask[b2] >> i) & 1u) {
-        const float* cm = s.com + 3 * m->body_rootid[b2];
-        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
-        float cr[3];
-        dm::cross3(cr, cd, off);
-        for (int k = 0; k < 3; k++) { dp[k] += cd[3 + k] + cr[k]; dr[k] += cd[k]; }
-      }
-      if ((m->body_ancmask[b1] >> i) & 1u) {
-        const float* cm = s.com + 3 * m->body_rootid[b1];
-        const float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]};
-        float cr[3];
-        dm::cross3(cr, cd, off);
-        for (int k = 0; k < 3; k++) { dp[k] -= cd[3 + k] + cr[k]; dr[k] -= cd[k]; }
-      }
-      float* J = s.Jc + m->con_joff[c] + a;
-      for (int k = 0; k < 3; k++) J[k * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dp);
-      if (dim == 6) for (int k = 0; k < 3; k++) J[(3 + k) * nd] = dm::dot3(s.cframe + 9 * c + 3 * k, dr);
-    });
-    // row velocities J_c qvel, one item per (contact, row) -- not a dim x ndof double loop inside the contact's lane
-    w.items(6 * n_con, [&](int it) {
-      const int idx = it / 6, k = it - 6 * idx, c = (int)s.ulist[idx];
-      if (k >= m->con_dim[c]) return;
-      const int nd = m->con_ndof[c];
-      const float* J = s.Jc + m->con_joff[c] + k * nd;
-      float vel = 0.f;
-      for (int a = 0; a < nd; a++) vel += J[a] * s.qvel[m->con_dof[c][a]];
-      s.jv[m->con_adr[c] + k] = vel;
-    });
-  } else
-  w.items(nca * nv, [&](int it) {
-    const int c = it / nv, i = it - c * nv;
-    const int co = con_of(m, s, c);   // model contact (positions, frames and constants are indexed by it; Jc by the compact c)
-    const int b1 = m->con_body1[co], b2 = m->con_body2[co];
-    float cd[6];
-    for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * i + k];
-    float p[3] = {s.cpos[3 * co], s.cpos[3 * co + 1], s.cpos[3 * co + 2]};
-    float diff[3] = {0.f, 0.f, 0.f};
-    if ((m->body_ancmask[b2] >> i) & 1u) {
-      const float* cm = s.com + 3 * m->body_rootid[b2];
-      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
-      dm::cross3(cr, cd, off);
-      for (int k = 0; k < 3; k++) diff[k] += cd[3 + k] + cr[k];
+  if constexpr (!M::D::is_static) {
+    // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
+    // contacts (derived.h: ws_carve).  A sample that touches with more runs the SAME constraint code on its overflow
+    // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
+    if (s.con_cap > 0 && nca > s.con_cap) {
+      Ws sg = s;
+      ws_overflow(sg, s.ovf, nv, nc, ne);
+      forward_constraints(w, m, sg, nca, nea);
+      return;
     }
-    if ((m->body_ancmask[b1] >> i) & 1u) {
-      const float* cm = s.com + 3 * m->body_rootid[b1];
-      float off[3] = {p[0] - cm[0], p[1] - cm[1], p[2] - cm[2]}, cr[3];
-      dm::cross3(cr, cd, off);
-      for (int k = 0; k < 3; k++) diff[k] -= cd[3 + k] + cr[k];
-    }
-    if constexpr (M::D::square) {   // dof-major pyramid rows J^T[i][4c + e] = Jn +- mu * Jt (one 16-byte store)
-      const float jn = dm::dot3(s.cframe + 9 * c, diff), t1 = dm::dot3(s.cframe + 9 * c + 3, diff) * m->con_friction[c][0];
-      const float t2 = dm::dot3(s.cframe + 9 * c + 6, diff) * m->con_friction[c][1];
-      float* jt = s.Jc + i * M::D::T + 4 * c;
-      jt[0] = jn + t1; jt[1] = jn - t1; jt[2] = jn + t2; jt[3] = jn - t2;
-    } else {
-      for (int a = 0; a < 3; a++) s.Jc[(c * 3 + a) * nv + i] = dm::dot3(s.cframe + 9 * co + 3 * a, diff);
-    }
-  });
-  // ---- constraint.make_constraint: per row D, aref (rows that are "off" get D = 0, aref = 0)
-  if constexpr (M::D::ell) {
-    // elliptic cones (_efc_contact_elliptic): one item per limit row and per contact; the friction rows' R follows
-    // from the normal row (impratio, friction ratios) and their reference acceleration has no position term
-    w.items(nl + M::D::NC, [&](int it) {
-      if (it < nl) {
-        const int r = it, ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
-        const float q = s.qpos[qa];
-        const float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
-        const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
-        const float sgn = dist_min < dist_max ? 1.f : -1.f;
-        s.lsign[r] = sgn;
-        if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
-        float k_, b_, imp;
-        kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
-        const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
-        s.aref[r] = -b_ * (sgn * s.qvel[da]) - k_ * imp * pos;
-        s.D[r] = 1.f / R;
-        return;
-      }
-      const int c = it - nl, r0 = m->con_adr[c], dim = m->con_dim[c];
-      if (s.con_on[c] == 0.f) {
-        for (int j = 0; j < dim; j++) { s.D[r0 + j] = 0.f; s.aref[r0 + j] = 0.f; }
-        return;
-      }
-      const float pos = s.cdist[c] - m->con_margin[c];
-      const float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
-      const float f0 = m->con_friction[c][0];
-      float k_, b_, imp;
-      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
-      const float iw1 = t / m->impratio;
-      for (int j = 0; j < dim; j++) {
-        float invw = j == 0 ? t : iw1;
-        if (j >= 2) { const float fj = m->con_friction[c][j - 1]; invw = iw1 * (f0 * f0) / (fj * fj); }
-        const float vel = s.jv[r0 + j];
-        const float R = dm::fmaxf_(invw * (1.f - imp) / imp, MJ_MINVAL);
-        s.aref[r0 + j] = -b_ * vel - k_ * imp * (j == 0 ? pos : 0.f);
-        s.D[r0 + j] = 1.f / R;
-      }
-    });
-  } else
-  w.items(nea, [&](int r) {
-    if (r < nl) {
-      const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
-      float q = s.qpos[qa];
-      float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
-      float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
-      float sgn = dist_min < dist_max ? 1.f : -1.f;
-      s.lsign[r] = sgn;
-      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
-      float k_, b_, imp;
-      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
-      float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
-      float vel = sgn * s.qvel[da];
-      s.aref[r] = -b_ * vel - k_ * imp * pos;
-      s.D[r] = 1.f / R;
-    } else {
-      const int c = con_of(m, s, (r - nl) >> 2);
-      s.lsign[r] = 0.f;
-      float pos = s.cdist[c] - m->con_margin[c];
-      if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
-      float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
-      float mu = m->con_friction[c][0];
-      float invweight = t + mu * mu * t;
-      invweight = invweight * 2.f * mu * mu / m->impratio;
-      float k_, b_, imp;
-      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
-      float R = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
-      float vel;
-      if constexpr (M::D::square) {
-        vel = 0.f;
-        for (int i = 0; i < M::D::NV; i++) vel += s.Jc[i * M::D::T + (r - nl)] * s.qvel[i];
-      } else {
-        vel = row_dot(m, s, r, s.qvel);
-      }
-      s.aref[r] = -b_ * vel - k_ * imp * pos;
-      s.D[r] = 1.f / R;
-    }
-  });
-  // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
-  DIAL_MARK(w, 2);
-  w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
-  if constexpr (M::D::is_static) {
-    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
-    w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
-  } else {
-#ifdef DIAL_LDS_CHOL
-    solve_spd(w, m, s, s.M, s.rhs, s.qas);
-#else
-    solve_spd_reg(w, m, s, s.M, s.rhs, s.qas);
-#endif
   }
-  DIAL_MARK(w, 3);
-  if (nea == 0) {
-    w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
-    return;
-  }
-  if constexpr (M::D::ell) {
-    solver_cone(w, m, s);  // elliptic cones: per-contact Newton solver (solver_cone.h)
-    return;
-  } else if constexpr (M::D::is_static) {
-    solver_reg(w, m, s);   // register-resident Newton solver (solver_reg.h)
-    return;
-  }
-
-  // ================================================================ solver.solve (Newton)
-  // warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
-  w.items(2 * nea + 2 * nv, [&](int it) {
-    if (it < nea) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
-    else if (it < 2 * nea) s.JarefS[it - nea] = row_dot(m, s, it - nea, s.qas) - s.aref[it - nea];
-    else if (it < 2 * nea + nv) {
-      const int i = it - 2 * nea;
-      float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.warm[j];
-      s.MaW[i] = acc;
-    } else {
-      const int i = it - 2 * nea - nv;
-      float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.qas[j];
-      s.MaS[i] = acc;
-    }
-  });
-  float cw, gw, cs, gs;
-  if (nea <= 64) {   // one row per lane: the four sums as one batch of stage-interleaved reductions
-    vfloat t4[4];
-    t4[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefW[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
-    t4[1] = w.per_lane([&](int l) { return l < nv ? (s.MaW[l] - s.qfs[l]) * (s.warm[l] - s.qas[l]) : 0.f; });
-    t4[2] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefS[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
-    t4[3] = w.per_lane([&](int l) { return l < nv ? (s.MaS[l] - s.qfs[l]) * (s.qas[l] - s.qas[l]) : 0.f; });
-    float r4[4];
-    w.vsumN(t4, r4);
-    cw = r4[0]; gw = r4[1]; cs = r4[2]; gs = r4[3];
-  } else {
-    cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-    gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
-    cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-    gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
-  }
-  const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
-  const bool use_warm = cost_w < cost_s;
-  w.items(nea + nv, [&](int it) {
-    if (it < nea) s.Jaref[it] = use_warm ? s.JarefW[it] : s.JarefS[it];
-    else {
-      const int i = it - nea;
-      s.qacc[i] = use_warm ? s.warm[i] : s.qas[i];
-      s.Ma[i] = use_warm ? s.MaW[i] : s.MaS[i];
-    }
-  });
-  float cost = use_warm ? cost_w : cost_s;
-  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
-  float prev_cost = INFINITY;
-  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
-  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
-
-  // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
-  auto constraint_grad = [&]() {
-    w.items(nea, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
-    w.items(nv, [&](int i) {
-      float qc = jt_dot(m, s, i, s.frc, nca);
-      s.qfc[i] = qc;
-      float g = s.Ma[i] - s.qfs[i] - qc;
-      s.grad[i] = g;
-      s.rhs[i] = g;
-    });
-  };
-  // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
-  auto newton_dir = [&]() {
-    w.items((nv * (nv + 1)) / 2, [&](int e) { s.H[e] = 0.f; });   // generic path only (see solver_reg.h for the other)
-    DIAL_MARK(w, 14);
-    w.items(ntri, [&](int it) {
-      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
-      float acc = 0.f;
-      if (i == j) {
-        int lr = m->dof_limrow[i];
-        if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
-      }
-      for (int c = 0; c < nca; c++) {
-        const float* jn = s.Jc + (c * 3) * nv;
-        float jni = jn[i], jnj = jn[j];
-        float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
-        const int co = con_of(m, s, c);
-        float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
-        const int r0 = nl + 4 * c;
-        float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
-        float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
-        acc += ((jni + t1i * mu1) * d0) * (jnj + t1j * mu1);
-        acc += ((jni - t1i * mu1) * d1) * (jnj - t1j * mu1);
-        acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
-        acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
-      }
-      s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
-    });
-    DIAL_MARK(w, 5);
-#ifdef DIAL_LDS_CHOL
-    solve_spd(w, m, s, s.H, s.rhs, s.search);
-#else
-    solve_spd_reg(w, m, s, s.H, s.rhs, s.search);
-#endif
-    w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
-  };
-
-  // Newton iterations.  Each stage appears once in the instruction stream (the kernel is instruction-cache
-  // sensitive): [forces + gradient] -> convergence test -> [H, Cholesky, search] -> [line search].
-  int niter = 0;
-  for (;;) {
-    constraint_grad();
-    float gn_b = 0.f;
-    const bool batched = nea <= 64;   // one row per lane: cost, Gauss term and |grad|^2 as one batch of reductions
-    if (batched) {
-      vfloat t3[3];
-      t3[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.Jaref[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
-      t3[1] = w.per_lane([&](int l) { return l < nv ? (s.Ma[l] - s.qfs[l]) * (s.qacc[l] - s.qas[l]) : 0.f; });
-      t3[2] = w.per_lane([&](int l) { return l < nv ? s.grad[l] * s.grad[l] : 0.f; });
-      float r3[3];
-      w.vsumN(t3, r3);
-      if (niter > 0) {
-        gauss = 0.5f * r3[1];
-        prev_cost = cost;
-        cost = 0.5f * r3[0] + gauss;
-      }
-      gn_b = r3[2];
-    } else if (niter > 0) {
-      float c2 = w.sum(nea, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
-      float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
-      gauss = 0.5f * g2;
-      prev_cost = cost;
-      cost = 0.5f * c2 + gauss;
-    }
-    DIAL_MARK(w, 4);
-    bool done;
-    if (m->iterations != 1) {
-      float gn = batched ? gn_b : w.sum(nv, [&](int i) { return s.grad[i] * s.grad[i]; });
-      float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
-      done = niter >= m->iterations || improvement < m->tolerance || gradient < m->tolerance;
-    } else {
-      done = niter >= 1;
-    }
-    if (done) break;
-    newton_dir();
-    DIAL_MARK(w, 6);
-    // ---------------- solver._linesearch
-    DIAL_MARK(w, 8);
-    w.items(nv + nea, [&](int it) {
-      if (it < nv) {
-        float acc = 0.f;
-        for (int j = 0; j < nv; j++) acc += msym(s, it, j) * s.search[j];
-        s.mv[it] = acc;
-      } else {
-        s.jv[it - nv] = row_dot(m, s, it - nv, s.search);
-      }
-    });
-    float sn2, s1, s2;
-    w.sum3(nv, [&](int i, float& a, float& b, float& c) {
-      float sv = s.search[i];
-      a = sv * sv; b = sv * s.Ma[i] - sv * s.qfs[i]; c = sv * s.mv[i];
-    }, sn2, s1, s2);
-    const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
-    const float gtol = m->tolerance * m->ls_tolerance * smag;
-    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r); models with more
-    // than 64 rows (the crate scene: 220) keep them in LDS and sum over the rows lane-strided
-    const bool wide = nea > 64;
-    const vfloat vJa = w.per_lane([&](int l) { return l < nea ? s.Jaref[l] : 0.f; });
-    const vfloat vjv = w.per_lane([&](int l) { return l < nea ? s.jv[l] : 0.f; });
-    const vfloat vD = w.per_lane([&](int l) { return l < nea ? s.D[l] : 0.f; });
-    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
-    const vfloat vzero = vsplat(0.f);
-    if (wide)
-      w.items(nea, [&](int r) {
-        const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
-        s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
-      });
-    auto ls_point = [&](float alpha) {
-      float q0, q1, q2;
-      if (!wide) {
-        const vbool act = vlt0(vJa + vjv * alpha);
-        vfloat t3[3] = {vsel(act, vq0, vzero), vsel(act, vq1, vzero), vsel(act, vq2, vzero)};
-        float r3[3];
-        w.vsumN(t3, r3);   // three reductions with interleaved stages (one latency chain instead of three)
-        q0 = r3[0]; q1 = r3[1]; q2 = r3[2];
-      } else {
-        w.sum3(nea, [&](int r, float& a, float& b, float& c) {
-          const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;
-          a = act ? s.quad[3 * r] : 0.f; b = act ? s.quad[3 * r + 1] : 0.f; c = act ? s.quad[3 * r + 2] : 0.f;
-        }, q0, q1, q2);
-      }
-      q0 += qg0; q1 += qg1; q2 += qg2;
-      const float cost = alpha * alpha * q2 + alpha * q1 + q0;
-      // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
-      // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
-      // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
-      const float d0 = DM_FMA(2.f * alpha, q2, q1);
-      const float d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
-      float pa, pn, pc, pd;
-      ls_pack(alpha, cost, d0, d1, pa, pn, pc, pd);   // integer keys: ls_bracket.h
-      LsPt p;
-      p.alpha = fbits(pa); p.nalpha = fbits(pn); p.cost = fbits(pc); p.d0 = fbits(pd);
-      return p;
-    };
-    const LsPt p0 = ls_point(0.f);
-    LsPt lo, hi;
-    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
-    const int kg = fkey(gtol), kng = fkey(-gtol);
-    bool swap = true;
-    int ls_iter = 0;
-    for (;;) {
-      const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
-      if (done) break;
-      const LsPt lo_next = ls_point(bitsf(lo.nalpha));
-      const LsPt hi_next = ls_point(bitsf(hi.nalpha));
-      const LsPt mid = ls_point(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));
-      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
-      ls_iter++;
-    }
-    float alpha;
-    const bool improved = ls_result(p0, lo, hi, alpha);
-    if (improved) {
-      w.items(nv + nea, [&](int it) {
-        if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }
-        else s.Jaref[it - nv] += s.jv[it - nv] * alpha;
-      });
-    }
-    niter++;
-    DIAL_MARK(w, 7);
-  }
-  w.items(nv, [&](int i) { s.warm[i] = s.qacc[i]; });
-  DIAL_MARK(w, 8);
+  forward_constraints(w, m, s, nca, nea);
 }
 
 // Task kinds a kernel instantiation can be asked to run (the dimension-specialised ones are per robot; dial_create checks).

@@ -39,6 +39,11 @@ struct RolloutIO {
   int n_first;               // rollout index of the launch's first wavefront (split launches)
   int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
   int debug_stall_piece1;    // test hook (DIAL_DEBUG_RELAY_STALL=k): relay piece k - 1 never hands over; 0 = off
+  // generic instantiation: contact cap of the LDS workspace (derived.h: ws_carve) and the per-wavefront overflow areas in
+  // global memory (ovf_words each, indexed by the wavefront's slot in the grid); con_cap = 0: full-size LDS workspace
+  int con_cap;
+  float* ovf;
+  int ovf_words;
 };
 
 template <class W, class M>

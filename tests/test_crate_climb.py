@@ -190,3 +190,47 @@ def test_emulated_reverse_once_on_the_crate(case):
     rep = witness_parity(o32, s_o, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), EX, model.nq + 2 * model.nv)
     if rep["witnessed"] == 0:
         assert _within(re["rews"], ro["rews"], TOL["rewss"]).all()
+
+
+def test_capped_workspace_and_its_overflow_path_are_bit_identical(case):
+    """The GPU rollout kernel sizes its LDS workspace for 16 TOUCHING contacts and runs a sample that touches with more on an
+    overflow area in global memory (derived.h: ws_carve / ws_overflow).  Same code, same order of operations: the results
+    must be bit-identical to the full-size workspace -- with a cap of 16 (never exceeded in these poses), of 2 (most steps
+    overflow) and of 1 (every touching step overflows).  The emulator process reads the cap from the environment, hence
+    the subprocesses."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {here!r})\n"
+        "from conftest import setup_case\n"
+        "import emu_lib, oracle as O\n"
+        "from test_crate_climb import touching_state, EX\n"
+        "dc, env, model, task, cfg = setup_case(EX, 12, 5, per_rollout=True)\n"
+        "o64 = O.Oracle(model, task, cfg, np.float64); o32 = O.Oracle(model, task, cfg, np.float32)\n"
+        "emu = emu_lib.Emu(model, task, cfg)\n"
+        "out = []\n"
+        "for seed in (0, 3):\n"
+        "    q, qd = touching_state(env, o64, seed)\n"
+        "    s0, _, _ = o32.env_reset(q, qd)\n"
+        "    us = np.random.default_rng(100 + seed).uniform(-1, 1, (12, 6, model.nu)).astype(np.float32)\n"
+        "    r = emu.rollout(s0, us, check_races=(seed == 0))\n"
+        "    out += [r[0], r[1], r[2]]\n"
+        "np.savez(sys.argv[1], *out)\n")
+    results = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for cap in ("", "16", "2", "1"):
+            envv = dict(os.environ)
+            envv.pop("DIAL_EMU_CON_CAP", None)
+            if cap:
+                envv["DIAL_EMU_CON_CAP"] = cap
+            path = os.path.join(tmp, f"cap{cap or 'none'}.npz")
+            subprocess.check_call([sys.executable, "-c", script, path], env=envv, cwd=here)
+            d = np.load(path)
+            results[cap] = [d[k] for k in d.files]
+    for cap in ("16", "2", "1"):
+        for a, b in zip(results[""], results[cap]):
+            assert np.array_equal(a, b), f"cap {cap}"

@@ -10,6 +10,7 @@
 #define DIAL_EMU 1
 #include "../../dial_mpc_amd/csrc/rollout_driver.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -17,19 +18,24 @@ namespace {
 template <class D>
 struct Runner {
   CModel<D> cm;
-  int ws_words;
+  int ws_words, con_cap = 0, ovf_words = 0;
   Runner(const dial_model* m, const dial_task* t, const dial_derived* dv) {
     fill_cmodel(&cm, m, t, dv);
     Ws s;
+    // DIAL_EMU_CON_CAP=k: the GPU rollout kernel's capped workspace (derived.h: ws_carve) + overflow area, on the host
+    if (const char* e = std::getenv("DIAL_EMU_CON_CAP")) con_cap = D::is_static ? 0 : std::atoi(e);
     ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
+                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap);
+    if (con_cap > 0) ovf_words = ws_overflow(s, (float*)0, m->nv, m->ncon, m->nefc);
   }
   void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
-    lds.assign(ws_words, 0.f);
+    // (the overflow area lives behind the LDS image in the same vector: the race detector then sees both)
+    lds.assign(ws_words + ovf_words, 0.f);
     ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
-             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0);
+             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap);
+    if (s.con_cap > 0) s.ovf = lds.data() + ws_words;
     w.lds = lds.data();
-    w.lds_words = ws_words;
+    w.lds_words = ws_words + ovf_words;
     w.check_races = check_races != 0;
   }
 };
