@@ -156,3 +156,38 @@ def test_crate_closed_loop_runs_and_approaches_the_crate():
     print(f"crate closed loop: base x {xs[0]:.3f} -> {xs[-1]:.3f}, reward {rews[1]:.3f} -> {rews[-1]:.3f}")
     assert np.all(np.isfinite(rews))
     assert xs[-1] > xs[0] + 0.1 and rews[-1] > rews[1]
+
+
+def test_crate_overflow_path_on_the_gpu_is_bit_identical():
+    """The rollout kernel's LDS workspace holds 14 touching contacts; a sample with more runs the second compiled copy of the
+    constraint code on its overflow area in global memory.  DIAL_CON_CAP (read at dial_create) = 1 sends every touching
+    step down that path, = 0 switches the cap off (full-size LDS workspace): all three must agree bit for bit."""
+    import os
+    import oracle as O
+    from dial_mpc_amd import _lib
+    N, H = 256, 12
+    dc, env, model, task, cfg = setup_case(EX, N, H)
+    o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
+    q, qd = _poses(env, o64)[5]
+    s0, _, _ = o32.env_reset(q, qd)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=3, Ybar_scale=0.2)
+    outs = {}
+    old = os.environ.get("DIAL_CON_CAP")
+    try:
+        for cap in ("14", "1", "0"):
+            os.environ["DIAL_CON_CAP"] = cap
+            ctx = _lib.Context(model, task, cfg)
+            lds = ctx.lib.dial_lds_bytes(ctx.h)
+            out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+            sc = ctx.debug_scratch()
+            outs[cap] = (lds, out["Ybar"].cpu().numpy(), out["rews"].cpu().numpy(), sc["qss"].copy(), sc["qdss"].copy())
+            del ctx
+    finally:
+        if old is None:
+            os.environ.pop("DIAL_CON_CAP", None)
+        else:
+            os.environ["DIAL_CON_CAP"] = old
+    assert outs["1"][0] < outs["14"][0] < outs["0"][0]            # three different LDS footprints
+    for cap in ("1", "14"):
+        for a, b in zip(outs["0"][1:], outs[cap][1:]):
+            assert np.array_equal(a, b), f"DIAL_CON_CAP={cap}"
