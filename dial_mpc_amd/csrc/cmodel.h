@@ -108,6 +108,11 @@ struct CModelGeneric<D, true> {
   int32_t con_sub[D::NC];
   int32_t crate_contact[DIAL_MAX_FEET];
   float crate_region[6], head_vec[3];
+  // dry friction (joint frictionloss): rows [nlim, nlim + nfri) of the constraint list, and the push-crate task's contacts
+  int32_t nfri, fri_dof[DIAL_MAX_FRI], dof_frirow[D::NV];
+  float fri_loss[DIAL_MAX_FRI], fri_solref[DIAL_MAX_FRI][2], fri_solimp[DIAL_MAX_FRI][5];
+  int32_t pc_foot_contact[2][2], pc_wanted[2], pc_n_unwanted, pc_unwanted[16];
+  float pc_wanted_zmax;
 };
 
 // Everything one env.step reads that is constant across samples and steps.
@@ -206,12 +211,19 @@ CM_DIM(dim_nl, NL, nlim)
 CM_DIM(dim_ne, NE, nefc)
 CM_DIM(dim_ntri, NTRI, ntri)
 #undef CM_DIM
+// dofs with dry friction: the generic instantiation only (the dimension-specialised robots have none)
+template <class M>
+CM_HD constexpr int dim_nf(const M* m) {
+  if constexpr (M::D::is_static) return 0;
+  else return m->nfri;
+}
 
 // ---- host: does a model fit a static instantiation exactly?
 template <class D>
 static inline bool dims_match(const dial_model* m) {
   bool ok = m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
-            m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL;
+            m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL &&
+            m->nfri == 0;   // (dry friction rows exist in the generic instantiation only)
   if constexpr (!D::Topo::dense) {   // the sparse factorisations are specialised to the dof tree as well
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }

@@ -66,17 +66,20 @@ static inline int dial_build_derived(const dial_model* m, dial_derived* dv) {
   for (int l = 0; l < m->nlim; l++) dv->dof_limrow[m->jnt_dofadr[m->lim_jnt[l]]] = l;
   // lower-triangle entries that can be non-zero: M[i][j] and (for world-only contacts) H[i][j] vanish unless
   // dof j is an ancestor of dof i (branch-induced sparsity)
+  // A contact between two MOVING bodies (push crate: robot vs the sliding crate) couples dofs of different branches: H loses the
+  // branch-induced sparsity, every lower-triangle entry can be non-zero (M itself stays sparse: its assembly tests the ancestor
+  // relation per entry).  Such models run on the generic instantiation, whose factorisation is dense anyway.
+  bool coupled = false;
+  for (int c = 0; c < m->ncon; c++) coupled = coupled || (dv->body_ancmask[m->con_body1[c]] != 0 && dv->body_ancmask[m->con_body2[c]] != 0);
   int t = 0;
   for (int i = 0; i < m->nv; i++)
     for (int j = 0; j <= i; j++)
-      if ((dv->dof_ancmask[i] >> j) & 1u) dv->tri[t++] = (uint16_t)((i << 8) | j);
+      if (coupled || ((dv->dof_ancmask[i] >> j) & 1u)) dv->tri[t++] = (uint16_t)((i << 8) | j);
   dv->ntri = t;
   dv->nhitem = 0;
   for (int p = 0; p < 8; p++) dv->hpass_n[p] = 0;
   if (m->cone == DIAL_CONE_ELLIPTIC) { dv->nhitem = 0; return DIAL_OK; }   // solver_cone.h assembles H per contact
-  for (int c = 0; c < m->ncon; c++)   // contacts between two MOVING bodies would fill H between branches (a body welded to
-                                      // the world -- the crate -- has no dofs and counts as the world)
-    if (dv->body_ancmask[m->con_body1[c]] != 0 && dv->body_ancmask[m->con_body2[c]] != 0) return DIAL_ERR_UNSUPPORTED;
+  if (coupled) return DIAL_OK;   // no sparse H work list: the generic instantiation assembles H over `tri` (dense here)
   // ---- H work list.  Contact c (world vs body2) touches dof i iff i moves body2; j is an ancestor of i, so
   // entry (i, j) is touched by exactly the contacts that touch i.
   if (m->ncon <= 8) {
@@ -304,6 +307,18 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int f = 0; f < DIAL_MAX_FEET; f++) o.crate_contact[f] = t->crate_contact[f];
     for (int k = 0; k < 6; k++) o.crate_region[k] = t->crate_region[k];
     for (int k = 0; k < 3; k++) o.head_vec[k] = t->head_vec[k];
+    o.nfri = m->nfri;
+    for (int i = 0; i < m->nv; i++) o.dof_frirow[i] = -1;
+    for (int q = 0; q < m->nfri && q < DIAL_MAX_FRI; q++) {
+      o.fri_dof[q] = m->fri_dof[q]; o.fri_loss[q] = m->fri_loss[q];
+      o.dof_frirow[m->fri_dof[q]] = m->nlim + q;
+      for (int k = 0; k < 2; k++) o.fri_solref[q][k] = m->fri_solref[q][k];
+      for (int k = 0; k < 5; k++) o.fri_solimp[q][k] = m->fri_solimp[q][k];
+    }
+    for (int f = 0; f < 2; f++) { o.pc_wanted[f] = t->pc_wanted[f]; for (int k = 0; k < 2; k++) o.pc_foot_contact[f][k] = t->pc_foot_contact[f][k]; }
+    o.pc_n_unwanted = t->pc_n_unwanted;
+    for (int k = 0; k < 16; k++) o.pc_unwanted[k] = t->pc_unwanted[k];
+    o.pc_wanted_zmax = t->pc_wanted_zmax;
   }
   if constexpr (D::ell) {
     int adr = m->nlim, joff = 0;

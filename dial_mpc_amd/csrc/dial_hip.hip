@@ -449,11 +449,11 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, DIAL_ERR_HIP, "dial_create: no HIP device available (the HIP path has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, DIAL_ERR_ARG, "dial_create: bad device index");
-  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_GO2_CRATE)
+  if (task->kind < DIAL_TASK_GO2_WALK || task->kind > DIAL_TASK_H1_PUSH_CRATE)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown task kind");
   {   // the reward phase unrolls over the feet of the task's robot (rollout_body.h: reward_phase)
     const bool go2 = task->kind == DIAL_TASK_GO2_WALK || task->kind == DIAL_TASK_GO2_SEQ_JUMP || task->kind == DIAL_TASK_GO2_CRATE;
-    const bool h1 = task->kind == DIAL_TASK_H1_WALK || task->kind == DIAL_TASK_H1_LOCO;
+    const bool h1 = task->kind == DIAL_TASK_H1_WALK || task->kind == DIAL_TASK_H1_LOCO || task->kind == DIAL_TASK_H1_PUSH_CRATE;
     if ((go2 && task->nfeet != 4) || (h1 && task->nfeet != 2))
       return fail(nullptr, DIAL_ERR_ARG, "dial_create: task.nfeet must be 4 for the Go2 tasks and 2 for the H1 tasks");
   }
@@ -461,6 +461,17 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     for (int f = 0; f < 4; f++)
       if (task->crate_contact[f] < 0 || task->crate_contact[f] >= model->ncon)
         return fail(nullptr, DIAL_ERR_ARG, "dial_create: task.crate_contact must index the model's contact list");
+  if (task->kind == DIAL_TASK_H1_PUSH_CRATE) {
+    bool ok = task->pc_n_unwanted >= 0 && task->pc_n_unwanted <= 16;
+    for (int f = 0; f < 2 && ok; f++) {
+      ok = task->pc_wanted[f] >= 0 && task->pc_wanted[f] < model->ncon;
+      for (int k = 0; k < 2; k++) ok = ok && task->pc_foot_contact[f][k] >= 0 && task->pc_foot_contact[f][k] < model->ncon;
+    }
+    for (int q = 0; ok && q < task->pc_n_unwanted; q++) ok = task->pc_unwanted[q] >= 0 && task->pc_unwanted[q] < model->ncon;
+    if (!ok) return fail(nullptr, DIAL_ERR_ARG, "dial_create: the push-crate task's contact indices must index the model's contact list");
+  }
+  if (model->nfri < 0 || model->nfri > DIAL_MAX_FRI || (model->nfri > 0 && model->cone != DIAL_CONE_PYRAMIDAL))
+    return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: dry friction (frictionloss) is supported for pyramidal models with <= DIAL_MAX_FRI such dofs");
   if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
   if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)

@@ -48,14 +48,15 @@ DIAL_DEV int con_of(const M*, const Ws& s, int c) {   // model contact of compac
 template <class M>
 DIAL_DEV RowRef row_ref(const M* m, const Ws& s, int r) {
   RowRef rr;
-  const int nl = dim_nl(m);
-  rr.is_lim = r < nl;
+  const int nl = dim_nl(m), nlf = nl + dim_nf(m);   // rows: limits | dry friction | 4 pyramid edges per contact
+  rr.is_lim = r < nlf;
   if (rr.is_lim) {
-    rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
+    if constexpr (M::D::is_static) rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
+    else rr.dof = r < nl ? m->jnt_dofadr[m->lim_jnt[r]] : m->fri_dof[r - nl];   // (a friction row is J = +e_dof: lsign = 1)
     rr.c = 0; rr.tan = 0; rr.f = 0.f;
   } else {
-    int e = (r - nl) & 3;
-    rr.c = (r - nl) >> 2;
+    int e = (r - nlf) & 3;
+    rr.c = (r - nlf) >> 2;
     rr.tan = 1 + (e >> 1);
     float mu = m->con_friction[con_of(m, s, rr.c)][rr.tan - 1];
     rr.f = (e & 1) ? -mu : mu;
@@ -77,10 +78,11 @@ DIAL_DEV float row_dot(const M* m, const Ws& s, int r, const float* v) {
 // (J^T f)_i over the first nca (compact) contacts
 template <class M>
 DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f, int nca) {
-  const int nv = dim_nv(m), nl = dim_nl(m);
+  const int nv = dim_nv(m), nl = dim_nl(m) + dim_nf(m);
   float acc = 0.f;
   int lr = m->dof_limrow[i];
   if (lr >= 0) acc += s.lsign[lr] * f[lr];
+  if constexpr (!M::D::is_static) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += f[fr]; }
   for (int c = 0; c < nca; c++) {
     float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
     const int co = con_of(m, s, c);
@@ -245,6 +247,32 @@ DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const
 template <class W, class M>
 DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int nea) {
   const int nv = dim_nv(m), nl = dim_nl(m), ntri = m->ntri;
+  const int nf = dim_nf(m), nlf = nl + nf;   // dry-friction rows sit between the limit rows and the contact rows
+  // cost (x 2), force and curvature of ONE row at the value j = J_r qacc - aref_r.  Inequality rows (limits, contacts) are
+  // active for j < 0; a dry-friction row (solver._update_constraint) is quadratic while |D j| < frictionloss, i.e. |j| < rf = R f,
+  // and beyond that exerts -+f with the cost f (-0.5 rf -+ j)
+  const auto row_floss = [&](int r) -> float {
+    if constexpr (M::D::is_static) return 0.f;
+    else return (r >= nl && r < nlf) ? m->fri_loss[r - nl] : 0.f;
+  };
+  const auto row_cost2 = [&](int r, float j) -> float {
+    const float d = s.D[r], f = row_floss(r);
+    if (f > 0.f) {
+      const float rf = f / d;
+      return j <= -rf ? 2.f * f * (-0.5f * rf - j) : (j >= rf ? 2.f * f * (-0.5f * rf + j) : d * j * j);
+    }
+    return j < 0.f ? d * j * j : 0.f;
+  };
+  const auto row_force = [&](int r, float j) -> float {
+    const float d = s.D[r], f = row_floss(r);
+    if (f > 0.f) { const float rf = f / d; return j <= -rf ? f : (j >= rf ? -f : d * -j); }
+    return j < 0.f ? d * -j : 0.f;
+  };
+  const auto row_curv = [&](int r, float j) -> float {
+    const float d = s.D[r], f = row_floss(r);
+    if (f > 0.f) { const float rf = f / d; return (j > -rf && j < rf) ? d : 0.f; }
+    return j < 0.f ? d : 0.f;
+  };
   // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
   DIAL_MARK(w, 1);
   if constexpr (M::D::ell) {
@@ -375,8 +403,18 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       float vel = sgn * s.qvel[da];
       s.aref[r] = -b_ * vel - k_ * imp * pos;
       s.D[r] = 1.f / R;
+    } else if (r < nlf) {
+      if constexpr (!M::D::is_static) {   // constraint._instantiate_friction: J = e_dof, pos = 0, aref = -b qvel
+        const int q = r - nl, da = m->fri_dof[q];
+        s.lsign[r] = 1.f;
+        float k_, b_, imp;
+        kbi(m, m->fri_solref[q], m->fri_solimp[q], 0.f, k_, b_, imp);
+        const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
+        s.aref[r] = -b_ * s.qvel[da];
+        s.D[r] = 1.f / R;
+      }
     } else {
-      const int c = con_of(m, s, (r - nl) >> 2);
+      const int c = con_of(m, s, (r - nlf) >> 2);
       s.lsign[r] = 0.f;
       float pos = s.cdist[c] - m->con_margin[c];
       if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
@@ -390,7 +428,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       float vel;
       if constexpr (M::D::square) {
         vel = 0.f;
-        for (int i = 0; i < M::D::NV; i++) vel += s.Jc[i * M::D::T + (r - nl)] * s.qvel[i];
+        for (int i = 0; i < M::D::NV; i++) vel += s.Jc[i * M::D::T + (r - nlf)] * s.qvel[i];
       } else {
         vel = row_dot(m, s, r, s.qvel);
       }
@@ -444,17 +482,17 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   float cw, gw, cs, gs;
   if (nea <= 64) {   // one row per lane: the four sums as one batch of stage-interleaved reductions
     vfloat t4[4];
-    t4[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefW[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[0] = w.per_lane([&](int l) { return l < nea ? row_cost2(l, s.JarefW[l]) : 0.f; });
     t4[1] = w.per_lane([&](int l) { return l < nv ? (s.MaW[l] - s.qfs[l]) * (s.warm[l] - s.qas[l]) : 0.f; });
-    t4[2] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.JarefS[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+    t4[2] = w.per_lane([&](int l) { return l < nea ? row_cost2(l, s.JarefS[l]) : 0.f; });
     t4[3] = w.per_lane([&](int l) { return l < nv ? (s.MaS[l] - s.qfs[l]) * (s.qas[l] - s.qas[l]) : 0.f; });
     float r4[4];
     w.vsumN(t4, r4);
     cw = r4[0]; gw = r4[1]; cs = r4[2]; gs = r4[3];
   } else {
-    cw = w.sum(nea, [&](int r) { float j = s.JarefW[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    cw = w.sum(nea, [&](int r) { return row_cost2(r, s.JarefW[r]); });
     gw = w.sum(nv, [&](int i) { return (s.MaW[i] - s.qfs[i]) * (s.warm[i] - s.qas[i]); });
-    cs = w.sum(nea, [&](int r) { float j = s.JarefS[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+    cs = w.sum(nea, [&](int r) { return row_cost2(r, s.JarefS[r]); });
     gs = w.sum(nv, [&](int i) { return (s.MaS[i] - s.qfs[i]) * (s.qas[i] - s.qas[i]); });
   }
   const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
@@ -475,7 +513,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
 
   // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
   auto constraint_grad = [&]() {
-    w.items(nea, [&](int r) { float j = s.Jaref[r]; s.frc[r] = j < 0.f ? s.D[r] * -j : 0.f; });
+    w.items(nea, [&](int r) { s.frc[r] = row_force(r, s.Jaref[r]); });
     w.items(nv, [&](int i) {
       float qc = jt_dot(m, s, i, s.frc, nca);
       s.qfc[i] = qc;
@@ -494,6 +532,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       if (i == j) {
         int lr = m->dof_limrow[i];
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
+        if constexpr (!M::D::is_static) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
       }
       for (int c = 0; c < nca; c++) {
         const float* jn = s.Jc + (c * 3) * nv;
@@ -501,7 +540,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
         const int co = con_of(m, s, c);
         float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
-        const int r0 = nl + 4 * c;
+        const int r0 = nlf + 4 * c;
         float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
         float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
         acc += ((jni + t1i * mu1) * d0) * (jnj + t1j * mu1);
@@ -529,7 +568,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     const bool batched = nea <= 64;   // one row per lane: cost, Gauss term and |grad|^2 as one batch of reductions
     if (batched) {
       vfloat t3[3];
-      t3[0] = w.per_lane([&](int l) { if (l >= nea) return 0.f; const float j = s.Jaref[l]; return j < 0.f ? s.D[l] * j * j : 0.f; });
+      t3[0] = w.per_lane([&](int l) { return l < nea ? row_cost2(l, s.Jaref[l]) : 0.f; });
       t3[1] = w.per_lane([&](int l) { return l < nv ? (s.Ma[l] - s.qfs[l]) * (s.qacc[l] - s.qas[l]) : 0.f; });
       t3[2] = w.per_lane([&](int l) { return l < nv ? s.grad[l] * s.grad[l] : 0.f; });
       float r3[3];
@@ -541,7 +580,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       }
       gn_b = r3[2];
     } else if (niter > 0) {
-      float c2 = w.sum(nea, [&](int r) { float j = s.Jaref[r]; return j < 0.f ? s.D[r] * j * j : 0.f; });
+      float c2 = w.sum(nea, [&](int r) { return row_cost2(r, s.Jaref[r]); });
       float g2 = w.sum(nv, [&](int i) { return (s.Ma[i] - s.qfs[i]) * (s.qacc[i] - s.qas[i]); });
       gauss = 0.5f * g2;
       prev_cost = cost;
@@ -591,18 +630,34 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
         s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
       });
+    // the three coefficients one row contributes at the step alpha (solver._eval_pt): an inequality row its quadratic while
+    // Jaref + alpha jv < 0; a dry-friction row its quadratic inside |x| < rf and the linear pieces f (-0.5 rf -+ x) outside
+    const auto row_terms = [&](int r, float ja, float jv, float d, float k0, float k1, float k2, float alpha, float& a, float& b, float& c) {
+      const float x = ja + jv * alpha, f = row_floss(r);
+      if (f > 0.f) {
+        const float rf = f / d;
+        const bool neg = x <= -rf, pos = x >= rf;
+        a = neg ? f * (-0.5f * rf - ja) : (pos ? f * (-0.5f * rf + ja) : k0);
+        b = neg ? -f * jv : (pos ? f * jv : k1);
+        c = (neg || pos) ? 0.f : k2;
+        return;
+      }
+      const bool act = x < 0.f;
+      a = act ? k0 : 0.f; b = act ? k1 : 0.f; c = act ? k2 : 0.f;
+    };
     auto ls_point = [&](float alpha) {
       float q0, q1, q2;
       if (!wide) {
-        const vbool act = vlt0(vJa + vjv * alpha);
-        vfloat t3[3] = {vsel(act, vq0, vzero), vsel(act, vq1, vzero), vsel(act, vq2, vzero)};
+        vfloat t3[3];
+        w.per_lane_n(t3, [&](int l, float* o) {
+          row_terms(l, lane_val(vJa, l), lane_val(vjv, l), lane_val(vD, l), lane_val(vq0, l), lane_val(vq1, l), lane_val(vq2, l), alpha, o[0], o[1], o[2]);
+        });
         float r3[3];
         w.vsumN(t3, r3);   // three reductions with interleaved stages (one latency chain instead of three)
         q0 = r3[0]; q1 = r3[1]; q2 = r3[2];
       } else {
         w.sum3(nea, [&](int r, float& a, float& b, float& c) {
-          const bool act = s.Jaref[r] + s.jv[r] * alpha < 0.f;
-          a = act ? s.quad[3 * r] : 0.f; b = act ? s.quad[3 * r + 1] : 0.f; c = act ? s.quad[3 * r + 2] : 0.f;
+          row_terms(r, s.Jaref[r], s.jv[r], s.D[r], s.quad[3 * r], s.quad[3 * r + 1], s.quad[3 * r + 2], alpha, a, b, c);
         }, q0, q1, q2);
       }
       q0 += qg0; q1 += qg1; q2 += qg2;
@@ -1227,7 +1282,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     } else {
       w.items(nc, [&](int c) { s.clist[c] = (float)c; });
     }
-    nea = nl + 4 * nca;
+    nea = nl + dim_nf(m) + 4 * nca;
   }
   if constexpr (!M::D::is_static) {
     // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
@@ -1249,7 +1304,8 @@ constexpr uint32_t task_kind_mask() {
   if (std::is_same<typename D::Topo, TopoGo2>::value) return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP);
   if (std::is_same<typename D::Topo, TopoH1>::value) return 1u << DIAL_TASK_H1_WALK;
   if (std::is_same<typename D::Topo, TopoH1Loco>::value) return 1u << DIAL_TASK_H1_LOCO;
-  return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP) | (1u << DIAL_TASK_H1_WALK) | (1u << DIAL_TASK_H1_LOCO);
+  return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP) | (1u << DIAL_TASK_H1_WALK) | (1u << DIAL_TASK_H1_LOCO) |
+         (D::is_static ? 0u : (1u << DIAL_TASK_H1_PUSH_CRATE));
 }
 
 // Velocity command of one env.step (unitree_go2_env.py:142-155, unitree_h1_env.py:199-212): component k < 3 of the linear,
@@ -1331,7 +1387,8 @@ DIAL_DEV float quat_yaw(const float* q) {
 template <bool FULL_INFO, class W, class M>
 DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   const int nu = dim_nu(m);
-  const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO;
+  const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO ||
+                    m->kind == DIAL_TASK_H1_PUSH_CRATE;
   // act2joint / act2tau (base_env.py:38-66) | desired foot heights from the gait clock (get_foot_step)
   w.items(nu + DIAL_MAX_FEET, [&](int it) {
     if (it < nu) {
@@ -1438,7 +1495,8 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   // dependent instruction after the other (4.7 k cycles per step, round 3 section profile).
   auto reward_phase = [&](auto KIND) {
     constexpr int kind = decltype(KIND)::value;
-    constexpr bool walk = kind == DIAL_TASK_GO2_WALK || kind == DIAL_TASK_H1_WALK || kind == DIAL_TASK_H1_LOCO;
+    constexpr bool walk = kind == DIAL_TASK_GO2_WALK || kind == DIAL_TASK_H1_WALK || kind == DIAL_TASK_H1_LOCO ||
+                          kind == DIAL_TASK_H1_PUSH_CRATE;
     constexpr int NF = (kind == DIAL_TASK_GO2_WALK || kind == DIAL_TASK_GO2_SEQ_JUMP) ? 4 : 2;   // feet (dial_create checks task.nfeet)
     auto term = [&](auto IT, const float* cmd) -> float {
       constexpr int it = decltype(IT)::value;
@@ -1467,6 +1525,10 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
               float e = (z_tar - zs) / 0.05f;
               reward_gaits += e * e;
               fz = zs - m->foot_radius;
+            } else if constexpr (kind == DIAL_TASK_H1_PUSH_CRATE) {   // the foot capsule's two floor contacts (unitree_h1_env.py:474-480)
+              float zf = dm::fminf_(s.cdist[m->pc_foot_contact[f][0]], s.cdist[m->pc_foot_contact[f][1]]);
+              reward_gaits += (z_tar - zf) * (z_tar - zf);
+              fz = zs;
             } else if (kind == DIAL_TASK_H1_WALK) {
               float zf = dm::fminf_(s.cdist[2 * f], s.cdist[2 * f + 1]);
               reward_gaits += (z_tar - zf) * (z_tar - zf);
@@ -1564,7 +1626,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         out = -(dh * dh);
       } else if (it == 6) {
         float reward_energy = 0.f;
-        if (kind == DIAL_TASK_H1_WALK)
+        if (kind == DIAL_TASK_H1_WALK || kind == DIAL_TASK_H1_PUSH_CRATE)
           for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1]; reward_energy += e * e; }
         if (kind == DIAL_TASK_H1_LOCO) {   // energy uses the post-step qvel; foot-level term shares this lane
           for (int a = 0; a < nu; a++) { float e = s.ctrl[a] / m->tau_range[a][1] * s.qvel[6 + a] / 160.0f; reward_energy += e * e; }
@@ -1618,12 +1680,24 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       r[6] = term(std::integral_constant<int, 6>{}, cmd);
       r[7] = FULL_INFO ? term(std::integral_constant<int, 7>{}, cmd) : 0.f;
       r[8] = kind == DIAL_TASK_H1_LOCO ? s.rpart[8] : 0.f;      // foot-level term, written by term 6
+      if constexpr (kind == DIAL_TASK_H1_PUSH_CRATE) {
+        // unitree_h1_env.py:525-531: +1 per hand on the crate (contact point below 1.1 m), -1 per other part touching it
+        float rc = 0.f;
+        for (int q = 0; q < 2; q++) {
+          const int cc = m->pc_wanted[q];
+          rc += (s.cdist[cc] < 1e-3f && s.cpos[3 * cc + 2] < m->pc_wanted_zmax) ? 1.f : 0.f;
+        }
+        for (int q = 0; q < m->pc_n_unwanted; q++) rc -= s.cdist[m->pc_unwanted[q]] < 1e-3f ? 1.f : 0.f;
+        r[8] = rc;
+      }
       const float dt = m->dt, step = info[DIAL_INFO_STEP];
       float reward;
       if (kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239
         reward = r[0] * 0.1f + r[1] * 0.5f + r[2] * 0.3f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 1.0f;
       } else if (kind == DIAL_TASK_H1_WALK) {    // unitree_h1_env.py:286-298
         reward = r[0] * 5.0f + r[1] * 0.5f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f;
+      } else if (kind == DIAL_TASK_H1_PUSH_CRATE) {   // unitree_h1_env.py:534-548 (air_time, pos and alive carry the weight 0.0)
+        reward = r[0] * 5.0f + r[1] * 0.01f + r[2] * 0.1f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f + r[6] * 0.01f + r[8] * 0.05f;
       } else if (kind == DIAL_TASK_H1_LOCO) {    // unitree_h1_env.py:812-827
         reward = r[0] * 10.0f + r[1] * 0.5f + r[2] * 0.5f + r[3] * 1.0f + r[4] * 1.0f + r[5] * 0.5f +
                  r[8] * 0.02f + r[6] * 0.01f;
@@ -1654,6 +1728,9 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     else if ((kmask >> DIAL_TASK_GO2_SEQ_JUMP & 1u) && kind_u == DIAL_TASK_GO2_SEQ_JUMP) reward_phase(std::integral_constant<int, DIAL_TASK_GO2_SEQ_JUMP>{});
     else if ((kmask >> DIAL_TASK_H1_WALK & 1u) && kind_u == DIAL_TASK_H1_WALK) reward_phase(std::integral_constant<int, DIAL_TASK_H1_WALK>{});
     else if ((kmask >> DIAL_TASK_H1_LOCO & 1u) && kind_u == DIAL_TASK_H1_LOCO) reward_phase(std::integral_constant<int, DIAL_TASK_H1_LOCO>{});
+    else if constexpr ((kmask >> DIAL_TASK_H1_PUSH_CRATE) & 1u) {
+      if (kind_u == DIAL_TASK_H1_PUSH_CRATE) reward_phase(std::integral_constant<int, DIAL_TASK_H1_PUSH_CRATE>{});
+    }
   }
   DIAL_MARK(w, 10);
   return s.info[DIAL_INFO_REWARD];

@@ -7,11 +7,13 @@ from dial_mpc_amd.envs.unitree_go2_env import (
     UnitreeGo2SeqJumpEnvConfig)
 from dial_mpc_amd.envs.manipulation import AllegroReorientEnv, AllegroReorientEnvConfig
 from dial_mpc_amd.envs.unitree_h1_env import (
-    UnitreeH1LocoEnv, UnitreeH1LocoEnvConfig, UnitreeH1WalkEnv, UnitreeH1WalkEnvConfig)
+    UnitreeH1LocoEnv, UnitreeH1LocoEnvConfig, UnitreeH1PushCrateEnv, UnitreeH1PushCrateEnvConfig, UnitreeH1WalkEnv,
+    UnitreeH1WalkEnvConfig)
 
 _configs: Dict[str, Any] = {
     "unitree_h1_walk": UnitreeH1WalkEnvConfig,
     "unitree_h1_loco": UnitreeH1LocoEnvConfig,
+    "unitree_h1_push_crate": UnitreeH1PushCrateEnvConfig,
     "unitree_go2_walk": UnitreeGo2EnvConfig,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnvConfig,
     "unitree_go2_crate_climb": UnitreeGo2CrateEnvConfig,
@@ -20,13 +22,14 @@ _configs: Dict[str, Any] = {
 _envs: Dict[str, Callable] = {
     "unitree_h1_walk": UnitreeH1WalkEnv,
     "unitree_h1_loco": UnitreeH1LocoEnv,      # unitree_h1_env.py:906
+    "unitree_h1_push_crate": UnitreeH1PushCrateEnv,   # unitree_h1_env.py:905 (generic kernel instantiation)
     "unitree_go2_walk": UnitreeGo2Env,
     "unitree_go2_seq_jump": UnitreeGo2SeqJumpEnv,
     "unitree_go2_crate_climb": UnitreeGo2CrateEnv,   # unitree_go2_env.py:808 (generic kernel instantiation)
     "allegro_reorient": AllegroReorientEnv,
 }
 # reference envs that are NEXT rows and not built yet
-_NOT_BUILT = ("unitree_h1_push_crate",)
+_NOT_BUILT = ()
 
 
 def register_config(name: str, config: Any):

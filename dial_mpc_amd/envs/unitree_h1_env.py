@@ -1,6 +1,6 @@
 """Unitree H1 walk/jog environment: config and task description with the reference's constants
 (dial_mpc/envs/unitree_h1_env.py:25-179) and the H1 loco environment (:570-858, legs + torso only,
-arms welded, two capsules per foot).  push_crate is a NEXT row."""
+arms welded, two capsules per foot) and the push-crate environment (:378-567, generic kernel instantiation)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -13,6 +13,7 @@ from dial_mpc_amd.envs.base_env import BaseEnv, BaseEnvConfig, System, load_mode
 
 TASK_H1_WALK = _abi.MACROS["DIAL_TASK_H1_WALK"]
 TASK_H1_LOCO = _abi.MACROS["DIAL_TASK_H1_LOCO"]
+TASK_H1_PUSH_CRATE = _abi.MACROS["DIAL_TASK_H1_PUSH_CRATE"]
 
 _KP = [200.0, 200.0, 200.0, 200.0, 60.0, 200.0, 200.0, 200.0, 200.0, 60.0, 200.0,
        60.0, 60.0, 60.0, 60.0, 60.0, 60.0, 60.0, 60.0]
@@ -130,4 +131,53 @@ class UnitreeH1LocoEnv(BaseEnv):
             ramp_up_time=cfg.ramp_up_time, done_height=self._done_height,
             init_pos_tar=self._init_pos_tar, n_stage=0, jump_dt=1.0,
         )
+        return d
+
+
+@dataclass
+class UnitreeH1PushCrateEnvConfig(UnitreeH1WalkEnvConfig):
+    pass
+
+
+class UnitreeH1PushCrateEnv(UnitreeH1WalkEnv):
+    """unitree_h1_env.py:382-567: the H1 (knee and foot capsules, torso box, hand spheres) behind a 1.2 m crate of 30 kg on a slide
+    joint with 50 N of dry friction (`frictionloss`).  The walk env's reward with other weights, the feet heights taken from
+    the foot capsules' floor contacts, and a contact term: +1 per hand on the crate (below 1.1 m), -1 per other robot part
+    that touches it."""
+    task_kind = TASK_H1_PUSH_CRATE
+
+    def __init__(self, config: UnitreeH1PushCrateEnvConfig = None):
+        super().__init__(config if config is not None else UnitreeH1PushCrateEnvConfig())
+        self.physical_joint_range = self.physical_joint_range[:-1]      # :385 (the last joint is the crate's)
+        self._init_pos_tar = np.array([0.0, 0.0, 1.2])                  # reset(), :399
+        # Upstream reads contact.dist / contact.pos by POSITION in its MJX release's contact array: z_feet from [2:4] and [6:8],
+        # wanted_contacts = [26, 27], unwanted_contacts = 14 .. 25 (:474-480, 525-531).  In geom-pair order -- floor against
+        # left knee, left foot, right knee, right foot (2 each), torso (4), hands (1 each), then the crate against the same
+        # eight geoms -- those positions are: the floor contacts of the two FOOT capsules; the two HAND spheres against the
+        # crate; every other robot geom against the crate.  Looked up here by geom identity in this compiler's list.
+        m = self.sys.model
+        gname, bname = m["names"]["geom"], m["names"]["body"]
+        floor, box = gname.index("floor"), gname.index("static_box")
+        gbody = [bname[int(b)] for b in m["geom_bodyid"]]
+        con = [(int(m["con_geom1"][c]), int(m["con_geom2"][c])) for c in range(int(m["ncon"]))]
+        self._pc_foot_contact = []
+        for foot in ("left_ankle_link", "right_ankle_link"):
+            hits = [c for c, (g1, g2) in enumerate(con) if g1 == floor and gbody[g2] == foot]
+            assert len(hits) == 2, f"{foot}: expected the two floor contacts of one foot capsule, found {hits}"
+            self._pc_foot_contact.append(hits)
+        hands = ("left_elbow_link", "right_elbow_link")
+        self._pc_wanted = [c for c, (g1, g2) in enumerate(con) if g2 == box and gbody[g1] in hands]
+        self._pc_unwanted = [c for c, (g1, g2) in enumerate(con) if g2 == box and gbody[g1] not in hands]
+        assert len(self._pc_wanted) == 2 and len(self._pc_unwanted) == 12, (self._pc_wanted, self._pc_unwanted)
+
+    def make_system(self, config: UnitreeH1WalkEnvConfig) -> System:
+        model = load_model("unitree_h1", "mjx_scene_h1_push_crate.xml")
+        return System(model).tree_replace({"opt.timestep": config.timestep})
+
+    def task_dict(self) -> Dict[str, Any]:
+        d = super().task_dict()
+        unw = np.zeros(16, dtype=np.int64)
+        unw[: len(self._pc_unwanted)] = self._pc_unwanted
+        d.update(pc_foot_contact=np.array(self._pc_foot_contact), pc_wanted=np.array(self._pc_wanted),
+                 pc_n_unwanted=len(self._pc_unwanted), pc_unwanted=unw, pc_wanted_zmax=1.1)
         return d

@@ -366,8 +366,16 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
                             frictionloss=float(a.get("frictionloss", 0)),
                             ref=float(a.get("ref", 0)) * (angle_scale if jtype == JNT_HINGE else 1.0),
                             margin=float(a.get("margin", 0)), solref=solref, solimp=solimp))
-                        if joints[-1]["stiffness"] != 0 or joints[-1]["frictionloss"] != 0:
-                            raise NotImplementedError("joint stiffness / frictionloss not supported")
+                        for key, dflt in (("solreffriction", [0.02, 1.0]), ("solimpfriction", [0.9, 0.95, 0.001, 0.5, 2.0])):
+                            val = np.array(dflt)
+                            if key in a:
+                                x = _floats(a[key])
+                                val[: len(x)] = x
+                            joints[-1][key] = val
+                        if joints[-1]["stiffness"] != 0:
+                            raise NotImplementedError("joint stiffness not supported")
+                        if joints[-1]["frictionloss"] != 0 and jtype == JNT_FREE:
+                            raise NotImplementedError("frictionloss on a free joint is not supported")
                 walk(e, bid, cc, depth + 1)
 
     wb = root.find("worldbody")
@@ -566,6 +574,7 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
             contacts.append(dict(base, kind=kind, sub=sub))
 
     lim_jnt = [ji for ji, j in enumerate(joints) if j["limited"]]
+    fri_jnt = [ji for ji, j in enumerate(joints) if j["frictionloss"] > 0]
 
     # ---- actuators
     acts = []
@@ -596,7 +605,8 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
     m: Dict[str, Any] = dict(
         nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ngeom=len(cgeoms), nsite=len(sites),
         ncon=len(contacts), nlim=len(lim_jnt),
-        nefc=len(lim_jnt) + (sum(c["dim"] for c in contacts) if elliptic else 4 * len(contacts)),
+        nfri=len(fri_jnt),
+        nefc=len(lim_jnt) + len(fri_jnt) + (sum(c["dim"] for c in contacts) if elliptic else 4 * len(contacts)),
         iterations=int(opt["iterations"]), ls_iterations=int(opt["ls_iterations"]),
         eulerdamp=0 if flags.get("eulerdamp", "enable") == "disable" else 1,
         cone=0 if opt["cone"] == "pyramidal" else 1,
@@ -654,6 +664,10 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         con_solimp=np.array([c["solimp"] for c in contacts]).reshape(-1, 5),
         con_margin=np.array([c["margin"] for c in contacts]),
         lim_jnt=np.array(lim_jnt, dtype=np.int64),
+        fri_dof=np.array([joints[ji]["dofadr"] for ji in fri_jnt], dtype=np.int64),
+        fri_loss=np.array([joints[ji]["frictionloss"] for ji in fri_jnt], dtype=np.float64),
+        fri_solref=np.array([joints[ji]["solreffriction"] for ji in fri_jnt], dtype=np.float64).reshape(-1, 2),
+        fri_solimp=np.array([joints[ji]["solimpfriction"] for ji in fri_jnt], dtype=np.float64).reshape(-1, 5),
         act_dofadr=np.array([a["dofadr"] for a in acts], dtype=np.int64),
         act_qposadr=np.array([a["qposadr"] for a in acts], dtype=np.int64),
         act_ctrllimited=np.array([int(a["ctrllimited"]) for a in acts], dtype=np.int64),

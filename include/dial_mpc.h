@@ -51,6 +51,7 @@ extern "C" {
 #define DIAL_MAX_CON 56    /* static contact list (Go2: 4, H1 walk: 4, Allegro: 19, Go2 crate scene: 52) */
 #define DIAL_MAX_EFC 240   /* constraint rows: limits + 4 per pyramidal / condim per elliptic contact (Allegro: 88, crate scene: 220) */
 #define DIAL_MAX_LIM 24    /* limited hinge joints                               */
+#define DIAL_MAX_FRI 4     /* dofs with frictionloss (push-crate scene: the crate's slide joint) */
 #define DIAL_MAX_FEET 4
 #define DIAL_MAX_STAGE 12  /* seq-jump stages                                    */
 #define DIAL_MAX_T 36      /* Hsample+1                                          */
@@ -109,6 +110,7 @@ extern "C" {
 #define DIAL_TASK_H1_LOCO 3
 #define DIAL_TASK_ALLEGRO 4
 #define DIAL_TASK_GO2_CRATE 5  /* UnitreeGo2CrateEnv.step (unitree_go2_env.py:679-795) */
+#define DIAL_TASK_H1_PUSH_CRATE 6  /* UnitreeH1PushCrateEnv.step (unitree_h1_env.py:418-566) */
 
 /* packed-state info slots (floats; integers are stored as exactly representable floats) */
 #define DIAL_INFO_STEP 0
@@ -207,6 +209,14 @@ typedef struct dial_model {
   float con_solimp[DIAL_MAX_CON][5];
   float con_margin[DIAL_MAX_CON];
   int32_t lim_jnt[DIAL_MAX_LIM];
+  /* dofs with dry friction (joint frictionloss; constraint._instantiate_friction of MJX): one constraint row each, placed
+   * between the limit rows and the contact rows (nefc = nlim + nfri + contact rows); solref / solimp = the joint's
+   * solreffriction / solimpfriction                                                                                  */
+  int32_t nfri;
+  int32_t fri_dof[DIAL_MAX_FRI];
+  float fri_loss[DIAL_MAX_FRI];
+  float fri_solref[DIAL_MAX_FRI][2];
+  float fri_solimp[DIAL_MAX_FRI][5];
   int32_t act_dofadr[DIAL_MAX_U];
   int32_t act_qposadr[DIAL_MAX_U];
   int32_t act_ctrllimited[DIAL_MAX_U];
@@ -267,6 +277,15 @@ typedef struct dial_task {
   int32_t crate_contact[DIAL_MAX_FEET];
   float crate_region[6];
   float head_vec[3];           /* head_pos = torso pos + R head_vec (:717-718)                                         */
+  /* push crate (unitree_h1_env.py:474-480, 525-531): upstream reads its MJX release's contact array by position --
+   * z_feet = min(dist[2:4]), min(dist[6:8]); wanted_contacts = [26, 27]; unwanted_contacts = 14 .. 25.  Enumerated in
+   * geom-pair order those are: the two floor contacts of each FOOT capsule; the two HAND spheres against the crate; every
+   * other robot geom against the crate.  The env class looks them up by geom identity in this model's contact list.  */
+  int32_t pc_foot_contact[2][2];
+  int32_t pc_wanted[2];
+  int32_t pc_n_unwanted;
+  int32_t pc_unwanted[16];
+  float pc_wanted_zmax;        /* 1.1 (:529)                                                                           */
 } dial_task;
 
 /* Planner configuration: DialConfig + the constant spline matrices

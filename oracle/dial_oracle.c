@@ -80,6 +80,7 @@ typedef struct {
   real qM[NV][NV], qL[NV][NV];
   real con_dist[NC], con_pos[NC][3], con_frame[NC][9];
   real efc_J[NE][NV], efc_D[NE], efc_aref[NE], efc_force[NE];
+  real efc_floss[NE];   /* frictionloss of a dry-friction row, 0 for every other row */
   int efc_on[NE];
   real qfrc_passive[NV], qfrc_bias[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV];
   real qacc[NV], qfrc_constraint[NV];
@@ -768,7 +769,7 @@ static void jacr_col(const dial_model* m, const odata* d, int body, int i, real*
 }
 /* first constraint row of contact c: limits, then 4 pyramid edges (pyramidal) or condim rows (elliptic) per contact */
 static int efc_adr(const dial_model* m, int c) {
-  int r = m->nlim;
+  int r = m->nlim + m->nfri;
   for (int k = 0; k < c; k++) r += m->cone == DIAL_CONE_ELLIPTIC ? m->con_dim[k] : 4;
   return r;
 }
@@ -796,6 +797,24 @@ static void make_constraint(const dial_model* m, odata* d) {
     d->efc_aref[r] = -b_ * vel - k_ * imp * pos;
     d->efc_D[r] = 1 / R;
   }
+  for (int q = 0; q < m->nlim; q++) d->efc_floss[q] = 0;
+  /* dry friction (constraint._instantiate_friction): one row per dof with frictionloss, J = e_dof, pos = 0 (the impedance is
+   * solimp's d0), aref = -b * qvel; the row's cost is quadratic up to |force| = frictionloss and linear beyond (solver) */
+  for (int q = 0; q < m->nfri; q++, r++) {
+    int da = m->fri_dof[q];
+    for (int i = 0; i < nv; i++) d->efc_J[r][i] = 0;
+    d->efc_J[r][da] = 1;
+    d->efc_on[r] = 1;
+    real solref[2] = {m->fri_solref[q][0], m->fri_solref[q][1]}, solimp[5];
+    for (int k = 0; k < 5; k++) solimp[k] = m->fri_solimp[q][k];
+    real k_, b_, imp;
+    kbi(m, solref, solimp, 0, &k_, &b_, &imp);
+    real R = r_max((real)m->dof_invweight0[da] * (1 - imp) / imp, MJ_MINVAL);
+    d->efc_aref[r] = -b_ * d->qvel[da];
+    d->efc_D[r] = 1 / R;
+    d->efc_floss[r] = (real)m->fri_loss[q];
+  }
+  for (int q = r; q < m->nefc; q++) d->efc_floss[q] = 0;
   /* elliptic contacts (constraint._efc_contact_elliptic): condim rows per contact = normal, 2 tangents, torsion,
    * 2 rolling; R of the friction rows follows from the normal row (impratio, friction ratios); the friction rows'
    * reference acceleration has no position term (pos_aref = 0) */
@@ -944,7 +963,7 @@ static real update_constraint_elliptic(const dial_model* m, const odata* d, sctx
     c->efc_force[r] = d->efc_D[r] * -c->Jaref[r] * (c->active[r] ? 1 : 0);
     cost += (real)0.5 * d->efc_D[r] * c->Jaref[r] * c->Jaref[r] * (c->active[r] ? 1 : 0);
   }
-  int r0 = m->nlim;
+  int r0 = m->nlim + m->nfri;
   for (int k = 0; k < m->ncon; k++) {
     int dim = m->con_dim[k];
     real mu = (real)m->con_friction[k][0] / r_sqrt((real)m->impratio);
@@ -993,7 +1012,19 @@ static void update_constraint(const dial_model* m, const odata* d, sctx* c) {
     c->cost = ccost + gauss;
     return;
   }
+  real fcost = 0;   /* cost of the dry-friction rows in their LINEAR zones (solver._update_constraint) */
   for (int r = 0; r < ne; r++) {
+    if (d->efc_floss[r] > 0) {
+      /* quadratic while |D Jaref| < frictionloss, i.e. |Jaref| < rf = R * frictionloss; beyond: force = -+frictionloss and
+       * cost = frictionloss * (-0.5 rf -+ Jaref) */
+      real f = d->efc_floss[r], rf = f / d->efc_D[r], j = c->Jaref[r];
+      int neg = j <= -rf, pos = j >= rf;
+      c->active[r] = !neg && !pos;
+      c->efc_force[r] = neg ? f : (pos ? -f : d->efc_D[r] * -j);
+      if (neg) fcost += f * (-(real)0.5 * rf - j);
+      if (pos) fcost += f * (-(real)0.5 * rf + j);
+      continue;
+    }
     c->active[r] = c->Jaref[r] < 0;
     c->efc_force[r] = d->efc_D[r] * -c->Jaref[r] * (c->active[r] ? 1 : 0);
   }
@@ -1007,7 +1038,7 @@ static void update_constraint(const dial_model* m, const odata* d, sctx* c) {
   gauss *= (real)0.5;
   real cost = 0;
   for (int r = 0; r < ne; r++) cost += d->efc_D[r] * c->Jaref[r] * c->Jaref[r] * (c->active[r] ? 1 : 0);
-  cost = (real)0.5 * cost + gauss;
+  cost = (real)0.5 * cost + fcost + gauss;
   c->gauss = gauss;
   c->prev_cost = c->cost;
   c->cost = cost;
@@ -1025,7 +1056,7 @@ static void update_gradient(const dial_model* m, const odata* d, sctx* c) {
   if (m->cone == DIAL_CONE_ELLIPTIC) {
     /* cone Hessian of the middle-zone contacts: H += J_c^T Hc J_c,
      * Hc = Dm diag(mu, f) [[1, -mu U^T / T], [-mu U / T, mu N / T^3 U U^T + (mu^2 - mu N / T) I]] diag(mu, f) */
-    int r0 = m->nlim;
+    int r0 = m->nlim + m->nfri;
     for (int k = 0; k < m->ncon; k++) {
       int dim = m->con_dim[k];
       if (c->zone[k] == 1) {
@@ -1077,10 +1108,17 @@ static void ctx_create(const dial_model* m, const odata* d, const real* qacc, sc
   }
 }
 typedef struct { real alpha, cost, deriv_0, deriv_1; } lspoint;
-static lspoint ls_point(int ne, const sctx* c, real alpha, const real* jv, real quad[][3], const real* quad_gauss) {
+static lspoint ls_point(int ne, const odata* d, const sctx* c, real alpha, const real* jv, real quad[][3], const real* quad_gauss) {
   real qt[3] = {quad_gauss[0], quad_gauss[1], quad_gauss[2]};
   for (int r = 0; r < ne; r++) {
     real x = c->Jaref[r] + alpha * jv[r];
+    if (d->efc_floss[r] > 0) {   /* dry friction (solver._eval_pt): quadratic inside |x| < rf, linear outside */
+      real f = d->efc_floss[r], rf = f / d->efc_D[r];
+      if (x <= -rf) { qt[0] += f * (-(real)0.5 * rf - c->Jaref[r]); qt[1] += -f * jv[r]; }
+      else if (x >= rf) { qt[0] += f * (-(real)0.5 * rf + c->Jaref[r]); qt[1] += f * jv[r]; }
+      else { qt[0] += quad[r][0]; qt[1] += quad[r][1]; qt[2] += quad[r][2]; }
+      continue;
+    }
     if (x < 0) { qt[0] += quad[r][0]; qt[1] += quad[r][1]; qt[2] += quad[r][2]; }
   }
   lspoint p;
@@ -1156,7 +1194,7 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
   static __thread real quad_c[NC][3], cone[NC][7];
   const int ell = m->cone == DIAL_CONE_ELLIPTIC;
   if (ell) {
-    int r0 = m->nlim;
+    int r0 = m->nlim + m->nfri;
     for (int k = 0; k < m->ncon; k++) {
       int dim = m->con_dim[k];
       real mu = (real)m->con_friction[k][0] / r_sqrt((real)m->impratio);
@@ -1172,7 +1210,7 @@ static void linesearch(const dial_model* m, const odata* d, sctx* c) {
       r0 += dim;
     }
   }
-#define LS_POINT(a) (ell ? ls_point_elliptic(m, c, (a), jv, quad, quad_gauss, quad_c, cone) : ls_point(ne, c, (a), jv, quad, quad_gauss))
+#define LS_POINT(a) (ell ? ls_point_elliptic(m, c, (a), jv, quad, quad_gauss, quad_c, cone) : ls_point(ne, d, c, (a), jv, quad, quad_gauss))
   lspoint p0 = LS_POINT(0);
   lspoint lo = LS_POINT(p0.alpha - p0.deriv_0 / p0.deriv_1), hi;
   if (lo.deriv_0 < p0.deriv_0) { hi = p0; } else { hi = lo; lo = p0; }
@@ -1467,7 +1505,7 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
     info[DIAL_INFO_REWARD] = reward;
     return reward;
   }
-  if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK || t->kind == DIAL_TASK_H1_LOCO) {
+  if (t->kind == DIAL_TASK_GO2_WALK || t->kind == DIAL_TASK_H1_WALK || t->kind == DIAL_TASK_H1_LOCO || t->kind == DIAL_TASK_H1_PUSH_CRATE) {
     /* unitree_go2_env.py:142-162 / unitree_h1_env.py:196-217: target ramp uses the PRE-increment step */
     for (int k = 0; k < 3; k++) {
       real v = t->cmd_vel[k], a = t->cmd_ang_vel[k];
@@ -1491,6 +1529,12 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
         z_feet[f] = zs;                                           /* unitree_go2_env.py:166 */
         reward_gaits += ((z_tar[f] - z_feet[f]) / (real)0.05) * ((z_tar[f] - z_feet[f]) / (real)0.05);
         fz = zs - (real)t->foot_radius;                           /* :178 */
+      } else if (t->kind == DIAL_TASK_H1_PUSH_CRATE) {
+        /* unitree_h1_env.py:474-480: min(contact.dist[2:4]), min(contact.dist[6:8]) = the two floor contacts of each foot
+         * capsule (include/dial_mpc.h: dial_task.pc_foot_contact) */
+        z_feet[f] = r_min(d->con_dist[t->pc_foot_contact[f][0]], d->con_dist[t->pc_foot_contact[f][1]]);
+        reward_gaits += (z_tar[f] - z_feet[f]) * (z_tar[f] - z_feet[f]);
+        fz = zs;
       } else if (t->kind == DIAL_TASK_H1_WALK) {
         z_feet[f] = r_min(d->con_dist[2 * f], d->con_dist[2 * f + 1]); /* unitree_h1_env.py:230-235 */
         reward_gaits += (z_tar[f] - z_feet[f]) * (z_tar[f] - z_feet[f]);
@@ -1541,6 +1585,21 @@ static real env_step(const dial_model* m, const dial_task* t, odata* d, real* in
       reward = reward_gaits * (real)10.0 + reward_upright * (real)0.5 + reward_yaw * (real)0.5 +
                reward_vel * (real)1.0 + reward_ang3 * (real)1.0 + reward_height * (real)0.5 +
                reward_foot_level * (real)0.02 + reward_energy * (real)0.01;
+    } else if (t->kind == DIAL_TASK_H1_PUSH_CRATE) { /* unitree_h1_env.py:520-548 */
+      real reward_energy = 0;
+      for (int a = 0; a < m->nu; a++) { real e = ctrl[a] / (real)t->tau_range[a][1]; reward_energy += e * e; }
+      reward_energy = -reward_energy;
+      /* :525-531: hands on the crate (below 1.1 m) count, every other part of the robot touching it is penalised */
+      real reward_contact = 0;
+      for (int q = 0; q < 2; q++) {
+        int cc = t->pc_wanted[q];
+        reward_contact += (d->con_dist[cc] < (real)1e-3 && d->con_pos[cc][2] < (real)t->pc_wanted_zmax) ? 1 : 0;
+      }
+      for (int q = 0; q < t->pc_n_unwanted; q++) reward_contact -= d->con_dist[t->pc_unwanted[q]] < (real)1e-3 ? 1 : 0;
+      /* reward_air_time, reward_pos and reward_alive carry the weight 0.0 upstream and are finite: left out */
+      reward = reward_gaits * (real)5.0 + reward_upright * (real)0.01 + reward_yaw * (real)0.1 +
+               reward_vel * (real)1.0 + reward_ang_vel * (real)1.0 + reward_height * (real)0.5 +
+               reward_energy * (real)0.01 + reward_contact * (real)0.05;
     } else { /* unitree_h1_env.py:282-298 */
       real reward_energy = 0;
       for (int a = 0; a < m->nu; a++) { real e = ctrl[a] / (real)t->tau_range[a][1]; reward_energy += e * e; }

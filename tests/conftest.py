@@ -50,6 +50,7 @@ TOL = dict(rewss=dict(rtol=5e-4, atol=5e-4), q=dict(rtol=0, atol=3e-4), qd=dict(
 KNIFE_EDGE_FRAC = {# crate scene: 52 candidate contacts, and the box narrow phases add discrete choices of their own (which vertices
                    # are lowest, which axis separates, which end of a capsule is nearer)
                    "unitree_go2_crate_climb": 0.05,
+                   "unitree_h1_push_crate": 0.05,
                    "unitree_go2_trot": 0.01, "unitree_go2_seq_jump": 0.01, "unitree_h1_jog": 0.01, "unitree_h1_loco": 0.03,
                    # 100 physics sub-steps of ball / fingertip impacts per rollout amplify 1-ulp differences past the gate
                    # for ~19 % of the rollouts at N=4096 H=24 (every one reproduced by the oracle at 1 ulp of jitter)

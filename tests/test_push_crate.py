@@ -1,0 +1,125 @@
+"""Push crate (UnitreeH1PushCrateEnv) on the CPU: compiled scene, the dry-friction row of the crate's slide
+joint pinned to its definition, and the kernel body (generic instantiation, host wave emulator) against the fp32 oracle
+from states in which the robot touches the sliding crate with hands, knees and torso."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle as O
+from conftest import TOL, _within, seeded_inputs, setup_case, witness_parity
+
+EX = "unitree_h1_push_crate"
+
+
+@pytest.fixture(scope="module")
+def case():
+    return setup_case(EX, 12, 5, per_rollout=True)
+
+
+def pushing_state(env, o64, seed, depth=0.002):
+    """Home pose with perturbed joints (arms raised towards the crate), the crate slid towards the robot until the deepest
+    robot / crate candidate penetrates by `depth`."""
+    rng = np.random.default_rng(seed)
+    md = env.sys.model
+    q = np.array(env._init_q, dtype=np.float64)
+    q[7:26] += rng.uniform(-0.15, 0.15, 19)
+    q[7 + 11] = q[7 + 15] = -rng.uniform(0.6, 1.4)          # shoulder pitch: arms forward
+    q[7 + 14] = q[7 + 18] = rng.uniform(0.0, 0.8)           # elbows
+    nv = env.sys.nv
+    box = md["names"]["geom"].index("static_box")
+    crate = [c for c in range(md["ncon"]) if int(md["con_geom2"][c]) == box]
+    q[26] = 1.5
+    for _ in range(60):
+        d = o64.forward_dump(q, np.zeros(nv))["con_dist"][crate]
+        dmin = float(d.min())
+        if abs(dmin + depth) < 1e-5:
+            break
+        q[26] -= (dmin + depth) * 0.9
+    qd = rng.normal(0, 0.2, nv)
+    return q, qd
+
+
+def test_compiled_scene_and_contact_lookup(case):
+    dc, env, model, task, cfg = case
+    md = env.sys.model
+    assert (md["nq"], md["nv"], md["nu"], md["nbody"], md["ngeom"], md["ncon"], md["nlim"], md["nfri"], md["nefc"]) == (27, 26, 19, 22, 9, 28, 19, 1, 132)
+    assert list(md["fri_dof"]) == [25] and float(md["fri_loss"][0]) == 50.0
+    names, bodies = md["names"]["geom"], md["names"]["body"]
+    gb = [bodies[int(b)] for b in md["geom_bodyid"]]
+    # z_feet: the floor contacts of the two foot capsules; wanted: the hand spheres against the crate; unwanted: the rest of the robot
+    for f, foot in enumerate(("left_ankle_link", "right_ankle_link")):
+        for c in task.pc_foot_contact[f]:
+            assert names[int(md["con_geom1"][c])] == "floor" and gb[int(md["con_geom2"][c])] == foot
+    for c in task.pc_wanted:
+        assert names[int(md["con_geom2"][c])] == "static_box" and gb[int(md["con_geom1"][c])].endswith("elbow_link")
+    unw = list(task.pc_unwanted)[: task.pc_n_unwanted]
+    assert len(unw) == 12 and all(names[int(md["con_geom2"][c])] == "static_box" for c in unw) and not set(unw) & set(task.pc_wanted)
+    # the crate never collides with the floor (contype 4 / conaffinity 1 against contype 2 / conaffinity 1)
+    assert not any(names[int(md["con_geom1"][c])] == "floor" and names[int(md["con_geom2"][c])] == "static_box" for c in range(md["ncon"]))
+
+
+def test_oracle_dry_friction_row_follows_its_definition(case):
+    """A 30 kg crate on a slide joint with frictionloss = 50 N, robot out of reach: sliding, it decelerates at exactly
+    f / m = 1.667 m/s^2 (the row sits in its linear zone: force = -f sign(v)); it stops without overshoot and STAYS (quadratic
+    zone: a static friction force that balances whatever is applied, up to 50 N)."""
+    dc, env, model, task, cfg = case
+    m2 = type(model).from_buffer_copy(model)
+    m2.iterations, m2.ls_iterations = 100, 50
+    o64 = O.Oracle(m2, task, cfg, np.float64)
+    nv, nq = model.nv, model.nq
+    q = np.array(env._init_q, dtype=np.float64)
+    q[2] = 3.0                                               # the robot hangs out of reach
+    v = np.zeros(nv)
+    v[25] = 0.5
+    d = o64.forward_dump(q, v)
+    assert abs(d["qacc"][25] + 50.0 / 30.0) < 1e-9 and abs(d["efc_force"][model.nlim] + 50.0) < 1e-9
+    v[25] = -0.5
+    d = o64.forward_dump(q, v)
+    assert abs(d["qacc"][25] - 50.0 / 30.0) < 1e-9
+    s, _, _ = o64.env_reset(q, np.r_[np.zeros(25), 0.5])
+    xs, vs = [], []
+    for _ in range(30):
+        s, _, _, _ = o64.env_step(s, np.zeros(model.nu))
+        xs.append(s[nq - 1])
+        vs.append(s[nq + 25])
+    vs = np.array(vs)
+    assert np.all(np.diff(vs[:14]) < 0) and np.allclose(np.diff(vs[:14]), -50.0 / 30.0 * 0.02, atol=1e-9)   # constant deceleration
+    assert np.all(np.abs(vs[16:]) < 1e-5) and abs(xs[-1] - xs[16]) < 1e-6                                  # at rest (the soft row decays geometrically), no creep
+    # stopping distance v0^2 / (2 a) = 0.075 m (semi-implicit Euler: slightly less)
+    assert 0.06 < xs[-1] - 1.0 < 0.08
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_emulated_generic_kernel_matches_oracle_while_pushing(case, seed):
+    dc, env, model, task, cfg = case
+    o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
+    emu = emu_lib.Emu(model, task, cfg)
+    nv, nu = model.nv, model.nu
+    q, qd = pushing_state(env, o64, seed)
+    s_o, xp_o, xq_o = o32.env_reset(q, qd)
+    s_e, xp_e, xq_e = emu.env_reset(q, qd, check_races=(seed == 0))
+    nqv = model.nq + nv
+    atol = np.full(s_o.shape, 2e-4)
+    atol[nqv:nqv + nv] = 2e-4 * max(1.0, float(np.abs(s_o[nqv:nqv + nv]).max()) * 1e-2)
+    assert np.all(np.abs(s_o - s_e) <= atol + 2e-4 * np.abs(s_o)), np.abs(s_o - s_e).max()
+    rng = np.random.default_rng(200 + seed)
+    us = rng.uniform(-1, 1, (dc.Nsample, dc.Hsample + 1, nu)).astype(np.float32)
+    r_e = emu.rollout(s_o, us, check_races=(seed == 0))
+    rep = witness_parity(o32, s_o, us, (r_e[0], r_e[1], r_e[2], r_e[3]), EX, model.nq + 2 * nv)
+    assert rep["rollouts"] == dc.Nsample
+    # the crate moved in at least some of the rollouts (its dof is the last one): the friction row left its quadratic zone
+    if seed == 0:
+        assert np.abs(r_e[2][:, :, 25]).max() > 1e-3
+
+
+def test_emulated_reverse_once_from_the_home_pose(case):
+    dc, env, model, task, cfg = case
+    o32 = O.Oracle(model, task, cfg, np.float32)
+    emu = emu_lib.Emu(model, task, cfg)
+    s_o, _, _ = o32.env_reset(env._init_q, np.zeros(model.nv))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+    ro = o32.reverse_once(s_o, Ybar, sigma, eps, full=True)
+    re = emu.rollout_nodes(s_o, Ybar, sigma, eps, check_races=False)
+    rep = witness_parity(o32, s_o, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), EX, model.nq + 2 * model.nv)
+    if rep["witnessed"] == 0:
+        assert _within(re["rews"], ro["rews"], TOL["rewss"]).all()

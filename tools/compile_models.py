@@ -17,6 +17,7 @@ MODELS = [
     ("unitree_go2", "mjx_scene_force_crate.xml"),
     ("unitree_h1", "mjx_scene_h1_walk.xml"),
     ("unitree_h1", "mjx_scene_h1_loco.xml"),
+    ("unitree_h1", "mjx_scene_h1_push_crate.xml"),
     ("wonik_allegro", "scene_left.xml"),
 ]
 
