@@ -455,7 +455,11 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(MaS, ls * nv) WS_TAKE(grad, ls * nv) WS_TAKE(search, ls * nv) WS_TAKE(mv, ls * nv)
   if (!ell) { WS_TAKE(qfc, ls * nv) }
   WS_TAKE(ysol, ls * nv)
-  WS_TAKE(L, with_L ? ntri : 0)   // packed Cholesky factor of the LDS solver (the register solver writes its factor over H)
+#ifdef DIAL_LDS_CHOL
+  WS_TAKE(L, with_L ? ntri : 0)   // packed Cholesky factor of the LDS Cholesky (reference implementation, rollout_body.h: solve_spd)
+#else
+  WS_TAKE(L, 0)                   // (the register L D L^T keeps its factor in VGPRs and the square `sq`)
+#endif
   WS_TAKE(sq, with_L ? DIAL_MAX_V * ((DIAL_MAX_V + 3) & ~3) : 0)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant

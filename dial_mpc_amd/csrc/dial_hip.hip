@@ -517,8 +517,19 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
         // scene that is 17.4 KB per wavefront -- NINE per CU, so that the 2049 rollouts of its example are resident at once
         // (at 16 the workspace is 18.3 KB, eight per CU = 2048 slots, and the 2049th rollout waits for a whole round)
         int cap = 14;
-        if (const char* e = getenv("DIAL_CON_CAP")) cap = atoi(e);
+        const char* e = getenv("DIAL_CON_CAP");
+        if (e) cap = atoi(e);
         if (cfg && model->cone == DIAL_CONE_PYRAMIDAL && cap > 0 && model->ncon > cap) {
+          // unless the cap was given: the largest one in 16 .. 8 with which NINE wavefronts fit a CU (8 x 256 + 1 rollouts of
+          // the examples' N = 2048 resident at once); 14 if none does.  Crate climb: 16 (17.2 KB), push crate: 9 (17.1 KB).
+          if (!e) {
+            for (int c = 16; c >= 8; c--) {
+              Ws st;
+              const int wds = ws_carve(st, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt, model->ngeom, model->nsite,
+                                       model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square, 0, c);
+              if ((size_t)wds * sizeof(float) <= (160 * 1024) / 9 / 512 * 512) { cap = c; break; }
+            }
+          }
           ctx->con_cap = cap;
           Ws so;
           ctx->ovf_words = ws_overflow(so, (float*)0, model->nv, model->ncon, model->nefc);

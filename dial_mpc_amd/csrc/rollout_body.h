@@ -1325,6 +1325,28 @@ DIAL_DEV void step_cmd(const M* m, const dial_task* tg, float step, float* cmd /
   }
 }
 
+// Push-crate task constants: they exist in the generic instantiation's constants only (cmodel.h: CModelGeneric); function
+// templates, so that code naming them also compiles (and is discarded) for the dimension-specialised instantiations.
+template <class M>
+DIAL_DEV int pc_foot_contact(const M* m, int f, int k) {
+  if constexpr (M::D::is_static) return 0;
+  else return m->pc_foot_contact[f][k];
+}
+template <class M>
+DIAL_DEV float pc_contact_reward(const M* m, const Ws& s) {
+  if constexpr (M::D::is_static) return 0.f;
+  else {
+    // unitree_h1_env.py:525-531: +1 per hand on the crate (contact point below 1.1 m), -1 per other part touching it
+    float rc = 0.f;
+    for (int q = 0; q < 2; q++) {
+      const int cc = m->pc_wanted[q];
+      rc += (s.cdist[cc] < 1e-3f && s.cpos[3 * cc + 2] < m->pc_wanted_zmax) ? 1.f : 0.f;
+    }
+    for (int q = 0; q < m->pc_n_unwanted; q++) rc -= s.cdist[m->pc_unwanted[q]] < 1e-3f ? 1.f : 0.f;
+    return rc;
+  }
+}
+
 // ================================================================ forward.euler (eulerdamp disabled)
 template <class W, class M>
 DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
@@ -1526,7 +1548,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
               reward_gaits += e * e;
               fz = zs - m->foot_radius;
             } else if constexpr (kind == DIAL_TASK_H1_PUSH_CRATE) {   // the foot capsule's two floor contacts (unitree_h1_env.py:474-480)
-              float zf = dm::fminf_(s.cdist[m->pc_foot_contact[f][0]], s.cdist[m->pc_foot_contact[f][1]]);
+              float zf = dm::fminf_(s.cdist[pc_foot_contact(m, f, 0)], s.cdist[pc_foot_contact(m, f, 1)]);
               reward_gaits += (z_tar - zf) * (z_tar - zf);
               fz = zs;
             } else if (kind == DIAL_TASK_H1_WALK) {
@@ -1680,16 +1702,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       r[6] = term(std::integral_constant<int, 6>{}, cmd);
       r[7] = FULL_INFO ? term(std::integral_constant<int, 7>{}, cmd) : 0.f;
       r[8] = kind == DIAL_TASK_H1_LOCO ? s.rpart[8] : 0.f;      // foot-level term, written by term 6
-      if constexpr (kind == DIAL_TASK_H1_PUSH_CRATE) {
-        // unitree_h1_env.py:525-531: +1 per hand on the crate (contact point below 1.1 m), -1 per other part touching it
-        float rc = 0.f;
-        for (int q = 0; q < 2; q++) {
-          const int cc = m->pc_wanted[q];
-          rc += (s.cdist[cc] < 1e-3f && s.cpos[3 * cc + 2] < m->pc_wanted_zmax) ? 1.f : 0.f;
-        }
-        for (int q = 0; q < m->pc_n_unwanted; q++) rc -= s.cdist[m->pc_unwanted[q]] < 1e-3f ? 1.f : 0.f;
-        r[8] = rc;
-      }
+      if constexpr (kind == DIAL_TASK_H1_PUSH_CRATE) r[8] = pc_contact_reward(m, s);
       const float dt = m->dt, step = info[DIAL_INFO_STEP];
       float reward;
       if (kind == DIAL_TASK_GO2_WALK) {          // unitree_go2_env.py:227-239

@@ -28,7 +28,7 @@ _envs: Dict[str, Callable] = {
     "unitree_go2_crate_climb": UnitreeGo2CrateEnv,   # unitree_go2_env.py:808 (generic kernel instantiation)
     "allegro_reorient": AllegroReorientEnv,
 }
-# reference envs that are NEXT rows and not built yet
+# reference envs that are not built (none: every env of the reference registry has a kernel)
 _NOT_BUILT = ()
 
 

@@ -1,12 +1,12 @@
 """Example list with the reference's names (dial_mpc/examples/__init__.py:1-15), restricted to the examples whose YAML
-ships here and whose env runs on the HIP path.  Upstream also lists `unitree_h1_push_crate`: that env is not built
-(DESIGN.md section 1); asking for it by env name raises NotImplementedError (envs/__init__.py)."""
+ships here and whose env runs on the HIP path -- all seven of the reference's envs."""
 examples = [
     "unitree_h1_jog",
     "unitree_h1_loco",
     "unitree_go2_trot",
     "unitree_go2_seq_jump",
     "unitree_go2_crate_climb",
+    "unitree_h1_push_crate",
     "allegro_reorient",
 ]
 

@@ -26,8 +26,10 @@ def test_registry_names_and_errors():
     assert "unitree_go2_trot" in examples and "unitree_go2_trot_deploy" in deploy_examples
     assert "unitree_go2_crate_climb" in examples
     assert dial_envs.get_config("unitree_go2_crate_climb") is dial_envs.UnitreeGo2CrateEnvConfig
-    with pytest.raises(NotImplementedError):
-        dial_envs.get_environment("unitree_h1_push_crate")     # exists upstream, not built here
+    assert "unitree_h1_push_crate" in examples                 # every env of the reference's registry is built
+    assert dial_envs.get_config("unitree_h1_push_crate") is dial_envs.UnitreeH1PushCrateEnvConfig
+    assert set(dial_envs._envs) == {"unitree_h1_walk", "unitree_h1_loco", "unitree_h1_push_crate", "unitree_go2_walk",
+                                    "unitree_go2_seq_jump", "unitree_go2_crate_climb", "allegro_reorient"}
     with pytest.raises(KeyError):
         dial_envs.get_environment("my_custom_jax_env")     # user JAX envs cannot run on the HIP path
 
