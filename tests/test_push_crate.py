@@ -123,3 +123,63 @@ def test_emulated_reverse_once_from_the_home_pose(case):
     rep = witness_parity(o32, s_o, ro["us"], (re["rewss"], re["qss"], re["qdss"], re["xss"]), EX, model.nq + 2 * model.nv)
     if rep["witnessed"] == 0:
         assert _within(re["rews"], ro["rews"], TOL["rewss"]).all()
+
+
+def test_converged_solve_with_a_friction_row_minimises_the_primal_cost(case):
+    """Robot pushing the crate, solver run to convergence: qacc must minimise
+        1/2 (a - a0)^T M (a - a0) + sum_ineq 1/2 D_r min(0, J_r a - aref_r)^2 + s_f(J_f a - aref_f),
+    s_f the dry-friction cost (quadratic 1/2 D x^2 inside |x| < R f, f (|x| - 1/2 R f) outside) -- checked with SciPy on the
+    oracle's own (M, a0, J, D, aref), in states where the friction row sits in its linear zone (crate sliding) and in its
+    quadratic zone (crate held by static friction)."""
+    from scipy.optimize import minimize
+    dc, env, model, task, cfg = case
+    m2 = type(model).from_buffer_copy(model)
+    m2.iterations, m2.ls_iterations = 200, 50
+    o64 = O.Oracle(m2, task, cfg, np.float64)
+    nv, nl = model.nv, model.nlim
+    zones = set()
+    for seed, vcrate in ((0, 0.0), (1, 0.4), (2, -0.3), (3, 0.0)):
+        q, qd = pushing_state(env, o64, seed, depth=0.004)
+        qd = 0.3 * qd
+        qd[25] = vcrate
+        d = o64.forward_dump(q, qd, ctrl=np.zeros(model.nu))
+        M, a0, J, D, aref = d["qM"], d["qacc_smooth"], d["efc_J"], d["efc_D"], d["efc_aref"]
+        fr = nl                                       # rows: limits | friction | contacts
+        f, rf = 50.0, 50.0 / D[fr]
+        ineq = np.ones(len(D), bool)
+        ineq[fr] = False
+
+        def fric(x):
+            return 0.5 * D[fr] * x * x if abs(x) < rf else f * (abs(x) - 0.5 * rf)
+
+        def dfric(x):
+            return D[fr] * x if abs(x) < rf else f * np.sign(x)
+
+        def cost(a):
+            r = J @ a - aref
+            ra = np.minimum(r[ineq], 0)
+            return 0.5 * (a - a0) @ M @ (a - a0) + 0.5 * np.sum(D[ineq] * ra * ra) + fric(r[fr])
+
+        def grad(a):
+            r = J @ a - aref
+            w = np.where(ineq, D * np.minimum(r, 0), 0.0)
+            w[fr] = dfric(r[fr])
+            return M @ (a - a0) + J.T @ w
+
+        def hess(a):
+            r = J @ a - aref
+            w = np.where(ineq, D * (r < 0), 0.0)
+            w[fr] = D[fr] if abs(r[fr]) < rf else 0.0
+            return M + (J.T * w) @ J
+
+        res = minimize(cost, d["qacc"] * 0 + a0, jac=grad, hess=hess, method="trust-exact", options=dict(gtol=1e-10, maxiter=2000))
+        assert np.linalg.norm(grad(res.x)) < 1e-6 * (1 + np.linalg.norm(M @ a0))
+        scale = 1 + np.abs(res.x).max()
+        assert np.abs(d["qacc"] - res.x).max() < 1e-5 * scale, (seed, np.abs(d["qacc"] - res.x).max(), d["niter"])
+        assert cost(d["qacc"]) <= cost(res.x) * (1 + 1e-9) + 1e-9
+        x = (J @ d["qacc"] - aref)[fr]
+        zones.add("quadratic" if abs(x) < rf else "linear")
+        # the force the row exerts: -D x inside, -+f outside
+        want = -D[fr] * x if abs(x) < rf else -f * np.sign(x)
+        assert abs(d["efc_force"][fr] - want) < 1e-6 * (1 + abs(want))
+    assert zones == {"quadratic", "linear"}, zones
