@@ -18,7 +18,9 @@
  *   dial_env_step       <- BaseEnv/<Env>.step         dial_mpc/envs/unitree_go2_env.py:126-261,
  *                                                     :403-521, dial_mpc/envs/unitree_h1_env.py:181-321,
  *                                                     :696-858 (H1 loco), dial_mpc/envs/manipulation.py:63-115
- *                                                     (Allegro in-hand reorientation + its act2joint override)
+ *                                                     (Allegro in-hand reorientation + its act2joint override),
+ *                                                     unitree_go2_env.py:679-795 (crate climb),
+ *                                                     unitree_h1_env.py:418-566 (push crate)
  *   dial_env_reset      <- <Env>.reset + pipeline_init  dial_mpc/envs/unitree_go2_env.py:101-124
  *   dial_model          <- brax System / mujoco MjModel built by BaseEnv.make_system
  *                                                     dial_mpc/envs/base_env.py:15-29

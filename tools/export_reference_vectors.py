@@ -55,7 +55,15 @@ def main():
     ps0 = state.pipeline_state
     import importlib.metadata as md
     versions = {p: md.version(p) for p in ("jax", "jaxlib", "mujoco", "mujoco-mjx", "brax", "jax-cosmo", "numpy")}
-    np.savez_compressed(args.out, versions=np.array(repr(versions)), qpos=np.asarray(ps0.qpos), qvel=np.asarray(ps0.qvel),
+    # The contact ARRAY of the reference's MJX release, for the two crate envs whose rewards read it by position
+    # (unitree_go2_env.py:750, unitree_h1_env.py:476-478, 525-526): geom ids per slot, so that the lookup by geom identity on
+    # our side (dial_task.crate_contact / pc_*; DESIGN.md section 1 "crate scenes") can be checked against the real order.
+    extra = {}
+    con = getattr(ps0, "contact", None)
+    if con is not None and getattr(con, "geom", None) is not None:
+        extra.update(contact_geom=np.asarray(con.geom), contact_dist=np.asarray(con.dist), contact_pos=np.asarray(con.pos),
+                     geom_names=np.array([env.sys.mj_model.geom(i).name for i in range(env.sys.mj_model.ngeom)]))
+    np.savez_compressed(args.out, **extra, versions=np.array(repr(versions)), qpos=np.asarray(ps0.qpos), qvel=np.asarray(ps0.qvel),
                         qacc_warmstart=np.asarray(ps0.qacc_warmstart), eps=eps, noise_scale=sigma, Ybar_in=Ybar,
                         us=np.asarray(us), rewss=np.asarray(rewss), qss=np.asarray(ps.q), qdss=np.asarray(ps.qd),
                         xss=np.asarray(ps.x.pos), Ybar=np.asarray(Ybar_out), rews=np.asarray(info["rews"]),
