@@ -482,8 +482,9 @@ def _first_principles_step(md, q, v, ctrl):
       M        = Hessian of T(q, v) = sum_b 1/2 (m |v_com|^2 + w^T I w)  (+ armature), body velocities by finite differences
       bias     = Hamel's form of Lagrange's equations (world-frame linear / body-frame angular quasi-velocities of the base)
       tau      = clipped motor torque - damping * v
-      contacts = foot spheres on the floor: dist = z_centre - r, point below the centre, frame (n, y, n x y); Jacobian rows =
-                 finite-difference velocity of the material contact point, 4 pyramid edges Jn +- mu Jt
+      contacts = foot spheres (Go2) / the end spheres of the foot capsules (H1) on the floor: dist = z_centre - r, point below
+                 the centre, frame (n, y, n x y) resp. (n, projected capsule axis, ...); Jacobian rows = finite-difference
+                 velocity of the material contact point, 4 pyramid edges Jn +- mu Jt
       qacc     = argmin 1/2 (a - a0)^T M (a - a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2
       v' = v + dt qacc,  q' = q (+) dt v'  (semi-implicit Euler, quaternion exponential of the body rate)"""
     from scipy.optimize import minimize
@@ -527,7 +528,6 @@ def _first_principles_step(md, q, v, ctrl):
     # ---- contacts: foot spheres on the floor
     k0 = mjcf.host_kinematics(md, q)
     n = np.array([0.0, 0.0, 1.0])
-    frame = np.array([n, [0.0, 1.0, 0.0], np.cross(n, [0.0, 1.0, 0.0])])
     J = np.zeros((nl + 4 * nc, nv))
     dist = np.zeros(nc)
     eps = 1e-6
@@ -535,6 +535,19 @@ def _first_principles_step(md, q, v, ctrl):
         g2, b2 = int(md["con_geom2"][c]), int(md["con_body2"][c])
         r = float(md["geom_size"][g2][0])
         ctr = k0["xpos"][b2] + k0["xmat"][b2] @ np.asarray(md["geom_pos"][g2], np.float64)
+        kind = int(md["con_kind"][c])
+        frame = np.array([n, [0.0, 1.0, 0.0], np.cross(n, [0.0, 1.0, 0.0])])
+        if kind in (1, 2):
+            # a capsule on the floor touches with the sphere at one of its ends; MJX's plane_capsule takes the first tangent
+            # along the capsule's axis projected into the plane (a CONVENTION: it orients the friction pyramid)
+            axis = (k0["xmat"][b2] @ mjcf.quat_to_mat(np.asarray(md["geom_quat"][g2], np.float64)))[:, 2]
+            ctr = ctr + (1.0 if kind == 1 else -1.0) * axis * float(md["geom_size"][g2][1])
+            b = axis - n * (n @ axis)
+            if np.linalg.norm(b) >= 0.5:
+                b = b / np.linalg.norm(b)
+                frame = np.array([n, b, np.cross(n, b)])
+        else:
+            assert kind == 0
         dist[c] = ctr[2] - r
         p = ctr - n * (r + 0.5 * dist[c])
         ploc = k0["xmat"][b2].T @ (p - k0["xpos"][b2])
@@ -606,3 +619,37 @@ def test_a_whole_physics_step_from_first_principles_matches_the_oracle():
     d1 = o64.forward_dump(q, v, ctrl=ctrl_used)
     v1 = v + dt * d1["qacc"]
     assert np.allclose(s1[nq:nq + nv], v1, atol=1e-9) and np.allclose(s1[:nq], _integrate(md, q, v1, dt), atol=1e-9)
+
+
+@pytest.mark.parametrize("example,nstates", [("unitree_go2_trot", 6), ("unitree_h1_jog", 3)])
+def test_first_principles_step_on_random_states(example, nstates):
+    """The same composition over several random states of the Go2 and the H1 (capsule feet): perturbed joints, base height
+    varied so that between one and all of the contacts are closed, random velocities and motor torques.  Gate: 1e-6 relative on
+    qacc and on the next state (finite-difference accuracy)."""
+    dc, env, model, task, cfg = setup_case(example, 8, 8)
+    md = env.sys.model
+    m2 = type(model).from_buffer_copy(model)
+    m2.iterations, m2.ls_iterations = 200, 50
+    o64 = O.Oracle(m2, task, cfg, np.float64)
+    nv = md["nv"]
+    rng = np.random.default_rng(11)
+    dt = float(md["timestep"])
+    closed = []
+    for k in range(nstates):
+        q = np.array(env._init_q, np.float64)
+        q[7:] += rng.uniform(-0.08, 0.08, nv - 6)
+        q[3:7] = mjcf.quat_mul(q[3:7], np.array([1.0, *rng.normal(0, 0.02, 3)]))
+        q[3:7] /= np.linalg.norm(q[3:7])
+        q[2] += rng.uniform(-0.006, 0.004)
+        v = rng.normal(0, 0.3, nv)
+        ctrl = rng.uniform(-10, 10, md["nu"])
+        q2, v2, parts = _first_principles_step(md, q, v, ctrl)
+        closed.append(int((parts["dist"] < 0).sum()))
+        d = o64.forward_dump(q, v, ctrl=ctrl)
+        scale = 1 + np.abs(parts["qacc"]).max()
+        assert np.allclose(d["con_dist"], parts["dist"], atol=1e-7)       # (the oracle reads the model constants as fp32)
+        assert np.abs(d["qacc"] - parts["qacc"]).max() < 1e-6 * scale, (example, k, np.abs(d["qacc"] - parts["qacc"]).max(), scale)
+        v_o = v + dt * d["qacc"]
+        assert np.abs(v2 - v_o).max() < 1e-6 * scale * dt + 1e-12
+        assert np.abs(q2 - _integrate(md, q, v_o, dt)).max() < 1e-6 * scale * dt * dt + 1e-12
+    assert max(closed) >= 2 and len(set(closed)) >= 1, closed
