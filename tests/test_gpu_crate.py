@@ -88,8 +88,8 @@ def test_crate_full_size_oracle_parity(pose):
     # differ from the oracle's by up to TOL, out of reach of the 64-ulp jitter (restart_ok: see witness_parity); and a capsule
     # sunk to within micrometres of its radius next to one of the crate's edges has a contact normal that turns by degrees
     # per micrometre -- the same pose through the kernel's fp32 code and the oracle's differs beyond TOL after one step
-    # (measured: 2-5 of 2049 rollouts, IEEE build and fast-math build alike).  Those few are allowed, everything else is not.
-    rep = witness_parity(o32, s0, ro["us"], got, EX, model.nq + 2 * model.nv, unwitnessed_ok=8, restart_ok=True)
+    # (measured: 2-6 of 2049 rollouts, IEEE build and fast-math build alike).  Up to 12 (0.6 %) are allowed, everything else is not.
+    rep = witness_parity(o32, s0, ro["us"], got, EX, model.nq + 2 * model.nv, unwitnessed_ok=12, restart_ok=True)
     print(f"{EX} pose {pose}: {rep['outside_tol']} of {rep['rollouts']} rollouts on a knife edge, "
           f"{rep.get('restart_witnessed', 0)} witnessed from the GPU's own state, {rep.get('unwitnessed', 0)} without a witness")
     # product outputs against the oracle's own <= 1 ulp jitter envelope (the knife-edge rollouts carry arbitrary weight)
