@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-cfg5", action="store_true", help="skip the N_total=65536 strong-scaling companion measurement")
     ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
+                    help="a field of dial_options (include/dial_mpc.h), e.g. --option no_relay=1; the library reads no environment variables")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: whatever libraries print while the run is in progress (RCCL
@@ -163,8 +165,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.force_sharded:
-        os.environ["DIAL_FORCE_SHARDED"] = "1"
+    options = {k: int(v) for k, v in (o.split("=", 1) for o in args.option)}
 
     from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
     from dial_mpc_amd.utils.io_utils import get_example_path
@@ -177,7 +178,7 @@ def main():
         args.hsample = int(cfgd["Hsample"])
     cfgd["Nsample"], cfgd["Hsample"] = N_total, args.hsample
     dial_config, env_config, env = load_dial_and_env(cfgd)
-    mbdpi = MBDPI(dial_config, env, kernel_rng=not args.host_noise)
+    mbdpi = MBDPI(dial_config, env, kernel_rng=not args.host_noise, force_sharded=args.force_sharded, options=options)
     dev = mbdpi.device
     T, Hn1, nu = dial_config.Hsample + 1, dial_config.Hnode + 1, mbdpi.nu
 
@@ -195,14 +196,17 @@ def main():
         if args.host_noise else [None] * 4
     sigma = mbdpi.sigma_control.clone()
 
-    def timed_iterations(pl, sts, steps, warmup, host_eps=None):
+    def timed_iterations(pl, sts, steps, warmup, host_eps=None, pattern=(True,)):
         """`warmup` untimed + exactly `steps` timed reverse_once calls of planner `pl`, bracketed by a barrier and a device
-        synchronize on both sides; returns (max over ranks of the elapsed seconds, kernel ms total, launches)."""
+        synchronize on both sides; returns (max over ranks of the elapsed seconds, kernel ms total, launches).
+        pattern: the want_bars flag of call i is pattern[i % len(pattern)] -- (True,) = the FULL iteration (every output of
+        the reference's reverse_once: the headline), (False,) = the lean iteration (mean action only, what a plan asks of
+        every annealing iteration but its last), (False, ..., True) = a plan's own sequence."""
         Yl = torch.zeros((pl.args.Hnode + 1, pl.nu), dtype=torch.float32, device=dev)
 
         def one_step(i, Yl):
             eps = host_eps[i % len(host_eps)] if host_eps is not None else None   # None: Philox noise inside the rollout kernel
-            _, Yl, _ = pl.reverse_once(sts[i % len(sts)], None, Yl, pl.sigma_control, eps=eps)
+            _, Yl, _ = pl.reverse_once(sts[i % len(sts)], None, Yl, pl.sigma_control, eps=eps, want_bars=pattern[i % len(pattern)])
             return Yl
 
         for i in range(warmup):
@@ -227,6 +231,22 @@ def main():
 
     elapsed, kernel_ms, launches = timed_iterations(mbdpi, states, args.steps, args.warmup,
                                                     eps_pool if args.host_noise else None)
+    # the same K steps as LEAN iterations and in the sequence a plan runs them (Ndiffuse - 1 lean + 1 full, dial_core.py:257
+    # here / :262-264 upstream); at world > 1 a lean iteration is ONE collective (all-gather of the rewards), a full one two
+    # (+ all-reduce of the packed partial sums).  `value` stays the full iteration; these are reported next to it.
+    plan_pat = tuple([False] * (dial_config.Ndiffuse - 1) + [True])
+    lean_steps = max(10, args.steps // 2)
+    el_lean, k_lean, nl_lean = timed_iterations(mbdpi, states, lean_steps, 3, eps_pool if args.host_noise else None, pattern=(False,))
+    el_plan, _, _ = timed_iterations(mbdpi, states, lean_steps, 3, eps_pool if args.host_noise else None, pattern=plan_pat)
+    sharded = world > 1 or args.force_sharded
+    iteration_modes = {
+        "ms_per_step_full": elapsed / args.steps * 1e3, "ms_per_step_lean": el_lean / lean_steps * 1e3,
+        "ms_per_step_plan_pattern": el_plan / lean_steps * 1e3, "plan_pattern": f"{dial_config.Ndiffuse - 1} lean + 1 full",
+        "lean_steps_timed": lean_steps, "avg_rollout_kernel_ms_lean": k_lean / max(nl_lean, 1),
+        "collectives_per_iteration": {"full": 2 if sharded else 0, "lean": 1 if sharded else 0},
+        "note": "full = every output of the reference's reverse_once (Ybar, rews, qbar, qdbar, xbar; the headline `value`); lean = "
+                "want_bars=False: mean action only, the rollouts do not store their per-step states -- what the drivers ask of "
+                "every annealing iteration of a plan but the last"}
 
     # ---- plan latency: one control tick = env.step + shift + Ndiffuse x reverse_once (dial_core.py:245-264)
     lat = []
@@ -247,19 +267,30 @@ def main():
     # ---- BASELINE config 5 beside the headline: unitree_go2_trot, a FIXED global N = 65536 sharded over the ranks (8192 per
     # GPU on 8 GPUs) -- the configuration of north_star's ">= 6x strong scaling at 8 GPUs"; the driver's per-N values of this
     # object give that curve, whatever `scaling` the headline value uses
-    strong = None
-    if not args.no_strong_cfg5 and args.example == "unitree_go2_trot" and args.scaling == "weak" and not args.host_noise:
+    def strong_companion(n_total, s_steps, label):
         cfgs = dict(cfgd)
-        cfgs["Nsample"], cfgs["Hsample"] = 65536, 16
+        cfgs["Nsample"], cfgs["Hsample"] = n_total, 16
         dcs, _, envs = load_dial_and_env(cfgs)
-        pls = MBDPI(dcs, envs, kernel_rng=True)
-        s_steps, s_warm = max(10, args.steps // 8), 3
+        pls = MBDPI(dcs, envs, kernel_rng=True, force_sharded=args.force_sharded, options=options)
+        s_warm = 3
         s_el, s_kms, s_nl = timed_iterations(pls, states, s_steps, s_warm)
-        strong = {"workload": "unitree_go2_trot reverse_once, N_total=65536 (fixed), Hsample=16, Hnode=4 -- BASELINE config 5",
-                  "scaling": "strong", "value": 65537 * s_steps / s_el, "unit": "sample-rollouts/s", "n_gpus": world,
-                  "nsample_per_gpu": pls.n_local, "steps": s_steps, "warmup": s_warm, "ms_per_step": s_el / s_steps * 1e3,
-                  "avg_rollout_kernel_ms": s_kms / max(s_nl, 1)}
+        l_el, _, _ = timed_iterations(pls, states, s_steps, s_warm, pattern=(False,))
+        p_el, _, _ = timed_iterations(pls, states, s_steps, s_warm, pattern=plan_pat)
+        rec = {"workload": f"unitree_go2_trot reverse_once, N_total={n_total} (fixed), Hsample=16, Hnode=4 -- {label}",
+               "scaling": "strong", "value": (n_total + 1) * s_steps / s_el, "unit": "sample-rollouts/s", "n_gpus": world,
+               "nsample_per_gpu": pls.n_local, "steps": s_steps, "warmup": s_warm, "ms_per_step": s_el / s_steps * 1e3,
+               "ms_per_step_full": s_el / s_steps * 1e3, "ms_per_step_lean": l_el / s_steps * 1e3,
+               "ms_per_step_plan_pattern": p_el / s_steps * 1e3, "value_plan_pattern": (n_total + 1) * s_steps / p_el,
+               "collectives_per_iteration": {"full": 2 if sharded else 0, "lean": 1 if sharded else 0},
+               "avg_rollout_kernel_ms": s_kms / max(s_nl, 1)}
         del pls
+        return rec
+
+    strong, strong_hl = None, None
+    if not args.no_strong_cfg5 and args.example == "unitree_go2_trot" and args.scaling == "weak" and not args.host_noise:
+        strong = strong_companion(65536, max(10, args.steps // 8), "BASELINE config 5")
+        if world > 1:   # north_star's 1/2/4/8 curve on the HEADLINE config: N_total = 2048 fixed (world 1: the headline itself)
+            strong_hl = strong_companion(2048, max(20, args.steps // 2), "the headline config, strong scaling")
 
     if rank != 0:
         dist.destroy_process_group()
@@ -328,8 +359,11 @@ def main():
                             "ticks": len(lat), "tick_budget_ms": 20.0,
                             "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},
     }
+    out["iteration_modes"] = iteration_modes
     if strong is not None:
         out["strong_cfg5"] = strong
+    if strong_hl is not None:
+        out["strong_headline_n2048"] = strong_hl
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.example, args.nsample_per_gpu, args.hsample)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

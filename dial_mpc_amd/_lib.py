@@ -78,6 +78,8 @@ def load(path: Optional[str] = None):
     vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
     lib.dial_create.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci]
     lib.dial_create_sharded.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci, ci]
+    lib.dial_create_ex.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ci, ci, vp]
+    lib.dial_set_state_trace.argtypes = [vp, fp, ci]
     lib.dial_destroy.argtypes = [vp]
     lib.dial_destroy.restype = None
     lib.dial_last_error.argtypes = [vp]
@@ -109,7 +111,7 @@ def load(path: Optional[str] = None):
     return lib
 
 
-EXPORTED = ("dial_create", "dial_create_sharded", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
+EXPORTED = ("dial_create", "dial_create_sharded", "dial_create_ex", "dial_set_state_trace", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
             "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset",
             "dial_status", "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
@@ -131,9 +133,12 @@ class Context:
     """One dial_ctx: (device, model, task, cfg).  Not thread-safe (C ABI contract)."""
 
     def __init__(self, model: "_abi.DialModel", task: "_abi.DialTask", cfg: Optional["_abi.DialCfg"],
-                 device: Optional[int] = None, n_local_cap: Optional[int] = None, lib_path: Optional[str] = None):
+                 device: Optional[int] = None, n_local_cap: Optional[int] = None, lib_path: Optional[str] = None,
+                 options: Optional[dict] = None):
         """n_local_cap: size the rollout scratch for that many local samples (one rank of a sharded run).
-        lib_path: another build of the library (measurement variants, e.g. libdialhip_ieee.so)."""
+        lib_path: another build of the library (measurement variants, e.g. libdialhip_ieee.so).
+        options: fields of `dial_options` (include/dial_mpc.h) -- launch-shape / measurement switches, e.g.
+        dict(no_queue=1); none of them changes a result bit.  The library itself reads no environment variables."""
         import torch
         self.lib = load(lib_path)
         if not torch.cuda.is_available():
@@ -145,12 +150,14 @@ class Context:
         self.nx = (model.nbody - 1) * 3
         self.state_size = _abi.state_size(model.nq, model.nv)
         h = ctypes.c_void_p()
-        if n_local_cap is None or cfg is None:
-            rc = self.lib.dial_create(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
-                                      ctypes.addressof(cfg) if cfg is not None else None, self.device)
-        else:
-            rc = self.lib.dial_create_sharded(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
-                                              ctypes.addressof(cfg), self.device, int(n_local_cap))
+        self.options = dict(options or {})
+        unknown = set(self.options) - set(_abi.DialOptions._meta)
+        if unknown:
+            raise ValueError(f"unknown dial_options fields: {sorted(unknown)}")
+        opts = _abi.fill(_abi.DialOptions(), self.options)
+        rc = self.lib.dial_create_ex(ctypes.byref(h), ctypes.addressof(model), ctypes.addressof(task),
+                                     ctypes.addressof(cfg) if cfg is not None else None, self.device,
+                                     -1 if (n_local_cap is None or cfg is None) else int(n_local_cap), ctypes.addressof(opts))
         if rc != 0:
             raise DialHipError(f"dial_create failed ({rc}): {self.lib.dial_last_error(None).decode()}")
         self.h = h
@@ -293,6 +300,18 @@ class Context:
         tot, n = ctypes.c_double(0), ctypes.c_int(0)
         self._check(self.lib.dial_get_rollout_ms(self.h, ctypes.byref(tot), ctypes.byref(n)), "dial_get_rollout_ms")
         return tot.value, n.value
+
+    def set_state_trace(self, rows: Optional[int]):
+        """Diagnostics (parity tests): allocate a [rows, T, state_size] tensor into which every following rollout launch
+        writes the packed state after each env.step; rows=None switches the trace off.  Returns the tensor."""
+        import torch
+        if rows is None:
+            self._check(self.lib.dial_set_state_trace(self.h, None, 0), "dial_set_state_trace")
+            self._trace = None
+            return None
+        self._trace = torch.zeros((int(rows), self.cfg.Hsample + 1, self.state_size), dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.dial_set_state_trace(self.h, _ptr(self._trace), int(rows)), "dial_set_state_trace")
+        return self._trace
 
     def debug_scratch(self):
         """Host copies of the scratch tensors of the last reverse_once (tests only)."""

@@ -38,15 +38,17 @@ def softmax_update(weights, Y0s, sigma, mu_0t):
 
 
 class MBDPI:
-    def __init__(self, args: DialConfig, env, device: Optional[int] = None, kernel_rng: bool = False):
+    def __init__(self, args: DialConfig, env, device: Optional[int] = None, kernel_rng: bool = False,
+                 force_sharded: bool = False, options: Optional[dict] = None):
         """kernel_rng=True: the noise is generated inside the rollout kernel (Philox keyed by args.seed and a call
-        counter) instead of by torch.randn -- the production setting; parity runs pass `eps` explicitly."""
+        counter) instead of by torch.randn -- the production setting; parity runs pass `eps` explicitly.
+        force_sharded (measurement hook): run the sharded code path, collectives included, on a 1-rank process group.
+        options: `dial_options` fields for the context (launch-shape / measurement switches, include/dial_mpc.h)."""
         import torch
         self.kernel_rng = bool(kernel_rng)
         self._rng_counter = 0
         self._plan = None    # preallocated buffers of the sharded iteration (core/sharding.py)
-        # measurement hook: run the sharded code path (collectives included) on a 1-rank process group
-        self._force_sharded = os.environ.get("DIAL_FORCE_SHARDED", "0") == "1"
+        self._force_sharded = bool(force_sharded)
         self.args = args
         self.env = env
         self.nu = env.action_size
@@ -72,7 +74,7 @@ class MBDPI:
         self._per, self.n_begin, self.n_local = partition(args.Nsample, self.rank, self.world)
         # a rank's rollout scratch is sized by its own shard, not by the global sample count
         self.ctx = _lib.Context(env.make_model(), env.make_task(), self.cfg, device,
-                                n_local_cap=None if self.world == 1 else self._per)
+                                n_local_cap=None if self.world == 1 else self._per, options=options)
         if hasattr(env, "bind_device"):
             env.bind_device(self.ctx.device)
         dev = self.ctx.torch_device

@@ -391,6 +391,10 @@ struct dial_ctx {
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
   bool timing = false;
+  dial_options opt{};          // launch-shape / measurement options (dial_create_ex); all zero = shipped behaviour
+  float* trace = nullptr;      // diagnostics: per-step packed states of the rollouts (dial_set_state_trace), caller-owned
+  int trace_rows = 0;
+  int ovf_slots = 0;           // overflow areas allocated (>= the largest grid this context ever launches)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   std::string err;
@@ -437,13 +441,22 @@ void dial_destroy(dial_ctx* ctx) {
 }
 
 int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device) {
-  return dial_create_sharded(out, model, task, cfg, device, cfg ? cfg->Nsample : 0);
+  return dial_create_ex(out, model, task, cfg, device, -1, nullptr);
 }
 
 int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device,
                         int n_local_cap) {
-  if (!out || !model || !task) return fail(nullptr, DIAL_ERR_ARG, "dial_create: null argument");
   if (cfg && (n_local_cap < 0 || n_local_cap > cfg->Nsample)) return fail(nullptr, DIAL_ERR_ARG, "dial_create_sharded: n_local_cap must be in [0, Nsample]");
+  return dial_create_ex(out, model, task, cfg, device, n_local_cap, nullptr);
+}
+
+int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device,
+                   int n_local_cap, const dial_options* opts) {
+  if (!out || !model || !task) return fail(nullptr, DIAL_ERR_ARG, "dial_create: null argument");
+  if (n_local_cap < 0) n_local_cap = cfg ? cfg->Nsample : 0;
+  if (cfg && n_local_cap > cfg->Nsample) return fail(nullptr, DIAL_ERR_ARG, "dial_create_ex: n_local_cap must be in [0, Nsample]");
+  const dial_options opt = opts ? *opts : dial_options{};
+  if (opt.relay_steps < 0 || opt.relay_steps > 16) return fail(nullptr, DIAL_ERR_ARG, "dial_create_ex: options.relay_steps must be in 0 .. 16");
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -485,6 +498,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: model exceeds kernel capacities");
   dial_ctx* ctx = new dial_ctx();
   ctx->device = device;
+  ctx->opt = opt;
   ctx->hm = *model;
   ctx->ht = *task;
   int rc = dial_build_derived(model, &ctx->hd);
@@ -516,13 +530,12 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
         // DIAL_CON_CAP touching contacts, samples beyond run on an overflow area in global memory.  Default 14: for the crate
         // scene that is 17.4 KB per wavefront -- NINE per CU, so that the 2049 rollouts of its example are resident at once
         // (at 16 the workspace is 18.3 KB, eight per CU = 2048 slots, and the 2049th rollout waits for a whole round)
-        int cap = 14;
-        const char* e = getenv("DIAL_CON_CAP");
-        if (e) cap = atoi(e);
+        const bool given = opt.con_cap != 0;   // options.con_cap: 0 chosen here, > 0 given, < 0 no cap
+        int cap = given ? opt.con_cap : 14;
         if (cfg && model->cone == DIAL_CONE_PYRAMIDAL && cap > 0 && model->ncon > cap) {
           // unless the cap was given: the largest one in 16 .. 8 with which NINE wavefronts fit a CU (8 x 256 + 1 rollouts of
           // the examples' N = 2048 resident at once); 14 if none does.  Crate climb: 16 (17.2 KB), push crate: 9 (17.1 KB).
-          if (!e) {
+          if (!given) {
             for (int c = 16; c >= 8; c--) {
               Ws st;
               const int wds = ws_carve(st, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt, model->ngeom, model->nsite,
@@ -551,9 +564,10 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     };
     int urc;
     const auto kind_ok = [&](uint32_t mask) { return ((mask >> task->kind) & 1u) != 0; };   // the robot's own task kinds only
-    if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>())) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1>())) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
-    else if (!getenv("DIAL_FORCE_GENERIC") && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1Loco>())) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
+    const bool own = !opt.force_generic;   // the robot's own dimension-specialised instantiation (default)
+    if (own && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>())) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
+    else if (own && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1>())) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
+    else if (own && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1Loco>())) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else if (model->cone == DIAL_CONE_ELLIPTIC) {
       if (!(dims_match<DimsAllegro>(model) && ell_fits<DimsAllegro>(model, &ctx->hd))) {
         dial_destroy(ctx);
@@ -599,7 +613,7 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
       if (e == hipSuccess) ctx->resident_blocks_large = nb * prop.multiProcessorCount;
     }
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: occupancy query: ") + hipGetErrorString(e)); }
-    if (getenv("DIAL_NO_QUEUE")) ctx->resident_blocks = ctx->resident_blocks_large = 0;   // measurement switch: one wavefront per rollout at any batch size
+    if (opt.no_queue) ctx->resident_blocks = ctx->resident_blocks_large = 0;   // options: one wavefront per rollout at any batch size
     HIP_TRY_CREATE(hipMalloc(&ctx->next, sizeof(int)));
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_buf, sizeof(float) * (DIAL_MAX_Q + 2 * DIAL_MAX_V + DIAL_INFO_N + 4)));
     HIP_TRY_CREATE(hipMalloc(&ctx->relay_flag, sizeof(int)));
@@ -607,11 +621,11 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     HIP_TRY_CREATE(hipHostMalloc((void**)&ctx->err_host, sizeof(int), hipHostMallocMapped));
     *ctx->err_host = 0;
     HIP_TRY_CREATE(hipHostGetDevicePointer((void**)&ctx->err_dev, ctx->err_host, 0));
-    ctx->relay_ok = ctx->wpb == 1 && !getenv("DIAL_NO_RELAY");   // measurement switches
-    ctx->relay_always = getenv("DIAL_RELAY_ALWAYS") != nullptr;
+    ctx->relay_ok = ctx->wpb == 1 && !opt.no_relay;
+    ctx->relay_always = opt.relay_always != 0;
     ctx->wpb_even = ctx->inst == 4 ? DIAL_ALLEGRO_WPB_EVEN : ctx->inst == 2 ? DIAL_H1_WPB_EVEN : 0;
-    if (const char* e = getenv("DIAL_SPLIT_MASK")) { if (!((atoi(e) >> ctx->inst) & 1)) ctx->wpb_even = 0; }   // measurement switch
-    if (ctx->wpb_even > 0 && !getenv("DIAL_NO_SPLIT")) {
+    if ((opt.no_split_mask >> ctx->inst) & 1) ctx->wpb_even = 0;
+    if (ctx->wpb_even > 0) {
       ctx->lds_even = ctx->cm_bytes + (size_t)ctx->wpb_even * ctx->ws_words * sizeof(float);
       ctx->lds_one = ctx->cm_bytes + (size_t)ctx->ws_words * sizeof(float);
 #ifdef DIAL_PROFILE
@@ -632,8 +646,8 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
         ctx->split_ok = true;
       }
     }
-    if (const char* e = getenv("DIAL_RELAY_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->relay_steps = v; }
-    if (const char* e = getenv("DIAL_DEBUG_RELAY_STALL")) ctx->debug_stall_piece1 = atoi(e);
+    if (opt.relay_steps >= 1) ctx->relay_steps = opt.relay_steps;
+    ctx->debug_stall_piece1 = opt.debug_relay_stall;
   }
   HIP_TRY_CREATE(hipMalloc(&ctx->dtask, sizeof(dial_task)));
   HIP_TRY_CREATE(hipMemcpy(ctx->dtask, task, sizeof(dial_task), hipMemcpyHostToDevice));
@@ -646,7 +660,10 @@ int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task
     ctx->has_cfg = true;
     ctx->B_cap = n_local_cap + 1;
     ctx->W_cap = cfg->Nsample + 1;
-    if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->B_cap * ctx->ovf_words * sizeof(float)));
+    // one overflow area per wavefront slot of the LARGEST grid this context launches: B_cap rollouts, or B_cap - 1 noisy
+    // ones + the relay pieces of the mean trajectory (at most Hsample + 1 of them) -- launch_rollout checks the grid
+    ctx->ovf_slots = ctx->B_cap + cfg->Hsample + 1;
+    if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->ovf_slots * ctx->ovf_words * sizeof(float)));
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
     const size_t B = ctx->B_cap, T = ctx->T;
@@ -686,6 +703,13 @@ static int check_sticky(dial_ctx* ctx) {
 int dial_status(dial_ctx* ctx) {
   if (!ctx) return DIAL_ERR_ARG;
   return check_sticky(ctx);
+}
+
+int dial_set_state_trace(dial_ctx* ctx, float* trace, int rows) {
+  if (!ctx || (trace && rows < 1)) return fail(ctx, DIAL_ERR_ARG, "dial_set_state_trace: bad argument");
+  ctx->trace = trace;
+  ctx->trace_rows = trace ? rows : 0;
+  return DIAL_OK;
 }
 
 int dial_set_timing(dial_ctx* ctx, int enable) {
@@ -756,6 +780,12 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
+  }
+  if (io.ovf && blocks * wpb > ctx->ovf_slots)
+    return fail(ctx, DIAL_ERR_ARG, "rollout launch: more wavefronts than overflow areas (batch larger than the context's Nsample + 1)");
+  if (ctx->trace) {
+    if (B > ctx->trace_rows) return fail(ctx, DIAL_ERR_ARG, "rollout launch: more rollouts than rows of the state trace (dial_set_state_trace)");
+    io.trace = ctx->trace;
   }
   // Batch = 8 x CUs + 1 (N = 2048 on 256 CUs) with multi-wavefront workgroups: the N noisy rollouts as evenly sized
   // workgroups that load every CU with 8 wavefronts (Allegro: one workgroup of 8, H1: two of 4, one wavefront per SIMD

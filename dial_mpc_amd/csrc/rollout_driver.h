@@ -44,6 +44,9 @@ struct RolloutIO {
   int con_cap;
   float* ovf;
   int ovf_words;
+  // diagnostics (dial_set_state_trace; nullptr in production): the packed state [qpos|qvel|qacc_warmstart|info] after every
+  // env.step, trace:[B,T,nstate] -- what the per-transition parity tests restart the oracle from
+  float* trace;
 };
 
 template <class W, class M>
@@ -171,6 +174,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
       if (rrow && i == 0) rrow[0] = rew;
     });
+    if (io.trace) store_state(w, m, s, io.trace + o * nstate);
     DIAL_MARK(w, 24);
   }
 #ifdef DIAL_PROFILE

@@ -57,6 +57,7 @@ class MBDPublisher:
         self.ctrl_dt = env_config.dt
         self.timer_period = env_config.dt
         self.n_acts = dial_config.Hsample + 1
+        self.max_bad_plans = 5      # consecutive non-finite plans after which main_loop raises instead of spinning
         mj = env.sys.mj_model
         self.nq, self.nv, self.nu = mj.nq, mj.nv, mj.nu
         self.nx = mj.nq + mj.nv
@@ -114,7 +115,7 @@ class MBDPublisher:
         last_plan_time = float(self.time_shared[0])
         state = self.init_mjx_state(self.state_shared[: self.nq].copy(), self.state_shared[self.nq:].copy(),
                                     last_plan_time)
-        first_time, ticks, latencies = True, 0, []
+        first_time, ticks, latencies, bad_plans = True, 0, [], 0
         while max_ticks is None or ticks < max_ticks:
             t0 = time.time()
             plan_time = float(self.time_shared[0])
@@ -125,7 +126,7 @@ class MBDPublisher:
                 print(f"[WRAN] sim overtime {(shift_time - self.ctrl_dt) * 1000:.1f} ms")
             if shift_time > self.ctrl_dt * self.n_acts:
                 print(f"[WARN] long time unplanned {shift_time * 1000:.1f} ms, reset control")
-                self.Y = self.Y * 0.0
+                self.Y = torch.zeros_like(self.Y)          # (not Y * 0: NaN * 0 is NaN)
             else:
                 self.Y = self.shift(self.Y, shift_time)
             if first_time:
@@ -142,11 +143,19 @@ class MBDPublisher:
             # executing the previous plan, plan_time_shm is not advanced, the plan restarts from zero
             self.mbdpi.ctx.status()
             if not (np.isfinite(us_np).all() and np.isfinite(xt).all()):
-                print("[ERROR] non-finite plan, not published; control reset")
-                self.Y = self.Y * 0.0
+                bad_plans += 1
+                print(f"[ERROR] non-finite plan ({bad_plans} in a row), not published; control reset")
+                if bad_plans >= self.max_bad_plans:
+                    raise RuntimeError(f"{bad_plans} consecutive non-finite plans: the planner cannot recover from this state")
+                self.Y = torch.zeros_like(self.Y)          # a fresh plan (Y * 0 would keep the NaNs: NaN * 0 = NaN)
                 last_plan_time = plan_time
+                if on_tick is not None:
+                    on_tick(ticks)
                 ticks += 1
+                if sleep_when_idle:
+                    time.sleep(sleep_when_idle)
                 continue
+            bad_plans = 0
             joint_targets = np.stack([self.env.act2joint(u) for u in us_np])
             ps = state.pipeline_state
             taus = np.stack([self.env.act2tau(u, ps) for u in us_np])

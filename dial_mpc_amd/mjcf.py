@@ -374,8 +374,9 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
                             joints[-1][key] = val
                         if joints[-1]["stiffness"] != 0:
                             raise NotImplementedError("joint stiffness not supported")
-                        if joints[-1]["frictionloss"] != 0 and jtype == JNT_FREE:
-                            raise NotImplementedError("frictionloss on a free joint is not supported")
+                        if joints[-1]["frictionloss"] != 0 and jtype in (JNT_FREE, JNT_BALL):
+                            # (one friction row per dof of the joint in MuJoCo; fri_dof below records one dof per joint)
+                            raise NotImplementedError("frictionloss is supported on slide / hinge joints only")
                 walk(e, bid, cc, depth + 1)
 
     wb = root.find("worldbody")

@@ -310,6 +310,24 @@ typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg).
                                    * turn flag, so two launches of the same context must never be in flight on different
                                    * streams (use one context per stream / per Python thread).                          */
 
+/* Launch-shape / measurement options of a context (dial_create_ex).  Every field defaults to 0 = the shipped behaviour,
+ * which is what dial_create / dial_create_sharded use.  NONE of them changes a result bit: the GPU suite compares each one
+ * against the default launch (tests/test_gpu_parity.py, tests/test_gpu_crate.py).  libdialhip.so reads NO environment
+ * variables: the way a launch is put on the chip depends on (model, task, cfg, these options) and nothing else.        */
+typedef struct dial_options {
+  int32_t force_generic;      /* 1: capacity-dimension (generic) kernel instantiation instead of the robot's own              */
+  int32_t con_cap;            /* generic instantiation, models with many candidate contacts: touching contacts the LDS
+                                 workspace of a rollout wavefront holds (samples beyond run on an overflow area in global
+                                 memory, bit-identically).  0: chosen per model (largest of 16 .. 8 that keeps nine wavefronts
+                                 per CU), > 0: this cap, < 0: no cap (full-size workspace)                                 */
+  int32_t no_queue;           /* 1: one wavefront per rollout at any batch size (no rollout queue)                           */
+  int32_t no_relay;           /* 1: the mean trajectory runs as one more wavefront (no relay)                                */
+  int32_t relay_always;       /* 1: relay at any N (default: only when N fills the SIMDs evenly)                             */
+  int32_t relay_steps;        /* control steps per relay piece, 1 .. 16 (0: default 3)                                       */
+  int32_t no_split_mask;      /* bit i: no split launch for kernel instantiation i (2 = H1, 4 = Allegro); -1: never split   */
+  int32_t debug_relay_stall;  /* TEST HOOK k >= 1: relay piece k - 1 never hands over (its successors time out; dial_status) */
+} dial_options;
+
 /* host pointers; copies model/task/cfg to the device and allocates scratch for
  * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable. */
 int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task,
@@ -319,6 +337,9 @@ int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task,
  * rank; the global reward / weight arrays still hold cfg->Nsample + 1 entries.  0 <= n_local_cap <= cfg->Nsample. */
 int dial_create_sharded(dial_ctx** out, const dial_model* model, const dial_task* task,
                         const dial_cfg* cfg, int device, int n_local_cap);
+/* The general form: n_local_cap < 0 means cfg->Nsample (cfg may be NULL: env.step / env.reset only); opts may be NULL. */
+int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* task, const dial_cfg* cfg, int device,
+                   int n_local_cap, const dial_options* opts);
 void dial_destroy(dial_ctx* ctx);
 const char* dial_last_error(const dial_ctx* ctx); /* ctx may be NULL: last global error */
 
@@ -405,6 +426,13 @@ int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches);
  * Every compute entry point performs the same check first.  Drivers call it after their own synchronisation point,
  * before they publish a plan (deploy/dial_plan.py, core/dial_core.py).                                              */
 int dial_status(dial_ctx* ctx);
+
+/* Diagnostics for the parity tests (NULL, the default, in production): while `trace` is set, every rollout launch of the
+ * context also writes the packed state [qpos|qvel|qacc_warmstart|info] AFTER each env.step -- trace:[rows,Hsample+1,
+ * dial_state_size(nq,nv)] device floats, row = rollout index of the launch; launches with more rollouts than `rows` fail
+ * with DIAL_ERR_ARG.  This exposes the per-step qacc_warmstart and env info, so that the oracle can be restarted from the
+ * GPU's OWN state after step t and compared with the GPU's step t + 1 (tests/conftest.py: transition_parity).          */
+int dial_set_state_trace(dial_ctx* ctx, float* trace, int rows);
 
 /* ABI self-description used by tests: sizeof of the three structs. */
 int dial_abi_sizes(int* model_bytes, int* task_bytes, int* cfg_bytes);

@@ -114,6 +114,83 @@ def one_step_consistency(o32, s0, us, got, rollouts, nq, nv, tol_scale=1.0, max_
     return report
 
 
+# share of the TRANSITIONS (one env.step from the device's own state) that may need a knife-edge witness under the shipped
+# solver settings (`_in_bracket`, truncated): 1.5 x the largest share measured on MI355X at the BASELINE sizes
+# (profiles/r04_transition_parity.txt), floor 0.5 %
+TRANSITION_WITNESS_FRAC = {"unitree_go2_trot": 0.02, "unitree_go2_seq_jump": 0.02, "unitree_h1_jog": 0.02, "unitree_h1_loco": 0.03,
+                           "allegro_reorient": 0.02, "unitree_go2_crate_climb": 0.05, "unitree_h1_push_crate": 0.05}
+
+
+def transition_sample(N, count, seed):
+    """`count` rollout indices of a launch of N + 1: the mean trajectory (index N) and count - 1 noisy ones."""
+    idx = np.random.default_rng(100 + seed).choice(N, min(count - 1, N), replace=False)
+    return np.concatenate([np.sort(idx), [N]])
+
+
+def transition_parity(o32, s0, us, got, trace, rollouts, nq, nv, example=None, tol_scale=1.0, max_draws=256, max_frac=None,
+                      unwitnessed_ok=0, check=True):
+    """Per-TRANSITION parity under the solver settings a model ships with (line-search rule `_in_bracket`, the envs' own
+    truncated iteration counts) -- the deterministic gate that the per-rollout comparison cannot be under that rule.
+
+    `trace` [B, T, nstate] is the device's OWN packed state after every env.step (dial_set_state_trace: qpos, qvel,
+    qacc_warmstart AND the env info -- step counter, targets, stage), `got` = its (rewss, qss, qdss, xss), `us` the
+    controls.  For every rollout n of `rollouts` and every step t the oracle is restarted from trace[n, t - 1] (t = 0: from
+    `s0`), advanced ONE env.step with us[n, t] and compared with the device's reward / q / qd / x.pos of step t at
+    tol_scale x TOL.  No chaos accumulates along the trajectory -- one solve, at most `iterations` Newton steps -- so the
+    gate is as tight at the last step as at the first.  A transition outside the gate is a solver knife edge (a bracket
+    candidate rejected on a zero slope, an active-set flip): it needs a WITNESS, a start state within 64 ulp (fp32) of the
+    device's in qpos / qvel / qacc_warmstart from which the oracle lands inside the gate; transitions without one fail the
+    test (beyond `unwitnessed_ok`), and the share that needs one is capped (TRANSITION_WITNESS_FRAC).
+    Returns a report with the direct-match share."""
+    rewss, qss, qdss, xss = got
+    T = us.shape[1]
+    ni = nq + 2 * nv                                                    # offset of the info block
+    rng = np.random.default_rng(11)
+
+    def step_err(st, n, t):
+        st2, xpos, _, _ = o32.env_step(st, us[n, t])
+        worst = 0.0
+        for a, b, tol in ((st2[ni + 21], rewss[n, t], TOL["rewss"]), (st2[:nq], qss[n, t], TOL["q"]),
+                          (st2[nq:nq + nv], qdss[n, t], TOL["qd"]), (xpos.reshape(-1), xss[n, t], TOL["x"])):
+            err = np.abs(np.asarray(a, np.float64) - b) / (tol["atol"] + tol["rtol"] * np.abs(b))
+            worst = max(worst, float(np.max(err)))
+        return worst
+
+    report = dict(transitions=0, direct=0, direct_worst=0.0, witnessed=0, unwitnessed=[], witness_ulp={})
+    for n in rollouts:
+        for t in range(T):
+            st = np.array(s0 if t == 0 else trace[n, t - 1], dtype=np.float32)
+            if t > 0:
+                assert st[ni] == t, (n, t, st[ni])                      # info.step of the device's state
+            report["transitions"] += 1
+            err = step_err(st, n, t)
+            if err <= tol_scale:
+                report["direct"] += 1
+                report["direct_worst"] = max(report["direct_worst"], err)
+                continue
+            found = None
+            for k in range(max_draws):
+                mag = 2.0 ** (k * 7 // max_draws)                       # 1, 2, 4 ... 64 ulp: smallest jitter first
+                stj = st.copy()
+                stj[:ni] += (rng.integers(-1, 2, size=ni) * mag * np.spacing(np.abs(st[:ni]))).astype(np.float32)
+                if step_err(stj, n, t) <= tol_scale:
+                    found = int(mag)
+                    break
+            if found is None:
+                report["unwitnessed"].append((int(n), int(t), round(err, 2)))
+            else:
+                report["witnessed"] += 1
+                report["witness_ulp"][found] = report["witness_ulp"].get(found, 0) + 1
+    report["direct_share"] = report["direct"] / max(report["transitions"], 1)
+    report["witnessed_share"] = report["witnessed"] / max(report["transitions"], 1)
+    if not check:
+        return report
+    assert len(report["unwitnessed"]) <= unwitnessed_ok, report
+    cap = max_frac if max_frac is not None else TRANSITION_WITNESS_FRAC.get(example, 0.02)
+    assert report["witnessed"] <= max(2, cap * report["transitions"]), report
+    return report
+
+
 def witness_parity(o32, s0, us, got, example, nstate, max_draws=256, unwitnessed_ok=0, max_frac=None, tail_scale=20.0,
                    restart_ok=False):
     """Per-rollout parity of `got` = (rewss, qss, qdss, xss) [B,T,...] against the fp32 oracle `o32` run on the same
@@ -271,7 +348,8 @@ DIST_FLOOR = dict(Ybar=3e-4, qbar=3e-4, qdbar=5e-3, xbar=3e-4, Ybar_t8=3e-4, qua
 DIST_PEAKED = ("Ybar", "qbar", "qdbar", "xbar", "ess_rel")
 
 
-def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_mag=1.0, scale=2.5, scale_peaked=4.0):
+def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=32, noise_mag=1.0, scale=2.5, scale_peaked=2.5, quantile=0.95,
+                        check=True):
     """Distribution-level parity of one reverse_once at full size under a solver rule that is a rounding lottery rollout
     by rollout (`_in_bracket` truncated; Allegro's 100 impact-rich sub-steps).
 
@@ -280,8 +358,9 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
     runs whose state is jittered by <= `noise_mag` ulp (fp32) before every step (oracle_rollout_jitter).  For every
     aggregate a caller consumes -- Ybar, qbar, qdbar, xbar -- and for the reward distribution (mean, std, seven quantiles,
     softmax effective sample size, the weighted mean action at 8 x the temperature), the GPU's distance from the
-    unperturbed oracle must not exceed `scale` x the LARGEST distance any ensemble member shows (`scale_peaked` for the
-    statistics in DIST_PEAKED; or the plain fp32 floor DIST_FLOOR, whichever is larger).  A kernel
+    unperturbed oracle must not exceed `scale` x the `quantile` (95th percentile) of the distances the ensemble members show
+    (`scale_peaked` for the statistics in DIST_PEAKED -- round 4: the same 2.5 as for the smooth ones, against 32 members
+    instead of the maximum of 8; or the plain fp32 floor DIST_FLOOR, whichever is larger).  A kernel
     that computes something else than the oracle -- a wrong force, a missed contact -- moves the aggregates far outside
     an envelope that 1 ulp of jitter spans; a kernel that differs by rounding stays inside.  Also reported / bounded: the
     share of rollouts outside the per-step gate, GPU vs ensemble."""
@@ -298,15 +377,18 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
         return float((~ok.all(1)).mean())
 
     names = ("Ybar", "qbar", "qdbar", "xbar", "Ybar_t8", "quantiles", "mean", "std")
-    env_d = {k: 0.0 for k in names + ("ess_rel", "outside")}
+    dev = {k: [] for k in names + ("ess_rel", "outside")}
     for k in range(members):
         roll = o32.rollout_jitter(s0, us, noise_seed=7919 * (k + 1), noise_mag=noise_mag)
         e = k4_fp64(roll[0], Y0s, roll[1], roll[2], roll[3], temp)
         for nme in names:
-            env_d[nme] = max(env_d[nme], float(np.max(np.abs(e[nme] - ref[nme]))))
-        env_d["ess_rel"] = max(env_d["ess_rel"], abs(e["ess"] / ref["ess"] - 1))
-        env_d["outside"] = max(env_d["outside"], outside(roll))
-    rep = dict(envelope=env_d, gpu={}, ess_oracle=float(ref["ess"]), ess_gpu=float(g["ess"]))
+            dev[nme].append(float(np.max(np.abs(e[nme] - ref[nme]))))
+        dev["ess_rel"].append(abs(e["ess"] / ref["ess"] - 1))
+        dev["outside"].append(outside(roll))
+    # the yardstick: the `quantile` of the members' deviations (the maximum of a heavy-tailed sample is a noisy yardstick)
+    env_d = {k: float(np.quantile(v, quantile)) for k, v in dev.items()}
+    env_max = {k: float(np.max(v)) for k, v in dev.items()}
+    rep = dict(envelope=env_d, envelope_max=env_max, members=members, gpu={}, ess_oracle=float(ref["ess"]), ess_gpu=float(g["ess"]))
     for nme in names:
         rep["gpu"][nme] = float(np.max(np.abs(g[nme] - ref[nme])))
     rep["gpu"]["ess_rel"] = abs(g["ess"] / ref["ess"] - 1)
@@ -315,10 +397,13 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=8, noise_m
     for nme, atol in (("Ybar", 1e-4), ("qbar", 1e-4), ("xbar", 1e-4), ("qdbar", 2e-3)):
         assert np.allclose(np.asarray(product[nme], np.float64).reshape(-1), g[nme], atol=atol), nme
     # ... and sit inside the oracle's jitter envelope
+    rep["ratio"] = {nme: rep["gpu"][nme] / max(env_d[nme], 1e-30) for nme in names + ("ess_rel",)}
+    if not check:                  # surveys (tools/transition_survey.py) print the report instead
+        return rep
     for nme in names + ("ess_rel",):
         bound = max(DIST_FLOOR[nme], (scale_peaked if nme in DIST_PEAKED else scale) * env_d[nme])
         assert rep["gpu"][nme] <= bound, (nme, rep)
-    assert rep["gpu"]["outside"] <= max(0.01, 1.5 * env_d["outside"] + 0.02), rep
+    assert rep["gpu"]["outside"] <= max(0.01, 1.5 * env_max["outside"] + 0.02), rep
     return rep
 
 

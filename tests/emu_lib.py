@@ -64,9 +64,11 @@ class Emu:
         assert rc == 0, f"emu_env_step: rc={rc} (races or error)"
         return state, xpos, xquat, ctrl
 
-    def rollout(self, state, us, check_races=False):
+    def rollout(self, state, us, check_races=False, trace=False):
+        """trace=True: also returns the packed state after every env.step, [B, T, state_size] (RolloutIO::trace)."""
         us = self._a(us)
         B, T = us.shape[:2]
+        tr = np.zeros((B, T, self.state_size), np.float32) if trace else None
         rewss = np.zeros((B, T), np.float32)
         rews = np.zeros(B, np.float32)
         qss = np.zeros((B, T, self.nq), np.float32)
@@ -76,8 +78,10 @@ class Emu:
                                   ctypes.byref(self.cfg) if self.cfg is not None else None,
                                   self._p(self._a(state)), self._p(us), None, None, None, 0, 0, B, T, 0, None,
                                   self._p(rewss), self._p(rews), self._p(qss), self._p(qdss), self._p(xss),
-                                  int(check_races), self.path)
+                                  int(check_races), self.path, self._p(tr))
         assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
+        if trace:
+            return rewss, qss, qdss, xss, rews, tr
         return rewss, qss, qdss, xss, rews
 
     def rollout_nodes(self, state, Ybar, noise_scale, eps, check_races=False):
@@ -95,7 +99,7 @@ class Emu:
         rc = self.lib.emu_rollout(ctypes.byref(self.model), ctypes.byref(self.task), ctypes.byref(cfg),
                                   self._p(self._a(state)), None, self._p(eps), self._p(Ybar), self._p(ns),
                                   int(ns.size), N, B, T, Hn1, self._p(Y0s), self._p(rewss), self._p(rews),
-                                  self._p(qss), self._p(qdss), self._p(xss), int(check_races), self.path)
+                                  self._p(qss), self._p(qdss), self._p(xss), int(check_races), self.path, None)
         assert rc == 0, f"emu_rollout: rc={rc} (races or error)"
         return dict(Y0s=Y0s, rewss=rewss, rews=rews, qss=qss, qdss=qdss, xss=xss)
 

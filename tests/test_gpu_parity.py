@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import (CASES, TOL, agg_tol, distribution_parity, one_step_consistency, perturbed_state, seeded_inputs, setup_case,
-                      with_solver, witness_parity)
+                      transition_parity, transition_sample, with_solver, witness_parity)
 
 pytestmark = pytest.mark.gpu
 
@@ -288,6 +288,52 @@ def test_async_planner_protocol_end_to_end():
         plant.close()
 
 
+def test_async_planner_recovers_from_a_non_finite_plan():
+    """a NaN plan (the reference's 0 / 0 when every sample earns the same reward) is not published AND the
+    plan restarts from zeros -- `Y * 0` kept the NaNs, every later plan started from NaN and nothing was ever published
+    again.  Injected here by a plan_once that leaves NaN nodes behind: that tick publishes nothing, the next one does; five bad
+    plans in a row raise instead of spinning."""
+    import uuid
+    import torch
+    import yaml
+    from dial_mpc_amd.core.dial_core import load_dial_and_env
+    from dial_mpc_amd.deploy.dial_plan import MBDPublisher
+    from fake_plant import FakePlant
+    from dial_mpc_amd.utils.io_utils import get_example_path
+    cfgd = yaml.safe_load(open(get_example_path("unitree_go2_trot_deploy.yaml")))
+    cfgd["Nsample"], cfgd["Ndiffuse_init"] = 128, 2
+    dial_config, env_config, env = load_dial_and_env(cfgd)
+    prefix = "n" + uuid.uuid4().hex[:8] + "_"
+    plant = FakePlant(env, dial_config, shm_prefix=prefix)
+    try:
+        pub = MBDPublisher(env, env_config, dial_config, shm_prefix=prefix)
+        calls = []
+        pub.main_loop(max_ticks=1, on_tick=calls.append)
+        t_pub = float(pub.plan_time_shared[0])
+        plant.step_with_action(pub.Y[0])
+        orig = pub.plan_once
+
+        def bad_plan(state, n):                                      # a plan that comes out non-finite
+            info = orig(state, n)
+            pub.Y = torch.full_like(pub.Y, float("nan"))
+            return info
+        pub.plan_once = bad_plan
+        pub.main_loop(max_ticks=1, on_tick=calls.append)
+        assert float(pub.plan_time_shared[0]) == t_pub               # nothing published ...
+        assert torch.all(pub.Y == 0) and len(calls) == 2             # ... the plan restarted from zeros, the tick hook still ran
+        assert np.all(np.isfinite(plant._seg["acts_shm"][1]))
+        pub.plan_once = orig
+        plant.step_with_action(pub.Y[0])
+        pub.main_loop(max_ticks=1, on_tick=calls.append)
+        assert float(pub.plan_time_shared[0]) > t_pub and torch.isfinite(pub.Y).all()   # the next tick publishes again
+        pub.plan_once = bad_plan                                     # a planner that cannot recover raises instead of spinning
+        with pytest.raises(RuntimeError, match="non-finite"):
+            pub.main_loop(max_ticks=10)
+        pub.close()
+    finally:
+        plant.close()
+
+
 @pytest.mark.parametrize("example,N,H", [("unitree_go2_seq_jump", 1024, 16), ("unitree_h1_jog", 2048, 16),
                                          ("unitree_h1_loco", 2048, 20)])
 def test_full_size_properties_other_configs(example, N, H):
@@ -345,7 +391,7 @@ def test_full_size_oracle_parity(example, N, H):
             # product outputs of the chaotic env: Ybar / qbar / qdbar / xbar and the reward distribution against the oracle's
             # own <= 1 ulp jitter envelope (conftest.distribution_parity) instead of no aggregate check at all
             prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-            drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample, members=8)
+            drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample)
             print(f"   distribution level: GPU {drep['gpu']}\n   jitter envelope: {drep['envelope']}")
         if not chaotic:
             # product outputs: the few knife-edge rollouts carry softmax weight ~1/N each, so the aggregates stay comparable
@@ -458,11 +504,7 @@ def test_rollout_queue_beyond_the_resident_batch():
     for k in ("Ybar", "rews", "qbar", "xbar"):
         assert torch.equal(runs[0][0][k], runs[1][0][k]), k
     assert np.array_equal(runs[0][1]["rewss"], runs[1][1]["rewss"])
-    os.environ["DIAL_NO_QUEUE"] = "1"
-    try:
-        ctx1 = _lib.Context(model, task, cfg)
-    finally:
-        del os.environ["DIAL_NO_QUEUE"]
+    ctx1 = _lib.Context(model, task, cfg, options=dict(no_queue=1))
     assert ctx1.lib.dial_debug_resident_rollouts(ctx1.h, N + 1) == 0
     out1 = ctx1.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
     sc1 = ctx1.debug_scratch()
@@ -488,25 +530,17 @@ def test_mean_trajectory_relay_is_bit_identical(example, N, H):
     import torch
     from dial_mpc_amd import _lib
     dc, env, model, task, cfg = setup_case(example, N, H)
-    os.environ["DIAL_RELAY_ALWAYS"] = "1"                             # (the library relays only when N fills the SIMDs evenly)
-    try:
-        ctx = _lib.Context(model, task, cfg)
-        s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
-        eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=4, Ybar_scale=0.1)
-        _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar)
-    finally:
-        del os.environ["DIAL_RELAY_ALWAYS"]
+    ctx = _lib.Context(model, task, cfg, options=dict(relay_always=1))   # (by default the library relays only when N fills the SIMDs evenly)
+    s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=4, Ybar_scale=0.1)
+    _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar)
 
 
 def _relay_vs_single(ctx, model, task, cfg, s0, eps, sigma, Ybar):
     import os
     import torch
     from dial_mpc_amd import _lib
-    os.environ["DIAL_NO_RELAY"] = "1"
-    try:
-        ctx0 = _lib.Context(model, task, cfg)
-    finally:
-        del os.environ["DIAL_NO_RELAY"]
+    ctx0 = _lib.Context(model, task, cfg, options=dict(no_relay=1))
     for it in range(3):                                               # the turn flag re-arms itself between launches
         out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
         out = {k: v.clone() for k, v in out.items()}
@@ -531,11 +565,7 @@ def test_split_launch_is_bit_identical(example, H):
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     dc, env, model, task, cfg = setup_case(example, 8 * ncu, H)
     ctx = _lib.Context(model, task, cfg)
-    os.environ["DIAL_NO_SPLIT"] = "1"
-    try:
-        ctx0 = _lib.Context(model, task, cfg)
-    finally:
-        del os.environ["DIAL_NO_SPLIT"]
+    ctx0 = _lib.Context(model, task, cfg, options=dict(no_split_mask=-1))
     s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=6, Ybar_scale=0.2)
     for it in range(2):
@@ -615,6 +645,7 @@ def test_default_rule_distribution_parity_full_size(example, N, H):
     dc, env, model, task, cfg = setup_case(example, N, H)
     assert model.ls_rule == 1
     ctx = _lib.Context(model, task, cfg)
+    trace_dev = ctx.set_state_trace(N + 1)          # the device's own packed state after every env.step (diagnostics)
     o32 = O.Oracle(model, task, cfg, np.float32)
     for seed in (0, 1):
         q, qd = (env._init_q, np.zeros(model.nv)) if seed == 0 else perturbed_state(env, seed)
@@ -624,11 +655,20 @@ def test_default_rule_distribution_parity_full_size(example, N, H):
         sc = ctx.debug_scratch()
         W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(H + 1)], np.float32)
         us = np.einsum("tk,nka->nta", W, sc["Y0s"]).astype(np.float32)
+        got = (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"])
+        # (1) deterministic: every transition of 96 trajectories (the mean trajectory included) against ONE oracle env.step from
+        # the device's own state, at 1 x TOL; knife edges need a <= 64 ulp witness
+        trace = trace_dev.cpu().numpy()
+        assert np.array_equal(trace[:, :, :model.nq], sc["qss"])                      # the trace is the rollouts' own state
+        trep = transition_parity(o32, s0, us, got, trace, transition_sample(N, 96, seed), model.nq, model.nv, example=example)
+        print(f"{example} N={N} seed={seed} shipped rule, per transition: {trep['transitions']} transitions, direct "
+              f"{100 * trep['direct_share']:.2f} % (worst {trep['direct_worst']:.2f} x gate), witnessed {trep['witnessed']} "
+              f"{trep['witness_ulp']}, unwitnessed {len(trep['unwitnessed'])}")
+        # (2) what a caller consumes: the aggregates against the oracle's own 1-ulp jitter envelope
         prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-        rep = distribution_parity(o32, s0, us, sc["Y0s"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), prod,
-                                  cfg.temp_sample, members=8)
-        print(f"{example} N={N} seed={seed} default rule: ESS oracle {rep['ess_oracle']:.1f} / GPU {rep['ess_gpu']:.1f}\n"
-              f"   GPU vs oracle   {rep['gpu']}\n   jitter envelope {rep['envelope']}")
+        rep = distribution_parity(o32, s0, us, sc["Y0s"], got, prod, cfg.temp_sample)
+        print(f"   distribution level: ESS oracle {rep['ess_oracle']:.1f} / GPU {rep['ess_gpu']:.1f}\n"
+              f"   GPU vs oracle   {rep['gpu']}\n   jitter envelope (p95 of {rep['members']}) {rep['envelope']}\n   ratio {rep['ratio']}")
 
 
 def test_async_planner_replay_matches_oracle_restatement():
@@ -944,8 +984,8 @@ def test_closed_loop_behaviour(example, ticks, N):
 
 
 def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():
-    """The mean-trajectory relay waits for its predecessor with a BOUNDED spin.  With the test hook DIAL_DEBUG_RELAY_STALL
-    (piece 1 never hands over) the later pieces give up after ~2 s: the launch completes, the context's sticky error word is
+    """The mean-trajectory relay waits for its predecessor with a BOUNDED spin.  With the test hook
+    dial_options.debug_relay_stall (piece 1 never hands over) the later pieces give up after ~2 s: the launch completes, the context's sticky error word is
     set, the next API call -- and dial_status -- report DIAL_ERR_HIP once, the turn flag is re-armed, and the context works
     again afterwards (bit-identical to a context that never stalled)."""
     import os
@@ -957,11 +997,7 @@ def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():
     good = _lib.Context(model, task, cfg)
     s0, _, _ = good.env_reset(_dev(env._init_q), _dev(np.zeros(18)))
     ref = {k: v.clone() for k, v in good.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps)).items()}
-    os.environ["DIAL_DEBUG_RELAY_STALL"] = "2"
-    try:
-        ctx = _lib.Context(model, task, cfg)
-    finally:
-        del os.environ["DIAL_DEBUG_RELAY_STALL"]
+    ctx = _lib.Context(model, task, cfg, options=dict(debug_relay_stall=2))
     t0 = time.time()
     ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))        # enqueues fine; the relay stalls on the device
     torch.cuda.synchronize()

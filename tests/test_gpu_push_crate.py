@@ -3,10 +3,13 @@ two moving bodies) vs the fp32 oracle, at small size from pushing poses and at t
 import numpy as np
 import pytest
 
-from conftest import distribution_parity, seeded_inputs, setup_case, witness_parity
+from conftest import distribution_parity, seeded_inputs, setup_case, transition_parity, transition_sample, witness_parity
 from test_push_crate import EX, pushing_state
 
 pytestmark = pytest.mark.gpu
+# transitions of the crate scenes that may stay without a witness: a capsule within micrometres of its radius next to a box
+# edge has a normal that turns by degrees per micrometre (crate scenes); measured on MI355X: see profiles/r04_transition_parity.txt
+CRATE_UNWITNESSED_TRANSITIONS = 2
 
 
 def _dev(x):
@@ -61,7 +64,7 @@ def test_push_crate_full_size_oracle_parity(pose):
     print(f"{EX} pose {pose}: {rep['outside_tol']} of {rep['rollouts']} rollouts on a knife edge, "
           f"{rep.get('restart_witnessed', 0)} witnessed from the GPU's own state, {rep.get('unwitnessed', 0)} without a witness")
     prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-    drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample, members=8)
+    drep = distribution_parity(o32, s0, ro["us"], sc["Y0s"], got, prod, cfg.temp_sample)
     print(f"   distribution level: GPU {drep['gpu']}\n   jitter envelope: {drep['envelope']}")
     rews_g = out["rews"].cpu().numpy().astype(np.float64)
     logp = (rews_g - rews_g[-1]) / rews_g.std() / float(cfg.temp_sample)
@@ -79,6 +82,7 @@ def test_push_crate_default_rule_distribution_parity():
     assert model.ls_rule == 1
     o32, o64 = O.Oracle(model, task, cfg, np.float32), O.Oracle(model, task, cfg, np.float64)
     ctx = _lib.Context(model, task, cfg)
+    trace_dev = ctx.set_state_trace(N + 1)
     q, qd = _poses(env, o64)[0]
     s0, _, _ = o32.env_reset(q, qd)
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0, Ybar_scale=0.2)
@@ -87,7 +91,14 @@ def test_push_crate_default_rule_distribution_parity():
     W = np.array([[cfg.W[t][k] for k in range(dc.Hnode + 1)] for t in range(H + 1)], np.float32)
     us = np.einsum("tk,nka->nta", W, sc["Y0s"]).astype(np.float32)
     prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-    rep = distribution_parity(o32, s0, us, sc["Y0s"], (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"]), prod, cfg.temp_sample, members=8)
+    got = (sc["rewss"], sc["qss"], sc["qdss"], sc["xss"])
+    # per transition, deterministic: the oracle restarted from the device's OWN traced state (q, qd, qacc_warmstart, info) after
+    # step t reproduces the device's step t + 1 at 1 x TOL; knife edges need a <= 64 ulp witness (conftest.transition_parity)
+    trep = transition_parity(o32, s0, us, got, trace_dev.cpu().numpy(), transition_sample(N, 96, 0), model.nq, model.nv,
+                             example=EX, unwitnessed_ok=CRATE_UNWITNESSED_TRANSITIONS)
+    print(f"{EX} shipped rule, per transition: {trep['transitions']} transitions, direct {100 * trep['direct_share']:.2f} % "
+          f"(worst {trep['direct_worst']:.2f} x gate), witnessed {trep['witnessed']} {trep['witness_ulp']}, unwitnessed {trep['unwitnessed']}")
+    rep = distribution_parity(o32, s0, us, sc["Y0s"], got, prod, cfg.temp_sample)
     print(f"{EX} default rule: ESS oracle {rep['ess_oracle']:.1f} / GPU {rep['ess_gpu']:.1f}\n   GPU vs oracle   {rep['gpu']}\n   jitter envelope {rep['envelope']}")
 
 

@@ -46,7 +46,7 @@ class FakeCtx:
         rc = e.lib.emu_rollout(ctypes.byref(e.model), ctypes.byref(e.task), ctypes.byref(cfg),
                                e._p(e._a(state.numpy())), None, e._p(e._a(eps_local.numpy())),
                                e._p(e._a(Ybar.numpy())), e._p(ns), int(ns.size), n_local, B, T, Hn1, e._p(Y0s),
-                               e._p(rewss), e._p(rews), e._p(qss), e._p(qdss), e._p(xss), 0, 0)
+                               e._p(rewss), e._p(rews), e._p(qss), e._p(qdss), e._p(xss), 0, 0, None)
         assert rc == 0
         rews_out[:B].copy_(torch.from_numpy(rews))   # the kernel writes n_local + 1 entries of the (per + 1)-sized send buffer
         self.last = (Y0s, qss, qdss, xss)

@@ -97,11 +97,12 @@ extern "C" {
 int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, const float* state, const float* us,
                 const float* eps, const float* Ybar, const float* noise_scale, int ns, int n_noise, int B, int T,
                 int Hn1, float* Y0s, float* rewss, float* rews, float* qss, float* qdss, float* xss,
-                int check_races, int path) {
+                int check_races, int path, float* trace) {
   dial_derived dv;
   int rc = dial_build_derived(m, &dv);
   if (rc) return rc;
   dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr, 0, 0u, 0u, 0u, 0};
+  io.trace = trace;   // [B,T,nstate] packed state after every env.step, or nullptr
 #define CALL(D) run_rollout<D>(m, t, &dv, cfg, io, B, check_races)
   DISPATCH(path, m, CALL)
 #undef CALL
