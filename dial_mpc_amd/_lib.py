@@ -26,43 +26,57 @@ class DialHipError(RuntimeError):
 IEEE_LIB_PATH = os.path.join(_CSRC, "libdialhip_ieee.so")
 
 
-def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str:
-    """Compile csrc/dial_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU).
+N_FAMILIES = 7     # robot families of csrc/kernel_list.h, one translation unit each (kern_family.hip -DDIAL_FAMILY=k)
+# device fast-math flags of the product build (the IEEE measurement variant drops them):
+# -fno-hip-fp32-correctly-rounded-divide-sqrt: fp32 divide / sqrt via v_rcp / v_sqrt sequences (<= 2.5 ulp)
+# instead of the IEEE fix-up chains; well inside the fp32 parity tolerance.
+# device only: -freciprocal-math (a/b -> a * v_rcp(b), no frexp/ldexp range scaling) and -fapprox-func
+# (native v_sqrt / v_rsq / v_exp / v_log without denormal fix-ups); finite-math is NOT assumed (+-inf
+# control ranges are compared against).  -fno-honor-nans: min / max / clip become single v_min / v_max instead of
+# compare + select chains.
+_FAST = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
+         "-Xarch_device", "-fno-honor-nans"]
+# -fno-slp-vectorize (both variants): the SLP pass packs pairs of scalar fp32 ops into v_pk_* and pays for it in v_mov
+# shuffles -- measured 5-6% slower on this issue-bound kernel.
+_COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_device", "-fno-slp-vectorize"]
 
-    ieee=True builds the MEASUREMENT variant libdialhip_ieee.so: the same source without the device fast-math flags below
+
+def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str:
+    """Compile the library for gfx950 in-tree (hipcc cross-compiles without a GPU): csrc/dial_hip.hip (host side, K4 / K5
+    kernels) and csrc/kern_family.hip once per robot family, the translation units IN PARALLEL, then one link.
+
+    ieee=True builds the MEASUREMENT variant libdialhip_ieee.so: the same sources without the device fast-math flags
     (correctly rounded divide / sqrt, no reciprocal-math, no approximate functions, NaNs honoured).  It is never the product
     path; the GPU suite loads it next to the product library to show how much of the knife-edge witness traffic is the
     fast-math rounding (tests/test_gpu_parity.py: test_ieee_build_needs_no_more_witnesses)."""
+    from concurrent.futures import ThreadPoolExecutor
     # every source of the library takes part in the staleness check (a stale .so must never ship silently)
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip"))) + [_abi.HEADER]
-    if ieee:
-        if not force and os.path.exists(IEEE_LIB_PATH) and all(os.path.getmtime(IEEE_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-            return IEEE_LIB_PATH
-        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Xarch_device", "-fno-slp-vectorize", "-o", IEEE_LIB_PATH, os.path.join(_CSRC, "dial_hip.hip")]
+    out = IEEE_LIB_PATH if ieee else LIB_PATH
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = _COMMON + ([] if ieee else _FAST) + ([] if ieee else os.environ.get("DIAL_HIPCC_EXTRA", "").split())
+    objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", "obj_" + os.path.basename(out))
+    os.makedirs(objdir, exist_ok=True)
+    units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
+    units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"], os.path.join(objdir, f"kern_family_{k}.o"))
+              for k in range(N_FAMILIES)]
+
+    def compile_unit(u):
+        src, defs, obj = u
+        cmd = [hipcc] + flags + defs + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        return IEEE_LIB_PATH
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-hip-fp32-correctly-rounded-divide-sqrt: fp32 divide / sqrt via v_rcp / v_sqrt sequences (<= 2.5 ulp)
-    # instead of the IEEE fix-up chains; well inside the fp32 parity tolerance (DESIGN.md section 5).
-    # device only: -freciprocal-math (a/b -> a * v_rcp(b), no frexp/ldexp range scaling) and -fapprox-func
-    # (native v_sqrt / v_rsq / v_exp / v_log without denormal fix-ups); finite-math is NOT assumed (+-inf
-    # control ranges are compared against).  -fno-slp-vectorize: the SLP pass packs pairs of scalar fp32 ops
-    # into v_pk_* and pays for it in v_mov shuffles -- measured 5-6% slower on this issue-bound kernel.
-    # -fno-honor-nans: min / max / clip become single v_min / v_max instead of compare + select chains.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
-           "-Xarch_device", "-fno-slp-vectorize", "-Xarch_device", "-fno-honor-nans", "-o", LIB_PATH,
-           os.path.join(_CSRC, "dial_hip.hip")] + os.environ.get("DIAL_HIPCC_EXTRA", "").split()
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, units))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 def load(path: Optional[str] = None):

@@ -14,6 +14,25 @@ struct BoxG {
   float c[3], q[4], h[3];   // centre, orientation (world-from-box quaternion), half sizes
 };
 
+// NO dynamically indexed private arrays in this file: an array indexed by a run-time value cannot live in registers, the
+// compiler puts it in scratch memory, and round 3's generic kernel carried 544 B of it per lane -- 865 MB of HBM traffic
+// per launch for 19.6 MB of algorithmic bytes (profiles/r03_pmc_unitree_go2_crate_climb.json).  Run-time choices among three
+// values are select chains (pick3), sorted lists are sorting networks on named registers, and the one structure that
+// really is a list of run-time length -- the clipping polygons of box_box -- lives in a lane-private slice of LDS.
+#ifdef DIAL_EMU
+#define DIAL_UNROLL_FULL
+#else
+#define DIAL_UNROLL_FULL _Pragma("unroll")
+#endif
+DIAL_DEV float pick3(float a0, float a1, float a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+DIAL_DEV float pick3v(const float* a, int k) { return pick3(a[0], a[1], a[2], k); }                  // a[k], a = 3 registers
+DIAL_DEV void pick_row(float* o, const float (*a)[3], int k) {                                       // o = a[k][:]
+  for (int c = 0; c < 3; c++) o[c] = pick3(a[0][c], a[1][c], a[2][c], k);
+}
+DIAL_DEV void cswap(float& a, float& b) { const float lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+// words of LDS one box-box candidate needs for its two clipping polygons (<= 10 vertices x 3 each)
+#define DIAL_BOX_POLY_WORDS 60
+
 DIAL_DEV void box_axes(const BoxG& b, float ax[3][3]) {   // ax[k] = world direction of the box's k-th axis
   float mat[9];
   dm::quat_to_mat(mat, b.q);
@@ -39,8 +58,8 @@ DIAL_DEV void sphere_box(const float* sc, float r, const BoxG& b, float& dist, f
     for (int k = 0; k < 3; k++) nl[k] /= len;
     dist = len - r;
   } else {
-    for (int k = 0; k < 3; k++) nl[k] = 0.f;
-    nl[kn] = p[kn] >= 0.f ? -1.f : 1.f;
+    const float sgn = pick3v(p, kn) >= 0.f ? -1.f : 1.f;
+    for (int k = 0; k < 3; k++) nl[k] = k == kn ? sgn : 0.f;
     dist = slack - r;                                    // slack = -(depth below the nearest face)
   }
   float n[3];
@@ -58,10 +77,13 @@ DIAL_DEV void plane_box(const float* n, const float* ppos, const BoxG& b, int su
   const float base = dm::dot3(rel, n);
   for (int k = 0; k < 3; k++) e[k] = b.h[k] * dm::dot3(n, ax[k]);
   float hv[8];
+  DIAL_UNROLL_FULL
   for (int i = 0; i < 8; i++) hv[i] = base + ((i & 1) ? e[0] : -e[0]) + ((i & 2) ? e[1] : -e[1]) + ((i & 4) ? e[2] : -e[2]);
   int pick = 0;
+  DIAL_UNROLL_FULL
   for (int i = 0; i < 8; i++) {
     int rank = 0;
+    DIAL_UNROLL_FULL
     for (int j = 0; j < 8; j++) rank += (hv[j] < hv[i] || (hv[j] == hv[i] && j < i)) ? 1 : 0;
     pick = rank == sub ? i : pick;
   }
@@ -78,22 +100,37 @@ DIAL_DEV void plane_box(const float* n, const float* ppos, const BoxG& b, int su
 // and piecewise quadratic in t; its pieces end where the point crosses one of the six slab planes.  A later piece replaces
 // an earlier one only if it is better by more than rounding (a capsule parallel to a face keeps its first end)
 DIAL_DEV float segment_box_t(const float* l0, const float* l1, const float* h) {
-  float cut[8];
-  int nc = 0;
-  cut[nc++] = 0.f;
-  for (int k = 0; k < 3; k++) {
-    const float dk = l1[k] - l0[k];
-    if (dk == 0.f) continue;
-    const float ta = (h[k] - l0[k]) / dk, tb = (-h[k] - l0[k]) / dk;
-    const float tlo = ta < tb ? ta : tb, thi = ta < tb ? tb : ta;
-    if (tlo > 0.f && tlo < 1.f) cut[nc++] = tlo;
-    if (thi > 0.f && thi < 1.f) cut[nc++] = thi;
+  // the cuts 0 < t < 1 where the point crosses a slab plane, sorted: eight NAMED values (0, up to six crossings, 1; unused
+  // entries are parked at 2 so that they sort to the end) through a 19-exchange sorting network -- the insertion sort over a
+  // dynamically indexed array this replaces lived in scratch memory.  Sorted values are what the pieces below depend on, so
+  // the result is the insertion sort's.
+  float c0 = 0.f, c1 = 2.f, c2 = 2.f, c3 = 2.f, c4 = 2.f, c5 = 2.f, c6 = 2.f, c7 = 1.f;
+  int nc = 2;
+  {
+    float* const slot[3][2] = {{&c1, &c2}, {&c3, &c4}, {&c5, &c6}};
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 3; k++) {
+      const float dk = l1[k] - l0[k];
+      if (dk == 0.f) continue;
+      const float ta = (h[k] - l0[k]) / dk, tb = (-h[k] - l0[k]) / dk;
+      const float tlo = ta < tb ? ta : tb, thi = ta < tb ? tb : ta;
+      if (tlo > 0.f && tlo < 1.f) { *slot[k][0] = tlo; nc++; }
+      if (thi > 0.f && thi < 1.f) { *slot[k][1] = thi; nc++; }
+    }
   }
-  cut[nc++] = 1.f;
-  for (int i = 1; i < nc; i++)            // sort (<= 8 entries)
-    for (int j = i; j > 0 && cut[j - 1] > cut[j]; j--) { const float x = cut[j]; cut[j] = cut[j - 1]; cut[j - 1] = x; }
+  // optimal 8-input network (19 compare-exchanges)
+  cswap(c0, c1); cswap(c2, c3); cswap(c4, c5); cswap(c6, c7);
+  cswap(c0, c2); cswap(c1, c3); cswap(c4, c6); cswap(c5, c7);
+  cswap(c1, c2); cswap(c5, c6); cswap(c0, c4); cswap(c3, c7);
+  cswap(c1, c5); cswap(c2, c6);
+  cswap(c1, c4); cswap(c3, c6);
+  cswap(c2, c4); cswap(c3, c5);
+  cswap(c3, c4);
+  const float cut[8] = {c0, c1, c2, c3, c4, c5, c6, c7};   // statically indexed below
   float best_t = 0.f, best_f = -1.f;
-  for (int i = 0; i + 1 < nc; i++) {
+  DIAL_UNROLL_FULL
+  for (int i = 0; i + 1 < 8; i++) {
+    if (i + 1 >= nc) continue;           // (pieces beyond the last real cut: the parked entries)
     const float t0 = cut[i], t1 = cut[i + 1], tm = 0.5f * (t0 + t1);
     float A = 0.f, B = 0.f, C = 0.f;    // f(t) = A t^2 + 2 B t + C over this piece
     for (int k = 0; k < 3; k++) {
@@ -133,8 +170,10 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
   const int kface = through ? (ka >= 0 ? ka : kb) : -1;          // enters through face ka, else (first end inside) leaves through kb
   const float t = through ? (ka >= 0 ? ta : (kb >= 0 ? tb : 0.f)) : segment_box_t(l0, l1, b.h);
   if (sub == 0 && kface >= 0) {
-    float nl[3] = {0.f, 0.f, 0.f}, n[3];
-    nl[kface] = l0[kface] + t * (l1[kface] - l0[kface]) >= 0.f ? -1.f : 1.f;
+    float nl[3], n[3];
+    const float l0f = pick3v(l0, kface), l1f = pick3v(l1, kface);
+    const float sgn = l0f + t * (l1f - l0f) >= 0.f ? -1.f : 1.f;
+    for (int k = 0; k < 3; k++) nl[k] = k == kface ? sgn : 0.f;
     dm::rotate(n, nl, b.q);
     dist = -r;
     for (int k = 0; k < 3; k++) pos[k] = e0[k] + t * (e1[k] - e0[k]) + n[k] * (r + dist * 0.5f);
@@ -148,7 +187,8 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
 
 // box against box (separating-axis test; see the description at DIAL_CON_BOX_BOX and oracle-independent notes in DESIGN.md).
 // Everything is done in A's frame: C = RA^T RB, t = RA^T (cB - cA).
-DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float* pos, float* fr) {
+// `poly`: DIAL_BOX_POLY_WORDS floats of LDS private to the calling lane (the two clipping polygons of a face contact).
+DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float* pos, float* fr, float* poly) {
   const float tw[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
   {   // bounding spheres more than 1 cm apart: nothing to do (all candidates parked; the normal is the centre line)
     const float gap = DM_SQRT(dm::dot3(tw, tw)) - DM_SQRT(dm::dot3(A.h, A.h)) - DM_SQRT(dm::dot3(B.h, B.h));
@@ -162,23 +202,29 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
   float axA[3][3], axB[3][3], C[3][3], Q[3][3], t[3];
   box_axes(A, axA);
   box_axes(B, axB);
+  DIAL_UNROLL_FULL
   for (int i = 0; i < 3; i++) {
     t[i] = dm::dot3(tw, axA[i]);
+    DIAL_UNROLL_FULL
     for (int j = 0; j < 3; j++) { C[i][j] = dm::dot3(axA[i], axB[j]); Q[i][j] = dm::absf(C[i][j]); }
   }
   int best = -1;
   float sbest = 0.f;
+  DIAL_UNROLL_FULL
   for (int i = 0; i < 3; i++) {          // faces of A
     const float sep = dm::absf(t[i]) - (A.h[i] + B.h[0] * Q[i][0] + B.h[1] * Q[i][1] + B.h[2] * Q[i][2]);
     if (best < 0 || sep > sbest) { best = i; sbest = sep; }
   }
+  DIAL_UNROLL_FULL
   for (int j = 0; j < 3; j++) {          // faces of B
     const float tb = t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j];
     const float sep = dm::absf(tb) - (B.h[j] + A.h[0] * Q[0][j] + A.h[1] * Q[1][j] + A.h[2] * Q[2][j]);
     if (sep > sbest) { best = 3 + j; sbest = sep; }
   }
   float nedge[3] = {0.f, 0.f, 0.f};       // world direction of the winning edge axis
-  for (int i = 0; i < 3; i++)
+  DIAL_UNROLL_FULL
+  for (int i = 0; i < 3; i++) {
+    DIAL_UNROLL_FULL
     for (int j = 0; j < 3; j++) {
       float L[3];
       dm::cross3(L, axA[i], axB[j]);
@@ -190,11 +236,20 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
       const float sep = dm::absf(dm::dot3(tw, L)) - (ra + rb);
       if (sep > sbest + 0.05f * dm::absf(sbest) + 1e-5f) { best = 6 + 3 * i + j; sbest = sep; for (int k = 0; k < 3; k++) nedge[k] = L[k]; }
     }
+  }
   const float mid[3] = {0.5f * (A.c[0] + B.c[0]), 0.5f * (A.c[1] + B.c[1]), 0.5f * (A.c[2] + B.c[2])};
   float n[3];
-  if (best < 3) { const float sg = t[best] >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = axA[best][k] * sg; }
-  else if (best < 6) { const float sg = dm::dot3(tw, axB[best - 3]) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = axB[best - 3][k] * sg; }
-  else { const float sg = dm::dot3(tw, nedge) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = nedge[k] * sg; }
+  if (best < 3) {
+    float ab[3];
+    pick_row(ab, axA, best);
+    const float sg = pick3v(t, best) >= 0.f ? 1.f : -1.f;
+    for (int k = 0; k < 3; k++) n[k] = ab[k] * sg;
+  } else if (best < 6) {
+    float bb[3];
+    pick_row(bb, axB, best - 3);
+    const float sg = dm::dot3(tw, bb) >= 0.f ? 1.f : -1.f;
+    for (int k = 0; k < 3; k++) n[k] = bb[k] * sg;
+  } else { const float sg = dm::dot3(tw, nedge) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = nedge[k] * sg; }
   make_frame(fr, n);
   if (sbest > 0.01f) {                    // clearly apart
     dist = sub == 0 ? sbest : 1.f;
@@ -204,64 +259,84 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
   if (best >= 6) {                        // edge - edge: closest points of the two supporting edges
     const int i = (best - 6) / 3, j = (best - 6) - 3 * i;
     float pa[3] = {A.c[0], A.c[1], A.c[2]}, pb[3] = {B.c[0], B.c[1], B.c[2]};
+    DIAL_UNROLL_FULL
     for (int k = 0; k < 3; k++) {
       if (k != i) { const float sk = dm::dot3(n, axA[k]) >= 0.f ? A.h[k] : -A.h[k]; for (int q = 0; q < 3; q++) pa[q] += sk * axA[k][q]; }
       if (k != j) { const float sk = dm::dot3(n, axB[k]) >= 0.f ? B.h[k] : -B.h[k]; for (int q = 0; q < 3; q++) pb[q] -= sk * axB[k][q]; }
     }
+    float ai[3], bj[3];
+    pick_row(ai, axA, i);
+    pick_row(bj, axB, j);
+    const float ahi = pick3v(A.h, i), bhj = pick3v(B.h, j);
     const float wv[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-    const float uu = dm::dot3(axA[i], axB[j]), q1 = dm::dot3(axA[i], wv), q2 = -dm::dot3(axB[j], wv), den = 1.f - uu * uu;
-    const float al = dm::clip((q1 + uu * q2) / den, -A.h[i], A.h[i]), be = dm::clip((uu * q1 + q2) / den, -B.h[j], B.h[j]);
+    const float uu = dm::dot3(ai, bj), q1 = dm::dot3(ai, wv), q2 = -dm::dot3(bj, wv), den = 1.f - uu * uu;
+    const float al = dm::clip((q1 + uu * q2) / den, -ahi, ahi), be = dm::clip((uu * q1 + q2) / den, -bhj, bhj);
     float gap = 0.f;
     for (int k = 0; k < 3; k++) {
-      const float ca = pa[k] + al * axA[i][k], cb = pb[k] + be * axB[j][k];
+      const float ca = pa[k] + al * ai[k], cb = pb[k] + be * bj[k];
       gap += (cb - ca) * n[k];
       pos[k] = 0.5f * (ca + cb);
     }
     dist = sub == 0 ? gap : 1.f;
     return;
   }
-  // face contact: reference box X (face axis kx, outward normal nref towards Y), incident box Y
+  // face contact: reference box X (face axis kx, outward normal nref towards Y), incident box Y -- copies selected value by
+  // value (a pointer to one of two private arrays would make both of them memory objects)
   const bool a_ref = best < 3;
-  const BoxG& X = a_ref ? A : B;
-  const BoxG& Y = a_ref ? B : A;
-  const float (*aX)[3] = a_ref ? axA : axB;
-  const float (*aY)[3] = a_ref ? axB : axA;
+  float aX[3][3], aY[3][3], Xh[3], Yh[3], Xc[3], Yc[3];
+  DIAL_UNROLL_FULL
+  for (int r = 0; r < 3; r++) {
+    Xh[r] = a_ref ? A.h[r] : B.h[r]; Yh[r] = a_ref ? B.h[r] : A.h[r];
+    Xc[r] = a_ref ? A.c[r] : B.c[r]; Yc[r] = a_ref ? B.c[r] : A.c[r];
+    DIAL_UNROLL_FULL
+    for (int c = 0; c < 3; c++) { aX[r][c] = a_ref ? axA[r][c] : axB[r][c]; aY[r][c] = a_ref ? axB[r][c] : axA[r][c]; }
+  }
   const int kx = a_ref ? best : best - 3, ux = (kx + 1) % 3, vx = (kx + 2) % 3;
   float nref[3];
   for (int k = 0; k < 3; k++) nref[k] = a_ref ? n[k] : -n[k];
   int my = 0;
   float amax = -1.f;
+  DIAL_UNROLL_FULL
   for (int k = 0; k < 3; k++) { const float a = dm::absf(dm::dot3(nref, aY[k])); if (a > amax) { amax = a; my = k; } }
   const int uy = (my + 1) % 3, vy = (my + 2) % 3;
-  const float sgy = dm::dot3(nref, aY[my]) >= 0.f ? -Y.h[my] : Y.h[my];   // the incident face looks back at X
+  float aXu[3], aXv[3], aYm[3], aYu[3], aYv[3];
+  pick_row(aXu, aX, ux); pick_row(aXv, aX, vx);
+  pick_row(aYm, aY, my); pick_row(aYu, aY, uy); pick_row(aYv, aY, vy);
+  const float Xhk = pick3v(Xh, kx), Xhu = pick3v(Xh, ux), Xhv = pick3v(Xh, vx);
+  const float Yhm = pick3v(Yh, my), Yhu = pick3v(Yh, uy), Yhv = pick3v(Yh, vy);
+  const float sgy = dm::dot3(nref, aYm) >= 0.f ? -Yhm : Yhm;   // the incident face looks back at X
   // incident face in reference-face coordinates (a, b) and signed distance d to the reference face
   float fc[3], cu[3], cv[3];   // face centre, half edges
   {
     float cw[3];
-    for (int k = 0; k < 3; k++) cw[k] = Y.c[k] + sgy * aY[my][k] - X.c[k];
-    fc[0] = dm::dot3(cw, aX[ux]); fc[1] = dm::dot3(cw, aX[vx]); fc[2] = dm::dot3(cw, nref) - X.h[kx];
-    cu[0] = Y.h[uy] * dm::dot3(aY[uy], aX[ux]); cu[1] = Y.h[uy] * dm::dot3(aY[uy], aX[vx]); cu[2] = Y.h[uy] * dm::dot3(aY[uy], nref);
-    cv[0] = Y.h[vy] * dm::dot3(aY[vy], aX[ux]); cv[1] = Y.h[vy] * dm::dot3(aY[vy], aX[vx]); cv[2] = Y.h[vy] * dm::dot3(aY[vy], nref);
+    for (int k = 0; k < 3; k++) cw[k] = Yc[k] + sgy * aYm[k] - Xc[k];
+    fc[0] = dm::dot3(cw, aXu); fc[1] = dm::dot3(cw, aXv); fc[2] = dm::dot3(cw, nref) - Xhk;
+    cu[0] = Yhu * dm::dot3(aYu, aXu); cu[1] = Yhu * dm::dot3(aYu, aXv); cu[2] = Yhu * dm::dot3(aYu, nref);
+    cv[0] = Yhv * dm::dot3(aYv, aXu); cv[1] = Yhv * dm::dot3(aYv, aXv); cv[2] = Yhv * dm::dot3(aYv, nref);
   }
-  float pa_[10][3], pb_[10][3];
+  // the two polygons of the clipping passes, 10 vertices x 3 each, in the lane's slice of LDS (run-time length, run-time index)
+  float* const pa_ = poly;
+  float* const pb_ = poly + 30;
   int np_ = 4;
   for (int k = 0; k < 3; k++) {
-    pa_[0][k] = fc[k] + cu[k] + cv[k]; pa_[1][k] = fc[k] - cu[k] + cv[k];
-    pa_[2][k] = fc[k] - cu[k] - cv[k]; pa_[3][k] = fc[k] + cu[k] - cv[k];
+    pa_[0 + k] = fc[k] + cu[k] + cv[k]; pa_[3 + k] = fc[k] - cu[k] + cv[k];
+    pa_[6 + k] = fc[k] - cu[k] - cv[k]; pa_[9 + k] = fc[k] + cu[k] - cv[k];
   }
   for (int pl = 0; pl < 4 && np_ > 0; pl++) {   // clip against a <= hu, -a <= hu, b <= hv, -b <= hv
     const int co = pl >> 1;
-    const float sg = (pl & 1) ? -1.f : 1.f, lim = co == 0 ? X.h[ux] : X.h[vx];
-    float (*src)[3] = (pl & 1) ? pb_ : pa_;
-    float (*dst)[3] = (pl & 1) ? pa_ : pb_;
+    const float sg = (pl & 1) ? -1.f : 1.f, lim = co == 0 ? Xhu : Xhv;
+    const float* src = (pl & 1) ? pb_ : pa_;
+    float* dst = (pl & 1) ? pa_ : pb_;
     int no = 0;
     for (int q = 0; q < np_; q++) {
       const int q2 = q + 1 < np_ ? q + 1 : 0;
-      const float fp = sg * src[q][co] - lim, fq = sg * src[q2][co] - lim;
-      if (fp <= 0.f) { for (int k = 0; k < 3; k++) dst[no][k] = src[q][k]; no++; }
+      const float sq0 = src[3 * q], sq1 = src[3 * q + 1], sq2 = src[3 * q + 2];
+      const float sr0 = src[3 * q2], sr1 = src[3 * q2 + 1], sr2 = src[3 * q2 + 2];
+      const float fp = sg * (co == 0 ? sq0 : sq1) - lim, fq = sg * (co == 0 ? sr0 : sr1) - lim;
+      if (fp <= 0.f) { dst[3 * no] = sq0; dst[3 * no + 1] = sq1; dst[3 * no + 2] = sq2; no++; }
       if ((fp <= 0.f) != (fq <= 0.f)) {
         const float wgt = fp / (fp - fq);
-        for (int k = 0; k < 3; k++) dst[no][k] = src[q][k] + wgt * (src[q2][k] - src[q][k]);
+        dst[3 * no] = sq0 + wgt * (sr0 - sq0); dst[3 * no + 1] = sq1 + wgt * (sr1 - sq1); dst[3 * no + 2] = sq2 + wgt * (sr2 - sq2);
         no++;
       }
     }
@@ -271,12 +346,14 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
   int pick = -1;
   for (int q = 0; q < np_; q++) {
     int rank = 0;
-    for (int o = 0; o < np_; o++) rank += (pa_[o][2] < pa_[q][2] || (pa_[o][2] == pa_[q][2] && o < q)) ? 1 : 0;
+    const float zq = pa_[3 * q + 2];
+    for (int o = 0; o < np_; o++) { const float zo = pa_[3 * o + 2]; rank += (zo < zq || (zo == zq && o < q)) ? 1 : 0; }
     pick = rank == sub ? q : pick;
   }
   if (pick < 0) { dist = 1.f; for (int k = 0; k < 3; k++) pos[k] = mid[k]; return; }
-  dist = pa_[pick][2];
-  for (int k = 0; k < 3; k++) pos[k] = X.c[k] + pa_[pick][0] * aX[ux][k] + pa_[pick][1] * aX[vx][k] + (X.h[kx] + pa_[pick][2] * 0.5f) * nref[k];
+  const float pk0 = pa_[3 * pick], pk1 = pa_[3 * pick + 1], pk2 = pa_[3 * pick + 2];
+  dist = pk2;
+  for (int k = 0; k < 3; k++) pos[k] = Xc[k] + pk0 * aXu[k] + pk1 * aXv[k] + (Xhk + pk2 * 0.5f) * nref[k];
 }
 
 }  // namespace dial

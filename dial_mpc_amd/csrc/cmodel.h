@@ -52,11 +52,20 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
 // ELL: elliptic friction cones (condim rows per contact, NE = NE_ELL_ rows in total): the contact Jacobian is stored
 // compactly (per contact only the dofs that move its two bodies, JCW_ words in total) and the Newton solver is
 // solver_cone.h instead of solver_reg.h; H couples all dofs, so it is factorised with the dense elimination order.
+// GEN: the GENERIC FEATURE SET -- any pyramidal model within the capacities: run-time contact compaction (the constraint
+// section works on the contacts that touch), the LDS Newton solver with a dense register L D L^T, box narrow phases, dry-friction
+// rows, the crate tasks, a capped LDS workspace with an overflow area.  Independent of STATIC (compile-time dimensions,
+// constants staged in LDS): DimsMax is generic at run-time dimensions with its constants in global memory; DimsGo2Crate /
+// DimsH1PushCrate (round 4) are the crate scenes' own instantiations -- generic features, compile-time dimensions, constants in
+// LDS shared by the nine wavefronts of a workgroup.
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
-          class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2, bool ELL_ = false, int NE_ELL_ = 0, int JCW_ = 4>
+          class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2, bool ELL_ = false, int NE_ELL_ = 0, int JCW_ = 4,
+          bool GEN_ = !STATIC>
 struct Dims {
   using Topo = Topo_;
   static constexpr bool is_static = STATIC;
+  static constexpr bool gen = GEN_;
+  static constexpr int NVP = STATIC ? NV_ : DIAL_MAX_V;   // dimension of the generic solver's dense register L D L^T
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr bool ell = ELL_;
   static constexpr int NE = ELL_ ? NE_ELL_ : NL_ + 4 * NC_;
@@ -81,6 +90,9 @@ using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;
 using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true, 192>;
 // Allegro: 19 contacts (14 x condim 3 + 5 x condim 6 = 72 rows) + 16 limits; compact Jacobian 8x3x4 + 6x3x8 + 6x6 + 4x6x10
 using DimsAllegro = Dims<true, 23, 22, 16, 23, 17, 6, 0, 19, 16, TopoAllegro, true, 64, true, 88, 516>;
+// the crate scenes: Go2 + floor + welded crate (52 candidate contacts), H1 + crate on a slide joint (28)
+using DimsGo2Crate = Dims<true, 19, 18, 12, 15, 13, 17, 5, 52, 12, TopoDense, false, 2, false, 0, 4, true>;
+using DimsH1PushCrate = Dims<true, 27, 26, 19, 22, 21, 9, 3, 28, 19, TopoDense, false, 2, false, 0, 4, true>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -101,11 +113,12 @@ void static_for(F&& f) {
 
 // What only the generic instantiation carries (box narrow phases and the crate task: include/dial_mpc.h).  An EMPTY base for
 // the dimension-specialised instantiations: their constants live in LDS, which is on the residency edge.
-template <class D, bool GENERIC = !D::is_static>
+template <class D, bool GENERIC = D::gen>
 struct CModelGeneric {};
 template <class D>
 struct CModelGeneric<D, true> {
   int32_t con_sub[D::NC];
+  int32_t con_bbslot[D::NC];   // box-box candidates: which lane-private slice of the polygon scratch (box_collide.h: box_box)
   int32_t crate_contact[DIAL_MAX_FEET];
   float crate_region[6], head_vec[3];
   // dry friction (joint frictionloss): rows [nlim, nlim + nfri) of the constraint list, and the push-crate task's contacts
@@ -214,7 +227,7 @@ CM_DIM(dim_ntri, NTRI, ntri)
 // dofs with dry friction: the generic instantiation only (the dimension-specialised robots have none)
 template <class M>
 CM_HD constexpr int dim_nf(const M* m) {
-  if constexpr (M::D::is_static) return 0;
+  if constexpr (!M::D::gen) return 0;
   else return m->nfri;
 }
 
@@ -223,7 +236,7 @@ template <class D>
 static inline bool dims_match(const dial_model* m) {
   bool ok = m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
             m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL &&
-            m->nfri == 0;   // (dry friction rows exist in the generic instantiation only)
+            (D::gen || m->nfri == 0);   // (dry friction rows exist in the generic feature set only)
   if constexpr (!D::Topo::dense) {   // the sparse factorisations are specialised to the dof tree as well
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }

@@ -302,8 +302,12 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 2; k++) o.con_solref[cidx][k] = m->con_solref[cidx][k];
   }
   o.cone = m->cone; o.eulerdamp = m->eulerdamp;
-  if constexpr (!D::is_static) {
-    for (int cidx = 0; cidx < m->ncon; cidx++) o.con_sub[cidx] = m->con_sub[cidx];
+  if constexpr (D::gen) {
+    int nbb = 0;
+    for (int cidx = 0; cidx < m->ncon; cidx++) {
+      o.con_sub[cidx] = m->con_sub[cidx];
+      o.con_bbslot[cidx] = m->con_kind[cidx] == DIAL_CON_BOX_BOX ? nbb++ : 0;
+    }
     for (int f = 0; f < DIAL_MAX_FEET; f++) o.crate_contact[f] = t->crate_contact[f];
     for (int k = 0; k < 6; k++) o.crate_region[k] = t->crate_region[k];
     for (int k = 0; k < 3; k++) o.head_vec[k] = t->head_vec[k];
@@ -407,8 +411,10 @@ WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 // `con_cap` (generic pyramidal layout only, 0 = off): size the contact Jacobian and the per-row arrays for that many TOUCHING
 // contacts instead of all ncon candidates (crate scene: 52 candidates, 4-8 touch; 31.6 KB -> 17.4 KB per wavefront at a cap of
 // 14, i.e. 9 instead of 5 wavefronts per CU); a sample that touches with more runs on ws_overflow's arrays.
+// `sq_n`: dimension of the generic solver's dense square `sq` (Dims::NVP).
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
-                   int ncon_all, int nefc_all, int nnode, bool with_L, bool square = false, int ell_jcw = 0, int con_cap = 0) {
+                   int ncon_all, int nefc_all, int nnode, bool with_L, bool square = false, int ell_jcw = 0, int con_cap = 0,
+                   int sq_n = DIAL_MAX_V) {
   int o = 0;
   const bool capped = con_cap > 0 && con_cap < ncon_all && !square && ell_jcw == 0;
   const int ncon = ncon_all;                                            // arrays indexed by the model's contact index
@@ -460,7 +466,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
 #else
   WS_TAKE(L, 0)                   // (the register L D L^T keeps its factor in VGPRs and the square `sq`)
 #endif
-  WS_TAKE(sq, with_L ? DIAL_MAX_V * ((DIAL_MAX_V + 3) & ~3) : 0)
+  WS_TAKE(sq, with_L ? sq_n * ((sq_n + 3) & ~3) : 0)
   o = o > u1 ? o : u1;
   WS_TAKE(Y, nnode * nu)   // last: its size is the only run-time quantity, every other offset is a constant
 #undef WS_TAKE

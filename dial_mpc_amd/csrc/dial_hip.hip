@@ -20,152 +20,25 @@
 #include <string>
 #include <vector>
 
-#include "rollout_driver.h"
+#include "kernel_list.h"
+
+// the kernels are compiled in their own translation units, one per robot family (kern_family.hip, built in parallel)
+#define DIAL_X(D, WPB, OCC, Q, TR) \
+  extern template __global__ void rollout_kernel<D, WPB, OCC, Q, TR>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
+#define DIAL_XE(D)                                                                                                              \
+  extern template __global__ void env_step_kernel<D>(const CModel<D>*, const dial_task*, float*, const float*, float*, float*, float*); \
+  extern template __global__ void env_reset_kernel<D>(const CModel<D>*, const float*, const float*, float*, float*, float*);
+DIAL_KERNELS_ALL(DIAL_X, DIAL_XE)
+#undef DIAL_X
+#undef DIAL_XE
 
 #define WSUM_CHUNKS 64
 
-// wavefronts per workgroup (they share one staged copy of the constants) / occupancy target of the Go2 instantiations:
-// small batches (every sample co-resident at 1 wavefront per workgroup) and large ones (LDS per wavefront matters)
-#ifndef DIAL_GO2_WPB_LARGE
-#define DIAL_GO2_WPB_LARGE 4
-#endif
-#ifndef DIAL_GO2_OCC_LARGE
-#define DIAL_GO2_OCC_LARGE 3
-#endif
-// Allegro: 15.3 KB of workspace per wavefront + 10.5 KB of shared constants.  9 wavefronts per workgroup = 148 KB = one
-// workgroup per CU = 2304 resident rollouts: the example's N + 1 = 2049 run in ONE round (8 per CU would leave the
-// 2049th rollout for a second round and double the launch time), BASELINE config 4 (4097) in two instead of three.
-#ifndef DIAL_ALLEGRO_WPB
-#define DIAL_ALLEGRO_WPB 9
-#endif
-// ... except when the batch is exactly N + 1 = 8 x CUs + 1: then 8 wavefronts per workgroup (one workgroup per CU, every CU
-// equally loaded) and the mean-trajectory rollout as a one-wavefront workgroup of its own (26.6 KB: fits beside a 133 KB
-// workgroup), launched on a side stream so that it runs concurrently
-#define DIAL_ALLEGRO_WPB_EVEN 8
-// H1: same idea with 4-wavefront workgroups (one wavefront per SIMD), two per CU: 1.012 -> 0.971 ms.  (H1 loco's
-// two-wavefront workgroups already load every CU with 8 wavefronts; the split measured 0.7 % slower there.)
-#define DIAL_H1_WPB_EVEN 4
-// The even launch keeps exactly 2 wavefronts on every SIMD.  Allegro's 8-wavefront kernel is compiled for that occupancy
-// (-3.3 % in the A/B, 7.70 -> 7.45 ms: the scheduler orders for latency at the lower occupancy target; the kernel still uses
-// 150 VGPRs, so the one-wavefront mean-trajectory workgroup finds room beside two of its wavefronts).  H1's must stay at the 3-wavefront budget: at 2 its registers leave no SIMD for the mean-trajectory workgroup, which
-// then runs AFTER the even launch (+50 %).
-#ifndef DIAL_EVEN_OCC_ALLEGRO
-#define DIAL_EVEN_OCC_ALLEGRO 2
-#endif
-#define DIAL_EVEN_OCC_H1 3
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
 
-// ------------------------------------------------------------------ kernels
-// Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
-// WPB wavefronts (= samples) per workgroup share ONE staged copy of the constants; each wavefront has
-// its own workspace.  WPB is chosen per robot so that N+1 = 2049 wavefronts are co-resident (>= 9 per CU):
-// Go2 1 (16 KB/wave), H1 3 (10 KB constants + 3 x 13.7 KB: 3 workgroups = 9 wavefronts per CU), H1 loco 2, generic 1.
-// This is the only workgroup-level barrier of the kernel (phase boundaries are
-// wavefront-scope fences, wave.h).
-template <class D, int WPB = 1>
-__device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
-                                                        int ws_words, int con_cap = 0) {
-  const CModel<D>* m = gm;
-  float* wsbase = smem;
-  if constexpr (D::is_static) {
-    constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspace 16-B aligned
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
-    __syncthreads();
-    m = reinterpret_cast<const CModel<D>*>(smem);
-    wsbase = smem + CMW;
-  }
-  // WPB == 1: LDS addresses stay immediates.  WPB > 1: the wavefront's workspace offset is made a scalar (it is
-  // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
-  if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
-  ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, D::is_static ? 0 : con_cap);
-  return m;
-}
-
-// OCC: minimum resident wavefronts per SIMD the register allocation must allow (3: <= 168 VGPRs, 4: <= 128)
-// QUEUE: the rollout-queue variant (see the loop below); the one-rollout-per-wavefront variant keeps nothing live across
-// rollouts (the loop costs the headline kernel 6 spilled VGPRs, H1 21)
-template <class D, int WPB, int OCC = 3, bool QUEUE = false>
-__global__ void __launch_bounds__(64 * WPB, OCC)
-rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
-               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  Ws s;
-  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap);
-  if constexpr (!D::is_static)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
-    s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
-  int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
-  int relay = -1;
-  if constexpr (WPB == 1 && !QUEUE) {
-    if (io.relay_flag && (int)blockIdx.x >= io.relay_base) { relay = (int)blockIdx.x - io.relay_base; n = B - 1; }
-  }
-  if (n >= B) return;
-  Wave w;
-  w.lane = threadIdx.x & 63;
-  w.lane_r = w.lane;
-#ifdef DIAL_PROFILE
-  w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
-  if (w.lane < 32) w.acc[w.lane] = 0;
-  __syncthreads();
-#endif
-#ifdef DIAL_PROFILE
-  unsigned long long t_start = wall_clock64();
-#endif
-  // `next` == nullptr: the grid covers the batch, one rollout per wavefront.  Otherwise the grid is exactly what the chip
-  // keeps resident and every wavefront draws its next rollout from the queue head when it finishes one: rollouts differ
-  // in length (solver iterations), and a workgroup's LDS is only handed to a new workgroup when its slowest wavefront
-  // is done -- the queue keeps every wavefront slot busy until the batch is empty
-  for (;;) {
-    dial::rollout_sample(w, m, tg, cfg, s, io, n, relay);
-#ifdef DIAL_PROFILE
-    if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
-      unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
-      p[0] = t_start; p[1] = wall_clock64(); p[2] = w.acc[27]; p[3] = w.acc[28]; p[4] = w.acc[30]; p[5] = w.acc[31];
-      for (int k = 27; k < 32; k++) w.acc[k] = 0;
-    }
-#endif
-    if constexpr (!QUEUE) break;
-    if (!next) break;
-    int nn = 0;
-    if (w.lane == 0) nn = atomicAdd(next, 1);
-    n = __builtin_amdgcn_readfirstlane(nn);
-    if (n >= B) break;
-#ifdef DIAL_PROFILE
-    t_start = wall_clock64();
-#endif
-  }
-}
-
-template <class D>
-__global__ void __launch_bounds__(64)
-env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg, float* state,
-                const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  Ws s;
-  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
-  Wave w;
-  w.lane = threadIdx.x;
-  w.lane_r = w.lane;
-  dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
-}
-
-template <class D>
-__global__ void __launch_bounds__(64)
-env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const float* qvel, float* state,
-                 float* xpos_out, float* xquat_out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  Ws s;
-  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
-  Wave w;
-  w.lane = threadIdx.x;
-  w.lane_r = w.lane;
-  dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
-}
-
+// ------------------------------------------------------------------ kernels (rollout / env.step / env.reset: rollout_kernel.h)
 // Deterministic block reductions (1024 threads = 16 wavefronts): DPP butterfly inside each wavefront, then a
 // fixed-order sum of the 16 partials.  The order never depends on timing => bit-identical on every rank.
 #define WK_THREADS 1024
@@ -360,7 +233,7 @@ struct dial_ctx {
   dial_cfg hc;
   dial_derived hd;
   bool has_cfg = false;
-  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1, 3 H1 loco, 4 Allegro (elliptic cones)
+  int inst = 0;               // 0 generic (DimsMax), 1 Go2, 2 H1, 3 H1 loco, 4 Allegro (elliptic cones), 5 Go2 crate climb, 6 H1 push crate
   void* dcm = nullptr;        // CModel<D> of the chosen instantiation (device)
   dial_task* dtask = nullptr;
   dial_cfg* dcfg = nullptr;
@@ -485,6 +358,13 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
   }
   if (model->nfri < 0 || model->nfri > DIAL_MAX_FRI || (model->nfri > 0 && model->cone != DIAL_CONE_PYRAMIDAL))
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: dry friction (frictionloss) is supported for pyramidal models with <= DIAL_MAX_FRI such dofs");
+  {   // box-box candidates keep their clipping polygons in LDS, in slices of the dead velocity temporaries cdofdot | cacc | cfl
+      // (box_collide.h: box_box, rollout_body.h: forward; 6 nv + 12 nbody words, derived.h: ws_carve)
+    int nbb = 0;
+    for (int c = 0; c < model->ncon; c++) nbb += model->con_kind[c] == DIAL_CON_BOX_BOX ? 1 : 0;
+    if (nbb * DIAL_BOX_POLY_WORDS > 6 * model->nv + 12 * model->nbody)
+      return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: too many box-box candidate contacts for the polygon scratch");
+  }
   if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
   if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)
@@ -524,8 +404,9 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       const int nnode = cfg ? cfg->Hnode + 1 : 0;
       const int ws0 = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, 0, dial::kNeedL<D>, D::square,
-                               D::ell ? D::JCW : 0);
-      if constexpr (!D::is_static) {
+                               D::ell ? D::JCW : 0, 0, D::NVP);
+      ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
+      if constexpr (D::gen) {
         // many candidate contacts, few of which touch (crate scene: 52 / 4-8): the rollout kernel's LDS workspace is sized for
         // DIAL_CON_CAP touching contacts, samples beyond run on an overflow area in global memory.  Default 14: for the crate
         // scene that is 17.4 KB per wavefront -- NINE per CU, so that the 2049 rollouts of its example are resident at once
@@ -535,12 +416,21 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
         if (cfg && model->cone == DIAL_CONE_PYRAMIDAL && cap > 0 && model->ncon > cap) {
           // unless the cap was given: the largest one in 16 .. 8 with which NINE wavefronts fit a CU (8 x 256 + 1 rollouts of
           // the examples' N = 2048 resident at once); 14 if none does.  Crate climb: 16 (17.2 KB), push crate: 9 (17.1 KB).
+          // (workgroups of wpb wavefronts that share one staged copy of the constants: 9 / wpb workgroups per CU)
           if (!given) {
+#ifdef DIAL_PROFILE
+            const size_t prof_bytes = 16 + (size_t)ctx->wpb * 32 * sizeof(unsigned long long);
+#else
+            const size_t prof_bytes = 0;
+#endif
+            const size_t budget = ctx->wpb > 1 ? ((size_t)160 * 1024 / (9 / ctx->wpb) - ctx->cm_bytes - prof_bytes) / ctx->wpb / 16 * 16
+                                               : (size_t)(160 * 1024) / 9 / 512 * 512;
             for (int c = 16; c >= 8; c--) {
               Ws st;
               const int wds = ws_carve(st, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt, model->ngeom, model->nsite,
-                                       model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square, 0, c);
-              if ((size_t)wds * sizeof(float) <= (160 * 1024) / 9 / 512 * 512) { cap = c; break; }
+                                       model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square, 0, c, D::NVP);
+              if ((size_t)wds * sizeof(float) <= budget) { cap = c; break; }
+              if (c == 8) cap = 8;   // (nothing fits nine: the smallest cap; dial_create then fails on the LDS check if that is too much)
             }
           }
           ctx->con_cap = cap;
@@ -550,8 +440,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       }
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square,
-                               D::ell ? D::JCW : 0, ctx->con_cap);
-      ctx->cm_bytes = D::is_static ? (int)(((sizeof(CModel<D>) + 15) / 16) * 16) : 0;
+                               D::ell ? D::JCW : 0, ctx->con_cap, D::NVP);
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
 #ifdef DIAL_PROFILE
@@ -575,6 +464,8 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       }
       ctx->inst = 4; ctx->wpb = DIAL_ALLEGRO_WPB; urc = upload(DimsAllegro{});
     }
+    else if (own && dims_match<DimsGo2Crate>(model) && kind_ok(dial::task_kind_mask<DimsGo2Crate>())) { ctx->inst = 5; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsGo2Crate{}); }
+    else if (own && dims_match<DimsH1PushCrate>(model) && kind_ok(dial::task_kind_mask<DimsH1PushCrate>())) { ctx->inst = 6; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsH1PushCrate{}); }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
@@ -589,6 +480,17 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
     if (e == hipSuccess && ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+    if (e == hipSuccess && ctx->inst == 4 && ctx->lds_rollout > 64 * 1024)
+      e = hipFuncSetAttribute((const void*)rollout_kernel<DimsAllegro, DIAL_ALLEGRO_WPB, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout);
+#define DIAL_BIG_LDS(D)                                                                                                                         \
+    if (e == hipSuccess && ctx->lds_rollout > 64 * 1024) {                                                                                     \
+      e = hipFuncSetAttribute((const void*)rollout_kernel<D, DIAL_CRATE_WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rollout_kernel<D, DIAL_CRATE_WPB, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rollout_kernel<D, DIAL_CRATE_WPB, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_rollout); \
+    }
+    if (ctx->inst == 5) { DIAL_BIG_LDS(DimsGo2Crate) }
+    if (ctx->inst == 6) { DIAL_BIG_LDS(DimsH1PushCrate) }
+#undef DIAL_BIG_LDS
     if (e == hipSuccess && ctx->inst == 1 && ctx->lds_large > 64 * 1024)
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -603,6 +505,8 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     else if (ctx->inst == 2) DIAL_RESIDENT(DimsH1, 3);
     else if (ctx->inst == 3) DIAL_RESIDENT(DimsH1Loco, 2);
     else if (ctx->inst == 4) DIAL_RESIDENT(DimsAllegro, DIAL_ALLEGRO_WPB);
+    else if (ctx->inst == 5) DIAL_RESIDENT(DimsGo2Crate, DIAL_CRATE_WPB);
+    else if (ctx->inst == 6) DIAL_RESIDENT(DimsH1PushCrate, DIAL_CRATE_WPB);
     else DIAL_RESIDENT(DimsMax, 1);
 #undef DIAL_RESIDENT
     ctx->n_simd = 4 * prop.multiProcessorCount;
@@ -662,7 +566,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     ctx->W_cap = cfg->Nsample + 1;
     // one overflow area per wavefront slot of the LARGEST grid this context launches: B_cap rollouts, or B_cap - 1 noisy
     // ones + the relay pieces of the mean trajectory (at most Hsample + 1 of them) -- launch_rollout checks the grid
-    ctx->ovf_slots = ctx->B_cap + cfg->Hsample + 1;
+    ctx->ovf_slots = ctx->B_cap + (cfg->Hsample + 1 > 16 ? cfg->Hsample + 1 : 16);   // (and a last workgroup of up to 9 wavefronts)
     if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->ovf_slots * ctx->ovf_words * sizeof(float)));
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
@@ -751,7 +655,8 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   }
   // batches beyond what the chip keeps resident: launch exactly the resident grid and let the wavefronts draw the
   // remaining rollouts from a queue (see rollout_kernel); the queue head starts behind the grid's own first rollouts
-  const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B;
+  const bool tracing = ctx->trace != nullptr;   // diagnostics: the TRACE instantiation on the plain grid (no queue / split / large-batch variant)
+  const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B && !tracing;
   const int wpb = large ? DIAL_GO2_WPB_LARGE : ctx->wpb;
   const int resident = large ? ctx->resident_blocks_large : ctx->resident_blocks;
   // mean-trajectory relay (one wavefront per workgroup, the launch's last rollout is the mean trajectory, everything is
@@ -776,7 +681,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   int blocks = io.relay_flag ? io.relay_base + (ctx->T + io.relay_steps - 1) / io.relay_steps : (B + wpb - 1) / wpb;
   int* next = nullptr;
   const bool has_queue_variant = large || ctx->inst != 1;   // Go2's small-batch kernel never exceeds the resident set (B <= DIAL_GO2_LARGE_B)
-  if (has_queue_variant && resident > 0 && blocks > resident && ctx->next) {
+  if (has_queue_variant && resident > 0 && blocks > resident && ctx->next && !tracing) {
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
@@ -790,7 +695,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // Batch = 8 x CUs + 1 (N = 2048 on 256 CUs) with multi-wavefront workgroups: the N noisy rollouts as evenly sized
   // workgroups that load every CU with 8 wavefronts (Allegro: one workgroup of 8, H1: two of 4, one wavefront per SIMD
   // each), the mean trajectory as a one-wavefront workgroup launched on the side stream (fork / join by events)
-  if (ctx->split_ok && !next && !io.us && io.n_noise == B - 1 && (B - 1) == 8 * (ctx->n_simd / 4)) {
+  if (ctx->split_ok && !tracing && !next && !io.us && io.n_noise == B - 1 && (B - 1) == 8 * (ctx->n_simd / 4)) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     dial::RolloutIO io1 = io;
@@ -820,6 +725,19 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     if (next) DIAL_LAUNCH_ROLLOUT_Q(D, WPB, true);                         \
     else DIAL_LAUNCH_ROLLOUT_Q(D, WPB, false);                             \
   } while (0)
+#define DIAL_LAUNCH_TRACE(D, WPB)                                                                           \
+  hipLaunchKernelGGL((rollout_kernel<D, WPB, 3, false, true>), dim3(blocks), dim3(64 * WPB), ctx->lds_rollout, \
+                     st, (const CModel<D>*)ctx->dcm, (const dial_task*)ctx->dtask,                          \
+                     (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, (int*)nullptr)
+  if (tracing) {
+    if (ctx->inst == 1) DIAL_LAUNCH_TRACE(DimsGo2, 1);
+    else if (ctx->inst == 2) DIAL_LAUNCH_TRACE(DimsH1, 3);
+    else if (ctx->inst == 3) DIAL_LAUNCH_TRACE(DimsH1Loco, 2);
+    else if (ctx->inst == 4) DIAL_LAUNCH_TRACE(DimsAllegro, DIAL_ALLEGRO_WPB);
+    else if (ctx->inst == 5) DIAL_LAUNCH_TRACE(DimsGo2Crate, DIAL_CRATE_WPB);
+    else if (ctx->inst == 6) DIAL_LAUNCH_TRACE(DimsH1PushCrate, DIAL_CRATE_WPB);
+    else DIAL_LAUNCH_TRACE(DimsMax, 1);
+  } else
   if (large)
     hipLaunchKernelGGL((rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>), dim3(blocks),
                        dim3(64 * DIAL_GO2_WPB_LARGE), ctx->lds_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask,
@@ -828,9 +746,12 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   else if (ctx->inst == 2) DIAL_LAUNCH_ROLLOUT(DimsH1, 3);
   else if (ctx->inst == 3) DIAL_LAUNCH_ROLLOUT(DimsH1Loco, 2);
   else if (ctx->inst == 4) DIAL_LAUNCH_ROLLOUT(DimsAllegro, DIAL_ALLEGRO_WPB);
+  else if (ctx->inst == 5) DIAL_LAUNCH_ROLLOUT(DimsGo2Crate, DIAL_CRATE_WPB);
+  else if (ctx->inst == 6) DIAL_LAUNCH_ROLLOUT(DimsH1PushCrate, DIAL_CRATE_WPB);
   else DIAL_LAUNCH_ROLLOUT(DimsMax, 1);
 #undef DIAL_LAUNCH_ROLLOUT
 #undef DIAL_LAUNCH_ROLLOUT_Q
+#undef DIAL_LAUNCH_TRACE
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
   return DIAL_OK;
@@ -1027,6 +948,8 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
   else if (ctx->inst == 2) DIAL_LAUNCH_STEP(DimsH1);
   else if (ctx->inst == 3) DIAL_LAUNCH_STEP(DimsH1Loco);
   else if (ctx->inst == 4) DIAL_LAUNCH_STEP(DimsAllegro);
+  else if (ctx->inst == 5) DIAL_LAUNCH_STEP(DimsGo2Crate);
+  else if (ctx->inst == 6) DIAL_LAUNCH_STEP(DimsH1PushCrate);
   else DIAL_LAUNCH_STEP(DimsMax);
 #undef DIAL_LAUNCH_STEP
   HIP_TRY(ctx, hipGetLastError());
@@ -1044,6 +967,8 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
   else if (ctx->inst == 2) DIAL_LAUNCH_RESET(DimsH1);
   else if (ctx->inst == 3) DIAL_LAUNCH_RESET(DimsH1Loco);
   else if (ctx->inst == 4) DIAL_LAUNCH_RESET(DimsAllegro);
+  else if (ctx->inst == 5) DIAL_LAUNCH_RESET(DimsGo2Crate);
+  else if (ctx->inst == 6) DIAL_LAUNCH_RESET(DimsH1PushCrate);
   else DIAL_LAUNCH_RESET(DimsMax);
 #undef DIAL_LAUNCH_RESET
   HIP_TRY(ctx, hipGetLastError());

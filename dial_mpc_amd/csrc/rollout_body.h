@@ -29,7 +29,7 @@ namespace dial {
 // Does the instantiation keep a Cholesky factor in LDS (LDS solver path)?  The dimension-specialised
 // instantiations factor in registers instead.
 template <class D>
-inline constexpr bool kNeedL = !D::is_static;
+inline constexpr bool kNeedL = D::gen;
 
 // ---------------------------------------------------------------- constraint rows (implicit J)
 // Row r < nlim is a joint-limit row (J = lsign * e_dof); the other rows are pyramid edges of contact
@@ -42,7 +42,7 @@ inline constexpr bool kNeedL = !D::is_static;
 struct RowRef { int is_lim, dof, c, tan; float f; };
 template <class M>
 DIAL_DEV int con_of(const M*, const Ws& s, int c) {   // model contact of compact contact c
-  if constexpr (M::D::is_static) return c;
+  if constexpr (!M::D::gen) return c;
   else return (int)s.clist[c];
 }
 template <class M>
@@ -51,7 +51,7 @@ DIAL_DEV RowRef row_ref(const M* m, const Ws& s, int r) {
   const int nl = dim_nl(m), nlf = nl + dim_nf(m);   // rows: limits | dry friction | 4 pyramid edges per contact
   rr.is_lim = r < nlf;
   if (rr.is_lim) {
-    if constexpr (M::D::is_static) rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
+    if constexpr (!M::D::gen) rr.dof = m->jnt_dofadr[m->lim_jnt[r]];
     else rr.dof = r < nl ? m->jnt_dofadr[m->lim_jnt[r]] : m->fri_dof[r - nl];   // (a friction row is J = +e_dof: lsign = 1)
     rr.c = 0; rr.tan = 0; rr.f = 0.f;
   } else {
@@ -82,7 +82,7 @@ DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f, int nca) {
   float acc = 0.f;
   int lr = m->dof_limrow[i];
   if (lr >= 0) acc += s.lsign[lr] * f[lr];
-  if constexpr (!M::D::is_static) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += f[fr]; }
+  if constexpr (M::D::gen) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += f[fr]; }
   for (int c = 0; c < nca; c++) {
     float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
     const int co = con_of(m, s, c);
@@ -221,14 +221,15 @@ namespace dial {
 // solver_reg.h, instantiated ONCE for the capacity dimension (DIAL_MAX_V, dense elimination order): A is copied into a
 // square with an identity block for the dofs the model does not have.  The LDS Cholesky above (one phase per column,
 // ~35 k cycles for 18 dofs) stays as the reference implementation the emulator tests compare against (-DDIAL_LDS_CHOL).
+template <int NP_>
 struct DimsPadV {
-  static constexpr int NV = DIAL_MAX_V;
+  static constexpr int NV = NP_;
   static constexpr bool square = true;
   using Topo = TopoDense;
 };
 template <class W, class M>
 DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const float* rhs, float* x) {
-  constexpr int NP = DIAL_MAX_V, S = kCholStride<NP>;
+  constexpr int NP = M::D::NVP, S = kCholStride<NP>;   // the capacity dimension, or the model's own (compile-time dimensions)
   const int nv = dim_nv(m);
   w.items(NP * S, [&](int e) {
     const int i = e / S, j = e - i * S;
@@ -237,7 +238,7 @@ DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const
     s.sq[e] = v;
   });
   const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
-  const vfloat xv = reg_chol_solve_v<DimsPadV, TopoDense>(w, m, s.sq, b, s.sq);
+  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoDense>(w, m, s.sq, b, s.sq);
   w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
 }
 
@@ -252,7 +253,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // active for j < 0; a dry-friction row (solver._update_constraint) is quadratic while |D j| < frictionloss, i.e. |j| < rf = R f,
   // and beyond that exerts -+f with the cost f (-0.5 rf -+ j)
   const auto row_floss = [&](int r) -> float {
-    if constexpr (M::D::is_static) return 0.f;
+    if constexpr (!M::D::gen) return 0.f;
     else return (r >= nl && r < nlf) ? m->fri_loss[r - nl] : 0.f;
   };
   const auto row_cost2 = [&](int r, float j) -> float {
@@ -404,7 +405,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       s.aref[r] = -b_ * vel - k_ * imp * pos;
       s.D[r] = 1.f / R;
     } else if (r < nlf) {
-      if constexpr (!M::D::is_static) {   // constraint._instantiate_friction: J = e_dof, pos = 0, aref = -b qvel
+      if constexpr (M::D::gen) {   // constraint._instantiate_friction: J = e_dof, pos = 0, aref = -b qvel
         const int q = r - nl, da = m->fri_dof[q];
         s.lsign[r] = 1.f;
         float k_, b_, imp;
@@ -439,7 +440,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
-  if constexpr (M::D::is_static) {
+  if constexpr (!M::D::gen) {
     const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
@@ -457,7 +458,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   if constexpr (M::D::ell) {
     solver_cone(w, m, s);  // elliptic cones: per-contact Newton solver (solver_cone.h)
     return;
-  } else if constexpr (M::D::is_static) {
+  } else if constexpr (!M::D::gen) {
     solver_reg(w, m, s);   // register-resident Newton solver (solver_reg.h)
     return;
   }
@@ -532,7 +533,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       if (i == j) {
         int lr = m->dof_limrow[i];
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
-        if constexpr (!M::D::is_static) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
+        if constexpr (M::D::gen) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
       }
       for (int c = 0; c < nca; c++) {
         const float* jn = s.Jc + (c * 3) * nv;
@@ -1160,7 +1161,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   });
   DIAL_MARK(w, 23);
   }
-  if constexpr (!M::D::is_static) w.items((nv * (nv + 1)) / 2, [&](int e) { s.M[e] = 0.f; });
+  if constexpr (M::D::gen) w.items((nv * (nv + 1)) / 2, [&](int e) { s.M[e] = 0.f; });
   // ---- M (lower triangle, support.make_m) | qfrc_smooth = passive - bias + actuator
   //      | collision_driver (static contact list)
   w.items(ntri + nv + nc, [&](int it) {
@@ -1195,7 +1196,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
       float radius = m->geom_size[g2][0];
       float* fr = s.cframe + 9 * c;
-      if constexpr (!M::D::is_static) {
+      if constexpr (M::D::gen) {
         if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) {   // box narrow phases (box_collide.h); geom2 is the box
           const auto box_of = [&](int g, BoxG& b) {
             const int bd = m->geom_bodyid[g];
@@ -1214,7 +1215,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
           else {
             BoxG b1;
             box_of(g1, b1);
-            box_box(b1, b2, m->con_sub[c], dist, cp, fr);
+            // the clipping polygons live in this candidate's slice of cdofdot | cacc | cfl (carved back to back, derived.h):
+            // the velocity temporaries are dead by now -- cfrc, which this phase still reads, lies behind them (dial_create
+            // checks that the slices fit)
+            box_box(b1, b2, m->con_sub[c], dist, cp, fr, s.cdofdot + DIAL_BOX_POLY_WORDS * m->con_bbslot[c]);
           }
           s.cdist[c] = dist;
           for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = cp[k];
@@ -1275,7 +1279,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
     }
   });
-  if constexpr (!M::D::is_static) {
+  if constexpr (M::D::gen) {
     // compact the contacts that touch (see con_of above); with more than 64 candidates the list would need a second pass
     if (nc <= 64) {
       nca = w.compact(nc, [&](int c) { return s.cdist[c] - m->con_margin[c] < 0.f; }, s.clist);
@@ -1284,7 +1288,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     }
     nea = nl + dim_nf(m) + 4 * nca;
   }
-  if constexpr (!M::D::is_static) {
+  if constexpr (M::D::gen) {
     // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
     // contacts (derived.h: ws_carve).  A sample that touches with more runs the SAME constraint code on its overflow
     // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
@@ -1304,8 +1308,10 @@ constexpr uint32_t task_kind_mask() {
   if (std::is_same<typename D::Topo, TopoGo2>::value) return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP);
   if (std::is_same<typename D::Topo, TopoH1>::value) return 1u << DIAL_TASK_H1_WALK;
   if (std::is_same<typename D::Topo, TopoH1Loco>::value) return 1u << DIAL_TASK_H1_LOCO;
+  if (std::is_same<D, DimsGo2Crate>::value) return 1u << DIAL_TASK_GO2_CRATE;   // (dispatched ahead of the reward phase)
+  if (std::is_same<D, DimsH1PushCrate>::value) return 1u << DIAL_TASK_H1_PUSH_CRATE;
   return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP) | (1u << DIAL_TASK_H1_WALK) | (1u << DIAL_TASK_H1_LOCO) |
-         (D::is_static ? 0u : (1u << DIAL_TASK_H1_PUSH_CRATE));
+         (D::gen ? (1u << DIAL_TASK_H1_PUSH_CRATE) | (1u << DIAL_TASK_GO2_CRATE) : 0u);
 }
 
 // Velocity command of one env.step (unitree_go2_env.py:142-155, unitree_h1_env.py:199-212): component k < 3 of the linear,
@@ -1329,12 +1335,12 @@ DIAL_DEV void step_cmd(const M* m, const dial_task* tg, float step, float* cmd /
 // templates, so that code naming them also compiles (and is discarded) for the dimension-specialised instantiations.
 template <class M>
 DIAL_DEV int pc_foot_contact(const M* m, int f, int k) {
-  if constexpr (M::D::is_static) return 0;
+  if constexpr (!M::D::gen) return 0;
   else return m->pc_foot_contact[f][k];
 }
 template <class M>
 DIAL_DEV float pc_contact_reward(const M* m, const Ws& s) {
-  if constexpr (M::D::is_static) return 0.f;
+  if constexpr (!M::D::gen) return 0.f;
   else {
     // unitree_h1_env.py:525-531: +1 per hand on the crate (contact point below 1.1 m), -1 per other part touching it
     float rc = 0.f;
@@ -1465,7 +1471,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
     DIAL_MARK(w, 10);
     return s.info[DIAL_INFO_REWARD];
   }
-  if constexpr (!M::D::is_static) {
+  if constexpr (M::D::gen && ((task_kind_mask<typename M::D>() >> DIAL_TASK_GO2_CRATE) & 1u)) {
     if (m->kind == DIAL_TASK_GO2_CRATE) {
       // UnitreeGo2CrateEnv.step (unitree_go2_env.py:679-795).  Of its eleven terms only four carry a non-zero weight:
       // head position (:711-719), upright (:720-723), yaw (:724-727) and the feet-on-the-crate count (:741-766); the

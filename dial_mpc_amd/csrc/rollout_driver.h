@@ -77,7 +77,10 @@ DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
 // everything that does not depend on its predecessor, waits for the predecessor's state, runs its control steps at the
 // highest issue priority and hands the state on.  Every piece is a different wavefront on a different SIMD, so the
 // "+1" rollout loads no SIMD for longer than relay_steps control steps.
-template <class W, class M>
+// TRACE (compile time): also write the packed state after every env.step to io.trace -- its own kernel instantiation, because
+// even a null-pointer test costs the production launch (measured +1.4 % on the Go2 headline: one more live kernel argument in a
+// kernel that already spills scalar registers; profiles/r04_ab_trace_hook.txt).
+template <bool TRACE = false, class W, class M>
 DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_cfg* cfg, const Ws& s,
                              const RolloutIO& io, int n, int relay = -1) {
   const int nq = dim_nq(m), nv = dim_nv(m), nu = dim_nu(m), nx = (dim_nb(m) - 1) * 3, T = io.T, Hn1 = io.Hn1;
@@ -147,6 +150,14 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #endif
   for (int st = st_begin; st < st_end; st++) {
     w.redraw_priority();
+#if !defined(DIAL_EMU) && defined(DIAL_EXP_LAUNDER)
+    // generic instantiation (constants in global memory): every `m->field` is a loop-invariant scalar load, and LICM hoists
+    // hundreds of them out of the step loop into registers that do not exist (round 3: 485 spilled SGPRs, 103 spilled VGPRs,
+    // 816 B of scratch per lane).  An opaque copy of the pointer per step keeps each load next to its use.
+    const M* m_step = m;
+    if constexpr (!M::D::is_static) asm volatile("" : "+s"(m_step));
+#define m m_step
+#endif
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {
       float u;
@@ -174,8 +185,11 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
       if (rrow && i == 0) rrow[0] = rew;
     });
-    if (io.trace) store_state(w, m, s, io.trace + o * nstate);
+    if constexpr (TRACE) { if (io.trace) store_state(w, m, s, io.trace + o * nstate); }
     DIAL_MARK(w, 24);
+#if !defined(DIAL_EMU) && defined(DIAL_EXP_LAUNDER)
+#undef m
+#endif
   }
 #ifdef DIAL_PROFILE
   DIAL_MARK(w, 11);

@@ -1,0 +1,118 @@
+// rollout_kernel.h -- the gfx950 kernels that run the per-sample body (rollout_driver.h): rollout_kernel (K1+K2+K3, one
+// wavefront per sample, 1-9 wavefronts per workgroup sharing the staged constants), env_step_kernel / env_reset_kernel
+// (K6, B = 1).  A header so that tools/isa/probe.hip can instantiate ONE kernel for ISA inspection (register / scratch /
+// spill counts) in seconds instead of building the whole library; dial_hip.hip is the only product translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rollout_driver.h"
+
+// Stage the dimension-specialised constants in LDS (static instantiations) and carve the workspace.
+// WPB wavefronts (= samples) per workgroup share ONE staged copy of the constants; each wavefront has
+// its own workspace.  WPB is chosen per robot so that N+1 = 2049 wavefronts are co-resident (>= 9 per CU):
+// Go2 1 (16 KB/wave), H1 3 (10 KB constants + 3 x 13.7 KB: 3 workgroups = 9 wavefronts per CU), H1 loco 2, generic 1.
+// This is the only workgroup-level barrier of the kernel (phase boundaries are
+// wavefront-scope fences, wave.h).
+template <class D, int WPB = 1>
+__device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
+                                                        int ws_words, int con_cap = 0) {
+  const CModel<D>* m = gm;
+  float* wsbase = smem;
+  if constexpr (D::is_static) {
+    constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspace 16-B aligned
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
+    __syncthreads();
+    m = reinterpret_cast<const CModel<D>*>(smem);
+    wsbase = smem + CMW;
+  }
+  // WPB == 1: LDS addresses stay immediates.  WPB > 1: the wavefront's workspace offset is made a scalar (it is
+  // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
+  if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
+  ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
+           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, D::gen ? con_cap : 0, D::NVP);
+  return m;
+}
+
+// OCC: minimum resident wavefronts per SIMD the register allocation must allow (3: <= 168 VGPRs, 4: <= 128)
+// QUEUE: the rollout-queue variant (see the loop below); the one-rollout-per-wavefront variant keeps nothing live across
+// rollouts (the loop costs the headline kernel 6 spilled VGPRs, H1 21)
+// TRACE: the diagnostics instantiation that also writes the per-step packed states (dial_set_state_trace)
+template <class D, int WPB, int OCC = 3, bool QUEUE = false, bool TRACE = false>
+__global__ void __launch_bounds__(64 * WPB, OCC)
+rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
+               const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Ws s;
+  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap);
+  if constexpr (D::gen)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
+    s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
+  int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
+  int relay = -1;
+  if constexpr (WPB == 1 && !QUEUE) {
+    if (io.relay_flag && (int)blockIdx.x >= io.relay_base) { relay = (int)blockIdx.x - io.relay_base; n = B - 1; }
+  }
+  if (n >= B) return;
+  Wave w;
+  w.lane = threadIdx.x & 63;
+  w.lane_r = w.lane;
+#ifdef DIAL_PROFILE
+  w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
+  if (w.lane < 32) w.acc[w.lane] = 0;
+  __syncthreads();
+#endif
+#ifdef DIAL_PROFILE
+  unsigned long long t_start = wall_clock64();
+#endif
+  // `next` == nullptr: the grid covers the batch, one rollout per wavefront.  Otherwise the grid is exactly what the chip
+  // keeps resident and every wavefront draws its next rollout from the queue head when it finishes one: rollouts differ
+  // in length (solver iterations), and a workgroup's LDS is only handed to a new workgroup when its slowest wavefront
+  // is done -- the queue keeps every wavefront slot busy until the batch is empty
+  for (;;) {
+    dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay);
+#ifdef DIAL_PROFILE
+    if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
+      unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
+      p[0] = t_start; p[1] = wall_clock64(); p[2] = w.acc[27]; p[3] = w.acc[28]; p[4] = w.acc[30]; p[5] = w.acc[31];
+      for (int k = 27; k < 32; k++) w.acc[k] = 0;
+    }
+#endif
+    if constexpr (!QUEUE) break;
+    if (!next) break;
+    int nn = 0;
+    if (w.lane == 0) nn = atomicAdd(next, 1);
+    n = __builtin_amdgcn_readfirstlane(nn);
+    if (n >= B) break;
+#ifdef DIAL_PROFILE
+    t_start = wall_clock64();
+#endif
+  }
+}
+
+template <class D>
+__global__ void __launch_bounds__(64)
+env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg, float* state,
+                const float* action, float* xpos_out, float* xquat_out, float* ctrl_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Ws s;
+  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
+  Wave w;
+  w.lane = threadIdx.x;
+  w.lane_r = w.lane;
+  dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
+}
+
+template <class D>
+__global__ void __launch_bounds__(64)
+env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const float* qvel, float* state,
+                 float* xpos_out, float* xquat_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Ws s;
+  const CModel<D>* m = stage_model<D>(gm, smem, s, 0, 0);
+  Wave w;
+  w.lane = threadIdx.x;
+  w.lane_r = w.lane;
+  dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
+}
+

@@ -23,16 +23,16 @@ struct Runner {
     fill_cmodel(&cm, m, t, dv);
     Ws s;
     // DIAL_EMU_CON_CAP=k: the GPU rollout kernel's capped workspace (derived.h: ws_carve) + overflow area, on the host
-    if (const char* e = std::getenv("DIAL_EMU_CON_CAP")) con_cap = D::is_static ? 0 : std::atoi(e);
+    if (const char* e = std::getenv("DIAL_EMU_CON_CAP")) con_cap = D::gen ? std::atoi(e) : 0;
     ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap);
+                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP);
     if (con_cap > 0) ovf_words = ws_overflow(s, (float*)0, m->nv, m->ncon, m->nefc);
   }
   void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
     // (the overflow area lives behind the LDS image in the same vector: the race detector then sees both)
     lds.assign(ws_words + ovf_words, 0.f);
     ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
-             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap);
+             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP);
     if (s.con_cap > 0) s.ovf = lds.data() + ws_words;
     w.lds = lds.data();
     w.lds_words = ws_words + ovf_words;
@@ -51,7 +51,7 @@ int run_rollout(const dial_model* m, const dial_task* t, const dial_derived* dv,
     Ws s;
     Wave w;
     r.setup(lds, s, w, check_races);
-    dial::rollout_sample(w, &r.cm, t, cfg, s, io, n);
+    dial::rollout_sample<true>(w, &r.cm, t, cfg, s, io, n);
     races += w.races;
   }
   return races;
@@ -88,6 +88,8 @@ int run_env_reset(const dial_model* m, const dial_task* t, const dial_derived* d
   if ((path) == 0 && dims_match<DimsGo2>(m)) return CALL(DimsGo2);     \
   if ((path) == 0 && dims_match<DimsH1>(m)) return CALL(DimsH1);       \
   if ((path) == 0 && dims_match<DimsH1Loco>(m)) return CALL(DimsH1Loco); \
+  if ((path) == 0 && dims_match<DimsGo2Crate>(m)) return CALL(DimsGo2Crate); \
+  if ((path) == 0 && dims_match<DimsH1PushCrate>(m)) return CALL(DimsH1PushCrate); \
   return CALL(DimsMax);
 
 }  // namespace
@@ -136,6 +138,8 @@ int emu_sizes(const dial_model* m, int* cmodel_bytes, int* ws_words) {
   if (dims_match<DimsH1>(m)) { Runner<DimsH1> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 2; }
   if (dims_match<DimsH1Loco>(m)) { Runner<DimsH1Loco> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 3; }
   if (dims_match<DimsAllegro>(m) && ell_fits<DimsAllegro>(m, &dv)) { Runner<DimsAllegro> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 4; }
+  if (dims_match<DimsGo2Crate>(m)) { Runner<DimsGo2Crate> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 5; }
+  if (dims_match<DimsH1PushCrate>(m)) { Runner<DimsH1PushCrate> r(m, &t, &dv); *cmodel_bytes = (int)sizeof(r.cm); *ws_words = r.ws_words; return 6; }
   Runner<DimsMax> r(m, &t, &dv);
   *cmodel_bytes = (int)sizeof(r.cm);
   *ws_words = r.ws_words;
@@ -152,7 +156,7 @@ int emu_box_contact(int kind, int sub, const float* g1, const float* g2, float* 
   if (kind == DIAL_CON_PLANE_BOX) dial::plane_box(ax1, g1, b2, sub, *dist, pos, frame);
   else if (kind == DIAL_CON_SPHERE_BOX) dial::sphere_box(g1, g1[7], b2, *dist, pos, frame);
   else if (kind == DIAL_CON_CAPSULE_BOX) dial::capsule_box(g1, ax1, g1[8], g1[7], b2, sub, *dist, pos, frame);
-  else if (kind == DIAL_CON_BOX_BOX) dial::box_box(b1, b2, sub, *dist, pos, frame);
+  else if (kind == DIAL_CON_BOX_BOX) { float poly[DIAL_BOX_POLY_WORDS]; dial::box_box(b1, b2, sub, *dist, pos, frame, poly); }
   else return -1;
   return 0;
 }
