@@ -60,11 +60,12 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
 // LDS shared by the nine wavefronts of a workgroup.
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
           class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2, bool ELL_ = false, int NE_ELL_ = 0, int JCW_ = 4,
-          bool GEN_ = !STATIC>
+          bool GEN_ = !STATIC, int NFRI_ = -1>
 struct Dims {
   using Topo = Topo_;
   static constexpr bool is_static = STATIC;
   static constexpr bool gen = GEN_;
+  static constexpr int NFRI = GEN_ ? NFRI_ : 0;   // dry-friction rows: compile-time count, -1 = run time (capacity-dimension kernel)
   static constexpr int NVP = STATIC ? NV_ : DIAL_MAX_V;   // dimension of the generic solver's dense register L D L^T
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr bool ell = ELL_;
@@ -91,8 +92,8 @@ using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true,
 // Allegro: 19 contacts (14 x condim 3 + 5 x condim 6 = 72 rows) + 16 limits; compact Jacobian 8x3x4 + 6x3x8 + 6x6 + 4x6x10
 using DimsAllegro = Dims<true, 23, 22, 16, 23, 17, 6, 0, 19, 16, TopoAllegro, true, 64, true, 88, 516>;
 // the crate scenes: Go2 + floor + welded crate (52 candidate contacts), H1 + crate on a slide joint (28)
-using DimsGo2Crate = Dims<true, 19, 18, 12, 15, 13, 17, 5, 52, 12, TopoDense, false, 2, false, 0, 4, true>;
-using DimsH1PushCrate = Dims<true, 27, 26, 19, 22, 21, 9, 3, 28, 19, TopoDense, false, 2, false, 0, 4, true>;
+using DimsGo2Crate = Dims<true, 19, 18, 12, 15, 13, 17, 5, 52, 12, TopoDense, false, 2, false, 0, 4, true, 0>;
+using DimsH1PushCrate = Dims<true, 27, 26, 19, 22, 21, 9, 3, 28, 19, TopoDense, false, 2, false, 0, 4, true, 1>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 
@@ -227,7 +228,7 @@ CM_DIM(dim_ntri, NTRI, ntri)
 // dofs with dry friction: the generic instantiation only (the dimension-specialised robots have none)
 template <class M>
 CM_HD constexpr int dim_nf(const M* m) {
-  if constexpr (!M::D::gen) return 0;
+  if constexpr (M::D::NFRI >= 0) return M::D::NFRI;
   else return m->nfri;
 }
 
@@ -236,7 +237,7 @@ template <class D>
 static inline bool dims_match(const dial_model* m) {
   bool ok = m->nq == D::NQ && m->nv == D::NV && m->nu == D::NU && m->nbody == D::NB && m->njnt == D::NJ &&
             m->ngeom == D::NG && m->nsite == D::NS && m->ncon == D::NC && m->nlim == D::NL &&
-            (D::gen || m->nfri == 0);   // (dry friction rows exist in the generic feature set only)
+            (D::NFRI < 0 || m->nfri == D::NFRI);   // (dry friction rows exist in the generic feature set only)
   if constexpr (!D::Topo::dense) {   // the sparse factorisations are specialised to the dof tree as well
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }

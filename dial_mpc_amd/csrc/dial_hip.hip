@@ -414,8 +414,10 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
         const bool given = opt.con_cap != 0;   // options.con_cap: 0 chosen here, > 0 given, < 0 no cap
         int cap = given ? opt.con_cap : 14;
         if (cfg && model->cone == DIAL_CONE_PYRAMIDAL && cap > 0 && model->ncon > cap) {
-          // unless the cap was given: the largest one in 16 .. 8 with which NINE wavefronts fit a CU (8 x 256 + 1 rollouts of
-          // the examples' N = 2048 resident at once); 14 if none does.  Crate climb: 16 (17.2 KB), push crate: 9 (17.1 KB).
+          // unless the cap was given: the largest one in 20 .. 4 with which NINE wavefronts fit a CU (8 x 256 + 1 rollouts of
+          // the examples' N = 2048 resident at once).  Round 4, the scenes' own instantiations (nine wavefronts share one staged
+          // copy of the constants): crate climb 18 (16.7 KB per wavefront), push crate 8 (16.8 KB); capacity-dimension
+          // instantiation: 16 (17.2 KB) / 9 (17.1 KB).
           // (workgroups of wpb wavefronts that share one staged copy of the constants: 9 / wpb workgroups per CU)
           if (!given) {
 #ifdef DIAL_PROFILE
@@ -425,12 +427,12 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
 #endif
             const size_t budget = ctx->wpb > 1 ? ((size_t)160 * 1024 / (9 / ctx->wpb) - ctx->cm_bytes - prof_bytes) / ctx->wpb / 16 * 16
                                                : (size_t)(160 * 1024) / 9 / 512 * 512;
-            for (int c = 16; c >= 8; c--) {
+            for (int c = 20; c >= 4; c--) {
               Ws st;
               const int wds = ws_carve(st, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt, model->ngeom, model->nsite,
                                        model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square, 0, c, D::NVP);
               if ((size_t)wds * sizeof(float) <= budget) { cap = c; break; }
-              if (c == 8) cap = 8;   // (nothing fits nine: the smallest cap; dial_create then fails on the LDS check if that is too much)
+              if (c == 4) cap = 4;   // (nothing fits nine: the smallest cap; dial_create then fails on the LDS check if that is too much)
             }
           }
           ctx->con_cap = cap;
@@ -464,11 +466,13 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       }
       ctx->inst = 4; ctx->wpb = DIAL_ALLEGRO_WPB; urc = upload(DimsAllegro{});
     }
-    else if (own && dims_match<DimsGo2Crate>(model) && kind_ok(dial::task_kind_mask<DimsGo2Crate>())) { ctx->inst = 5; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsGo2Crate{}); }
-    else if (own && dims_match<DimsH1PushCrate>(model) && kind_ok(dial::task_kind_mask<DimsH1PushCrate>())) { ctx->inst = 6; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsH1PushCrate{}); }
+    // (options.con_cap < 0 -- no cap, the full-size workspace -- does not fit nine wavefronts per workgroup: capacity-dimension kernel)
+    else if (own && opt.con_cap >= 0 && dims_match<DimsGo2Crate>(model) && kind_ok(dial::task_kind_mask<DimsGo2Crate>())) { ctx->inst = 5; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsGo2Crate{}); }
+    else if (own && opt.con_cap >= 0 && dims_match<DimsH1PushCrate>(model) && kind_ok(dial::task_kind_mask<DimsH1PushCrate>())) { ctx->inst = 6; ctx->wpb = DIAL_CRATE_WPB; urc = upload(DimsH1PushCrate{}); }
     else { ctx->inst = 0; ctx->wpb = 1; urc = upload(DimsMax{}); }
     if (urc != DIAL_OK) { dial_destroy(ctx); return fail(nullptr, urc, "dial_create: uploading the model constants failed"); }
   }
+  if (!cfg) ctx->lds_rollout = ctx->lds_bytes;   // no cfg: env.step / env.reset only -- no rollout launch, no capped workspace to size
   if (ctx->lds_rollout > 160 * 1024 || ctx->lds_bytes > 64 * 1024) {
     dial_destroy(ctx);
     return fail(nullptr, DIAL_ERR_ARG, "dial_create: LDS workspace exceeds the 160 KiB of a CU");

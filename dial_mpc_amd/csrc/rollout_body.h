@@ -82,7 +82,7 @@ DIAL_DEV float jt_dot(const M* m, const Ws& s, int i, const float* f, int nca) {
   float acc = 0.f;
   int lr = m->dof_limrow[i];
   if (lr >= 0) acc += s.lsign[lr] * f[lr];
-  if constexpr (M::D::gen) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += f[fr]; }
+  if constexpr (M::D::NFRI != 0) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += f[fr]; }
   for (int c = 0; c < nca; c++) {
     float jn = s.Jc[(c * 3) * nv + i], j1 = s.Jc[(c * 3 + 1) * nv + i], j2 = s.Jc[(c * 3 + 2) * nv + i];
     const int co = con_of(m, s, c);
@@ -253,7 +253,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // active for j < 0; a dry-friction row (solver._update_constraint) is quadratic while |D j| < frictionloss, i.e. |j| < rf = R f,
   // and beyond that exerts -+f with the cost f (-0.5 rf -+ j)
   const auto row_floss = [&](int r) -> float {
-    if constexpr (!M::D::gen) return 0.f;
+    if constexpr (M::D::NFRI == 0) return 0.f;
     else return (r >= nl && r < nlf) ? m->fri_loss[r - nl] : 0.f;
   };
   const auto row_cost2 = [&](int r, float j) -> float {
@@ -405,7 +405,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       s.aref[r] = -b_ * vel - k_ * imp * pos;
       s.D[r] = 1.f / R;
     } else if (r < nlf) {
-      if constexpr (M::D::gen) {   // constraint._instantiate_friction: J = e_dof, pos = 0, aref = -b qvel
+      if constexpr (M::D::NFRI != 0) {   // constraint._instantiate_friction: J = e_dof, pos = 0, aref = -b qvel
         const int q = r - nl, da = m->fri_dof[q];
         s.lsign[r] = 1.f;
         float k_, b_, imp;
@@ -533,7 +533,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       if (i == j) {
         int lr = m->dof_limrow[i];
         if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
-        if constexpr (M::D::gen) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
+        if constexpr (M::D::NFRI != 0) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
       }
       for (int c = 0; c < nca; c++) {
         const float* jn = s.Jc + (c * 3) * nv;
@@ -618,24 +618,11 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     const float smag = DM_SQRT(sn2) * m->meaninertia * (float)(nv > 1 ? nv : 1);
     const float gtol = m->tolerance * m->ls_tolerance * smag;
     const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
-    // per-row quadratic coefficients live in registers for the whole line search (lane r <-> efc row r); models with more
-    // than 64 rows (the crate scene: 220) keep them in LDS and sum over the rows lane-strided
-    const bool wide = nea > 64;
-    const vfloat vJa = w.per_lane([&](int l) { return l < nea ? s.Jaref[l] : 0.f; });
-    const vfloat vjv = w.per_lane([&](int l) { return l < nea ? s.jv[l] : 0.f; });
-    const vfloat vD = w.per_lane([&](int l) { return l < nea ? s.D[l] : 0.f; });
-    const vfloat vq0 = (vJa * 0.5f) * vJa * vD, vq1 = vjv * vJa * vD, vq2 = (vjv * 0.5f) * vjv * vD;
-    const vfloat vzero = vsplat(0.f);
-    if (wide)
-      w.items(nea, [&](int r) {
-        const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
-        s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
-      });
     // the three coefficients one row contributes at the step alpha (solver._eval_pt): an inequality row its quadratic while
     // Jaref + alpha jv < 0; a dry-friction row its quadratic inside |x| < rf and the linear pieces f (-0.5 rf -+ x) outside
-    const auto row_terms = [&](int r, float ja, float jv, float d, float k0, float k1, float k2, float alpha, float& a, float& b, float& c) {
-      const float x = ja + jv * alpha, f = row_floss(r);
-      if (f > 0.f) {
+    const auto row_terms = [&](float f, float ja, float jv, float d, float k0, float k1, float k2, float alpha, float& a, float& b, float& c) {
+      const float x = ja + jv * alpha;
+      if (M::D::NFRI != 0 && f > 0.f) {
         const float rf = f / d;
         const bool neg = x <= -rf, pos = x >= rf;
         a = neg ? f * (-0.5f * rf - ja) : (pos ? f * (-0.5f * rf + ja) : k0);
@@ -646,51 +633,116 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       const bool act = x < 0.f;
       a = act ? k0 : 0.f; b = act ? k1 : 0.f; c = act ? k2 : 0.f;
     };
-    auto ls_point = [&](float alpha) {
-      float q0, q1, q2;
-      if (!wide) {
-        vfloat t3[3];
-        w.per_lane_n(t3, [&](int l, float* o) {
-          row_terms(l, lane_val(vJa, l), lane_val(vjv, l), lane_val(vD, l), lane_val(vq0, l), lane_val(vq1, l), lane_val(vq2, l), alpha, o[0], o[1], o[2]);
-        });
-        float r3[3];
-        w.vsumN(t3, r3);   // three reductions with interleaved stages (one latency chain instead of three)
-        q0 = r3[0]; q1 = r3[1]; q2 = r3[2];
-      } else {
-        w.sum3(nea, [&](int r, float& a, float& b, float& c) {
-          row_terms(r, s.Jaref[r], s.jv[r], s.D[r], s.quad[3 * r], s.quad[3 * r + 1], s.quad[3 * r + 2], alpha, a, b, c);
-        }, q0, q1, q2);
-      }
-      q0 += qg0; q1 += qg1; q2 += qg2;
-      const float cost = alpha * alpha * q2 + alpha * q1 + q0;
-      // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
-      // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
-      // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
-      const float d0 = DM_FMA(2.f * alpha, q2, q1);
-      const float d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
-      float pa, pn, pc, pd;
-      ls_pack(alpha, cost, d0, d1, pa, pn, pc, pd);   // integer keys: ls_bracket.h
-      LsPt p;
-      p.alpha = fbits(pa); p.nalpha = fbits(pn); p.cost = fbits(pc); p.d0 = fbits(pd);
-      return p;
-    };
-    const LsPt p0 = ls_point(0.f);
-    LsPt lo, hi;
-    ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
     const int kg = fkey(gtol), kng = fkey(-gtol);
-    bool swap = true;
-    int ls_iter = 0;
-    for (;;) {
-      const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
-      if (done) break;
-      const LsPt lo_next = ls_point(bitsf(lo.nalpha));
-      const LsPt hi_next = ls_point(bitsf(hi.nalpha));
-      const LsPt mid = ls_point(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));
-      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
-      ls_iter++;
-    }
     float alpha;
-    const bool improved = ls_result(p0, lo, hi, alpha);
+    bool improved;
+    if (nea <= 64) {
+      // Up to 64 rows (after compaction that is every step of the crate scenes but the rare ones with > 13 touching contacts):
+      // the THREE trial points of a bracketing iteration (lo_next, hi_next, mid) are evaluated at once by three 16-lane groups,
+      // as in solver_reg.h -- lane (g, l) = (lane >> 4, lane & 15) owns rows l, l + 16, l + 32, l + 48 for point g; per row a
+      // handful of selects and three adds, then three interleaved 16-lane DPP reductions, and every lane of a group finishes
+      // its point (cost, slope, Newton step, integer keys), so that the scalar bracket logic fetches 4 words per point.
+      // (Round 3 evaluated the points one after the other, each with full-wave reductions: 19 k of 114 k cycles per step.)
+      constexpr int RPL = 4;
+      const vfloat vzero = vsplat(0.f);
+      vfloat lJa[RPL], ljv[RPL], lD[RPL], lF[RPL], Q0[RPL], Q1[RPL], Q2[RPL];
+      constexpr bool has_fri = M::D::NFRI != 0;   // only then the three-zone rows exist (and D / frictionloss stay live)
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const auto rowi = [&](int l) { return (l & 15) + 16 * q; };
+        lJa[q] = w.per_lane([&](int l) { const int r = rowi(l); return (l < 48 && r < nea) ? s.Jaref[r] : 0.f; });
+        ljv[q] = w.per_lane([&](int l) { const int r = rowi(l); return (l < 48 && r < nea) ? s.jv[r] : 0.f; });
+        lD[q] = w.per_lane([&](int l) { const int r = rowi(l); return (l < 48 && r < nea) ? s.D[r] : 0.f; });
+        lF[q] = w.per_lane([&](int l) { const int r = rowi(l); return (has_fri && l < 48 && r < nea) ? row_floss(r) : 0.f; });
+        const vfloat dja = lD[q] * lJa[q], djv = lD[q] * ljv[q];
+        Q0[q] = (lJa[q] * 0.5f) * dja;
+        Q1[q] = ljv[q] * dja;
+        Q2[q] = (ljv[q] * 0.5f) * djv;
+      }
+      const vbool g0 = w.lane_lt(16), g01 = w.lane_lt(32);
+      vfloat pk[4];
+      auto ls_eval3 = [&](float a0, float a1, float a2) {
+        const vfloat va = vsel(g0, vsplat(a0), vsel(g01, vsplat(a1), vsplat(a2)));
+        vfloat t3[3] = {vzero, vzero, vzero};
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+          vfloat c3[3];
+          w.per_lane_n(c3, [&](int l, float* o) {
+            row_terms(has_fri ? lane_val(lF[q], l) : 0.f, lane_val(lJa[q], l), lane_val(ljv[q], l), lane_val(lD[q], l), lane_val(Q0[q], l),
+                      lane_val(Q1[q], l), lane_val(Q2[q], l), lane_val(va, l), o[0], o[1], o[2]);
+          });
+          t3[0] = t3[0] + c3[0]; t3[1] = t3[1] + c3[1]; t3[2] = t3[2] + c3[2];
+        }
+        w.row16_sum3(t3[0], t3[1], t3[2]);
+        const vfloat q0 = t3[0] + vsplat(qg0), q1 = t3[1] + vsplat(qg1), q2 = t3[2] + vsplat(qg2);
+        const vfloat vcost = (va * va) * q2 + va * q1 + q0;
+        // single-rounding slope 2 alpha q2 + q1, as on the reference's platform (XLA contracts it into an FMA): with two
+        // roundings the slope at a Newton point evaluates to EXACTLY 0 about half of the time, `_in_bracket` rejects such a
+        // candidate and the truncated search falls back to bisection -- a rounding lottery the reference does not play
+        const vfloat vd0 = vfma(va * 2.f, q2, q1);
+        const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
+        w.per_lane_n(pk, [&](int l, float* o) {
+          ls_pack(lane_val(va, l), lane_val(vcost, l), lane_val(vd0, l), lane_val(vd1, l), o[0], o[1], o[2], o[3]);
+        });
+      };
+      auto point_at = [&](int lane) {   // all four words of the point held by the group that starts at `lane`
+        LsPt p;
+        p.alpha = fbits(bcast(pk[0], lane)); p.nalpha = fbits(bcast(pk[1], lane)); p.cost = fbits(bcast(pk[2], lane)); p.d0 = fbits(bcast(pk[3], lane));
+        return p;
+      };
+      ls_eval3(0.f, 0.f, 0.f);
+      const LsPt p0 = point_at(0);
+      ls_eval3(bitsf(p0.nalpha), bitsf(p0.nalpha), bitsf(p0.nalpha));
+      LsPt lo, hi;
+      ls_open(p0, point_at(0), lo, hi);
+      bool swap = true;
+      int ls_iter = 0;
+      for (;;) {
+        const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
+        if (done) break;
+        ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
+        swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+                              [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
+        ls_iter++;
+      }
+      improved = ls_result(p0, lo, hi, alpha);
+    } else {
+      // more than 64 rows: the coefficients stay in LDS, the points are evaluated one after the other with lane-strided sums
+      w.items(nea, [&](int r) {
+        const float ja = s.Jaref[r], jv = s.jv[r], d = s.D[r];
+        s.quad[3 * r] = (ja * 0.5f) * ja * d; s.quad[3 * r + 1] = jv * ja * d; s.quad[3 * r + 2] = (jv * 0.5f) * jv * d;
+      });
+      auto ls_point = [&](float alpha_) {
+        float q0, q1, q2;
+        w.sum3(nea, [&](int r, float& a, float& b, float& c) {
+          row_terms(row_floss(r), s.Jaref[r], s.jv[r], s.D[r], s.quad[3 * r], s.quad[3 * r + 1], s.quad[3 * r + 2], alpha_, a, b, c);
+        }, q0, q1, q2);
+        q0 += qg0; q1 += qg1; q2 += qg2;
+        const float cost_ = alpha_ * alpha_ * q2 + alpha_ * q1 + q0;
+        const float d0 = DM_FMA(2.f * alpha_, q2, q1);   // single rounding (see above)
+        const float d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+        float pa, pn, pc, pd;
+        ls_pack(alpha_, cost_, d0, d1, pa, pn, pc, pd);   // integer keys: ls_bracket.h
+        LsPt p;
+        p.alpha = fbits(pa); p.nalpha = fbits(pn); p.cost = fbits(pc); p.d0 = fbits(pd);
+        return p;
+      };
+      const LsPt p0 = ls_point(0.f);
+      LsPt lo, hi;
+      ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
+      bool swap = true;
+      int ls_iter = 0;
+      for (;;) {
+        const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
+        if (done) break;
+        const LsPt lo_next = ls_point(bitsf(lo.nalpha));
+        const LsPt hi_next = ls_point(bitsf(hi.nalpha));
+        const LsPt mid = ls_point(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));
+        swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
+        ls_iter++;
+      }
+      improved = ls_result(p0, lo, hi, alpha);
+    }
     if (improved) {
       w.items(nv + nea, [&](int it) {
         if (it < nv) { s.qacc[it] += s.search[it] * alpha; s.Ma[it] += s.mv[it] * alpha; }
@@ -1443,6 +1495,9 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   });
   DIAL_MARK(w, 25);
   for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
+#ifndef DIAL_EMU
+    if constexpr (M::D::gen) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // see rollout_driver.h: the step loop
+#endif
     forward(w, m, s);
     euler(w, m, s);
     DIAL_MARK(w, 9);

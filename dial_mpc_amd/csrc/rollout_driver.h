@@ -150,13 +150,13 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #endif
   for (int st = st_begin; st < st_end; st++) {
     w.redraw_priority();
-#if !defined(DIAL_EMU) && defined(DIAL_EXP_LAUNDER)
-    // generic instantiation (constants in global memory): every `m->field` is a loop-invariant scalar load, and LICM hoists
-    // hundreds of them out of the step loop into registers that do not exist (round 3: 485 spilled SGPRs, 103 spilled VGPRs,
-    // 816 B of scratch per lane).  An opaque copy of the pointer per step keeps each load next to its use.
-    const M* m_step = m;
-    if constexpr (!M::D::is_static) asm volatile("" : "+s"(m_step));
-#define m m_step
+#ifndef DIAL_EMU
+    // generic feature set: lane-derived LDS addresses and masks are loop invariants of this T-step loop; hoisted, they are
+    // dozens of VGPRs that live for the whole kernel and get spilled to scratch (round 4 ISA probe of the crate-climb kernel:
+    // 73 spilled VGPRs, 36 of them stored right here at the loop entry; with the opaque copy of the lane id per step and per
+    // physics frame: 0 spilled VGPRs, 0 B of scratch).  (The dimension-specialised register-solver kernels have no spills to cure: there the hoisted addresses pay for
+    // themselves -- measured 5 % slower with the laundering, DESIGN.md.)
+    if constexpr (M::D::gen) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // (and once per physics frame: rollout_body.h env_step)
 #endif
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {
@@ -187,9 +187,6 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     });
     if constexpr (TRACE) { if (io.trace) store_state(w, m, s, io.trace + o * nstate); }
     DIAL_MARK(w, 24);
-#if !defined(DIAL_EMU) && defined(DIAL_EXP_LAUNDER)
-#undef m
-#endif
   }
 #ifdef DIAL_PROFILE
   DIAL_MARK(w, 11);

@@ -117,8 +117,11 @@ def one_step_consistency(o32, s0, us, got, rollouts, nq, nv, tol_scale=1.0, max_
 # share of the TRANSITIONS (one env.step from the device's own state) that may need a knife-edge witness under the shipped
 # solver settings (`_in_bracket`, truncated): 1.5 x the largest share measured on MI355X at the BASELINE sizes
 # (profiles/r04_transition_parity.txt), floor 0.5 %
-TRANSITION_WITNESS_FRAC = {"unitree_go2_trot": 0.02, "unitree_go2_seq_jump": 0.02, "unitree_h1_jog": 0.02, "unitree_h1_loco": 0.03,
-                           "allegro_reorient": 0.02, "unitree_go2_crate_climb": 0.05, "unitree_h1_push_crate": 0.05}
+TRANSITION_WITNESS_FRAC = {"unitree_go2_trot": 0.078, "unitree_go2_seq_jump": 0.098, "unitree_h1_jog": 0.073, "unitree_h1_loco": 0.071,
+                           "allegro_reorient": 0.005, "unitree_go2_crate_climb": 0.163, "unitree_h1_push_crate": 0.154}
+# measured (MI355X, 96 trajectories x 2 start states per env, profiles/r04_transition_parity.txt): direct match 93.5-96.8 % of
+# the transitions for the legged robots (Allegro 99.8-100 %, crate scenes 89.1-94.1 %), every other one witnessed -- all but 6 of
+# 1675 at 1 ulp, those 6 at 2 ulp -- and NONE without a witness, the crate scenes included.
 
 
 def transition_sample(N, count, seed):
@@ -401,7 +404,10 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=32, noise_
     if not check:                  # surveys (tools/transition_survey.py) print the report instead
         return rep
     for nme in names + ("ess_rel",):
-        bound = max(DIST_FLOOR[nme], (scale_peaked if nme in DIST_PEAKED else scale) * env_d[nme])
+        floor = DIST_FLOOR[nme]
+        if nme == "qdbar":     # the per-entry gate of qd is relative as well (TOL["qdbar"]: 5e-3 + 2e-3 |qd|; velocities reach 10 rad/s)
+            floor += TOL["qdbar"]["rtol"] * float(np.max(np.abs(ref["qdbar"])))
+        bound = max(floor, (scale_peaked if nme in DIST_PEAKED else scale) * env_d[nme])
         assert rep["gpu"][nme] <= bound, (nme, rep)
     assert rep["gpu"]["outside"] <= max(0.01, 1.5 * env_max["outside"] + 0.02), rep
     return rep

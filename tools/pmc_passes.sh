@@ -13,6 +13,7 @@ for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_INSTS_VSKIPPED" \
             "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES" ; do
   i=$((i+1))
+  if [ -n "${PMC_PASSES:-}" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi   # PMC_PASSES="1 3 4": only those passes
   rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/pass$i -o p -- $CMD > $OUT/pass$i.log 2>&1
   echo "pass $i rc=$?"
 done
