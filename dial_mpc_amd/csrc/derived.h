@@ -389,6 +389,7 @@ struct Ws {
   float *con_on, *cwd, *cwa, *cwb, *ccf, *vec0, *vec1, *ulist;
   // generic instantiation: the contacts that touch, compacted (rollout_body.h: con_of)
   float *clist, *sq;   // sq: DIAL_MAX_V x DIAL_MAX_V square the register Cholesky reads (rollout_body.h: solve_spd_reg)
+  float *cmu;          // friction coefficients (mu1, mu2) of the compact contacts: the solver's loops read them by compact index
   // generic instantiation, rollout kernel: the Jacobian and the per-row arrays above are sized for con_cap touching contacts
   // (0 = for all ncon); `ovf` = this sample's full-size copy of them in global memory (ws_overflow), used when more touch
   float* ovf;
@@ -434,7 +435,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
   WS_TAKE(qfs, nv) WS_TAKE(qas, nv) WS_TAKE(qacc, nv) WS_TAKE(Ma, nv) WS_TAKE(rhs, nv)
   WS_TAKE(con_on, ell * ncon) WS_TAKE(qfc, ell * nv) WS_TAKE(ulist, ell * (nefc > 0 ? 68 : 0))
-  WS_TAKE(clist, with_L ? ncon : 0)
+  WS_TAKE(clist, with_L ? ncon : 0) WS_TAKE(cmu, with_L ? 2 * (capped ? con_cap : ncon) : 0)
   const int u0 = o;
   // A1: dead after the cinert/cdof phase ...
   WS_TAKE(xmat, 0) WS_TAKE(xipos, nbody * 3) WS_TAKE(ximat, nbody * 9) WS_TAKE(xanchor, njnt * 3)
@@ -479,7 +480,7 @@ WS_HD int ws_overflow(Ws& s, float* base, int nv, int ncon, int nefc) {
 #define WS_TAKE(name, n) s.name = base + o; o += (((n) + 3) & ~3);
   WS_TAKE(Jc, ncon * 3 * nv)
   WS_TAKE(D, nefc) WS_TAKE(aref, nefc) WS_TAKE(lsign, nefc) WS_TAKE(Jaref, nefc)
-  WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(quad, nefc * 3)
+  WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4) WS_TAKE(JarefW, nefc) WS_TAKE(JarefS, nefc) WS_TAKE(quad, nefc * 3) WS_TAKE(cmu, 2 * ncon)
 #undef WS_TAKE
   return o;
 }

@@ -464,21 +464,51 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   }
 
   // ================================================================ solver.solve (Newton)
+  // The products J v, M v, J^T f of this solver run over the contacts' three FRAME rows (Jn, Jt1, Jt2), not over the four pyramid
+  // rows J_e = Jn +- mu Jt: J_e . v = Jn . v +- mu (Jt . v) -- 3 dot products per contact instead of 4 x 2 -- and J^T f =
+  // Jn^T (f0+f1+f2+f3) + Jt1^T mu1 (f0-f1) + Jt2^T mu2 (f2-f3).  The friction coefficients are read by COMPACT index (s.cmu,
+  // filled once per step below): inside a loop of run-time length a table look-up through the compaction list is two
+  // dependent LDS round trips per iteration that nothing can be scheduled around (round 4 section profile: 20 k + 17 k of the
+  // crate scene's 114 k cycles per step sat in these products).  `fdot`: scratch for the frame-row products, in s.quad
+  // (free until the Hessian's weights / a wide line search).
+  w.items(nca, [&](int c) {
+    const int co = con_of(m, s, c);
+    s.cmu[2 * c] = m->con_friction[co][0];
+    s.cmu[2 * c + 1] = m->con_friction[co][1];
+  });
+  float* const fdot = s.quad;
+  // value of constraint row r given the frame-row products `fd` (stride: 1 vector) and the vector itself
+  const auto row_from = [&](int r, const float* fd, const float* v) -> float {
+    if (r < nl) return s.lsign[r] * v[m->jnt_dofadr[m->lim_jnt[r]]];
+    if constexpr (M::D::NFRI != 0) { if (r < nlf) return v[m->fri_dof[r - nl]]; }
+    const int c = (r - nlf) >> 2, e = (r - nlf) & 3;
+    const float mu = s.cmu[2 * c + (e >> 1)], ft = fd[3 * c + 1 + (e >> 1)];
+    return fd[3 * c] + ((e & 1) ? -mu : mu) * ft;
+  };
   // warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
-  w.items(2 * nea + 2 * nv, [&](int it) {
-    if (it < nea) s.JarefW[it] = row_dot(m, s, it, s.warm) - s.aref[it];
-    else if (it < 2 * nea) s.JarefS[it - nea] = row_dot(m, s, it - nea, s.qas) - s.aref[it - nea];
-    else if (it < 2 * nea + nv) {
-      const int i = it - 2 * nea;
-      float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.warm[j];
-      s.MaW[i] = acc;
+  w.items(3 * nca + nv, [&](int it) {
+    if (it < 3 * nca) {   // frame row `it` against both candidates: one pass over the row
+      const float* J = s.Jc + it * nv;
+      float aw0 = 0.f, aw1 = 0.f, as0 = 0.f, as1 = 0.f;
+      int i = 0;
+      for (; i + 1 < nv; i += 2) {
+        aw0 += J[i] * s.warm[i]; aw1 += J[i + 1] * s.warm[i + 1];
+        as0 += J[i] * s.qas[i]; as1 += J[i + 1] * s.qas[i + 1];
+      }
+      if (i < nv) { aw0 += J[i] * s.warm[i]; as0 += J[i] * s.qas[i]; }
+      fdot[it] = aw0 + aw1;
+      fdot[3 * nca + it] = as0 + as1;
     } else {
-      const int i = it - 2 * nea - nv;
-      float acc = 0.f;
-      for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.qas[j];
-      s.MaS[i] = acc;
+      const int i = it - 3 * nca;
+      float aw = 0.f, as = 0.f;
+      for (int j = 0; j < nv; j++) { const float mij = msym(s, i, j); aw += mij * s.warm[j]; as += mij * s.qas[j]; }
+      s.MaW[i] = aw;
+      s.MaS[i] = as;
     }
+  });
+  w.items(nea, [&](int r) {
+    s.JarefW[r] = row_from(r, fdot, s.warm) - s.aref[r];
+    s.JarefS[r] = row_from(r, fdot + 3 * nca, s.qas) - s.aref[r];
   });
   float cw, gw, cs, gs;
   if (nea <= 64) {   // one row per lane: the four sums as one batch of stage-interleaved reductions
@@ -514,9 +544,30 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
 
   // _update_constraint forces + _update_gradient; returns through LDS (frc, qfc, grad)
   auto constraint_grad = [&]() {
-    w.items(nea, [&](int r) { s.frc[r] = row_force(r, s.Jaref[r]); });
+    // per contact the three force combinations the frame rows see: (f0+f1+f2+f3, mu1 (f0-f1), mu2 (f2-f3))
+    w.items(nca, [&](int c) {
+      const int r0 = nlf + 4 * c;
+      const float f0 = row_force(r0, s.Jaref[r0]), f1 = row_force(r0 + 1, s.Jaref[r0 + 1]);
+      const float f2 = row_force(r0 + 2, s.Jaref[r0 + 2]), f3 = row_force(r0 + 3, s.Jaref[r0 + 3]);
+      fdot[3 * c] = (f0 + f1) + (f2 + f3);
+      fdot[3 * c + 1] = s.cmu[2 * c] * (f0 - f1);
+      fdot[3 * c + 2] = s.cmu[2 * c + 1] * (f2 - f3);
+    });
     w.items(nv, [&](int i) {
-      float qc = jt_dot(m, s, i, s.frc, nca);
+      float qa = 0.f, qb = 0.f;
+      const int lr = m->dof_limrow[i];
+      if (lr >= 0) qa += s.lsign[lr] * row_force(lr, s.Jaref[lr]);
+      if constexpr (M::D::NFRI != 0) { const int fr = m->dof_frirow[i]; if (fr >= 0) qa += row_force(fr, s.Jaref[fr]); }
+      const float* J = s.Jc + i;
+      int c = 0;
+      for (; c + 1 < nca; c += 2) {   // two contacts per trip: six independent fetches in flight
+        const float* Ja = J + 3 * c * nv;
+        const float* Jb = Ja + 3 * nv;
+        qa += (Ja[0] * fdot[3 * c] + Ja[nv] * fdot[3 * c + 1]) + Ja[2 * nv] * fdot[3 * c + 2];
+        qb += (Jb[0] * fdot[3 * c + 3] + Jb[nv] * fdot[3 * c + 4]) + Jb[2 * nv] * fdot[3 * c + 5];
+      }
+      if (c < nca) { const float* Ja = J + 3 * c * nv; qa += (Ja[0] * fdot[3 * c] + Ja[nv] * fdot[3 * c + 1]) + Ja[2 * nv] * fdot[3 * c + 2]; }
+      float qc = qa + qb;
       s.qfc[i] = qc;
       float g = s.Ma[i] - s.qfs[i] - qc;
       s.grad[i] = g;
@@ -525,32 +576,84 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   };
   // H = M + J^T diag(D*active) J (lower triangle), Cholesky, search = -H^-1 grad
   auto newton_dir = [&]() {
-    w.items((nv * (nv + 1)) / 2, [&](int e) { s.H[e] = 0.f; });   // generic path only (see solver_reg.h for the other)
-    DIAL_MARK(w, 14);
-    w.items(ntri, [&](int it) {
-      const int i = m->tri[it] >> 8, j = m->tri[it] & 0xff;
-      float acc = 0.f;
-      if (i == j) {
-        int lr = m->dof_limrow[i];
-        if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
-        if constexpr (M::D::NFRI != 0) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
-      }
-      for (int c = 0; c < nca; c++) {
-        const float* jn = s.Jc + (c * 3) * nv;
-        float jni = jn[i], jnj = jn[j];
-        float t1i = jn[nv + i], t1j = jn[nv + j], t2i = jn[2 * nv + i], t2j = jn[2 * nv + j];
-        const int co = con_of(m, s, c);
-        float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
-        const int r0 = nlf + 4 * c;
-        float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
-        float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
-        acc += ((jni + t1i * mu1) * d0) * (jnj + t1j * mu1);
-        acc += ((jni - t1i * mu1) * d1) * (jnj - t1j * mu1);
-        acc += ((jni + t2i * mu2) * d2) * (jnj + t2j * mu2);
-        acc += ((jni - t2i * mu2) * d3) * (jnj - t2j * mu2);
-      }
-      s.H[tri_idx(i, j)] = s.M[tri_idx(i, j)] + acc;
+    // The contact part of H as a DENSE GEMM on the matrix cores: with the five weights of a contact's 3 x 3 block
+    //   W = [[d0+d1+d2+d3, mu1 (d0-d1), mu2 (d2-d3)], [., mu1^2 (d0+d1), 0], [., 0, mu2^2 (d2+d3)]]   (d_e = D of the active edges)
+    // the four pyramid rows J_e = Jn +- mu Jt of contact c contribute Jc^T W Jc (Jc = the contact's 3 frame rows), i.e.
+    //   H = M + [Jc_0 ... Jc_n]^T blockdiag(W_c) [Jc_0 ... Jc_n]   =   A (nv x 3 nca)  .  B (3 nca x nv),   B = W Jc.
+    // One v_mfma_f32_32x32x2_f32 multiplies a 32 x 2 slice of A with a 2 x 32 slice of B into the 32 x 32 accumulator tile
+    // (16 VGPRs): two per contact (frame rows 0-1, then row 2 and a zero row), A and B built lane-wise from THREE LDS reads
+    // per contact (lane = column / dof l & 31, k-slot l >> 5).  With 8-16 touching contacts K = 24 .. 48: this IS the batched
+    // dense GEMM that pays on MFMA -- the per-entry VALU loop over contacts it replaces took 12.6 k of the crate scene's 114 k
+    // cycles per step (profiles/r04_sections_*crate*), where the Go2's 4-contact, work-list assembly did not (round 2:
+    // profiles/r02_ubench_mfma_jtdj.txt).  Structural zeros (dofs of different branches under world-only contacts) come out
+    // as exact zeros: every product of such a pair has a zero factor.
+    const int nent = (nv * (nv + 1)) / 2;
+    w.items(nca, [&](int c) {   // the contact's weights, laid out for the two k-slots: [W00 W01 W02 | W02 0 W22] and [W01 W11 0 | 0 0 0]
+      const int co = con_of(m, s, c), r0 = nlf + 4 * c;
+      const float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
+      const float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
+      const float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
+      const float W00 = (d0 + d1) + (d2 + d3), W01 = mu1 * (d0 - d1), W11 = (mu1 * mu1) * (d0 + d1);
+      const float W02 = mu2 * (d2 - d3), W22 = (mu2 * mu2) * (d2 + d3);
+      float* q = s.quad + 12 * c;   // (free here: the line search fills it later, and only when there are more than 64 rows)
+      q[0] = W00; q[1] = W01; q[2] = W02; q[3] = W02; q[4] = 0.f; q[5] = W22;
+      q[6] = W01; q[7] = W11; q[8] = 0.f; q[9] = 0.f; q[10] = 0.f; q[11] = 0.f;
     });
+    DIAL_MARK(w, 14);
+    // limit / friction rows only touch the diagonal
+    const auto diag_rows = [&](int i) -> float {
+      float acc = 0.f;
+      const int lr = m->dof_limrow[i];
+      if (lr >= 0 && s.Jaref[lr] < 0.f) acc += s.D[lr];  // lsign^2 = 1
+      if constexpr (M::D::NFRI != 0) { const int fr = m->dof_frirow[i]; if (fr >= 0) acc += row_curv(fr, s.Jaref[fr]); }
+      return acc;
+    };
+#ifndef DIAL_EMU
+    {
+      typedef float f16v __attribute__((ext_vector_type(16)));
+      f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int col = w.lane & 31, half = w.lane >> 5;
+      const bool live = col < nv;
+      const float* jcol = s.Jc + (live ? col : 0);
+      const float* qh = s.quad + 6 * half;
+      for (int c = 0; c < nca; c++) {
+        const float* J = jcol + 3 * c * nv;
+        const float jn = live ? J[0] : 0.f, jt1 = live ? J[nv] : 0.f, jt2 = live ? J[2 * nv] : 0.f;
+        const float* q = qh + 12 * c;
+        const float b1 = (q[0] * jn + q[1] * jt1) + q[2] * jt2;
+        const float b2 = (q[3] * jn + q[4] * jt1) + q[5] * jt2;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? jt1 : jn, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : jt2, b2, acc, 0, 0, 0);
+      }
+      // accumulator a of lane (col, half) is entry (row, col), row = 8 (a / 4) + 4 half + a % 4 (profiles/r02_ubench_mfma_jtdj.txt);
+      // the lower triangle goes to the packed H
+#pragma unroll
+      for (int a = 0; a < 16; a++) {
+        const int row = (a >> 2) * 8 + half * 4 + (a & 3);
+        if (row < nv && col <= row) {
+          const int e = tri_idx(row, col);
+          s.H[e] = (s.M[e] + acc[a]) + (row == col ? diag_rows(row) : 0.f);
+        }
+      }
+      w.sync();
+    }
+#else
+    // host emulator: the same algebra entry by entry (the matrix cores' internal summation order is not modelled)
+    w.items(nent, [&](int e) {
+      int i = 0;
+      while (((i + 1) * (i + 2)) / 2 <= e) i++;
+      const int j = e - (i * (i + 1)) / 2;
+      float acc = 0.f;
+      for (int c = 0; c < nca; c++) {
+        const float* J = s.Jc + 3 * c * nv;
+        const float* q = s.quad + 12 * c;
+        const float jn = J[j], jt1 = J[nv + j], jt2 = J[2 * nv + j];
+        acc += J[i] * ((q[0] * jn + q[1] * jt1) + q[2] * jt2) + J[nv + i] * ((q[6] * jn + q[7] * jt1) + q[8] * jt2);
+        acc += J[2 * nv + i] * ((q[3] * jn + q[4] * jt1) + q[5] * jt2);
+      }
+      s.H[e] = (s.M[e] + acc) + (i == j ? diag_rows(i) : 0.f);
+    });
+#endif
     DIAL_MARK(w, 5);
 #ifdef DIAL_LDS_CHOL
     solve_spd(w, m, s, s.H, s.rhs, s.search);
@@ -564,6 +667,10 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // sensitive): [forces + gradient] -> convergence test -> [H, Cholesky, search] -> [line search].
   int niter = 0;
   for (;;) {
+#ifndef DIAL_EMU
+    asm volatile("" : "+v"(w.lane));   // (as at the top of the step loop, rollout_driver.h: nothing lane-derived is hoisted out of
+    w.lane_r = w.lane;                 //  the Newton loop into registers that the Hessian tile and the line search need)
+#endif
     constraint_grad();
     float gn_b = 0.f;
     const bool batched = nea <= 64;   // one row per lane: cost, Gauss term and |grad|^2 as one batch of reductions
@@ -601,15 +708,22 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     DIAL_MARK(w, 6);
     // ---------------- solver._linesearch
     DIAL_MARK(w, 8);
-    w.items(nv + nea, [&](int it) {
-      if (it < nv) {
-        float acc = 0.f;
-        for (int j = 0; j < nv; j++) acc += msym(s, it, j) * s.search[j];
-        s.mv[it] = acc;
+    w.items(3 * nca + nv, [&](int it) {
+      if (it < 3 * nca) {
+        const float* J = s.Jc + it * nv;
+        float a0 = 0.f, a1 = 0.f;
+        int i = 0;
+        for (; i + 1 < nv; i += 2) { a0 += J[i] * s.search[i]; a1 += J[i + 1] * s.search[i + 1]; }
+        if (i < nv) a0 += J[i] * s.search[i];
+        fdot[it] = a0 + a1;
       } else {
-        s.jv[it - nv] = row_dot(m, s, it - nv, s.search);
+        const int i = it - 3 * nca;
+        float acc = 0.f;
+        for (int j = 0; j < nv; j++) acc += msym(s, i, j) * s.search[j];
+        s.mv[i] = acc;
       }
     });
+    w.items(nea, [&](int r) { s.jv[r] = row_from(r, fdot, s.search); });
     float sn2, s1, s2;
     w.sum3(nv, [&](int i, float& a, float& b, float& c) {
       float sv = s.search[i];
@@ -1344,7 +1458,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
     // contacts (derived.h: ws_carve).  A sample that touches with more runs the SAME constraint code on its overflow
     // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
-    if (s.con_cap > 0 && nca > s.con_cap) {
+    if (s.con_cap > 0 && nca > s.con_cap && s.ovf != nullptr) {   // (a capped workspace always comes with its overflow area)
       Ws sg = s;
       ws_overflow(sg, s.ovf, nv, nc, ne);
       forward_constraints(w, m, sg, nca, nea);

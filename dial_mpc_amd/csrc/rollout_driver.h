@@ -185,7 +185,9 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
       if (rrow && i == 0) rrow[0] = rew;
     });
+#ifndef DIAL_PROFILE   // (profiling builds carry no state trace: the combination trips an LLVM address-space bug in the DimsMax kernel)
     if constexpr (TRACE) { if (io.trace) store_state(w, m, s, io.trace + o * nstate); }
+#endif
     DIAL_MARK(w, 24);
   }
 #ifdef DIAL_PROFILE
