@@ -150,6 +150,18 @@ DIAL_DEV float segment_box_t(const float* l0, const float* l1, const float* h) {
 // 0: the contact is then where the axis crosses the surface, with the normal of the face it crosses and dist = -radius --
 // the continuation of the shallow case (closest point -> surface point, same face normal).
 DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r, const BoxG& b, int sub, float& dist, float* pos, float* fr) {
+  {   // broad phase, as in box_box: bounding spheres more than 1 cm apart -- both candidates parked (dist >= margin: no rows, and
+      // nothing reads the position of a capsule contact that does not touch); the normal is the centre line.  All the capsule
+      // lanes of a wavefront take this exit while the robot is away from the box, and the ~600-instruction routine is skipped.
+    const float tw[3] = {b.c[0] - ctr[0], b.c[1] - ctr[1], b.c[2] - ctr[2]};
+    const float gap = DM_SQRT(dm::dot3(tw, tw)) - (hl + r) - DM_SQRT(dm::dot3(b.h, b.h));
+    if (gap > 0.01f) {
+      dist = sub == 0 ? gap : 1.f;
+      for (int k = 0; k < 3; k++) pos[k] = 0.5f * (ctr[k] + b.c[k]);
+      make_frame(fr, tw);
+      return;
+    }
+  }
   float e0[3], e1[3], r0[3], r1[3], l0[3], l1[3];
   for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; r0[k] = e0[k] - b.c[k]; r1[k] = e1[k] - b.c[k]; }
   dm::inv_rotate(l0, r0, b.q);

@@ -39,6 +39,11 @@ struct TopoAllegro {  // free object (0..5) and four independent 4-hinge fingers
   static constexpr ParentTable<22> T{{-1, 0, 1, 2, 3, 4, -1, 6, 7, 8, -1, 10, 11, 12, -1, 14, 15, 16, -1, 18, 19, 20}};
   static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
 };
+struct TopoH1PushCrate {   // the H1's tree (TopoH1) and the crate's slide dof (25), a root of its own
+  static constexpr bool dense = false;
+  static constexpr ParentTable<26> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5, 16, 17, 18, 19, 16, 21, 22, 23, -1}};
+  static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
+};
 struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms are welded to the torso
   static constexpr bool dense = false;
   static constexpr ParentTable<17> T{{-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 5, 11, 12, 13, 14, 5}};
@@ -60,13 +65,17 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
 // LDS shared by the nine wavefronts of a workgroup.
 template <bool STATIC, int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NC_, int NL_,
           class Topo_ = TopoDense, bool SQUARE_ = false, int NHI_ = 2, bool ELL_ = false, int NE_ELL_ = 0, int JCW_ = 4,
-          bool GEN_ = !STATIC, int NFRI_ = -1>
+          bool GEN_ = !STATIC, int NFRI_ = -1, bool HDENSE_ = true>
 struct Dims {
   using Topo = Topo_;
   static constexpr bool is_static = STATIC;
   static constexpr bool gen = GEN_;
   static constexpr int NFRI = GEN_ ? NFRI_ : 0;   // dry-friction rows: compile-time count, -1 = run time (capacity-dimension kernel)
-  static constexpr int NVP = STATIC ? NV_ : DIAL_MAX_V;   // dimension of the generic solver's dense register L D L^T
+  static constexpr int NVP = STATIC ? NV_ : DIAL_MAX_V;   // dimension of the generic solver's register L D L^T
+  // generic feature set at compile-time dimensions: M is factorised with the dof tree's fill-free order (Topo); H = M + J^T D J
+  // keeps that sparsity as long as every contact is against the world (crate climb: the crate is welded) and loses it when a
+  // contact couples two moving bodies (push crate: robot against the sliding crate)
+  static constexpr bool h_dense = HDENSE_;
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NC = NC_, NL = NL_;
   static constexpr bool ell = ELL_;
   static constexpr int NE = ELL_ ? NE_ELL_ : NL_ + 4 * NC_;
@@ -92,8 +101,8 @@ using DimsH1Loco = Dims<true, 18, 17, 11, 21, 12, 5, 3, 8, 11, TopoH1Loco, true,
 // Allegro: 19 contacts (14 x condim 3 + 5 x condim 6 = 72 rows) + 16 limits; compact Jacobian 8x3x4 + 6x3x8 + 6x6 + 4x6x10
 using DimsAllegro = Dims<true, 23, 22, 16, 23, 17, 6, 0, 19, 16, TopoAllegro, true, 64, true, 88, 516>;
 // the crate scenes: Go2 + floor + welded crate (52 candidate contacts), H1 + crate on a slide joint (28)
-using DimsGo2Crate = Dims<true, 19, 18, 12, 15, 13, 17, 5, 52, 12, TopoDense, false, 2, false, 0, 4, true, 0>;
-using DimsH1PushCrate = Dims<true, 27, 26, 19, 22, 21, 9, 3, 28, 19, TopoDense, false, 2, false, 0, 4, true, 1>;
+using DimsGo2Crate = Dims<true, 19, 18, 12, 15, 13, 17, 5, 52, 12, TopoGo2, false, 2, false, 0, 4, true, 0, false>;
+using DimsH1PushCrate = Dims<true, 27, 26, 19, 22, 21, 9, 3, 28, 19, TopoH1PushCrate, false, 2, false, 0, 4, true, 1, true>;
 using DimsMax = Dims<false, DIAL_MAX_Q, DIAL_MAX_V, DIAL_MAX_U, DIAL_MAX_BODY, DIAL_MAX_JNT, DIAL_MAX_GEOM,
                      DIAL_MAX_SITE, DIAL_MAX_CON, DIAL_MAX_LIM>;
 

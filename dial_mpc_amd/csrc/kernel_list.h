@@ -5,12 +5,17 @@
 #include "rollout_kernel.h"
 
 // wavefronts per workgroup (they share one staged copy of the constants) / occupancy target of the Go2 instantiations:
-// small batches (every sample co-resident at 1 wavefront per workgroup) and large ones (LDS per wavefront matters)
+// small batches (every sample co-resident at 1 wavefront per workgroup, 168 VGPRs, 2 wavefronts per SIMD at N = 2048) and
+// large ones, where wavefront slots are what counts.  Round 4: EIGHT wavefronts per workgroup (78 KB: two workgroups = 16
+// wavefronts per CU) compiled for FOUR wavefronts per SIMD -- possible without spills since the opaque lane id per step
+// (wave.h: launder) took the kernel from 168 VGPRs + 15 spilled to 125 -- instead of round 2's 4 per workgroup / 3 per SIMD:
+// 4096 resident rollouts instead of 3072; N = 4096 +14.6 %, 8192 +3 %, 16384 +9 %, 65536 +11.4 % (one box, alternating runs,
+// profiles/r04_go2_large_batch_ab.txt).
 #ifndef DIAL_GO2_WPB_LARGE
-#define DIAL_GO2_WPB_LARGE 4
+#define DIAL_GO2_WPB_LARGE 8
 #endif
 #ifndef DIAL_GO2_OCC_LARGE
-#define DIAL_GO2_OCC_LARGE 3
+#define DIAL_GO2_OCC_LARGE 4
 #endif
 // Allegro: 15.3 KB of workspace per wavefront + 10.5 KB of shared constants.  9 wavefronts per workgroup = 148 KB = one
 // workgroup per CU = 2304 resident rollouts: the example's N + 1 = 2049 run in ONE round (8 per CU would leave the

@@ -227,7 +227,8 @@ struct DimsPadV {
   static constexpr bool square = true;
   using Topo = TopoDense;
 };
-template <class W, class M>
+// TopoT: the fill pattern of A (TopoDense, or the dof tree when A has exact zeros off it: see Dims::h_dense)
+template <class TopoT = TopoDense, class W, class M>
 DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const float* rhs, float* x) {
   constexpr int NP = M::D::NVP, S = kCholStride<NP>;   // the capacity dimension, or the model's own (compile-time dimensions)
   const int nv = dim_nv(m);
@@ -238,7 +239,16 @@ DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const
     s.sq[e] = v;
   });
   const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
-  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoDense>(w, m, s.sq, b, s.sq);
+  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
+  w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
+}
+// the same with the square already in s.sq (the Hessian's accumulator tile is written straight into it)
+template <class TopoT = TopoDense, class W, class M>
+DIAL_DEV void solve_sq_reg(W& w, const M* m, const Ws& s, const float* rhs, float* x) {
+  constexpr int NP = M::D::NVP;
+  const int nv = dim_nv(m);
+  const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
+  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
   w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
 }
 
@@ -447,7 +457,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
 #ifdef DIAL_LDS_CHOL
     solve_spd(w, m, s, s.M, s.rhs, s.qas);
 #else
-    solve_spd_reg(w, m, s, s.M, s.rhs, s.qas);
+    solve_spd_reg<typename M::D::Topo>(w, m, s, s.M, s.rhs, s.qas);
 #endif
   }
   DIAL_MARK(w, 3);
@@ -589,8 +599,8 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     // as exact zeros: every product of such a pair has a zero factor.
     const int nent = (nv * (nv + 1)) / 2;
     w.items(nca, [&](int c) {   // the contact's weights, laid out for the two k-slots: [W00 W01 W02 | W02 0 W22] and [W01 W11 0 | 0 0 0]
-      const int co = con_of(m, s, c), r0 = nlf + 4 * c;
-      const float mu1 = m->con_friction[co][0], mu2 = m->con_friction[co][1];
+      const int r0 = nlf + 4 * c;
+      const float mu1 = s.cmu[2 * c], mu2 = s.cmu[2 * c + 1];
       const float d0 = s.Jaref[r0] < 0.f ? s.D[r0] : 0.f, d1 = s.Jaref[r0 + 1] < 0.f ? s.D[r0 + 1] : 0.f;
       const float d2 = s.Jaref[r0 + 2] < 0.f ? s.D[r0 + 2] : 0.f, d3 = s.Jaref[r0 + 3] < 0.f ? s.D[r0 + 3] : 0.f;
       const float W00 = (d0 + d1) + (d2 + d3), W01 = mu1 * (d0 - d1), W11 = (mu1 * mu1) * (d0 + d1);
@@ -625,17 +635,37 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? jt1 : jn, b1, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : jt2, b2, acc, 0, 0, 0);
       }
-      // accumulator a of lane (col, half) is entry (row, col), row = 8 (a / 4) + 4 half + a % 4 (profiles/r02_ubench_mfma_jtdj.txt);
-      // the lower triangle goes to the packed H
+      DIAL_MARK(w, 12);
+      // accumulator a of lane (col, half) is entry (row, col), row = 8 (a / 4) + 4 half + a % 4 (profiles/r02_ubench_mfma_jtdj.txt).
+      // The tile goes STRAIGHT into the square the register L D L^T reads (s.sq, both triangles; identity block for the dofs a
+      // capacity-dimension model does not have): no packed H, no packed -> square copy.
+      // (Compile-time dimensions only: in the capacity-dimension kernel this write-back runs into an LLVM address-space
+      // inference bug -- "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base" --; it keeps the packed H.)
+      constexpr int NP = M::D::NVP, SS = kCholStride<NP>;
+      if constexpr (!M::D::is_static) {
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+          const int row = (a >> 2) * 8 + half * 4 + (a & 3);
+          if (row < nv && col <= row) { const int e = tri_idx(row, col); s.H[e] = s.M[e] + acc[a]; }
+        }
+        w.sync();
+        w.items(nv, [&](int i) { s.H[tri_idx(i, i)] += diag_rows(i); });
+      } else {
 #pragma unroll
       for (int a = 0; a < 16; a++) {
         const int row = (a >> 2) * 8 + half * 4 + (a & 3);
-        if (row < nv && col <= row) {
-          const int e = tri_idx(row, col);
-          s.H[e] = (s.M[e] + acc[a]) + (row == col ? diag_rows(row) : 0.f);
+        if (row < NP && col < NP) {
+          const bool in = row < nv && col < nv;
+          const int hi_ = row > col ? row : col, lo_ = row > col ? col : row;
+          const float mv_ = s.M[in ? tri_idx(hi_, lo_) : 0];   // (an unconditional fetch from a clamped index: no select of addresses)
+          s.sq[row * SS + col] = in ? mv_ + acc[a] : (row == col ? 1.f : 0.f);
         }
       }
       w.sync();
+      // the limit / friction rows' diagonal terms in a phase of their own (inside the unrolled tile loop each was a divergent
+      // branch with two dependent LDS round trips: 16 of them made the write-back cost more than the GEMM)
+      w.items(nv, [&](int i) { s.sq[i * SS + i] += diag_rows(i); });
+      }
     }
 #else
     // host emulator: the same algebra entry by entry (the matrix cores' internal summation order is not modelled)
@@ -657,8 +687,11 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     DIAL_MARK(w, 5);
 #ifdef DIAL_LDS_CHOL
     solve_spd(w, m, s, s.H, s.rhs, s.search);
+#elif defined(DIAL_EMU)
+    solve_spd_reg<std::conditional_t<M::D::h_dense, TopoDense, typename M::D::Topo>>(w, m, s, s.H, s.rhs, s.search);
 #else
-    solve_spd_reg(w, m, s, s.H, s.rhs, s.search);
+    if constexpr (M::D::is_static) solve_sq_reg<std::conditional_t<M::D::h_dense, TopoDense, typename M::D::Topo>>(w, m, s, s.rhs, s.search);
+    else solve_spd_reg(w, m, s, s.H, s.rhs, s.search);
 #endif
     w.items(nv, [&](int i) { s.search[i] = -s.search[i]; });
   };
@@ -1460,7 +1493,14 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
     if (s.con_cap > 0 && nca > s.con_cap && s.ovf != nullptr) {   // (a capped workspace always comes with its overflow area)
       Ws sg = s;
-      ws_overflow(sg, s.ovf, nv, nc, ne);
+      float* ovf = s.ovf;
+#ifndef DIAL_EMU
+      // (opaque to the optimiser: with the provenance of both workspaces in sight LLVM merges the two copies of the constraint
+      //  code into one over pointer PHIs and trips over its own address-space inference -- "Illegal instruction detected:
+      //  V_CMP_NE_U32 0, $src_shared_base" -- in the capacity-dimension kernel; the overflow copy simply uses flat accesses)
+      asm volatile("" : "+v"(ovf));
+#endif
+      ws_overflow(sg, ovf, nv, nc, ne);
       forward_constraints(w, m, sg, nca, nea);
       return;
     }
@@ -1471,11 +1511,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 // Task kinds a kernel instantiation can be asked to run (the dimension-specialised ones are per robot; dial_create checks).
 template <class D>
 constexpr uint32_t task_kind_mask() {
+  if (std::is_same<D, DimsGo2Crate>::value) return 1u << DIAL_TASK_GO2_CRATE;   // (dispatched ahead of the reward phase)
+  if (std::is_same<D, DimsH1PushCrate>::value) return 1u << DIAL_TASK_H1_PUSH_CRATE;
   if (std::is_same<typename D::Topo, TopoGo2>::value) return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP);
   if (std::is_same<typename D::Topo, TopoH1>::value) return 1u << DIAL_TASK_H1_WALK;
   if (std::is_same<typename D::Topo, TopoH1Loco>::value) return 1u << DIAL_TASK_H1_LOCO;
-  if (std::is_same<D, DimsGo2Crate>::value) return 1u << DIAL_TASK_GO2_CRATE;   // (dispatched ahead of the reward phase)
-  if (std::is_same<D, DimsH1PushCrate>::value) return 1u << DIAL_TASK_H1_PUSH_CRATE;
   return (1u << DIAL_TASK_GO2_WALK) | (1u << DIAL_TASK_GO2_SEQ_JUMP) | (1u << DIAL_TASK_H1_WALK) | (1u << DIAL_TASK_H1_LOCO) |
          (D::gen ? (1u << DIAL_TASK_H1_PUSH_CRATE) | (1u << DIAL_TASK_GO2_CRATE) : 0u);
 }
@@ -1610,7 +1650,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
   DIAL_MARK(w, 25);
   for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
 #ifndef DIAL_EMU
-    if constexpr (M::D::gen) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // see rollout_driver.h: the step loop
+    if (w.launder) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // see rollout_driver.h: the step loop
 #endif
     forward(w, m, s);
     euler(w, m, s);

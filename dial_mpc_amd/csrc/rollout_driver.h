@@ -156,7 +156,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     // 73 spilled VGPRs, 36 of them stored right here at the loop entry; with the opaque copy of the lane id per step and per
     // physics frame: 0 spilled VGPRs, 0 B of scratch).  (The dimension-specialised register-solver kernels have no spills to cure: there the hoisted addresses pay for
     // themselves -- measured 5 % slower with the laundering, DESIGN.md.)
-    if constexpr (M::D::gen) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // (and once per physics frame: rollout_body.h env_step)
+    if (w.launder) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // (and once per physics frame: rollout_body.h env_step)
 #endif
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     w.items(nu, [&](int a) {

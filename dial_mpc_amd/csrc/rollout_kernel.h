@@ -57,6 +57,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   Wave w;
   w.lane = threadIdx.x & 63;
   w.lane_r = w.lane;
+  w.launder = D::gen || OCC >= 4;   // (see wave.h)
 #ifdef DIAL_PROFILE
   w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
   if (w.lane < 32) w.acc[w.lane] = 0;
@@ -100,6 +101,7 @@ env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   Wave w;
   w.lane = threadIdx.x;
   w.lane_r = w.lane;
+  w.launder = D::gen;
   dial::env_step_single(w, m, tg, s, state, action, xpos_out, xquat_out, ctrl_out);
 }
 

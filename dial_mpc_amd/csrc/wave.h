@@ -59,6 +59,7 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 
 #define DIAL_MARK(w, id)
 struct Wave {
+  bool launder = false;   // (GPU only: opaque lane id per step, see the HIP Wave)
   float* lds = nullptr;
   int lds_words = 0;
   bool check_races = false;
@@ -315,6 +316,10 @@ struct Wave {
   // Refreshing lane_r once per region (one solve, one line search) keeps the masks short-lived.
   int lane_r;
   __device__ __forceinline__ void begin_region() { int l = lane; asm volatile("" : "+v"(l)); lane_r = l; }
+  // Opaque copy of the lane id once per control step / physics frame (rollout_driver.h, rollout_body.h): set by the kernel for
+  // the instantiations whose hoisted lane-derived addresses would not fit the register budget (generic feature set; the
+  // 128-VGPR large-batch build of the Go2).  A compile-time constant after inlining.
+  bool launder = false;
   // Issue priority, re-drawn pseudo-randomly (4 levels, hash of rollout index and draw count) twice per physics step.
   // The SIMD's arbiter serves the OLDEST ready wavefront first: of the two or three wavefronts that share a SIMD the
   // oldest runs at its solo pace and the youngest on what is left, so rollouts of equal length finish 410 ... 615 us

@@ -87,7 +87,8 @@ extern "C" {
 #define DIAL_CON_PLANE_BOX 5    /* geom1 plane, geom2 box: con_sub = k-th lowest of the 8 vertices (k < 4)              */
 #define DIAL_CON_SPHERE_BOX 6   /* geom1 sphere, geom2 box: closest point of the box to the centre                      */
 #define DIAL_CON_CAPSULE_BOX 7  /* geom1 capsule, geom2 box: con_sub 0 = the segment point closest to the box, 1 = the
-                                   segment end farther from that point (both as spheres of the capsule's radius)       */
+                                   segment end farther from that point (both as spheres of the capsule's radius); bounding
+                                   spheres more than 1 cm apart: both candidates parked at dist > 0 (as DIAL_CON_BOX_BOX) */
 #define DIAL_CON_BOX_BOX 8      /* separating-axis test; face contact: incident face clipped against the reference face,
                                    con_sub = k-th deepest point (k < 4); edge contact: one point (con_sub 0)            */
 

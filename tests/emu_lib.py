@@ -19,8 +19,10 @@ def build():
     srcs.append(_abi.HEADER)
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(f) for f in srcs):
         return
+    tmp = f"{_SO}.{os.getpid()}.tmp"     # atomic: parallel test workers may all find the library stale at once
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fno-strict-aliasing",
-                           "-ffp-contract=off", "-o", _SO, os.path.join(_HERE, "emu.cpp")])
+                           "-ffp-contract=off", "-o", tmp, os.path.join(_HERE, "emu.cpp")])
+    os.replace(tmp, _SO)
 
 
 class Emu:

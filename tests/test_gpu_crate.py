@@ -191,7 +191,7 @@ def test_crate_overflow_path_on_the_gpu_is_bit_identical():
         sc = ctx.debug_scratch()
         outs[cap] = (lds, out["Ybar"].cpu().numpy(), out["rews"].cpu().numpy(), sc["qss"].copy(), sc["qdss"].copy())
         del ctx
-    assert outs[1][0] < outs[14][0] < outs[-1][0]            # three different LDS footprints
+    assert outs[1][0] < outs[14][0]                          # different LDS footprints (the uncapped context runs the capacity-dimension kernel, one wavefront per workgroup)
     for cap in (1, 14):
         for a, b in zip(outs[-1][1:], outs[cap][1:]):
             assert np.array_equal(a, b), f"con_cap={cap}"

@@ -21,6 +21,8 @@ NAMES = {24: "per-step output stores", 25: "ctrl (act2tau) + gait clock", 0: "ki
          9: "euler", 10: "ctrl + reward", 11: "act/output/IO", 14: "(newton_dir entry)", 15: "(forward entry)",
          28: "EVENTS (all samples, cumulative): 2nd Newton iterations", 29: "  ... with an unchanged active set",
          30: "  line-search iterations", 31: "  Newton iterations"}
+if len(sys.argv) > 1 and "crate" in sys.argv[1]:
+    NAMES.update({14: "H: contact weights", 12: "H: GEMM loop (2 MFMA per touching contact)", 5: "H: accumulator tile -> packed H"})
 if len(sys.argv) > 1 and sys.argv[1] == "allegro_reorient":
     NAMES.update({27: "EVENTS (all samples): contributing units (sum over solves)", 28: "  constraint solves (physics sub-steps)",
                   29: "  Newton iterations on the 3-points-per-pass line search (<= 16 units)",
