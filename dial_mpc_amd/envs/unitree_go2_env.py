@@ -10,7 +10,7 @@ from typing import Any, Dict, Union
 
 import numpy as np
 
-from dial_mpc_amd import _abi
+from dial_mpc_amd import _abi, mjcf
 from dial_mpc_amd.envs.base_env import BaseEnv, BaseEnvConfig, System, load_model
 
 TASK_GO2_WALK = _abi.MACROS["DIAL_TASK_GO2_WALK"]
@@ -173,7 +173,14 @@ class UnitreeGo2SeqJumpEnv(UnitreeGo2Env):
 
 @dataclass
 class UnitreeGo2CrateEnvConfig(UnitreeGo2EnvConfig):
-    pass
+    # Not upstream keys (both optional): the order of MJX's contact ARRAY as data, for comparisons against a reference run.
+    # contact_slots: [[geom1, geom2], ...] MuJoCo geom ids per array position, as tools/export_reference_vectors.py records
+    #   them (mjcf.reorder_contacts rebuilds the model's contact list in that order / multiplicity);
+    # contact_lookup: "identity" (default) finds the reward's contacts by geom identity in whatever order the list has;
+    #   "literal" uses upstream's hard-coded positions (unitree_go2_env.py:750) -- meaningful once contact_slots reproduces
+    #   the array of the MJX release upstream ran.
+    contact_slots: Any = None
+    contact_lookup: str = "identity"
 
 
 class UnitreeGo2CrateEnv(UnitreeGo2Env):
@@ -203,11 +210,18 @@ class UnitreeGo2CrateEnv(UnitreeGo2Env):
             hits = [c for c in range(int(m["ncon"])) if int(m["con_geom1"][c]) == g and int(m["con_geom2"][c]) == box]
             assert len(hits) == 1, f"foot geom {foot!r} has no contact with the crate in the compiled model"
             self._crate_contact.append(hits[0])
+        self._crate_contact_identity = list(self._crate_contact)
+        if getattr(self._config, "contact_lookup", "identity") == "literal":
+            self._crate_contact = [16, 17, 18, 19]                           # :750, verbatim
+        elif getattr(self._config, "contact_lookup", "identity") != "identity":
+            raise ValueError("contact_lookup must be 'identity' or 'literal'")
         self._crate_region = np.array([1.0, 1.6, -0.45, 0.45, 0.59, 0.61])   # :753-760
         self._head_vec = np.array([0.285, 0.0, 0.0])                         # :717
 
     def make_system(self, config: UnitreeGo2EnvConfig) -> System:
         model = load_model("unitree_go2", "mjx_scene_force_crate.xml")
+        if getattr(config, "contact_slots", None) is not None:
+            model = mjcf.reorder_contacts(model, [tuple(p) for p in config.contact_slots], ids="mujoco")
         return System(model).tree_replace({"opt.timestep": config.timestep})
 
     def _randomize_dict(self) -> Dict[str, Any]:

@@ -8,7 +8,7 @@ from typing import Any, Dict, Union
 
 import numpy as np
 
-from dial_mpc_amd import _abi
+from dial_mpc_amd import _abi, mjcf
 from dial_mpc_amd.envs.base_env import BaseEnv, BaseEnvConfig, System, load_model
 
 TASK_H1_WALK = _abi.MACROS["DIAL_TASK_H1_WALK"]
@@ -136,7 +136,10 @@ class UnitreeH1LocoEnv(BaseEnv):
 
 @dataclass
 class UnitreeH1PushCrateEnvConfig(UnitreeH1WalkEnvConfig):
-    pass
+    # optional, not upstream keys -- see UnitreeGo2CrateEnvConfig: the contact ARRAY's order as data, and whether the reward's
+    # contacts are found by geom identity or at upstream's literal positions (unitree_h1_env.py:474-480, 525-531)
+    contact_slots: Any = None
+    contact_lookup: str = "identity"
 
 
 class UnitreeH1PushCrateEnv(UnitreeH1WalkEnv):
@@ -168,10 +171,18 @@ class UnitreeH1PushCrateEnv(UnitreeH1WalkEnv):
         hands = ("left_elbow_link", "right_elbow_link")
         self._pc_wanted = [c for c, (g1, g2) in enumerate(con) if g2 == box and gbody[g1] in hands]
         self._pc_unwanted = [c for c, (g1, g2) in enumerate(con) if g2 == box and gbody[g1] not in hands]
-        assert len(self._pc_wanted) == 2 and len(self._pc_unwanted) == 12, (self._pc_wanted, self._pc_unwanted)
+        # (12 with this compiler's candidate counts; a contact array rebuilt from a reference run may list a pair more often)
+        assert len(self._pc_wanted) == 2 and 12 <= len(self._pc_unwanted) <= 16, (self._pc_wanted, self._pc_unwanted)
+        self._pc_identity = ([list(h) for h in self._pc_foot_contact], list(self._pc_wanted), list(self._pc_unwanted))
+        if getattr(self._config, "contact_lookup", "identity") == "literal":   # upstream's positions, verbatim
+            self._pc_foot_contact, self._pc_wanted, self._pc_unwanted = [[2, 3], [6, 7]], [26, 27], list(range(14, 26))
+        elif getattr(self._config, "contact_lookup", "identity") != "identity":
+            raise ValueError("contact_lookup must be 'identity' or 'literal'")
 
     def make_system(self, config: UnitreeH1WalkEnvConfig) -> System:
         model = load_model("unitree_h1", "mjx_scene_h1_push_crate.xml")
+        if getattr(config, "contact_slots", None) is not None:
+            model = mjcf.reorder_contacts(model, [tuple(p) for p in config.contact_slots], ids="mujoco")
         return System(model).tree_replace({"opt.timestep": config.timestep})
 
     def task_dict(self) -> Dict[str, Any]:

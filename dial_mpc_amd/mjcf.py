@@ -645,6 +645,7 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
         dof_bodyid=np.array(dof_bodyid), dof_jntid=np.array(dof_jntid),
         dof_parentid=np.array(dof_parentid), dof_armature=np.array(dof_armature),
         dof_damping=np.array(dof_damping), dof_invweight0=np.zeros(nv),
+        geom_mjid=np.array([next(k for k, h in enumerate(geoms_all) if h is g) for g in cgeoms], dtype=np.int64),   # MuJoCo / MJX geom id of every collision geom
         geom_type=np.array([g["type"] for g in cgeoms]),
         geom_bodyid=np.array([g["body"] for g in cgeoms]),
         geom_pos=np.array([g["pos"] for g in cgeoms]).reshape(-1, 3),
@@ -683,6 +684,74 @@ def compile_mjcf(path: str, mesh_inertia: str = "convex") -> Dict[str, Any]:
     m["keyframes"] = {k: v.tolist() for k, v in keys.items()}
     _set_const(m)
     return m
+
+
+# ---------------------------------------------------------------- the contact ARRAY as data
+# The order of the static contact list (and how many candidates a geom pair contributes) is MJX-internal -- pair grouping by
+# collision function, per-function candidate counts that changed between releases -- and the reference's crate envs read
+# that array by POSITION (unitree_go2_env.py:750, unitree_h1_env.py:469-470, 522-523).  The list is therefore data, not
+# code: `contact_slots(model)` names the geom pair of every position, `reorder_contacts(model, slots)` rebuilds the list in
+# any given order / multiplicity -- e.g. the per-slot geom ids that tools/export_reference_vectors.py records from a
+# reference run -- without touching the compiler, the oracle or a kernel (all of them consume dial_model.con_*).
+_CON_KEYS = ("con_kind", "con_geom1", "con_geom2", "con_body1", "con_body2", "con_dim", "con_sub", "con_friction", "con_solref",
+             "con_solimp", "con_margin")
+# candidate contacts one pair of that kind can be asked for (con_sub < this; candidates the geometry does not produce are parked
+# at dist = 1: box_box ranks the <= 8 points of the clipped face, plane_box the 8 vertices, capsule_box has its two spheres)
+_MAX_SUB = {5: 8, 6: 1, 7: 2, 8: 8}
+
+
+def contact_slots(m: Dict[str, Any], ids: str = "index") -> List[tuple]:
+    """(geom1, geom2) of every position of the model's contact list -- as indices into the model's collision-geom list
+    (ids="index"), as MuJoCo / MJX geom ids (ids="mujoco": what a reference run's contact.geom holds) or as names."""
+    g = m["names"]["geom"] if ids == "name" else (np.asarray(m["geom_mjid"]).tolist() if ids == "mujoco" else list(range(int(m["ngeom"]))))
+    return [(g[int(a)], g[int(b)]) for a, b in zip(np.asarray(m["con_geom1"]), np.asarray(m["con_geom2"]))]
+
+
+def reorder_contacts(m: Dict[str, Any], slots, ids: str = "index") -> Dict[str, Any]:
+    """A copy of the compiled model whose contact list follows `slots`: one (geom1, geom2) pair -- collision-geom indices,
+    unique names, or (ids="mujoco") MuJoCo / MJX geom ids as a reference run records them; in either order -- per position of
+    the wanted contact ARRAY.  The k-th occurrence of a pair takes the pair's k-th
+    candidate (con_sub = k); a pair may be listed MORE often than this compiler emits it (box kinds: up to 8, the extra
+    candidates carry the next con_sub and come out parked when the geometry has no such point).  Pairs the compiler emits but
+    `slots` does not mention keep their candidates, appended after the listed ones in their old order (the physics is unchanged
+    by any reordering: rows are summed in another order, nothing else)."""
+    names = m["names"]["geom"]
+    ncon = int(m["ncon"])
+    arr = {k: np.asarray(m[k]) for k in _CON_KEYS}
+    mjid = np.asarray(m["geom_mjid"]).tolist() if ids == "mujoco" else None
+    idx = lambda g: names.index(g) if isinstance(g, str) else (mjid.index(int(g)) if mjid is not None else int(g))  # noqa: E731
+    by_pair: Dict[tuple, List[int]] = {}
+    for c in range(ncon):
+        by_pair.setdefault((int(arr["con_geom1"][c]), int(arr["con_geom2"][c])), []).append(c)
+    for v in by_pair.values():
+        v.sort(key=lambda c: int(arr["con_sub"][c]) * 4 + (int(arr["con_kind"][c]) == 2))   # plane-capsule: the +axis end first
+    used: Dict[tuple, int] = {}
+    order: List[tuple] = []                         # (source contact, con_sub override or None)
+    for a, b in slots:
+        ia, ib = idx(a), idx(b)
+        key = (ia, ib) if (ia, ib) in by_pair else (ib, ia)
+        if key not in by_pair:
+            raise ValueError(f"contact slot ({a}, {b}): the compiled model has no contact between these geoms")
+        k = used.get(key, 0)
+        used[key] = k + 1
+        cands = by_pair[key]
+        if k < len(cands):
+            order.append((cands[k], None))
+        else:
+            kind = int(arr["con_kind"][cands[0]])
+            if k >= _MAX_SUB.get(kind, len(cands)):
+                raise ValueError(f"contact slot ({a}, {b}): occurrence {k + 1} exceeds what contact kind {kind} can produce")
+            order.append((cands[0], k))
+    listed = {c for c, sub in order if sub is None}
+    order += [(c, None) for c in range(ncon) if c not in listed]
+    out = dict(m)
+    for key in _CON_KEYS:
+        out[key] = np.stack([arr[key][c] for c, _ in order]) if arr[key].ndim > 1 else np.array([arr[key][c] for c, _ in order])
+    out["con_sub"] = np.array([int(arr["con_sub"][c]) if sub is None else sub for c, sub in order], dtype=np.int64)
+    out["ncon"] = len(order)
+    out["nefc"] = int(m["nefc"]) + (int(np.sum(out["con_dim"])) - int(np.sum(arr["con_dim"])) if int(m.get("cone", 0)) == 1
+                                    else 4 * (len(order) - ncon))
+    return out
 
 
 def _mat_to_quat(R):

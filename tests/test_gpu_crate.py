@@ -172,9 +172,11 @@ def test_crate_closed_loop_runs_and_approaches_the_crate():
 
 
 def test_crate_overflow_path_on_the_gpu_is_bit_identical():
-    """The rollout kernel's LDS workspace holds 14 touching contacts; a sample with more runs the second compiled copy of the
-    constraint code on its overflow area in global memory.  dial_options.con_cap = 1 sends every touching step down that
-    path, < 0 switches the cap off (full-size LDS workspace): all three must agree bit for bit."""
+    """The rollout kernel's LDS workspace holds a capped number of touching contacts; a sample with more runs the second compiled
+    copy of the constraint code on its overflow area in global memory.  dial_options.con_cap = 1 sends every touching step
+    down that path, < 0 switches the cap off (full-size LDS workspace, capacity-dimension kernel only).  Within one kernel
+    instantiation all caps must agree bit for bit; the scene's own instantiation (compile-time dimensions, dof-tree
+    factorisation) and the capacity-dimension one (dense factorisation) agree to rounding."""
     import oracle as O
     from dial_mpc_amd import _lib
     N, H = 256, 12
@@ -184,17 +186,23 @@ def test_crate_overflow_path_on_the_gpu_is_bit_identical():
     s0, _, _ = o32.env_reset(q, qd)
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=3, Ybar_scale=0.2)
     outs = {}
-    for cap in (14, 1, -1):
-        ctx = _lib.Context(model, task, cfg, options=dict(con_cap=cap))
-        lds = ctx.lib.dial_lds_bytes(ctx.h)
-        out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
-        sc = ctx.debug_scratch()
-        outs[cap] = (lds, out["Ybar"].cpu().numpy(), out["rews"].cpu().numpy(), sc["qss"].copy(), sc["qdss"].copy())
-        del ctx
-    assert outs[1][0] < outs[14][0]                          # different LDS footprints (the uncapped context runs the capacity-dimension kernel, one wavefront per workgroup)
-    for cap in (1, 14):
-        for a, b in zip(outs[-1][1:], outs[cap][1:]):
-            assert np.array_equal(a, b), f"con_cap={cap}"
+    for generic, caps in ((0, (0, 14, 1)), (1, (0, 14, 1, -1))):
+        for cap in caps:
+            ctx = _lib.Context(model, task, cfg, options=dict(con_cap=cap, force_generic=generic))
+            lds = ctx.lib.dial_lds_bytes(ctx.h)
+            out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+            sc = ctx.debug_scratch()
+            outs[(generic, cap)] = (lds, out["Ybar"].cpu().numpy(), out["rews"].cpu().numpy(), sc["qss"].copy(), sc["qdss"].copy())
+            del ctx
+    assert outs[(0, 1)][0] < outs[(0, 14)][0] < outs[(0, 0)][0]          # three different LDS footprints (nine wavefronts each)
+    assert outs[(1, 1)][0] < outs[(1, 14)][0] < outs[(1, -1)][0]
+    for generic, caps in ((0, (14, 1)), (1, (14, 1, -1))):
+        for cap in caps:
+            for a, b in zip(outs[(generic, 0)][1:], outs[(generic, cap)][1:]):
+                assert np.array_equal(a, b), f"force_generic={generic} con_cap={cap}"
+    # the two instantiations against each other: same physics, different summation / elimination orders
+    same = np.abs(outs[(0, 0)][3] - outs[(1, 0)][3]).reshape(N + 1, -1).max(1) <= TOL["q"]["atol"]
+    assert same.mean() > 0.9, same.mean()
 
 
 def test_crate_overflow_path_under_the_relay_at_full_size():
