@@ -46,7 +46,18 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
     """Time the CPU oracle (kind = "port") on this box's host cores.  Test-infrastructure code is used
     here ONLY as the reported baseline, never on the timed GPU path."""
     cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # The container's CPU BUDGET, not its affinity mask, is what the port can use: the GPU boxes of this pool expose 256 hardware
+    # threads with a cgroup quota of 16 CPUs (profiles/r04_cpu_scaling.txt: perfect per-thread pace up to 32 threads, 2.9 x slower
+    # per thread at 64, 134 x at 256 -- round 3's "parallel efficiency" problem was threads fighting over the quota).
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    budget = cores if quota is None else max(1, min(cores, int(round(2 * quota))))   # (up to 2 x: the quota is enforced per period)
+    os.environ.setdefault("OMP_NUM_THREADS", str(budget))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
@@ -66,7 +77,7 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
         best_nt, best_t = cores, None
-        for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
+        for nt in sorted({budget, max(1, budget // 2), max(1, budget // 4), min(budget, 32), min(budget, 16), min(budget, 8)}, reverse=True):
             gomp.omp_set_num_threads(nt)
             o32.reverse_once(s0, Ybar, sigma, eps)
             ta = time.perf_counter()
@@ -102,6 +113,7 @@ def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_
         pass
     return {"value": (N + 1) * reps / dt, "unit": "sample-rollouts/s", "cores": cores, "kind": "port",
             "ns_per_env_step_per_thread": ns_per_step, "single_thread_us_per_env_step": single_us, "host_threads_available": host_threads,
+            "cgroup_cpu_quota": quota,
             "physics_steps_per_env_step": n_frames, "build": build_note,
             "sample": f"{reps} x reverse_once(N={N}, H={H}) fp32 C oracle ({build_note}), OpenMP over samples on {cores} "
                       f"threads (best of a scan up to the {host_threads} available), {dt:.2f} s wall = {dt * cores:.0f} core-s, {ns_per_step / 1e3:.0f} us per env.step per thread; "

@@ -903,6 +903,78 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   DIAL_MARK(w, 8);
 }
 
+// Suffix sum of `src` (stride `st`, component k) up the exclusive tail of chain c into `dst` -- leaf first, as the plain loop
+//   for (q = len - 1; q >= excl; q--) { acc += src[st * body_q + k]; dst[st * body_q + k] = acc; }
+// does it, with a FIXED trip count for the compile-time instantiations: the chain's bodies come as two 32-bit words, every
+// fetch is issued before the first addition (the table-driven loop paid two dependent LDS round trips per body).
+// kFixedTrip: where it pays.  Measured on one box (profiles/r04_ab_fixed_trip.txt): Allegro -3.0 % (five roots, 22 bodies:
+// the COM loop was its longest serial stretch); Go2 +2.5 %, H1 +3.4 %, H1 loco +6 % SLOWER -- those kernels hoist every
+// lane-derived address out of the step loop and sit at the 168-VGPR budget: the unrolled fetches' addresses pushed 14 / 31 /
+// 25 registers into scratch.  The generic-feature-set kernels re-derive addresses per step (wave.h: launder) and have room.
+template <class M>
+inline constexpr bool kFixedTrip = M::D::is_static && (M::D::ell || M::D::gen);
+template <class M>
+DIAL_DEV void chain_suffix_sum(const M* m, int c, int k, int st, const float* src, float* dst) {
+  const int len = m->chain_len[c], ex = m->chain_excl[c];
+  if constexpr (kFixedTrip<M>) {
+    constexpr int CL = M::D::CHAINLEN;
+    static_assert(CL == 8, "chain_body rows are read as two 32-bit words");
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(m->chain_body[c]);
+    const uint32_t w0 = cw[0], w1 = cw[1];
+    int cb[CL];
+    float v[CL];
+#pragma unroll
+    for (int q = 0; q < CL; q++) {
+      const int b = (int)(((q < 4 ? w0 : w1) >> (8 * (q & 3))) & 255u);
+      cb[q] = q < len ? b : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < CL; q++) v[q] = src[st * cb[q] + k];
+    float acc = 0.f;
+#pragma unroll
+    for (int q = CL - 1; q >= 0; q--) {
+      const bool on = q < len && q >= ex;
+      const float t = acc + v[q];
+      acc = on ? t : acc;
+      if (on) dst[st * cb[q] + k] = acc;
+    }
+  } else {
+    float acc = 0.f;
+    for (int q = len - 1; q >= ex; q--) {
+      const int b = m->chain_body[c][q];
+      acc += src[st * b + k];
+      dst[st * b + k] = acc;
+    }
+  }
+}
+// The bodies no chain tail covers (branching bodies and what lies above them), deepest first: dst[b] = own[b] + sum of dst[child]
+template <class M>
+DIAL_DEV void shared_subtree_sum(const M* m, int k, int st, const float* own, float* dst) {
+  if constexpr (kFixedTrip<M>) {
+#pragma unroll
+    for (int sh = 0; sh < 4; sh++) {
+      if (sh < m->nshared) {
+        const int b = m->shared_body[sh], nch = m->shared_nchild[sh];
+        const uint32_t cw = *reinterpret_cast<const uint32_t*>(m->shared_child[sh]);
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = dst[st * (int)(q < nch ? (cw >> (8 * q)) & 255u : 0u) + k];
+        float acc = own[st * b + k];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const float t = acc + v[q]; acc = q < nch ? t : acc; }
+        dst[st * b + k] = acc;
+      }
+    }
+  } else {
+    for (int sh = 0; sh < m->nshared; sh++) {
+      const int b = m->shared_body[sh];
+      float acc = own[st * b + k];
+      for (int q = 0; q < m->shared_nchild[sh]; q++) acc += dst[st * m->shared_child[sh][q] + k];
+      dst[st * b + k] = acc;
+    }
+  }
+}
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
@@ -1074,6 +1146,19 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     const int b = it / 3, k = it - 3 * b;
     if (b == 0 || m->body_parent[b] != 0) return;
     float mp = 0.f, ms = 0.f;
+    if constexpr (kFixedTrip<M>) {
+      // fixed trip count, bodies outside the subtree masked: every fetch is issued up front.  (A loop whose length comes out
+      // of a table pays one exposed LDS round trip per body; same additions in the same order.)
+      const int e = m->body_subtree_end[b];
+#pragma unroll
+      for (int d = M::D::NB - 1; d >= 1; d--) {
+        const bool on = d >= b && d < e;
+        const float x = s.xipos[3 * d + k], mm = m->body_mass[d];
+        const float t1 = mp + x * mm, t2 = ms + mm;
+        mp = on ? t1 : mp;
+        ms = on ? t2 : ms;
+      }
+    } else
     for (int d = m->body_subtree_end[b] - 1; d >= b; d--) {
       mp += s.xipos[3 * d + k] * m->body_mass[d];
       ms += m->body_mass[d];
@@ -1265,12 +1350,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     w.items(10 * m->nchain + nb, [&](int it) {
       if (it < 10 * m->nchain) {
         const int c = it / 10, k = it - 10 * c;
-        float acc = 0.f;
-        for (int q = m->chain_len[c] - 1; q >= m->chain_excl[c]; q--) {
-          const int b = m->chain_body[c][q];
-          acc += s.cinert[10 * b + k];
-          s.crb[10 * b + k] = acc;
-        }
+        chain_suffix_sum(m, c, k, 10, s.cinert, s.crb);
       } else {
         const int b = it - 10 * m->nchain;
         float ci[10], ca[6], cv[6], f1[6], f2[6], f3[6];
@@ -1286,20 +1366,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       if (it < 10) {          // crb of the branching bodies, deepest first (one lane per component: no cross-lane order)
         const int k = it;
         s.crb[k] = 0.f;       // world body
-        for (int sh = 0; sh < m->nshared; sh++) {
-          const int b = m->shared_body[sh];
-          float acc = s.cinert[10 * b + k];
-          for (int q = 0; q < m->shared_nchild[sh]; q++) acc += s.crb[10 * m->shared_child[sh][q] + k];
-          s.crb[10 * b + k] = acc;
-        }
+        shared_subtree_sum(m, k, 10, s.cinert, s.crb);
       } else {                // cfrc suffix sums up the exclusive chain tails
         const int c = (it - 10) / 6, k = (it - 10) - 6 * c;
-        float acc = 0.f;
-        for (int q = m->chain_len[c] - 1; q >= m->chain_excl[c]; q--) {
-          const int b = m->chain_body[c][q];
-          acc += s.cfl[6 * b + k];
-          s.cfrc[6 * b + k] = acc;
-        }
+        chain_suffix_sum(m, c, k, 6, s.cfl, s.cfrc);
       }
     });
     DIAL_MARK(w, 22);
@@ -1313,12 +1383,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
         for (int k = 0; k < 6; k++) s.Fd[6 * i + k] = f[k];
       } else {                // cfrc of the branching bodies
         const int k = it - nv;
-        for (int sh = 0; sh < m->nshared; sh++) {
-          const int b = m->shared_body[sh];
-          float acc = s.cfl[6 * b + k];
-          for (int q = 0; q < m->shared_nchild[sh]; q++) acc += s.cfrc[6 * m->shared_child[sh][q] + k];
-          s.cfrc[6 * b + k] = acc;
-        }
+        shared_subtree_sum(m, k, 6, s.cfl, s.cfrc);
       }
     });
     DIAL_MARK(w, 23);

@@ -57,7 +57,10 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   Wave w;
   w.lane = threadIdx.x & 63;
   w.lane_r = w.lane;
-  w.launder = D::gen || OCC >= 4;   // (see wave.h)
+#ifndef DIAL_LAUNDER_STATIC
+#define DIAL_LAUNDER_STATIC 0   // A/B switch: the opaque lane id per step for EVERY instantiation
+#endif
+  w.launder = D::gen || OCC >= 4 || DIAL_LAUNDER_STATIC;   // (see wave.h)
 #ifdef DIAL_PROFILE
   w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
   if (w.lane < 32) w.acc[w.lane] = 0;
