@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-cfg5", action="store_true", help="skip the N_total=65536 strong-scaling companion measurement")
     ap.add_argument("--ticks", type=int, default=100, help="control ticks for the plan-latency measurement")
+    ap.add_argument("--full-only", action="store_true",
+                    help="profiling runs: every launch is the FULL iteration (no lean / plan-pattern loops, plan ticks with want_bars on "
+                         "every iteration), so that per-dispatch averages of rocprofv3 are those of the headline launch")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
                     help="a field of dial_options (include/dial_mpc.h), e.g. --option no_relay=1; the library reads no environment variables")
     args = ap.parse_args()
@@ -248,8 +251,13 @@ def main():
     # (+ all-reduce of the packed partial sums).  `value` stays the full iteration; these are reported next to it.
     plan_pat = tuple([False] * (dial_config.Ndiffuse - 1) + [True])
     lean_steps = max(10, args.steps // 2)
-    el_lean, k_lean, nl_lean = timed_iterations(mbdpi, states, lean_steps, 3, eps_pool if args.host_noise else None, pattern=(False,))
-    el_plan, _, _ = timed_iterations(mbdpi, states, lean_steps, 3, eps_pool if args.host_noise else None, pattern=plan_pat)
+    lean_pat, plan_run = ((True,), (True,)) if args.full_only else ((False,), plan_pat)
+    el_lean, k_lean, nl_lean = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, 3 if not args.full_only else 0,
+                                                eps_pool if args.host_noise else None, pattern=lean_pat)
+    el_plan, _, _ = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, 3 if not args.full_only else 0,
+                                     eps_pool if args.host_noise else None, pattern=plan_run)
+    if args.full_only:
+        el_lean, el_plan, lean_steps = 0.0, 0.0, 1     # (not measured in this mode)
     sharded = world > 1 or args.force_sharded
     iteration_modes = {
         "ms_per_step_full": elapsed / args.steps * 1e3, "ms_per_step_lean": el_lean / lean_steps * 1e3,
@@ -271,7 +279,7 @@ def main():
         Yp = mbdpi.shift(Yp)
         for i in range(dial_config.Ndiffuse):
             _, Yp, _ = mbdpi.reverse_once(state, None, Yp, sigma * dial_config.traj_diffuse_factor ** i,
-                                          eps=eps_pool[(tick + i) % len(eps_pool)], want_bars=(i == dial_config.Ndiffuse - 1))
+                                          eps=eps_pool[(tick + i) % len(eps_pool)], want_bars=(args.full_only or i == dial_config.Ndiffuse - 1))
         torch.cuda.synchronize()
         if tick > 0:
             lat.append((time.perf_counter() - a) * 1e3)
@@ -327,12 +335,14 @@ def main():
     # HBM traffic / instruction counters of THIS configuration from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same command, tools/pmc_passes.sh -> tools/pmc_to_json.py); null when the batch measured there is not the one run here
     traffic, traffic_src, valu_per_step, lane_util, stall = None, None, None, None, None
-    pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.example}.json")
+    pmc_path = os.path.join(ROOT, "profiles", f"r04_pmc_{args.example}.json")
+    if not os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.example}.json")
     if os.path.exists(pmc_path) and world == 1:
         pmc = json.load(open(pmc_path))
         if pmc.get("Nsample") == args.nsample_per_gpu and pmc.get("Hsample") == args.hsample:
             traffic = pmc.get("hbm_bytes_per_launch")
-            traffic_src = f"profiles/r03_pmc_{args.example}.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, per reverse_once)"
+            traffic_src = f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, per full reverse_once)"
             valu_per_step = pmc.get("valu_insts_per_wave_env_step")
             lane_util = pmc.get("valu_active_lanes_per_inst")
             stall = pmc.get("wave_time_breakdown")
