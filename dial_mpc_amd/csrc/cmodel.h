@@ -241,6 +241,31 @@ CM_HD constexpr int dim_nf(const M* m) {
   else return m->nfri;
 }
 
+// Host: is the model the quadruped this layout assumes (smooth_quad.h; beyond the dof tree dims_match checks)?  World, a free trunk
+// (body 1), four legs of three one-hinge bodies in depth-first order, the floor plane as geom 0, one sphere and one site per calf,
+// the trunk's site first, one plane-sphere contact per foot in leg order.
+static inline bool quad_fits(const dial_model* m) {
+  if (m->nbody != 14 || m->njnt != 13 || m->nv != 18 || m->nq != 19 || m->ngeom != 5 || m->nsite != 5 || m->ncon != 4) return false;
+  if (m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
+      m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1)
+    return false;
+  for (int r = 0; r < 4; r++)
+    for (int k = 0; k < 3; k++) {
+      const int b = 2 + 3 * r + k, j = b - 1;
+      if (m->body_parent[b] != (k == 0 ? 1 : b - 1) || m->body_jntnum[b] != 1 || m->body_jntadr[b] != j ||
+          m->jnt_type[j] != DIAL_JNT_HINGE || m->jnt_qposadr[j] != b + 5 || m->jnt_dofadr[j] != b + 4 || m->body_dofadr[b] != b + 4)
+        return false;
+    }
+  if (m->geom_bodyid[0] != 0 || m->site_bodyid[0] != 1) return false;
+  for (int r = 0; r < 4; r++) {
+    const int calf = 4 + 3 * r;
+    if (m->geom_bodyid[1 + r] != calf || m->site_bodyid[1 + r] != calf || m->con_kind[r] != DIAL_CON_PLANE_SPHERE ||
+        m->con_geom1[r] != 0 || m->con_geom2[r] != 1 + r)
+      return false;
+  }
+  return true;
+}
+
 // ---- host: does a model fit a static instantiation exactly?
 template <class D>
 static inline bool dims_match(const dial_model* m) {
@@ -250,6 +275,7 @@ static inline bool dims_match(const dial_model* m) {
   if constexpr (!D::Topo::dense) {   // the sparse factorisations are specialised to the dof tree as well
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }
+  if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
   return ok;
 }
 

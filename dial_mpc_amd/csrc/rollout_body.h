@@ -215,6 +215,7 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 #include "ls_bracket.h"
 #include "solver_reg.h"
 #include "solver_cone.h"
+#include "smooth_quad.h"
 namespace dial {
 
 // Generic instantiation: x = A^-1 rhs for the packed SPD matrix A (M or H) with the register-resident L D L^T of
@@ -982,6 +983,11 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   const int ne = dim_ne(m), nl = dim_nl(m), ntri = m->ntri;   // ntri: structurally non-zero entries of M / H
   int nca = nc, nea = ne;   // contacts / rows the constraint section works on (generic instantiation: the touching ones)
 
+  if constexpr (kQuadDims<typename M::D>) {   // quadruped topology: the whole position / velocity stage in registers (smooth_quad.h)
+    forward_smooth_quad(w, m, s);
+    forward_constraints(w, m, s, nca, nea);
+    return;
+  }
   DIAL_MARK(w, 15);
   // ---- smooth.kinematics
   const bool kin_fast = m->kin_fast != 0;   // every body has at most one joint (wave-uniform)

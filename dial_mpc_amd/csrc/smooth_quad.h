@@ -1,0 +1,376 @@
+// smooth_quad.h -- the position / velocity stage of mjx.forward (smooth.kinematics, com_pos, com_vel, crb, rne, make_m,
+// qfrc_smooth, the foot contacts) for a QUADRUPED topology, held in registers: no LDS hand-over between its sub-stages.
+//
+// rollout_body.h: forward() runs these sub-stages as ~14 LDS phases (bodies / dofs / chains -> lanes, results handed on
+// through LDS).  On a lone wavefront that is 23 k of the Go2's 59 k cycles per env.step (profiles/r04_sections_unitree_go2_trot_
+// cycles.txt): every phase starts with table look-ups and dependent LDS round trips, the chain walks and subtree sums are
+// serial loops over LDS, and N = 2048 gives a SIMD two wavefronts -- the launch is as long as one rollout's dependence chain.
+// For the topology "free trunk + legs of three one-hinge bodies" (TopoGo2) the tree fits the DPP network instead:
+//
+//   lane 16 r + d  (row r = leg r):  d = 0 the trunk (every row keeps its own copy), d = 1, 2, 3 hip, thigh, calf of leg r,
+//                                    d = 4 .. 9 of row 0: the trunk's six dofs (rows of M and of qfrc_smooth only)
+//
+// so that "my parent" is the lane below (DPP row_shr:1), "my child" the lane above (row_shl:1) and the trunk is an ordinary
+// v_readlane broadcast.  Root-to-leaf sweeps (poses, velocities, accelerations) are three rounds of row_shr + compose,
+// leaf-to-root sums (composite inertia, body forces) two rounds of row_shl + add plus one wave reduction over the four hips.
+// Every lane loads its own constants and state once, all arithmetic is register-to-register, and what later stages consume
+// (xpos, xquat, site positions, com, cvel, cdof, M, qfrc_smooth, the four foot contacts) is stored at the end; xipos, ximat,
+// cinert, cacc, cfl, cfrc, crb and F are never materialised.  Same formulas as forward() (each block names its counterpart);
+// sums over bodies are taken in a different order (rounding level: covered by the oracle parity tests, not bit-identical to
+// the phase version, which stays the implementation of every other robot and the reference -DDIAL_NO_QUAD builds compare to).
+#pragma once
+#include "derived.h"
+#include "dmath.h"
+
+namespace dial {
+
+#ifdef DIAL_NO_QUAD
+template <class D>
+inline constexpr bool kQuadDims = false;
+#else
+template <class D>
+inline constexpr bool kQuadDims = std::is_same<D, DimsGo2>::value;
+#endif
+
+template <class W, class M>
+DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
+  constexpr int S = M::D::S;
+  static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "quadruped layout: trunk + 4 legs of 3");
+  DIAL_MARK(w, 15);
+  // lane roles (derived from the lane id only: loop invariants)
+  //   body lane:  d <= 3 (trunk copies d == 0; only lane 0 stores / counts the trunk)      body b, joint b - 1
+  //   dof lane:   leg lanes (dof b + 4) and lanes 4 .. 9 (trunk dof d - 4)
+  // ---- smooth.kinematics: local transforms (leg lanes), absolute pose (trunk lanes); forward(): kin_fast
+  vfloat PL[14];   // [0..7): world pose pos(3) quat(4); [7..14): leg lanes' transform relative to the parent l_p(3) l_q(4)
+  w.per_lane_n(PL, [&](int l, float* o) {
+    const int d = l & 15, r = l >> 4;
+    const bool leg = d >= 1 && d <= 3;
+    const int b = leg ? 3 * r + d + 1 : 1, ji = b - 1, qa = leg ? b + 5 : 7;
+    float tq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+    dm::normalize4(tq);
+    const int bflags = m->body_flags[b];
+    float lq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+    float lp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
+    const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+    const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+    float qloc[4], qb[4], t0[3], t1[3];
+    dm::axis_angle_to_quat(qloc, ja, s.qpos[qa] - m->qpos0[qa]);
+    if (bflags & 1) { qb[0] = qloc[0]; qb[1] = qloc[1]; qb[2] = qloc[2]; qb[3] = qloc[3]; }
+    else dm::quat_mul(qb, lq, qloc);
+    if (!(bflags & 2)) {
+      if (bflags & 1) { t0[0] = jp[0]; t0[1] = jp[1]; t0[2] = jp[2]; }
+      else dm::rotate(t0, jp, lq);
+      dm::rotate(t1, jp, qb);
+      for (int k = 0; k < 3; k++) lp[k] += t0[k] - t1[k];
+    }
+    for (int k = 0; k < 3; k++) { o[k] = leg ? 0.f : s.qpos[k]; o[7 + k] = lp[k]; }
+    for (int k = 0; k < 4; k++) { o[3 + k] = leg ? (k == 0 ? 1.f : 0.f) : tq[k]; o[10 + k] = qb[k]; }
+  });
+  // root-to-leaf: a lane at depth d is final after round d (its parent, the lane below, after round d - 1)
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 3; it++) {
+    vfloat Q[7], N[7];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 7; k++) Q[k] = w.template row_shr<1>(PL[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const int d = l & 15;
+      const bool leg = d >= 1 && d <= 3;
+      const float pp[3] = {lane_val(Q[0], l), lane_val(Q[1], l), lane_val(Q[2], l)};
+      const float pq[4] = {lane_val(Q[3], l), lane_val(Q[4], l), lane_val(Q[5], l), lane_val(Q[6], l)};
+      const float lp[3] = {lane_val(PL[7], l), lane_val(PL[8], l), lane_val(PL[9], l)};
+      const float lq[4] = {lane_val(PL[10], l), lane_val(PL[11], l), lane_val(PL[12], l), lane_val(PL[13], l)};
+      float pos[3], quat[4];
+      dm::rotate(pos, lp, pq);
+      for (int k = 0; k < 3; k++) pos[k] += pp[k];
+      dm::quat_mul(quat, pq, lq);
+      for (int k = 0; k < 3; k++) o[k] = leg ? pos[k] : lane_val(PL[k], l);
+      for (int k = 0; k < 4; k++) o[3 + k] = leg ? quat[k] : lane_val(PL[3 + k], l);
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 7; k++) PL[k] = N[k];
+  }
+  DIAL_MARK(w, 0);
+  // ---- local_to_global: inertial frames (all bodies), the foot geom and site (calf lanes), the trunk's site (trunk lanes)
+  vfloat F[22];   // xipos(3) ximat(9) | mass-weighted xipos(3), mass | site(3) | foot geom centre(3)
+  w.per_lane_n(F, [&](int l, float* o) {
+    const int d = l & 15, r = l >> 4;
+    const bool leg = d >= 1 && d <= 3, counted = leg || l == 0;
+    const int b = leg ? 3 * r + d + 1 : 1, gs = d == 3 ? 1 + r : 0;
+    const float p[3] = {lane_val(PL[0], l), lane_val(PL[1], l), lane_val(PL[2], l)};
+    const float q[4] = {lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l)};
+    const float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
+    const float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+    const float sp[3] = {m->site_pos[gs][0], m->site_pos[gs][1], m->site_pos[gs][2]};
+    const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
+    const float mass = m->body_mass[b];
+    float t3[3], qi[4], mat[9], ts[3], tg[3];
+    dm::rotate(t3, ip, q);
+    dm::quat_mul(qi, q, iq);
+    dm::quat_to_mat(mat, qi);
+    dm::rotate(ts, sp, q);
+    dm::rotate(tg, gp, q);
+    for (int k = 0; k < 3; k++) {
+      const float xi = p[k] + t3[k];
+      o[k] = xi;
+      o[12 + k] = counted ? xi * mass : 0.f;
+      o[16 + k] = p[k] + ts[k];
+      o[19 + k] = p[k] + tg[k];
+    }
+    for (int k = 0; k < 9; k++) o[3 + k] = mat[k];
+    o[15] = counted ? mass : 0.f;
+  });
+  DIAL_MARK(w, 16);
+  // ---- smooth.com_pos: one wave reduction (the 13 bodies form one kinematic tree)
+  float com[3];
+  {
+    vfloat c4[4] = {F[12], F[13], F[14], F[15]};
+    float r4[4];
+    w.vsumN(c4, r4);
+    for (int k = 0; k < 3; k++) com[k] = r4[3] < MJ_MINVAL ? bcast(F[k], 0) : r4[k] / r4[3];
+  }
+  // the trunk's pose, rotation matrix and rotational cdofs: the same value in every lane
+  const float tpos[3] = {bcast(PL[0], 0), bcast(PL[1], 0), bcast(PL[2], 0)};
+  const float tquat[4] = {bcast(PL[3], 0), bcast(PL[4], 0), bcast(PL[5], 0), bcast(PL[6], 0)};
+  float Rt[9], cdT[3][6];
+  dm::quat_to_mat(Rt, tquat);
+  const float offt[3] = {com[0] - tpos[0], com[1] - tpos[1], com[2] - tpos[2]};
+  for (int i = 0; i < 3; i++) {
+    const float a[3] = {Rt[i], Rt[3 + i], Rt[6 + i]};
+    float cr[3];
+    dm::cross3(cr, a, offt);
+    for (int k = 0; k < 3; k++) { cdT[i][k] = a[k]; cdT[i][3 + k] = cr[k]; }
+  }
+  DIAL_MARK(w, 17);
+  // ---- cinert (body lanes) and cdof (dof lanes)
+  vfloat X[16];   // cinert(10) | local force cfl(6): the quantities summed over subtrees
+  vfloat CD[6];
+  {
+    vfloat T[16];
+    w.per_lane_n(T, [&](int l, float* o) {
+      const int d = l & 15, r = l >> 4;
+      const bool leg = d >= 1 && d <= 3, body = d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
+      const int b = leg ? 3 * r + d + 1 : 1, ji = b - 1, kd = tdof ? d - 4 : 3;
+      const float R[9] = {lane_val(F[3], l), lane_val(F[4], l), lane_val(F[5], l), lane_val(F[6], l), lane_val(F[7], l),
+                          lane_val(F[8], l), lane_val(F[9], l), lane_val(F[10], l), lane_val(F[11], l)};
+      const float off[3] = {lane_val(F[0], l) - com[0], lane_val(F[1], l) - com[1], lane_val(F[2], l) - com[2]};
+      const float mb = m->body_mass[b], oo = dm::dot3(off, off);
+      const float in0 = m->body_inertia[b][0], in1 = m->body_inertia[b][1], in2 = m->body_inertia[b][2];
+      const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+      for (int e = 0; e < 6; e++) {
+        const int i = ii[e], j = jj[e];
+        const float v = R[3 * i] * in0 * R[3 * j] + R[3 * i + 1] * in1 * R[3 * j + 1] + R[3 * i + 2] * in2 * R[3 * j + 2];
+        const float hh = (i == j ? oo : 0.f) - off[i] * off[j];
+        o[e] = body ? v + hh * mb : 0.f;
+      }
+      for (int k = 0; k < 3; k++) o[6 + k] = body ? off[k] * mb : 0.f;
+      o[9] = body ? mb : 0.f;
+      // cdof: hinge = [axis, axis x (com - anchor)]; trunk dof k < 3: [0, e_k], k >= 3: column k - 3 of the trunk's xmat
+      const float bq[4] = {lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l)};
+      const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+      const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+      float anchor[3], jaxis[3], cr[3];
+      if (m->body_flags[b] & 2) { anchor[0] = 0.f; anchor[1] = 0.f; anchor[2] = 0.f; }
+      else dm::rotate(anchor, jp, bq);
+      for (int k = 0; k < 3; k++) anchor[k] += lane_val(PL[k], l);
+      dm::rotate(jaxis, ja, bq);
+      const float offj[3] = {com[0] - anchor[0], com[1] - anchor[1], com[2] - anchor[2]};
+      dm::cross3(cr, jaxis, offj);
+      // (the trunk's rotational cdofs are blended with 0 / 1 weights, not selected: a select chain over the elements of a local
+      //  array is turned into a dynamically indexed scratch array by the optimiser -- 80 B of private memory in the ISA)
+      const float w0 = kd == 3 ? 1.f : 0.f, w1 = kd == 4 ? 1.f : 0.f, w2 = kd == 5 ? 1.f : 0.f;
+      for (int k = 0; k < 3; k++) {
+        const float ta = w0 * cdT[0][k] + w1 * cdT[1][k] + w2 * cdT[2][k];
+        const float tl = (k == kd ? 1.f : 0.f) + (w0 * cdT[0][3 + k] + w1 * cdT[1][3 + k] + w2 * cdT[2][3 + k]);
+        o[10 + k] = leg ? jaxis[k] : (tdof ? ta : 0.f);
+        o[13 + k] = leg ? cr[k] : (tdof ? tl : 0.f);
+      }
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 10; k++) X[k] = T[k];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) CD[k] = T[10 + k];
+  }
+  DIAL_MARK(w, 18);
+  // ---- smooth.com_vel + cdof_dot + rne forward: the trunk's velocity / acceleration (every lane the same), then root-to-leaf
+  vfloat VA[12];   // cvel(6) | cacc(6)
+  {
+    const float qv[6] = {s.qvel[0], s.qvel[1], s.qvel[2], s.qvel[3], s.qvel[4], s.qvel[5]};
+    const float vs[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};   // the rotational dofs see the velocity after the translational ones
+    float velT[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};
+    float accT[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
+    for (int j = 0; j < 3; j++) {
+      float cdd[6];
+      dm::motion_cross(cdd, vs, cdT[j]);
+      for (int k = 0; k < 6; k++) { accT[k] += cdd[k] * qv[3 + j]; velT[k] += cdT[j][k] * qv[3 + j]; }
+    }
+    w.per_lane_n(VA, [&](int l, float* o) {
+      const bool trunk = (l & 15) == 0;
+      for (int k = 0; k < 6; k++) { o[k] = trunk ? velT[k] : 0.f; o[6 + k] = trunk ? accT[k] : 0.f; }
+    });
+  }
+  const vfloat QVL = w.per_lane([&](int l) {
+    const int d = l & 15, r = l >> 4;
+    const bool leg = d >= 1 && d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
+    return s.qvel[leg ? 3 * r + d + 5 : (tdof ? d - 4 : 0)];   // this dof lane's velocity
+  });
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 3; it++) {
+    vfloat Q[12], N[12];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 12; k++) Q[k] = w.template row_shr<1>(VA[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const int d = l & 15;
+      const bool leg = d >= 1 && d <= 3;
+      const float vp[6] = {lane_val(Q[0], l), lane_val(Q[1], l), lane_val(Q[2], l), lane_val(Q[3], l), lane_val(Q[4], l), lane_val(Q[5], l)};
+      const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
+      const float qv = lane_val(QVL, l);
+      float cdd[6];
+      dm::motion_cross(cdd, vp, cd);
+      for (int k = 0; k < 6; k++) {
+        const float a = lane_val(Q[6 + k], l) + cdd[k] * qv, v = vp[k] + cd[k] * qv;
+        o[k] = leg ? v : lane_val(VA[k], l);
+        o[6 + k] = leg ? a : lane_val(VA[6 + k], l);
+      }
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 12; k++) VA[k] = N[k];
+  }
+  DIAL_MARK(w, 19);
+  // ---- rne: local body forces cfl = cinert cacc + cvel x* (cinert cvel)
+  {
+    vfloat T[6];
+    w.per_lane_n(T, [&](int l, float* o) {
+      const bool body = (l & 15) <= 3;
+      float ci[10], ca[6], cv[6], f1[6], f2[6], f3[6];
+      for (int k = 0; k < 10; k++) ci[k] = lane_val(X[k], l);
+      for (int k = 0; k < 6; k++) { cv[k] = lane_val(VA[k], l); ca[k] = lane_val(VA[6 + k], l); }
+      dm::inert_mul(f1, ci, ca);
+      dm::inert_mul(f2, ci, cv);
+      dm::motion_cross_force(f3, cv, f2);
+      for (int k = 0; k < 6; k++) o[k] = body ? f1[k] + f3[k] : 0.f;
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) X[10 + k] = T[k];
+  }
+  // ---- subtree sums (smooth.crb, rne backward): leaf-to-root along the legs, then the trunk = own + the four hips
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 2; it++) {
+    vfloat Q[16], N[16];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 16; k++) Q[k] = w.template row_shl<1>(X[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const bool on = (l & 15) == 2 - it;
+      for (int k = 0; k < 16; k++) o[k] = on ? lane_val(X[k], l) + lane_val(Q[k], l) : lane_val(X[k], l);
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 16; k++) X[k] = N[k];
+  }
+  float XT[16];   // the trunk's composite inertia and subtree force
+  {
+    vfloat H[16];
+    w.per_lane_n(H, [&](int l, float* o) {
+      const bool hip = (l & 15) == 1;
+      for (int k = 0; k < 16; k++) o[k] = hip ? lane_val(X[k], l) : 0.f;
+    });
+    float hs[16];
+    w.vsumN(H, hs);
+    for (int k = 0; k < 16; k++) XT[k] = bcast(X[k], 0) + hs[k];
+  }
+  DIAL_MARK(w, 22);
+  // ---- F_i = crb cdof_i, M = F . cdof over the ancestors (support.make_m), qfrc_smooth = passive - bias + actuator
+  vfloat MO[11];   // columns 0..5 (trunk dofs) | own diagonal | parent dof | grandparent dof | qfrc_smooth | (unused)
+  {
+    vfloat P1[6], P2[6];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) { P1[k] = w.template row_shr<1>(CD[k]); P2[k] = w.template row_shr<2>(CD[k]); }
+    w.per_lane_n(MO, [&](int l, float* o) {
+      const int d = l & 15, r = l >> 4;
+      const bool leg = d >= 1 && d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
+      const int b = leg ? 3 * r + d + 1 : 1, i = leg ? b + 4 : (tdof ? d - 4 : 0);
+      float crb[10], cfrc[6], cd[6], f[6];
+      for (int k = 0; k < 10; k++) crb[k] = leg ? lane_val(X[k], l) : XT[k];
+      for (int k = 0; k < 6; k++) { cfrc[k] = leg ? lane_val(X[10 + k], l) : XT[10 + k]; cd[k] = lane_val(CD[k], l); }
+      dm::inert_mul(f, crb, cd);
+      const float arm = m->dof_armature[i];
+      for (int j = 0; j < 6; j++) {
+        float v = 0.f;
+        if (j < 3) v = f[3 + j];
+        else for (int k = 0; k < 6; k++) v += f[k] * cdT[j - 3][k];
+        o[j] = (tdof && j == i) ? v + arm : v;
+      }
+      float own = 0.f, p1 = 0.f, p2 = 0.f, bias = 0.f;
+      for (int k = 0; k < 6; k++) {
+        own += f[k] * cd[k];
+        p1 += f[k] * lane_val(P1[k], l);
+        p2 += f[k] * lane_val(P2[k], l);
+        bias += cd[k] * cfrc[k];
+      }
+      o[6] = own + arm; o[7] = p1; o[8] = p2;
+      const float passive = -m->dof_damping[i] * lane_val(QVL, l);
+      float actf = 0.f;
+      const int a = m->dof_act[i];
+      const int aa = a >= 0 ? a : 0;
+      {
+        float c = s.ctrl[aa];
+        if (m->act_ctrllimited[aa]) c = dm::clip(c, m->act_ctrlrange[aa][0], m->act_ctrlrange[aa][1]);
+        const float force = m->act_isposition[aa] ? m->act_kp[aa] * (c - s.qpos[m->act_qposadr[aa]]) : c;
+        actf = a >= 0 ? m->act_gear[aa] * force : 0.f;
+      }
+      o[9] = passive - bias + actf;
+      o[10] = 0.f;
+    });
+  }
+  DIAL_MARK(w, 23);
+  // ---- collision_driver: the four plane-sphere foot contacts (collision_primitive plane_sphere), frame = make_frame(n)
+  float pn[3], pfr[9];
+  {
+    const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
+    float mat[9];
+    dm::quat_to_mat(mat, gq);
+    pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
+    make_frame(pfr, pn);
+  }
+  // ---- everything later stages read, stored once
+  w.items(64, [&](int l) {
+    const int d = l & 15, r = l >> 4;
+    const bool leg = d >= 1 && d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
+    const int b = leg ? 3 * r + d + 1 : 1;
+    if (leg || l == 0) {
+      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(PL[k], l);
+      store4(s.xquat + 4 * b, lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l));
+      for (int k = 0; k < 3; k++) store2(s.cvel + 6 * b + 2 * k, lane_val(VA[2 * k], l), lane_val(VA[2 * k + 1], l));
+    }
+    if (l == 0) {
+      for (int k = 0; k < 3; k++) { s.com[3 * m->body_rootid[1] + k] = com[k]; s.spos[k] = lane_val(F[16 + k], l); }
+      for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
+    }
+    if (d == 3) {
+      const int c = r, g2 = 1 + r;
+      const float ctr[3] = {lane_val(F[19], l), lane_val(F[20], l), lane_val(F[21], l)};
+      const float radius = m->geom_size[g2][0];
+      const float diff[3] = {ctr[0] - m->geom_pos[0][0], ctr[1] - m->geom_pos[0][1], ctr[2] - m->geom_pos[0][2]};
+      const float dist = dm::dot3(diff, pn) - radius;
+      s.cdist[c] = dist;
+      for (int k = 0; k < 3; k++) { s.cpos[3 * c + k] = ctr[k] - pn[k] * (radius + 0.5f * dist); s.spos[3 * g2 + k] = lane_val(F[16 + k], l); }
+      for (int k = 0; k < 9; k++) s.cframe[9 * c + k] = pfr[k];
+    }
+    if (leg || tdof) {
+      const int i = leg ? b + 4 : d - 4;
+      for (int k = 0; k < 3; k++) store2(s.cdof + 6 * i + 2 * k, lane_val(CD[2 * k], l), lane_val(CD[2 * k + 1], l));
+      const float qf = lane_val(MO[9], l);
+      s.qfs[i] = qf;
+      s.rhs[i] = qf;
+      for (int j = 0; j < 6; j++) {
+        if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
+      }
+      if (leg) {
+        s.M[i * S + i] = lane_val(MO[6], l);
+        if (d >= 2) { const float v = lane_val(MO[7], l); s.M[i * S + i - 1] = v; s.M[(i - 1) * S + i] = v; }
+        if (d == 3) { const float v = lane_val(MO[8], l); s.M[i * S + i - 2] = v; s.M[(i - 2) * S + i] = v; }
+      }
+    }
+  });
+  DIAL_MARK(w, 1);
+}
+
+}  // namespace dial

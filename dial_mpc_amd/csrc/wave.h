@@ -54,6 +54,9 @@ inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
 inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
 // two consecutive floats from an 8-byte aligned address (one ds_read_b64 on the GPU)
 inline void load2(const float* p, float& a, float& b) { a = p[0]; b = p[1]; }
+// two / four consecutive floats to an 8- / 16-byte aligned address (one ds_write_b64 / b128 on the GPU)
+inline void store2(float* p, float a, float b) { p[0] = a; p[1] = b; }
+inline void store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
@@ -128,6 +131,11 @@ struct Wave {
   void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
     for (int l = 0; l < 64; l++) { const float* p = f(l); a.x[l] = p[0]; b.x[l] = p[1]; c.x[l] = p[2]; d.x[l] = p[3]; }
   }
+  // value of the lane N below / above inside the aligned row of 16 lanes (0 where the row ends; DPP row_shr / row_shl on the GPU)
+  template <int N>
+  vfloat row_shr(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) >= N ? v.x[l - N] : 0.f; return r; }
+  template <int N>
+  vfloat row_shl(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) + N <= 15 ? v.x[l + N] : 0.f; return r; }
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
@@ -217,6 +225,8 @@ __device__ __forceinline__ float bcast(vfloat v, int lane) {
 }
 __device__ __forceinline__ float lane_val(vfloat v, int) { return v; }
 __device__ __forceinline__ void load2(const float* p, float& a, float& b) { const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y; }
+__device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -303,6 +313,14 @@ struct Wave {
   }
   __device__ __forceinline__ vfloat quad_xor2(vfloat v) {   // quad_perm [2,3,0,1]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+  }
+  template <int N>
+  __device__ __forceinline__ vfloat row_shr(vfloat v) {   // DPP row_shr:N, lanes without a source read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+  }
+  template <int N>
+  __device__ __forceinline__ vfloat row_shl(vfloat v) {   // DPP row_shl:N
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
   }
   template <class F>
   __device__ __forceinline__ void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
