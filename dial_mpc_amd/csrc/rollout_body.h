@@ -2048,6 +2048,7 @@ template <class W, class M>
 DIAL_DEV void init_square(W& w, const M* m, const Ws& s) {
   (void)m;
   if constexpr (M::D::square) w.items(M::D::NV * M::D::S, [&](int e) { s.M[e] = 0.f; });
+  if constexpr (kQuadDims<typename M::D>) init_quad(w, m, s);
 }
 
 }  // namespace dial

@@ -37,6 +37,13 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
   constexpr int S = M::D::S;
   static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "quadruped layout: trunk + 4 legs of 3");
   DIAL_MARK(w, 15);
+#if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
+  // An opaque copy of the lane id for this stage: its role masks and table addresses are loop invariants of the T-step loop,
+  // and hoisted they are ~20 more VGPRs that live through the solver, which sits on the 168-register budget (ISA probe: 24
+  // spilled VGPRs, 100 B of scratch); re-derived per step they cost a few dozen integer instructions.
+  const int lane_keep = w.lane;
+  { int lq = w.lane; asm volatile("" : "+v"(lq)); w.lane = lq; }
+#endif
   // lane roles (derived from the lane id only: loop invariants)
   //   body lane:  d <= 3 (trunk copies d == 0; only lane 0 stores / counts the trunk)      body b, joint b - 1
   //   dof lane:   leg lanes (dof b + 4) and lanes 4 .. 9 (trunk dof d - 4)
@@ -307,28 +314,28 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       }
       o[6] = own + arm; o[7] = p1; o[8] = p2;
       const float passive = -m->dof_damping[i] * lane_val(QVL, l);
-      float actf = 0.f;
+      // (every operand fetched unconditionally: inside `if (ctrllimited)` / `if (isposition)` the fetches were four dependent
+      //  LDS round trips under exec masks)
       const int a = m->dof_act[i];
       const int aa = a >= 0 ? a : 0;
-      {
-        float c = s.ctrl[aa];
-        if (m->act_ctrllimited[aa]) c = dm::clip(c, m->act_ctrlrange[aa][0], m->act_ctrlrange[aa][1]);
-        const float force = m->act_isposition[aa] ? m->act_kp[aa] * (c - s.qpos[m->act_qposadr[aa]]) : c;
-        actf = a >= 0 ? m->act_gear[aa] * force : 0.f;
-      }
+      const float c0 = s.ctrl[aa], lo = m->act_ctrlrange[aa][0], hi = m->act_ctrlrange[aa][1], kp = m->act_kp[aa];
+      const float qp = s.qpos[m->act_qposadr[aa]], gear = m->act_gear[aa];
+      const float c = m->act_ctrllimited[aa] ? dm::clip(c0, lo, hi) : c0;
+      const float force = m->act_isposition[aa] ? kp * (c - qp) : c;
+      const float actf = a >= 0 ? gear * force : 0.f;
       o[9] = passive - bias + actf;
       o[10] = 0.f;
     });
   }
   DIAL_MARK(w, 23);
-  // ---- collision_driver: the four plane-sphere foot contacts (collision_primitive plane_sphere), frame = make_frame(n)
-  float pn[3], pfr[9];
+  // ---- collision_driver: the four plane-sphere foot contacts (collision_primitive plane_sphere); their frame make_frame(n)
+  // depends on the floor plane only: written once per kernel (init_quad)
+  float pn[3];
   {
     const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
     float mat[9];
     dm::quat_to_mat(mat, gq);
     pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
-    make_frame(pfr, pn);
   }
   // ---- everything later stages read, stored once
   w.items(64, [&](int l) {
@@ -352,7 +359,6 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       const float dist = dm::dot3(diff, pn) - radius;
       s.cdist[c] = dist;
       for (int k = 0; k < 3; k++) { s.cpos[3 * c + k] = ctr[k] - pn[k] * (radius + 0.5f * dist); s.spos[3 * g2 + k] = lane_val(F[16 + k], l); }
-      for (int k = 0; k < 9; k++) s.cframe[9 * c + k] = pfr[k];
     }
     if (leg || tdof) {
       const int i = leg ? b + 4 : d - 4;
@@ -360,6 +366,8 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       const float qf = lane_val(MO[9], l);
       s.qfs[i] = qf;
       s.rhs[i] = qf;
+      // (predicated stores under branches: redirecting the lanes that are off to a dump word instead measured the same,
+      //  profiles/r04_ab_smooth_quad.txt)
       for (int j = 0; j < 6; j++) {
         if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
       }
@@ -370,7 +378,24 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       }
     }
   });
+#if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
+  w.lane = lane_keep;
+#endif
   DIAL_MARK(w, 1);
+}
+
+// Once per kernel: what the stage above never rewrites -- the contact frames of the four plane-sphere contacts
+// (collision_primitive make_frame(plane normal)).
+template <class W, class M>
+DIAL_DEV void init_quad(W& w, const M* m, const Ws& s) {
+  w.items(M::D::NC, [&](int c) {
+    const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
+    float mat[9], fr[9];
+    dm::quat_to_mat(mat, gq);
+    const float n[3] = {mat[2], mat[5], mat[8]};
+    make_frame(fr, n);
+    for (int k = 0; k < 9; k++) s.cframe[9 * c + k] = fr[k];
+  });
 }
 
 }  // namespace dial
