@@ -7,6 +7,7 @@
 // instantiation (capacity dimensions, constants read from global memory) serves any other model.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/dial_mpc.h"
 
 // ---- compile-time dof-tree topology of a robot (enables branch-induced sparsity in the factorisations)
@@ -50,6 +51,24 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
   static constexpr bool anc(int i, int j) { return topo_anc(T, i, j); }
 };
 
+// ---- row layout of the register-resident position / velocity stage (smooth_rows.h): robots that are one kinematic tree
+// under a free root.  maxd = deepest chain below the root (0: the robot does not use the stage); merge_dst / merge_src = the
+// lanes of the one body that lies on two chains (owner / copy), -1: none.  rows_build (below) derives the same from the model.
+template <class Topo>
+struct RowsOf { static constexpr int maxd = 0, merge_src = -1, merge_dst = -1; };
+template <>
+struct RowsOf<TopoH1> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; };       // torso: row 2 owns it, row 3 copies it
+template <>
+struct RowsOf<TopoH1Loco> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; };   // (arms welded: chain members without dofs)
+#define ROWS_BODY 1    /* the lane carries a body of its chain (copies included)            */
+#define ROWS_OWNER 2   /* ... and is the one that stores it and counts its mass / forces    */
+#define ROWS_JOINT 4   /* the body has a hinge (copies included: they propagate velocities) */
+#define ROWS_DOF 8     /* owner of a hinge: writes the dof's row of M, qfrc_smooth, cdof    */
+#define ROWS_TDOF 16   /* stands for one of the root's six dofs                             */
+struct RowTab {
+  uint8_t body[64], flags[64], dof[64], geom[64][2], site[64];
+};
+struct RowTabNone {};
 // SQUARE: M / H live in LDS as full nv x S squares (S = nv rounded up to 4: every row is ds_read_b128-able and no
 // index arithmetic or sparsity masks are needed when rows are fetched into registers), the contact Jacobian as
 // dof-major pyramid rows (J^T[i][4c + e]) and H is assembled from a contact-sparse work list (NHI = its capacity).
@@ -94,6 +113,19 @@ struct Dims {
   static constexpr int NANC = 12;   // max dofs on a root-to-body path (Go2: 9, H1: 11)
   static constexpr int NCHAIN = 8;  // max root-to-leaf chains (Go2: 4 legs, H1: 2 legs + 2 arms)
   static constexpr int CHAINLEN = 8;  // max bodies on a chain (Go2: 4, H1: 6)
+  // the tables only the LDS-phase version of forward()'s position / velocity stage reads (lower-triangle entry list, ancestor
+  // lists): dropped from the LDS-resident constants of the robots whose stage runs in registers (smooth_quad.h / smooth_rows.h)
+#ifdef DIAL_NO_QUAD
+  static constexpr bool quad_stage = false;
+#else
+  static constexpr bool quad_stage = !GEN_ && !ELL_ && SQUARE_ && std::is_same<Topo_, TopoGo2>::value;
+#endif
+#ifdef DIAL_NO_ROWS
+  static constexpr bool rows_stage = false;
+#else
+  static constexpr bool rows_stage = !GEN_ && !ELL_ && SQUARE_ && RowsOf<Topo_>::maxd > 0;
+#endif
+  static constexpr bool phase_tabs = !quad_stage && !rows_stage;
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;
@@ -151,7 +183,7 @@ struct CModel : CModelGeneric<D_> {
   int32_t body_subtree_end[D::NB], body_rootid[D::NB];
   uint32_t body_ancmask[D::NB];
   int32_t body_nanc[D::NB];              // number of ancestor-or-own dofs of body b ...
-  uint8_t body_anc[D::NB][D::NANC];      // ... and their indices, root first
+  uint8_t body_anc[D::phase_tabs ? D::NB : 1][D::NANC];      // ... and their indices, root first (phase version of forward() only)
   int32_t body_flags[D::NB];             // bit 0: body_quat is identity, bit 1: all joint anchors at the body origin, bit 2: free joint
   int32_t kin_fast;                      // every body has at most one joint: parent-independent local transforms (forward())
   float body_pos[D::NB][3], body_quat[D::NB][4], body_ipos[D::NB][3], body_iquat[D::NB][4];
@@ -176,7 +208,7 @@ struct CModel : CModelGeneric<D_> {
   uint32_t dof_descmask[D::NV];          // bit j: dof j is a descendant-or-self of dof i
   int32_t dof_blk0[D::NV], dof_blk1[D::NV];   // dofs of the same kinematic tree: the non-zero columns of row i of M
   float dof_armature[D::NV], dof_damping[D::NV], dof_invweight0[D::NV];
-  uint16_t tri[D::NTRI + (D::NTRI & 1)];
+  uint16_t tri[D::phase_tabs ? D::NTRI + (D::NTRI & 1) : 2];   // (phase version of forward() and the generic solver only)
   // H work list (square layout), derived from dial_derived::hitem and padded with no-op items to whole passes:
   //   hrec[it][0] = i*T | (j*T) << 10 | c0 << 20 | c1 << 23 | c2 << 26 | c3 << 29      (word offsets into J^T)
   //   hrec[it][1] = i*S+j | (j*S+i) << 10 | limit-row weight index << 20 (NE+3: a zero word) | pcode << 26 |
@@ -208,6 +240,8 @@ struct CModel : CModelGeneric<D_> {
   float dt, action_scale, foot_radius, gait_duty, gait_cadence, gait_amp, gait_phase[DIAL_MAX_FEET];
   float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3], init_ang_vel_tar[3];
   float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2], joint_offset[D::NU];
+  // ---- lane layout of the register-resident position / velocity stage (smooth_rows.h), robots that use it
+  typename std::conditional<(!D::gen && !D::ell && D::square && RowsOf<typename D::Topo>::maxd > 0), RowTab, RowTabNone>::type rows;
 };
 
 // ---- runtime / compile-time dimension accessors
@@ -241,6 +275,66 @@ CM_HD constexpr int dim_nf(const M* m) {
   else return m->nfri;
 }
 
+// Host: the row layout of smooth_rows.h for a model (false: the model is not one tree of hinge / welded bodies under a free
+// root with at most four chains of <= maxd bodies, at most one body shared by two chains (directly below the root), at most two
+// geoms and one site per body, plane-sphere / plane-capsule contacts).
+static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* merge_src, int* merge_dst) {
+  for (int l = 0; l < 64; l++) { t->body[l] = 0; t->flags[l] = 0; t->dof[l] = 0; t->geom[l][0] = 255; t->geom[l][1] = 255; t->site[l] = 255; }
+  *merge_src = -1; *merge_dst = -1;
+  if (maxd < 1 || maxd > 7 || m->nbody < 2 || m->nbody > 64) return false;
+  if (m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
+      m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1)
+    return false;
+  for (int b = 2; b < m->nbody; b++) {
+    if (m->body_parent[b] < 1 || m->body_rootid[b] != 1 || m->body_jntnum[b] > 1) return false;
+    if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] != DIAL_JNT_HINGE) return false;
+  }
+  int owner[64];
+  for (int b = 0; b < 64; b++) owner[b] = -1;
+  int row = 0;
+  for (int b = 1; b < m->nbody; b++) {
+    bool leaf = true;
+    for (int c2 = b + 1; c2 < m->nbody; c2++) leaf = leaf && m->body_parent[c2] != b;
+    if (!leaf) continue;
+    int path[64], len = 0;
+    for (int bb = b; bb > 0 && len < 64; bb = m->body_parent[bb]) path[len++] = bb;
+    if (row >= 4 || len - 1 > maxd) return false;
+    for (int d = 0; d < len; d++) {
+      const int bb = path[len - 1 - d], l = 16 * row + d;
+      t->body[l] = (uint8_t)bb;
+      t->flags[l] |= ROWS_BODY;
+      if (owner[bb] < 0) { owner[bb] = l; t->flags[l] |= ROWS_OWNER; }
+      else if (d >= 1) {   // a body on two chains
+        if (d != 1 || *merge_src >= 0) return false;
+        *merge_src = l; *merge_dst = owner[bb];
+      }
+      if (d >= 1 && m->body_jntnum[bb] == 1) {
+        t->flags[l] |= ROWS_JOINT;
+        t->dof[l] = (uint8_t)m->body_dofadr[bb];
+        if (t->flags[l] & ROWS_OWNER) t->flags[l] |= ROWS_DOF;
+      }
+    }
+    row++;
+  }
+  for (int k = 0; k < 6; k++) { t->flags[8 + k] = ROWS_TDOF; t->dof[8 + k] = (uint8_t)k; }
+  for (int g = 0; g < m->ngeom; g++) {
+    const int b = m->geom_bodyid[g], l = b == 0 ? 14 : owner[b];   // lane 14: the world's geoms (identity pose)
+    if (l < 0) return false;
+    if (t->geom[l][0] == 255) t->geom[l][0] = (uint8_t)g;
+    else if (t->geom[l][1] == 255) t->geom[l][1] = (uint8_t)g;
+    else return false;
+  }
+  for (int si = 0; si < m->nsite; si++) {
+    const int b = m->site_bodyid[si];
+    if (b == 0 || owner[b] < 0 || t->site[owner[b]] != 255) return false;
+    t->site[owner[b]] = (uint8_t)si;
+  }
+  for (int c = 0; c < m->ncon; c++) {
+    const int k = m->con_kind[c];
+    if (k != DIAL_CON_PLANE_SPHERE && k != DIAL_CON_PLANE_CAPSULE_P && k != DIAL_CON_PLANE_CAPSULE_N) return false;
+  }
+  return true;
+}
 // Host: is the model the quadruped this layout assumes (smooth_quad.h; beyond the dof tree dims_match checks)?  World, a free trunk
 // (body 1), four legs of three one-hinge bodies in depth-first order, the floor plane as geom 0, one sphere and one site per calf,
 // the trunk's site first, one plane-sphere contact per foot in leg order.
@@ -276,6 +370,12 @@ static inline bool dims_match(const dial_model* m) {
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }
   if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
+  if constexpr (!D::gen && !D::ell && D::square && RowsOf<typename D::Topo>::maxd > 0) {   // smooth_rows.h: the layout must come out as compiled
+    using RT = RowsOf<typename D::Topo>;
+    RowTab t;
+    int ms, md;
+    ok = ok && rows_build(m, &t, RT::maxd, &ms, &md) && ms == RT::merge_src && md == RT::merge_dst;
+  }
   return ok;
 }
 

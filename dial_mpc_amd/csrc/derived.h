@@ -181,7 +181,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     {
       int na = 0;
       for (int i = 0; i < m->nv && na < D::NANC; i++)
-        if ((dv->body_ancmask[b] >> i) & 1u) o.body_anc[b][na++] = (uint8_t)i;
+        if ((dv->body_ancmask[b] >> i) & 1u) { if constexpr (D::phase_tabs) o.body_anc[b][na] = (uint8_t)i; na++; }
       o.body_nanc[b] = na;
       int flags = 0;
       if (m->body_quat[b][0] == 1.f && m->body_quat[b][1] == 0.f && m->body_quat[b][2] == 0.f && m->body_quat[b][3] == 0.f) flags |= 1;
@@ -242,6 +242,10 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
       if (fits) o.nshared = ns;
     }
   }
+  if constexpr (!D::gen && !D::ell && D::square && RowsOf<typename D::Topo>::maxd > 0) {
+    int ms, md;
+    rows_build(m, &o.rows, RowsOf<typename D::Topo>::maxd, &ms, &md);   // (dims_match<D> has checked that it succeeds)
+  }
   for (int j = 0; j < m->njnt; j++) {
     o.jnt_type[j] = m->jnt_type[j]; o.jnt_qposadr[j] = m->jnt_qposadr[j]; o.jnt_dofadr[j] = m->jnt_dofadr[j];
     o.jnt_bodyid[j] = m->jnt_bodyid[j]; o.jnt_margin[j] = m->jnt_margin[j];
@@ -265,7 +269,7 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     while (!((mask >> (hi - 1)) & 1u)) hi--;
     o.dof_blk0[i] = lo; o.dof_blk1[i] = hi;
   }
-  for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
+  if constexpr (D::phase_tabs) for (int e = 0; e < dv->ntri; e++) o.tri[e] = dv->tri[e];
   if constexpr (D::square && !D::ell) {
     static_assert(D::NHI % 64 == 0 && D::NV * D::T < 1024 && D::NV * D::S < 1024 && D::NE + 4 < 64, "hrec field widths");
     o.nhitem = dv->nhitem <= D::NHI ? dv->nhitem : 0;

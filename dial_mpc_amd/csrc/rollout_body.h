@@ -216,6 +216,7 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 #include "solver_reg.h"
 #include "solver_cone.h"
 #include "smooth_quad.h"
+#include "smooth_rows.h"
 namespace dial {
 
 // Generic instantiation: x = A^-1 rhs for the packed SPD matrix A (M or H) with the register-resident L D L^T of
@@ -985,6 +986,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
 
   if constexpr (kQuadDims<typename M::D>) {   // quadruped topology: the whole position / velocity stage in registers (smooth_quad.h)
     forward_smooth_quad(w, m, s);
+    forward_constraints(w, m, s, nca, nea);
+    return;
+  }
+  if constexpr (kRowsDims<typename M::D>) {   // one tree under a free root (H1): the same stage on the row layout (smooth_rows.h)
+    forward_smooth_rows(w, m, s);
+    w.items(nc, [&](int c) { rows_collide(m, s, c); });
     forward_constraints(w, m, s, nca, nea);
     return;
   }

@@ -24,13 +24,8 @@
 
 namespace dial {
 
-#ifdef DIAL_NO_QUAD
 template <class D>
-inline constexpr bool kQuadDims = false;
-#else
-template <class D>
-inline constexpr bool kQuadDims = std::is_same<D, DimsGo2>::value;
-#endif
+inline constexpr bool kQuadDims = D::quad_stage;
 
 template <class W, class M>
 DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
