@@ -350,11 +350,11 @@ static inline bool quad_fits(const dial_model* m) {
           m->jnt_type[j] != DIAL_JNT_HINGE || m->jnt_qposadr[j] != b + 5 || m->jnt_dofadr[j] != b + 4 || m->body_dofadr[b] != b + 4)
         return false;
     }
-  if (m->geom_bodyid[0] != 0 || m->site_bodyid[0] != 1) return false;
+  if (m->geom_bodyid[0] != 0 || m->site_bodyid[0] != 1 || (m->nlim & 3) != 0) return false;   // (limit rows fill whole 16-byte groups)
   for (int r = 0; r < 4; r++) {
     const int calf = 4 + 3 * r;
     if (m->geom_bodyid[1 + r] != calf || m->site_bodyid[1 + r] != calf || m->con_kind[r] != DIAL_CON_PLANE_SPHERE ||
-        m->con_geom1[r] != 0 || m->con_geom2[r] != 1 + r)
+        m->con_geom1[r] != 0 || m->con_geom2[r] != 1 + r || m->con_body1[r] != 0 || m->con_body2[r] != calf)
       return false;
   }
   return true;

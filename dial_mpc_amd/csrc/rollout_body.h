@@ -330,7 +330,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       for (int a = 0; a < nd; a++) vel += J[a] * s.qvel[m->con_dof[c][a]];
       s.jv[m->con_adr[c] + k] = vel;
     });
-  } else
+  } else if constexpr (!M::D::quad_stage)   // (quadruped stage: Jacobian and rows come out of smooth_quad.h)
   w.items(nca * nv, [&](int it) {
     const int c = it / nv, i = it - c * nv;
     const int co = con_of(m, s, c);   // model contact (positions, frames and constants are indexed by it; Jc by the compact c)
@@ -400,7 +400,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         s.D[r0 + j] = 1.f / R;
       }
     });
-  } else
+  } else if constexpr (!M::D::quad_stage)
   w.items(nea, [&](int r) {
     if (r < nl) {
       const int ji = m->lim_jnt[r], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];

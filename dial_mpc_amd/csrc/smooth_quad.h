@@ -150,7 +150,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     vfloat T[16];
     w.per_lane_n(T, [&](int l, float* o) {
       const int d = l & 15, r = l >> 4;
-      const bool leg = d >= 1 && d <= 3, body = d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
+      const bool leg = d >= 1 && d <= 3, body = d <= 3, tdof = d >= 4 && d <= 9;   // (trunk dofs: in every row, for its contact's Jacobian)
       const int b = leg ? 3 * r + d + 1 : 1, ji = b - 1, kd = tdof ? d - 4 : 3;
       const float R[9] = {lane_val(F[3], l), lane_val(F[4], l), lane_val(F[5], l), lane_val(F[6], l), lane_val(F[7], l),
                           lane_val(F[8], l), lane_val(F[9], l), lane_val(F[10], l), lane_val(F[11], l)};
@@ -236,6 +236,110 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     });
     DIAL_UNROLL_FULL
     for (int k = 0; k < 12; k++) VA[k] = N[k];
+  }
+  // the bodies' outputs are complete: stored now (fewer registers to carry through the rest of the stage)
+  w.items(64, [&](int l) {
+    const int d = l & 15, r = l >> 4;
+    const bool leg = d >= 1 && d <= 3;
+    const int b = leg ? 3 * r + d + 1 : 1;
+    if (leg || l == 0) {
+      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(PL[k], l);
+      store4(s.xquat + 4 * b, lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l));
+      for (int k = 0; k < 3; k++) store2(s.cvel + 6 * b + 2 * k, lane_val(VA[2 * k], l), lane_val(VA[2 * k + 1], l));
+    }
+    if (l == 0) {
+      for (int k = 0; k < 3; k++) { s.com[3 * m->body_rootid[1] + k] = com[k]; s.spos[k] = lane_val(F[16 + k], l); }
+      for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
+    }
+    if (d == 3) for (int k = 0; k < 3; k++) s.spos[3 * (1 + r) + k] = lane_val(F[16 + k], l);
+  });
+  // ---- collision_driver (the four plane-sphere foot contacts), the contact Jacobian and constraint.make_constraint, fused:
+  // forward_constraints()'s first two LDS phases (72 (contact, dof) items; 28 rows with an 18-term J qvel each) become
+  //   * calf lanes: distance, contact point, the four pyramid rows' D and aref -- their velocity is the contact POINT's
+  //     velocity (J qvel = cvel.lin + cvel.ang x (p - com), the body velocity this lane holds) projected on the frame;
+  //   * dof lanes: the contact of their own row only (a leg dof moves no other foot; lanes 4..9 of EVERY row stand for the
+  //     trunk's dofs against that row's contact): one 16-byte store of J^T[i][4c..4c+3]; the other entries of a leg dof's row
+  //     are structural zeros written once per kernel (init_quad);
+  //   * leg lanes: their joint's limit row.
+  {
+    float pn[3];
+    {
+      const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
+      float mat[9];
+      dm::quat_to_mat(mat, gq);
+      pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
+    }
+    const float fr[9] = {s.cframe[0], s.cframe[1], s.cframe[2], s.cframe[3], s.cframe[4], s.cframe[5], s.cframe[6], s.cframe[7], s.cframe[8]};
+    vfloat CP[4];   // contact point (3), distance
+    w.per_lane_n(CP, [&](int l, float* o) {
+      const int r = l >> 4, g2 = 1 + r;
+      const float ctr[3] = {lane_val(F[19], l), lane_val(F[20], l), lane_val(F[21], l)};
+      const float radius = m->geom_size[g2][0];
+      const float diff[3] = {ctr[0] - m->geom_pos[0][0], ctr[1] - m->geom_pos[0][1], ctr[2] - m->geom_pos[0][2]};
+      const float dist = dm::dot3(diff, pn) - radius;
+      for (int k = 0; k < 3; k++) o[k] = ctr[k] - pn[k] * (radius + 0.5f * dist);
+      o[3] = dist;
+    });
+    vfloat PC[3];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 3; k++) PC[k] = w.template row_bcast<3>(CP[k]);   // the calf lane's contact point, to its whole row
+    // (three compute-and-store phases, each with a short live range: one fused phase cost the 128-register large-batch build 15 spills)
+    w.items(64, [&](int l) {   // -- Jacobian of contact r with respect to this lane's dof (world vs the calf: jacp_b2 only)
+      const int d = l & 15, r = l >> 4;
+      const bool leg = d >= 1 && d <= 3, tk = d >= 4 && d <= 9;
+      if (!(leg || tk)) return;
+      const int i = leg ? 3 * r + d + 5 : d - 4;
+      const float mu1 = m->con_friction[r][0], mu2 = m->con_friction[r][1];
+      const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
+      const float off[3] = {lane_val(PC[0], l) - com[0], lane_val(PC[1], l) - com[1], lane_val(PC[2], l) - com[2]};
+      float cr[3];
+      dm::cross3(cr, cd, off);
+      const float diff[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]};
+      const float jn = dm::dot3(fr, diff), t1 = dm::dot3(fr + 3, diff) * mu1, t2 = dm::dot3(fr + 6, diff) * mu2;
+      store4(s.Jc + i * M::D::T + 4 * r, jn + t1, jn - t1, jn + t2, jn - t2);
+    });
+    w.items(64, [&](int l) {   // -- the contact's four pyramid rows (calf lanes)
+      const int d = l & 15, r = l >> 4;
+      if (d != 3) return;
+      const float mu1 = m->con_friction[r][0], mu2 = m->con_friction[r][1];
+      const float pos = lane_val(CP[3], l) - m->con_margin[r];
+      const float t = m->body_invweight0[m->con_body1[r]] + m->body_invweight0[m->con_body2[r]];
+      float invweight = t + mu1 * mu1 * t;
+      invweight = invweight * 2.f * mu1 * mu1 / m->impratio;
+      float k_, b_, imp;
+      kbi(m, m->con_solref[r], m->con_solimp[r], pos, k_, b_, imp);
+      const float Rr = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
+      const float va[3] = {lane_val(VA[0], l), lane_val(VA[1], l), lane_val(VA[2], l)};
+      const float off[3] = {lane_val(CP[0], l) - com[0], lane_val(CP[1], l) - com[1], lane_val(CP[2], l) - com[2]};
+      float cr[3];
+      dm::cross3(cr, va, off);
+      const float vp[3] = {lane_val(VA[3], l) + cr[0], lane_val(VA[4], l) + cr[1], lane_val(VA[5], l) + cr[2]};
+      const float vn = dm::dot3(fr, vp), v1 = dm::dot3(fr + 3, vp) * mu1, v2 = dm::dot3(fr + 6, vp) * mu2;
+      const bool on = pos < 0.f;
+      const float dd = on ? 1.f / Rr : 0.f, ar = -k_ * imp * pos;
+      constexpr int NL = M::D::NL;
+      store4(s.D + NL + 4 * r, dd, dd, dd, dd);
+      store4(s.aref + NL + 4 * r, on ? ar - b_ * (vn + v1) : 0.f, on ? ar - b_ * (vn - v1) : 0.f, on ? ar - b_ * (vn + v2) : 0.f, on ? ar - b_ * (vn - v2) : 0.f);
+      s.cdist[r] = lane_val(CP[3], l);
+      for (int k = 0; k < 3; k++) s.cpos[3 * r + k] = lane_val(CP[k], l);
+    });
+    w.items(64, [&](int l) {   // -- the joint's limit row (leg lanes)
+      const int d = l & 15, r = l >> 4;
+      if (!(d >= 1 && d <= 3)) return;
+      const int b = 3 * r + d + 1, ji = b - 1, i = b + 4, qa = b + 5, lr = m->dof_limrow[i];
+      if (lr < 0) return;
+      const float q = s.qpos[qa];
+      const float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+      const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+      const float sgn = dist_min < dist_max ? 1.f : -1.f;
+      float k_, b_, imp;
+      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      const float Rr = dm::fmaxf_(m->dof_invweight0[i] * (1.f - imp) / imp, MJ_MINVAL);
+      const bool on = pos < 0.f;
+      s.lsign[lr] = sgn;
+      s.D[lr] = on ? 1.f / Rr : 0.f;
+      s.aref[lr] = on ? -b_ * (sgn * lane_val(QVL, l)) - k_ * imp * pos : 0.f;
+    });
   }
   DIAL_MARK(w, 19);
   // ---- rne: local body forces cfl = cinert cacc + cvel x* (cinert cvel)
@@ -323,38 +427,11 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     });
   }
   DIAL_MARK(w, 23);
-  // ---- collision_driver: the four plane-sphere foot contacts (collision_primitive plane_sphere); their frame make_frame(n)
-  // depends on the floor plane only: written once per kernel (init_quad)
-  float pn[3];
-  {
-    const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
-    float mat[9];
-    dm::quat_to_mat(mat, gq);
-    pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
-  }
-  // ---- everything later stages read, stored once
+  // ---- the dofs' outputs
   w.items(64, [&](int l) {
     const int d = l & 15, r = l >> 4;
     const bool leg = d >= 1 && d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
     const int b = leg ? 3 * r + d + 1 : 1;
-    if (leg || l == 0) {
-      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(PL[k], l);
-      store4(s.xquat + 4 * b, lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l));
-      for (int k = 0; k < 3; k++) store2(s.cvel + 6 * b + 2 * k, lane_val(VA[2 * k], l), lane_val(VA[2 * k + 1], l));
-    }
-    if (l == 0) {
-      for (int k = 0; k < 3; k++) { s.com[3 * m->body_rootid[1] + k] = com[k]; s.spos[k] = lane_val(F[16 + k], l); }
-      for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
-    }
-    if (d == 3) {
-      const int c = r, g2 = 1 + r;
-      const float ctr[3] = {lane_val(F[19], l), lane_val(F[20], l), lane_val(F[21], l)};
-      const float radius = m->geom_size[g2][0];
-      const float diff[3] = {ctr[0] - m->geom_pos[0][0], ctr[1] - m->geom_pos[0][1], ctr[2] - m->geom_pos[0][2]};
-      const float dist = dm::dot3(diff, pn) - radius;
-      s.cdist[c] = dist;
-      for (int k = 0; k < 3; k++) { s.cpos[3 * c + k] = ctr[k] - pn[k] * (radius + 0.5f * dist); s.spos[3 * g2 + k] = lane_val(F[16 + k], l); }
-    }
     if (leg || tdof) {
       const int i = leg ? b + 4 : d - 4;
       for (int k = 0; k < 3; k++) store2(s.cdof + 6 * i + 2 * k, lane_val(CD[2 * k], l), lane_val(CD[2 * k + 1], l));
@@ -380,9 +457,11 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
 }
 
 // Once per kernel: what the stage above never rewrites -- the contact frames of the four plane-sphere contacts
-// (collision_primitive make_frame(plane normal)).
+// (collision_primitive make_frame(plane normal)), the structural zeros of the contact Jacobian, lsign of the contact rows.
 template <class W, class M>
 DIAL_DEV void init_quad(W& w, const M* m, const Ws& s) {
+  w.items(M::D::NV * M::D::T, [&](int e) { s.Jc[e] = 0.f; });                 // J^T: a leg's dofs move no other leg's foot
+  w.items(4 * M::D::NC, [&](int e) { s.lsign[M::D::NL + e] = 0.f; });        // (the solver reads a contact row's lsign as its zero word)
   w.items(M::D::NC, [&](int c) {
     const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
     float mat[9], fr[9];

@@ -136,6 +136,9 @@ struct Wave {
   vfloat row_shr(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) >= N ? v.x[l - N] : 0.f; return r; }
   template <int N>
   vfloat row_shl(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) + N <= 15 ? v.x[l + N] : 0.f; return r; }
+  // value of lane N of the own row of 16 lanes (DPP row_newbcast on the GPU)
+  template <int N>
+  vfloat row_bcast(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~15) + N]; return r; }
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
@@ -321,6 +324,10 @@ struct Wave {
   template <int N>
   __device__ __forceinline__ vfloat row_shl(vfloat v) {   // DPP row_shl:N
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+  }
+  template <int N>
+  __device__ __forceinline__ vfloat row_bcast(vfloat v) {   // DPP row_newbcast:N (gfx90a+): lane N of the own row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
   }
   template <class F>
   __device__ __forceinline__ void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
