@@ -249,6 +249,9 @@ struct dial_ctx {
   int ws_words = 0, cm_bytes = 0, wpb = 1;
   int* next = nullptr;         // rollout queue head (batches larger than the chip keeps resident)
   float* relay_buf = nullptr;  // mean-trajectory relay: state handed from piece to piece, and the turn flag
+  float* slice_buf = nullptr;  // time-sliced rollout queue (rollout_kernel.h): one hand-over slot and one turn flag per rollout
+  int* slice_flag = nullptr;
+  int slice_cap = 0, slice_stride = 0, slice_steps = 3;
   int* relay_flag = nullptr;
   int* err_host = nullptr;     // sticky error word: pinned host memory the kernels can write (relay time-out) ...
   int* err_dev = nullptr;      // ... and its device-side address
@@ -302,7 +305,7 @@ void dial_destroy(dial_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->next, ctx->relay_buf, ctx->relay_flag, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
-                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial, ctx->ovf};
+                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial, ctx->ovf, ctx->slice_buf, ctx->slice_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -330,6 +333,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
   if (cfg && n_local_cap > cfg->Nsample) return fail(nullptr, DIAL_ERR_ARG, "dial_create_ex: n_local_cap must be in [0, Nsample]");
   const dial_options opt = opts ? *opts : dial_options{};
   if (opt.relay_steps < 0 || opt.relay_steps > 16) return fail(nullptr, DIAL_ERR_ARG, "dial_create_ex: options.relay_steps must be in 0 .. 16");
+  if (opt.slice_steps < 0 || opt.slice_steps > 16) return fail(nullptr, DIAL_ERR_ARG, "dial_create_ex: options.slice_steps must be in 0 .. 16");
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -574,6 +578,16 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->ovf_slots * ctx->ovf_words * sizeof(float)));
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
+    // time-sliced queue: models whose rollouts differ in length (the elliptic solver runs to convergence), batches beyond the
+    // resident set
+    if (ctx->inst == 4 && !opt.no_slice && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb) {
+      ctx->slice_stride = model->nq + 2 * model->nv + DIAL_INFO_N + 4;
+      ctx->slice_cap = ctx->B_cap;
+      if (opt.slice_steps >= 1) ctx->slice_steps = opt.slice_steps;
+      HIP_TRY_CREATE(hipMalloc(&ctx->slice_buf, sizeof(float) * (size_t)ctx->slice_stride * ctx->B_cap));
+      HIP_TRY_CREATE(hipMalloc(&ctx->slice_flag, sizeof(int) * (size_t)ctx->B_cap));
+      HIP_TRY_CREATE(hipMemset(ctx->slice_flag, 0, sizeof(int) * (size_t)ctx->B_cap));
+    }
     const size_t B = ctx->B_cap, T = ctx->T;
     HIP_TRY_CREATE(hipMalloc(&ctx->dcfg, sizeof(dial_cfg)));
     HIP_TRY_CREATE(hipMemcpy(ctx->dcfg, cfg, sizeof(dial_cfg), hipMemcpyHostToDevice));
@@ -603,6 +617,7 @@ static int check_sticky(dial_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->relay_flag) (void)hipMemset(ctx->relay_flag, 0, sizeof(int));
+  if (ctx->slice_flag) (void)hipMemset(ctx->slice_flag, 0, sizeof(int) * (size_t)ctx->slice_cap);
   __atomic_store_n(ctx->err_host, 0, __ATOMIC_RELEASE);
   return fail(ctx, DIAL_ERR_HIP, "an earlier rollout launch gave up: a piece of the mean-trajectory relay never got its turn "
                                  "(results of that launch and of the launches queued behind it are invalid)");
@@ -689,6 +704,14 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
+    if (ctx->slice_buf && B <= ctx->slice_cap && ctx->T > ctx->slice_steps) {   // time-sliced: (piece, rollout) items
+      io.relay_buf = ctx->slice_buf;
+      io.relay_flag = ctx->slice_flag;
+      io.relay_stride = ctx->slice_stride;
+      io.relay_steps = ctx->slice_steps;
+      io.slice_pieces = (ctx->T + ctx->slice_steps - 1) / ctx->slice_steps;
+      io.err_word = ctx->err_dev;
+    }
   }
   if (io.ovf && blocks * wpb > ctx->ovf_slots)
     return fail(ctx, DIAL_ERR_ARG, "rollout launch: more wavefronts than overflow areas (batch larger than the context's Nsample + 1)");

@@ -35,6 +35,11 @@ struct RolloutIO {
   float* relay_buf;          // packed state + running reward sum handed from piece to piece
   int* relay_flag;           // index of the piece that may run
   int relay_steps;
+  // time-sliced rollout queue (batches beyond the resident set whose rollouts differ in length, rollout_kernel.h): EVERY rollout
+  // is cut into pieces, relay_buf / relay_flag are arrays with one slot per rollout (relay_stride floats apart); 0: the classic
+  // relay of the mean trajectory alone (one slot)
+  int relay_stride;
+  int slice_pieces;          // pieces per rollout (time-sliced queue), else 0
   int relay_base;            // index of the first relay workgroup of the launch
   int n_first;               // rollout index of the launch's first wavefront (split launches)
   int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
@@ -121,6 +126,8 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   float rsum = 0.f;
   w.set_rollout(n);
 #ifndef DIAL_EMU
+  float* const rbuf = io.relay_buf ? io.relay_buf + (size_t)n * io.relay_stride : nullptr;   // this rollout's hand-over slot
+  int* const rflag = io.relay_flag ? io.relay_flag + (io.relay_stride ? n : 0) : nullptr;
   if (relay > 0) {
     // wait for the predecessor (it was dispatched before this wavefront: it is running or done), then take its state
     // (bounded: a wavefront that never gets its turn -- ~0.2 s -- gives up instead of hanging the GPU: it raises the
@@ -129,9 +136,10 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     int timed_out = 0;
     if (w.lane == 0) {
       unsigned spins = 0;
-      while (__hip_atomic_load(io.relay_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != relay && ++spins < (1u << 20))
+      const unsigned spin_max = io.relay_stride ? (1u << 23) : (1u << 20);   // (sliced queue: a predecessor may itself be waiting)
+      while (__hip_atomic_load(rflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != relay && ++spins < spin_max)
         __builtin_amdgcn_s_sleep(4);
-      timed_out = spins >= (1u << 20);
+      timed_out = spins >= spin_max;
     }
     timed_out = __builtin_amdgcn_readfirstlane(timed_out);
     if (timed_out) {
@@ -143,10 +151,10 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    load_state(w, m, s, io.relay_buf);
-    rsum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    load_state(w, m, s, rbuf);
+    rsum = __hip_atomic_load(rbuf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (relay >= 0) w.hold_priority(3);
+  if (relay >= 0 && io.relay_stride == 0) w.hold_priority(3);   // (the lone relay rollout; the sliced queue keeps the fair sharing)
 #endif
   for (int st = st_begin; st < st_end; st++) {
     w.redraw_priority();
@@ -200,13 +208,13 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #ifndef DIAL_EMU
   if (relay >= 0 && relay + 1 == io.debug_stall_piece1) return;   // test hook: a piece that never hands over (its successors time out)
   if (relay >= 0 && st_end < T) {   // hand over: state, running sum, then the flag (release)
-    store_state(w, m, s, io.relay_buf);
-    w.items(1, [&](int) { io.relay_buf[nstate] = rsum; });
+    store_state(w, m, s, rbuf);
+    w.items(1, [&](int) { rbuf[nstate] = rsum; });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (w.lane == 0) __hip_atomic_store(io.relay_flag, relay + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (w.lane == 0) __hip_atomic_store(rflag, relay + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  if (relay >= 0 && w.lane == 0) __hip_atomic_store(io.relay_flag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // last piece: re-arm
+  if (relay >= 0 && w.lane == 0) __hip_atomic_store(rflag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // last piece: re-arm
 #endif
   if (io.rews) {
     const float mean = rsum / (float)T;

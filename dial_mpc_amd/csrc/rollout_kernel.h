@@ -73,7 +73,16 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   // keeps resident and every wavefront draws its next rollout from the queue head when it finishes one: rollouts differ
   // in length (solver iterations), and a workgroup's LDS is only handed to a new workgroup when its slowest wavefront
   // is done -- the queue keeps every wavefront slot busy until the batch is empty
+  // Time-sliced queue (io.slice_pieces > 0, QUEUE variant): the queue holds (piece, rollout) items in piece-major order --
+  // item q = piece q / B of rollout q % B -- so that all rollouts advance together and the launch ends when the WORK is done,
+  // not when the slot that drew two long rollouts is (Allegro, 4097 rollouts on 2304 slots: durations 3.3 .. 11.5 ms,
+  // profiles/r04_wave_times.txt).  A piece waits for its predecessor's hand-over (rollout_driver.h: the relay protocol, one
+  // slot per rollout); predecessors are always EARLIER items, i.e. running or done: no deadlock.
+  int q = n - io.n_first;   // queue position of this wavefront's first item (= its grid index)
   for (;;) {
+    if constexpr (QUEUE) {
+      if (io.slice_pieces > 0) { relay = q / B; n = q - relay * B; }
+    }
     dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay);
 #ifdef DIAL_PROFILE
     if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
@@ -87,7 +96,8 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
     int nn = 0;
     if (w.lane == 0) nn = atomicAdd(next, 1);
     n = __builtin_amdgcn_readfirstlane(nn);
-    if (n >= B) break;
+    q = n;
+    if (n >= (io.slice_pieces > 0 ? io.slice_pieces * B : B)) break;
 #ifdef DIAL_PROFILE
     t_start = wall_clock64();
 #endif

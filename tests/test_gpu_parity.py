@@ -518,6 +518,38 @@ def test_rollout_queue_beyond_the_resident_batch():
     assert rep["rollouts"] == len(idx)
 
 
+def test_time_sliced_queue_is_bit_identical():
+    """Allegro batches beyond the resident set run through the TIME-SLICED queue (rollout_kernel.h: (piece, rollout) items in
+    piece-major order, states handed on through global memory): bit-identical to the plain queue of whole rollouts and to the
+    one-wavefront-per-rollout launch, repeatable, for two piece lengths (one that does not divide the horizon)."""
+    import torch
+    from dial_mpc_amd import _lib
+    N, H = 2500, 7
+    dc, env, model, task, cfg = setup_case("allegro_reorient", N, H)
+    s0 = None
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=2, Ybar_scale=0.2)
+    outs = []
+    for opts in (dict(), dict(slice_steps=2), dict(no_slice=1), dict(no_queue=1)):
+        ctx = _lib.Context(model, task, cfg, options=opts)
+        slots = ctx.lib.dial_debug_resident_rollouts(ctx.h, N + 1)
+        assert (slots == 0) if opts.get("no_queue") else (0 < slots < N + 1), (opts, slots)
+        if s0 is None:
+            s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+        for rep in range(2 if not opts else 1):
+            out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+            torch.cuda.synchronize()
+            ctx.status()
+            sc = ctx.debug_scratch()
+            outs.append(({k: out[k].clone() for k in ("Ybar", "rews", "qbar", "xbar")}, {k: np.array(sc[k]) for k in ("rewss", "qss", "qdss", "xss")}))
+    assert np.isfinite(outs[0][1]["rewss"]).all()
+    for o, sc in outs[1:]:
+        for k in o:
+            assert torch.equal(o[k], outs[0][0][k]), k
+        for k in sc:
+            assert np.array_equal(sc[k], outs[0][1][k]), k
+
+
+
 @pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 2048, 16), ("unitree_go2_seq_jump", 1024, 20), ("unitree_go2_trot", 100, 7)])
 def test_mean_trajectory_relay_is_bit_identical(example, N, H):
     """The mean-trajectory rollout cut into pieces that different wavefronts run one after the other (state handed over
