@@ -252,6 +252,7 @@ struct dial_ctx {
   float* slice_buf = nullptr;  // time-sliced rollout queue (rollout_kernel.h): one hand-over slot and one turn flag per rollout
   int* slice_flag = nullptr;
   int slice_cap = 0, slice_stride = 0, slice_steps = 3;
+  int* work_stat = nullptr;    // lag-based issue priority (wave.h): the launch's running totals (solver iterations, control steps)
   int* relay_flag = nullptr;
   int* err_host = nullptr;     // sticky error word: pinned host memory the kernels can write (relay time-out) ...
   int* err_dev = nullptr;      // ... and its device-side address
@@ -305,7 +306,7 @@ void dial_destroy(dial_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   void* ptrs[] = {ctx->dcm, ctx->dtask, ctx->dcfg, ctx->prof, ctx->next, ctx->relay_buf, ctx->relay_flag, ctx->Y0s, ctx->rewss, ctx->rews, ctx->qss,
-                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial, ctx->ovf, ctx->slice_buf, ctx->slice_flag};
+                  ctx->qdss,   ctx->xss,   ctx->weights, ctx->partial, ctx->ovf, ctx->slice_buf, ctx->slice_flag, ctx->work_stat};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -578,6 +579,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     if (ctx->con_cap > 0) HIP_TRY_CREATE(hipMalloc(&ctx->ovf, (size_t)ctx->ovf_slots * ctx->ovf_words * sizeof(float)));
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
+    if (ctx->inst == 4 && !opt.no_lag_priority) HIP_TRY_CREATE(hipMalloc(&ctx->work_stat, 2 * sizeof(int)));
     // time-sliced queue: models whose rollouts differ in length (the elliptic solver runs to convergence), batches beyond the
     // resident set
     if (ctx->inst == 4 && !opt.no_slice && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb) {
@@ -712,6 +714,10 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
       io.slice_pieces = (ctx->T + ctx->slice_steps - 1) / ctx->slice_steps;
       io.err_word = ctx->err_dev;
     }
+  }
+  if (ctx->work_stat && !io.slice_pieces && !tracing) {   // everything resident (or the plain queue): the slow rollouts first
+    HIP_TRY(ctx, hipMemsetAsync(ctx->work_stat, 0, 2 * sizeof(int), st));
+    io.work_stat = ctx->work_stat;
   }
   if (io.ovf && blocks * wpb > ctx->ovf_slots)
     return fail(ctx, DIAL_ERR_ARG, "rollout launch: more wavefronts than overflow areas (batch larger than the context's Nsample + 1)");

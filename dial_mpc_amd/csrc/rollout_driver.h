@@ -40,6 +40,9 @@ struct RolloutIO {
   // relay of the mean trajectory alone (one slot)
   int relay_stride;
   int slice_pieces;          // pieces per rollout (time-sliced queue), else 0
+  // lag-based issue priority (wave.h; models with data-dependent rollout lengths, everything resident): [0] solver iterations,
+  // [1] control steps completed by all rollouts of the launch so far; nullptr: the pseudo-random fair sharing
+  int* work_stat;
   int relay_base;            // index of the first relay workgroup of the launch
   int n_first;               // rollout index of the launch's first wavefront (split launches)
   int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
@@ -177,8 +180,29 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       s.act[a] = u;
     });
     DIAL_MARK(w, 11);
+    const int work0 = w.work;
     float rew = env_step<false>(w, m, tg, s);
     rsum += rew;
+#ifndef DIAL_EMU
+    if constexpr (M::D::ell) {
+      if (io.work_stat && relay < 0) {   // once per control step: add own work to the launch totals, compare rates, set the level
+        int lvl = 0;
+        if (w.lane == 0) {
+          const int tot_w = atomicAdd(io.work_stat, w.work - work0) + (w.work - work0);
+          const int tot_s = atomicAdd(io.work_stat + 1, 1) + 1;
+          // own rate vs the running average: w.work / (st + 1 - st_begin)  <>  tot_w / tot_s
+          const float own = (float)w.work * (float)tot_s, avg = (float)tot_w * (float)(st + 1 - st_begin);
+#ifndef DIAL_LAG_T1
+#define DIAL_LAG_T1 1.0f    // thresholds measured on the Allegro example (profiles/r04_ab_lag_priority.txt): 0.85 / 1.05 / 1.25 -> 7.29 ms,
+#define DIAL_LAG_T2 1.2f    // 1.0 / 1.2 / 1.4 -> 7.17 ms, 0.9 / 1.0 / 1.1 -> 7.42 ms, 1.1 / 1.3 / 1.5 and 1.0 / 1.3 / 1.6 -> 7.2 ms;
+#define DIAL_LAG_T3 1.4f    // fair pseudo-random sharing (options.no_lag_priority) 7.48 ms
+#endif
+          lvl = own > DIAL_LAG_T3 * avg ? 3 : (own > DIAL_LAG_T2 * avg ? 2 : (own > DIAL_LAG_T1 * avg ? 1 : 0));
+        }
+        w.prio_level = __builtin_amdgcn_readfirstlane(lvl);
+      }
+    }
+#endif
     // per-step outputs: wave-uniform row pointers (scalar address arithmetic), one pass -- lane i stores element i
     // of each row that is that long
     const size_t o = (size_t)n * T + st;

@@ -477,6 +477,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       for_on_rows([&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
     }
     niter++;
+    w.work++;
 #ifdef DIAL_PROFILE
     if (w.lane == 0 && w.acc) { w.acc[30] += ls_iter; w.acc[31] += 1; w.acc[29] += fast ? 1 : 0; }
 #endif

@@ -145,6 +145,7 @@ struct Wave {
   void begin_region() {}
   void set_rollout(int) {}
   void redraw_priority() {}
+  int work = 0;   // (GPU: solver iterations of this rollout so far, see the HIP Wave)
   // reverse the first n lanes: result[l] = v[n-1-l] for l < n (0 elsewhere)
   vfloat lane_reverse(const vfloat& v, int n) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = l < n ? v.x[n - 1 - l] : 0.f; return r; }
   // plain LDS fence between SPMD stores and later loads (the GPU needs the wait, the emulator nothing)
@@ -353,11 +354,24 @@ struct Wave {
   // Results do not depend on it.  -DDIAL_FIXED_PRIORITY keeps the hardware default (measurement switch).
   unsigned prio_seed = 0, prio_ctr = 0;
   bool prio_held = false;
-  __device__ __forceinline__ void set_rollout(int n) { prio_seed = (unsigned)n * 2654435761u; prio_ctr = 0; prio_held = false; }
+  // Rollouts of data-dependent length (elliptic solver: Newton iterations until convergence): fair sharing makes the launch as
+  // long as the slowest rollout AT ITS FAIR SHARE of its SIMD.  Instead a rollout that is behind -- more solver iterations per
+  // control step so far than the launch's running average (RolloutIO::work_stat) -- gets the higher issue priority: it runs
+  // closer to its solo pace while its faster SIMD-mates, which have slack, give way.  `work`: this rollout's Newton iterations.
+  int work = 0;
+  int prio_level = -1;   // >= 0: the lag-based level, set once per control step (rollout_driver.h); redraws re-apply it
+  __device__ __forceinline__ void apply_level(int L) {
+    if (L <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (L == 1) __builtin_amdgcn_s_setprio(1);
+    else if (L == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
+  __device__ __forceinline__ void set_rollout(int n) { prio_seed = (unsigned)n * 2654435761u; prio_ctr = 0; prio_held = false; work = 0; prio_level = -1; }
   __device__ __forceinline__ void hold_priority(int) { prio_held = true; __builtin_amdgcn_s_setprio(3); }   // relay pieces
   __device__ __forceinline__ void redraw_priority() {
 #ifndef DIAL_FIXED_PRIORITY
     if (prio_held) return;
+    if (prio_level >= 0) { apply_level(prio_level); return; }
     prio_ctr++;
     const unsigned h = (prio_seed + prio_ctr * 0x9E3779B1u) >> 30;
     if (h == 0) __builtin_amdgcn_s_setprio(0);

@@ -331,6 +331,8 @@ typedef struct dial_options {
                                  cones: the Allegro hand) go through the plain rollout queue (whole rollouts) instead of the
                                  time-sliced one (pieces of `slice_steps` control steps, handed on through global memory)   */
   int32_t slice_steps;        /* control steps per piece of the time-sliced queue, 1 .. 16 (0: default 3)                    */
+  int32_t no_lag_priority;    /* 1: pseudo-random fair SIMD sharing also for models with data-dependent rollout lengths
+                                 (default there: the rollouts that are behind get the higher issue priority)                */
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for
