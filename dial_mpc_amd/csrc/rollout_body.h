@@ -977,6 +977,98 @@ DIAL_DEV void shared_subtree_sum(const M* m, int k, int st, const float* own, fl
   }
 }
 
+// collision_driver: contact c of the static list (narrow phases: plane-sphere / plane-capsule end; elliptic models also
+// sphere-capsule and capsule-capsule; generic feature set also the box routines of box_collide.h)
+template <class M>
+DIAL_DEV void collide_contact(const M* m, const Ws& s, int c) {
+  const int g1 = m->con_geom1[c], g2 = m->con_geom2[c];
+  float n[3] = {s.gaxis[3 * g1], s.gaxis[3 * g1 + 1], s.gaxis[3 * g1 + 2]};
+  float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
+  float radius = m->geom_size[g2][0];
+  float* fr = s.cframe + 9 * c;
+  if constexpr (M::D::gen) {
+    if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) {   // box narrow phases (box_collide.h); geom2 is the box
+      const auto box_of = [&](int g, BoxG& b) {
+        const int bd = m->geom_bodyid[g];
+        const float bq[4] = {s.xquat[4 * bd], s.xquat[4 * bd + 1], s.xquat[4 * bd + 2], s.xquat[4 * bd + 3]};
+        const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
+        dm::quat_mul(b.q, bq, gq);
+        for (int k = 0; k < 3; k++) { b.c[k] = s.gpos[3 * g + k]; b.h[k] = m->geom_size[g][k]; }
+      };
+      BoxG b2;
+      box_of(g2, b2);
+      const float p1[3] = {s.gpos[3 * g1], s.gpos[3 * g1 + 1], s.gpos[3 * g1 + 2]};
+      float dist, cp[3];
+      if (m->con_kind[c] == DIAL_CON_PLANE_BOX) plane_box(n, p1, b2, m->con_sub[c], dist, cp, fr);
+      else if (m->con_kind[c] == DIAL_CON_SPHERE_BOX) sphere_box(p1, m->geom_size[g1][0], b2, dist, cp, fr);
+      else if (m->con_kind[c] == DIAL_CON_CAPSULE_BOX) capsule_box(p1, n, m->geom_size[g1][1], m->geom_size[g1][0], b2, m->con_sub[c], dist, cp, fr);
+      else {
+        BoxG b1;
+        box_of(g1, b1);
+        // the clipping polygons live in this candidate's slice of cdofdot | cacc | cfl (carved back to back, derived.h):
+        // the velocity temporaries are dead by now -- cfrc, which this phase still reads, lies behind them (dial_create
+        // checks that the slices fit)
+        box_box(b1, b2, m->con_sub[c], dist, cp, fr, s.cdofdot + DIAL_BOX_POLY_WORDS * m->con_bbslot[c]);
+      }
+      s.cdist[c] = dist;
+      for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = cp[k];
+      return;
+    }
+  }
+  if constexpr (M::D::ell) {
+    if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
+      // MJX sphere_capsule / capsule_capsule: closest points on the capsule segment(s), then _sphere_sphere
+      const float ax2[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]}, hl2 = m->geom_size[g2][1];
+      float b0[3], b1[3], p1[3], p2[3];
+      for (int k = 0; k < 3; k++) { b0[k] = ctr[k] - ax2[k] * hl2; b1[k] = ctr[k] + ax2[k] * hl2; }
+      if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE) {
+        for (int k = 0; k < 3; k++) p1[k] = s.gpos[3 * g1 + k];
+        closest_segment_point(p2, b0, b1, p1);
+      } else {
+        const float hl1 = m->geom_size[g1][1];
+        float a0[3], a1[3];
+        for (int k = 0; k < 3; k++) { a0[k] = s.gpos[3 * g1 + k] - n[k] * hl1; a1[k] = s.gpos[3 * g1 + k] + n[k] * hl1; }
+        closest_segment_to_segment(p1, p2, a0, a1, b0, b1);
+      }
+      const float r1 = m->geom_size[g1][0];
+      float nn[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      const float len = DM_SQRT(dm::dot3(nn, nn));
+      if (len == 0.f) { nn[0] = 1.f; nn[1] = 0.f; nn[2] = 0.f; }
+      else for (int k = 0; k < 3; k++) nn[k] /= len;
+      const float dist = len - (r1 + radius);
+      s.cdist[c] = dist;
+      for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = p1[k] + nn[k] * (r1 + dist * 0.5f);
+      make_frame(fr, nn);
+      s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
+      return;
+    }
+  }
+  if (m->con_kind[c] == DIAL_CON_PLANE_SPHERE) {
+    make_frame(fr, n);   // collision_primitive make_frame(n)
+  } else {
+    float axis[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]};
+    float na = dm::dot3(n, axis), bb[3];
+    for (int k = 0; k < 3; k++) bb[k] = axis[k] - n[k] * na;
+    float bn = DM_SQRT(dm::dot3(bb, bb));
+    if (bn < 0.5f) {
+      bb[0] = 0.f; bb[1] = 0.f; bb[2] = 0.f;
+      if (-0.5f < n[1] && n[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
+    } else {
+      for (int k = 0; k < 3; k++) bb[k] /= bn;
+    }
+    float cc[3];
+    dm::cross3(cc, n, bb);
+    for (int k = 0; k < 3; k++) { fr[k] = n[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
+    float sgn = m->con_kind[c] == DIAL_CON_PLANE_CAPSULE_P ? 1.f : -1.f, hl = m->geom_size[g2][1];
+    for (int k = 0; k < 3; k++) ctr[k] += sgn * axis[k] * hl;
+  }
+  float diff[3] = {ctr[0] - s.gpos[3 * g1], ctr[1] - s.gpos[3 * g1 + 1], ctr[2] - s.gpos[3 * g1 + 2]};
+  float dist = dm::dot3(diff, n) - radius;
+  s.cdist[c] = dist;
+  for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = ctr[k] - n[k] * (radius + 0.5f * dist);
+  if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
+}
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
@@ -1468,92 +1560,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       s.qfs[i] = qf;
       s.rhs[i] = qf;
     } else {
-      const int c = it - ntri - nv, g1 = m->con_geom1[c], g2 = m->con_geom2[c];
-      float n[3] = {s.gaxis[3 * g1], s.gaxis[3 * g1 + 1], s.gaxis[3 * g1 + 2]};
-      float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
-      float radius = m->geom_size[g2][0];
-      float* fr = s.cframe + 9 * c;
-      if constexpr (M::D::gen) {
-        if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) {   // box narrow phases (box_collide.h); geom2 is the box
-          const auto box_of = [&](int g, BoxG& b) {
-            const int bd = m->geom_bodyid[g];
-            const float bq[4] = {s.xquat[4 * bd], s.xquat[4 * bd + 1], s.xquat[4 * bd + 2], s.xquat[4 * bd + 3]};
-            const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
-            dm::quat_mul(b.q, bq, gq);
-            for (int k = 0; k < 3; k++) { b.c[k] = s.gpos[3 * g + k]; b.h[k] = m->geom_size[g][k]; }
-          };
-          BoxG b2;
-          box_of(g2, b2);
-          const float p1[3] = {s.gpos[3 * g1], s.gpos[3 * g1 + 1], s.gpos[3 * g1 + 2]};
-          float dist, cp[3];
-          if (m->con_kind[c] == DIAL_CON_PLANE_BOX) plane_box(n, p1, b2, m->con_sub[c], dist, cp, fr);
-          else if (m->con_kind[c] == DIAL_CON_SPHERE_BOX) sphere_box(p1, m->geom_size[g1][0], b2, dist, cp, fr);
-          else if (m->con_kind[c] == DIAL_CON_CAPSULE_BOX) capsule_box(p1, n, m->geom_size[g1][1], m->geom_size[g1][0], b2, m->con_sub[c], dist, cp, fr);
-          else {
-            BoxG b1;
-            box_of(g1, b1);
-            // the clipping polygons live in this candidate's slice of cdofdot | cacc | cfl (carved back to back, derived.h):
-            // the velocity temporaries are dead by now -- cfrc, which this phase still reads, lies behind them (dial_create
-            // checks that the slices fit)
-            box_box(b1, b2, m->con_sub[c], dist, cp, fr, s.cdofdot + DIAL_BOX_POLY_WORDS * m->con_bbslot[c]);
-          }
-          s.cdist[c] = dist;
-          for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = cp[k];
-          return;
-        }
-      }
-      if constexpr (M::D::ell) {
-        if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE || m->con_kind[c] == DIAL_CON_CAPSULE_CAPSULE) {
-          // MJX sphere_capsule / capsule_capsule: closest points on the capsule segment(s), then _sphere_sphere
-          const float ax2[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]}, hl2 = m->geom_size[g2][1];
-          float b0[3], b1[3], p1[3], p2[3];
-          for (int k = 0; k < 3; k++) { b0[k] = ctr[k] - ax2[k] * hl2; b1[k] = ctr[k] + ax2[k] * hl2; }
-          if (m->con_kind[c] == DIAL_CON_SPHERE_CAPSULE) {
-            for (int k = 0; k < 3; k++) p1[k] = s.gpos[3 * g1 + k];
-            closest_segment_point(p2, b0, b1, p1);
-          } else {
-            const float hl1 = m->geom_size[g1][1];
-            float a0[3], a1[3];
-            for (int k = 0; k < 3; k++) { a0[k] = s.gpos[3 * g1 + k] - n[k] * hl1; a1[k] = s.gpos[3 * g1 + k] + n[k] * hl1; }
-            closest_segment_to_segment(p1, p2, a0, a1, b0, b1);
-          }
-          const float r1 = m->geom_size[g1][0];
-          float nn[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-          const float len = DM_SQRT(dm::dot3(nn, nn));
-          if (len == 0.f) { nn[0] = 1.f; nn[1] = 0.f; nn[2] = 0.f; }
-          else for (int k = 0; k < 3; k++) nn[k] /= len;
-          const float dist = len - (r1 + radius);
-          s.cdist[c] = dist;
-          for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = p1[k] + nn[k] * (r1 + dist * 0.5f);
-          make_frame(fr, nn);
-          s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
-          return;
-        }
-      }
-      if (m->con_kind[c] == DIAL_CON_PLANE_SPHERE) {
-        make_frame(fr, n);   // collision_primitive make_frame(n)
-      } else {
-        float axis[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]};
-        float na = dm::dot3(n, axis), bb[3];
-        for (int k = 0; k < 3; k++) bb[k] = axis[k] - n[k] * na;
-        float bn = DM_SQRT(dm::dot3(bb, bb));
-        if (bn < 0.5f) {
-          bb[0] = 0.f; bb[1] = 0.f; bb[2] = 0.f;
-          if (-0.5f < n[1] && n[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
-        } else {
-          for (int k = 0; k < 3; k++) bb[k] /= bn;
-        }
-        float cc[3];
-        dm::cross3(cc, n, bb);
-        for (int k = 0; k < 3; k++) { fr[k] = n[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
-        float sgn = m->con_kind[c] == DIAL_CON_PLANE_CAPSULE_P ? 1.f : -1.f, hl = m->geom_size[g2][1];
-        for (int k = 0; k < 3; k++) ctr[k] += sgn * axis[k] * hl;
-      }
-      float diff[3] = {ctr[0] - s.gpos[3 * g1], ctr[1] - s.gpos[3 * g1 + 1], ctr[2] - s.gpos[3 * g1 + 2]};
-      float dist = dm::dot3(diff, n) - radius;
-      s.cdist[c] = dist;
-      for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = ctr[k] - n[k] * (radius + 0.5f * dist);
-      if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
+      collide_contact(m, s, it - ntri - nv);
     }
   });
   if constexpr (M::D::gen) {
