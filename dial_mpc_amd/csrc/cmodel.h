@@ -55,16 +55,20 @@ struct TopoH1Loco {  // free pelvis, 2 legs of 5, torso yaw (dof 16); the arms a
 // under a free root.  maxd = deepest chain below the root (0: the robot does not use the stage); merge_dst / merge_src = the
 // lanes of the one body that lies on two chains (owner / copy), -1: none.  rows_build (below) derives the same from the model.
 template <class Topo>
-struct RowsOf { static constexpr int maxd = 0, merge_src = -1, merge_dst = -1; };
+struct RowsOf { static constexpr int maxd = 0, merge_src = -1, merge_dst = -1; static constexpr bool static_root = false; };
 template <>
-struct RowsOf<TopoH1> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; };       // torso: row 2 owns it, row 3 copies it
+struct RowsOf<TopoH1> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; static constexpr bool static_root = false; };       // torso: row 2 owns it, row 3 copies it
 template <>
-struct RowsOf<TopoH1Loco> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; };   // (arms welded: chain members without dofs)
+struct RowsOf<TopoH1Loco> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; static constexpr bool static_root = false; };   // (arms welded: chain members without dofs)
+// Allegro: the free object on its own (body 1), four fingers of four hinges + a welded tip under the palm, which is welded to the world
+template <>
+struct RowsOf<TopoAllegro> { static constexpr int maxd = 5, merge_src = -1, merge_dst = -1; static constexpr bool static_root = true; };
 #define ROWS_BODY 1    /* the lane carries a body of its chain (copies included)            */
 #define ROWS_OWNER 2   /* ... and is the one that stores it and counts its mass / forces    */
 #define ROWS_JOINT 4   /* the body has a hinge (copies included: they propagate velocities) */
 #define ROWS_DOF 8     /* owner of a hinge: writes the dof's row of M, qfrc_smooth, cdof    */
-#define ROWS_TDOF 16   /* stands for one of the root's six dofs                             */
+#define ROWS_TDOF 16   /* stands for one of the free body's six dofs                        */
+#define ROWS_SOLO 32   /* static-root layout: the free body, a tree of its own (lane 15)   */
 struct RowTab {
   uint8_t body[64], flags[64], dof[64], geom[64][2], site[64];
 };
@@ -123,7 +127,7 @@ struct Dims {
 #ifdef DIAL_NO_ROWS
   static constexpr bool rows_stage = false;
 #else
-  static constexpr bool rows_stage = !GEN_ && !ELL_ && SQUARE_ && RowsOf<Topo_>::maxd > 0;
+  static constexpr bool rows_stage = !GEN_ && SQUARE_ && RowsOf<Topo_>::maxd > 0;
 #endif
   static constexpr bool phase_tabs = !quad_stage && !rows_stage;
 };
@@ -241,7 +245,7 @@ struct CModel : CModelGeneric<D_> {
   float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3], init_ang_vel_tar[3];
   float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2], joint_offset[D::NU];
   // ---- lane layout of the register-resident position / velocity stage (smooth_rows.h), robots that use it
-  typename std::conditional<(!D::gen && !D::ell && D::square && RowsOf<typename D::Topo>::maxd > 0), RowTab, RowTabNone>::type rows;
+  typename std::conditional<(!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0), RowTab, RowTabNone>::type rows;
 };
 
 // ---- runtime / compile-time dimension accessors
@@ -278,10 +282,60 @@ CM_HD constexpr int dim_nf(const M* m) {
 // Host: the row layout of smooth_rows.h for a model (false: the model is not one tree of hinge / welded bodies under a free
 // root with at most four chains of <= maxd bodies, at most one body shared by two chains (directly below the root), at most two
 // geoms and one site per body, plane-sphere / plane-capsule contacts).
-static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* merge_src, int* merge_dst) {
+static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* merge_src, int* merge_dst, bool static_root = false) {
   for (int l = 0; l < 64; l++) { t->body[l] = 0; t->flags[l] = 0; t->dof[l] = 0; t->geom[l][0] = 255; t->geom[l][1] = 255; t->site[l] = 255; }
   *merge_src = -1; *merge_dst = -1;
   if (maxd < 1 || maxd > 7 || m->nbody < 2 || m->nbody > 64) return false;
+  if (static_root) {
+    // body 1 = the free body on its own, body 2 = the chains' root, welded to the world; everything else hangs off body 2
+    if (m->nbody < 3 || m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
+        m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1 ||
+        m->body_parent[2] != 0 || m->body_jntnum[2] != 0 || m->body_rootid[2] != 2)
+      return false;
+    for (int b = 3; b < m->nbody; b++) {
+      if (m->body_parent[b] < 2 || m->body_rootid[b] != 2 || m->body_jntnum[b] > 1) return false;
+      if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] != DIAL_JNT_HINGE) return false;
+    }
+    int owner[64];
+    for (int b = 0; b < 64; b++) owner[b] = -1;
+    int row = 0;
+    for (int b = 2; b < m->nbody; b++) {
+      bool leaf = true;
+      for (int c2 = b + 1; c2 < m->nbody; c2++) leaf = leaf && m->body_parent[c2] != b;
+      if (!leaf) continue;
+      int path[64], len = 0;
+      for (int bb = b; bb > 0 && len < 64; bb = m->body_parent[bb]) path[len++] = bb;
+      if (row >= 4 || len - 1 > maxd) return false;
+      for (int d = 0; d < len; d++) {
+        const int bb = path[len - 1 - d], l = 16 * row + d;
+        t->body[l] = (uint8_t)bb;
+        t->flags[l] |= ROWS_BODY;
+        if (owner[bb] < 0) { owner[bb] = l; t->flags[l] |= ROWS_OWNER; }
+        else if (d >= 1) return false;   // no body on two chains in this form
+        if (d >= 1 && m->body_jntnum[bb] == 1) {
+          t->flags[l] |= ROWS_JOINT | ROWS_DOF;
+          t->dof[l] = (uint8_t)m->body_dofadr[bb];
+        }
+      }
+      row++;
+    }
+    t->body[15] = 1; t->flags[15] = ROWS_BODY | ROWS_OWNER | ROWS_SOLO; owner[1] = 15;
+    for (int k = 0; k < 6; k++) { t->flags[8 + k] = ROWS_TDOF; t->dof[8 + k] = (uint8_t)k; }
+    for (int g = 0; g < m->ngeom; g++) {
+      const int b = m->geom_bodyid[g], l = b == 0 ? 14 : owner[b];
+      if (l < 0) return false;
+      if (t->geom[l][0] == 255) t->geom[l][0] = (uint8_t)g;
+      else if (t->geom[l][1] == 255) t->geom[l][1] = (uint8_t)g;
+      else return false;
+    }
+    for (int si = 0; si < m->nsite; si++) {
+      const int b = m->site_bodyid[si];
+      if (b == 0 || owner[b] < 0 || t->site[owner[b]] != 255) return false;
+      t->site[owner[b]] = (uint8_t)si;
+    }
+    for (int c = 0; c < m->ncon; c++) if (m->con_kind[c] >= DIAL_CON_PLANE_BOX) return false;
+    return true;
+  }
   if (m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
       m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1)
     return false;
@@ -370,11 +424,11 @@ static inline bool dims_match(const dial_model* m) {
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }
   if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
-  if constexpr (!D::gen && !D::ell && D::square && RowsOf<typename D::Topo>::maxd > 0) {   // smooth_rows.h: the layout must come out as compiled
+  if constexpr (!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) {   // smooth_rows.h: the layout must come out as compiled
     using RT = RowsOf<typename D::Topo>;
     RowTab t;
     int ms, md;
-    ok = ok && rows_build(m, &t, RT::maxd, &ms, &md) && ms == RT::merge_src && md == RT::merge_dst;
+    ok = ok && rows_build(m, &t, RT::maxd, &ms, &md, RT::static_root) && ms == RT::merge_src && md == RT::merge_dst;
   }
   return ok;
 }

@@ -32,6 +32,8 @@
 #define DM_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+#define DM_FLT_MIN 1.17549435e-38f   // smallest normal fp32
+
 namespace dm {
 DIAL_DEV float fminf_(float a, float b) { return a < b ? a : b; }
 DIAL_DEV float fmaxf_(float a, float b) { return a > b ? a : b; }

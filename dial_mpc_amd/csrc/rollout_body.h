@@ -1083,7 +1083,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   }
   if constexpr (kRowsDims<typename M::D>) {   // one tree under a free root (H1): the same stage on the row layout (smooth_rows.h)
     forward_smooth_rows(w, m, s);
-    w.items(nc, [&](int c) { rows_collide(m, s, c); });
+    w.items(nc, [&](int c) { collide_contact(m, s, c); });
     forward_constraints(w, m, s, nca, nea);
     return;
   }
@@ -1670,7 +1670,11 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
     if (m->jnt_type[ji] == DIAL_JNT_FREE) {
       for (int k = 0; k < 3; k++) s.qpos[qa + k] += dt * s.qvel[da + k];
       float v[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
-      float nrm = DM_SQRT(dm::dot3(v, v)), axis[3] = {1.f, 0.f, 0.f}, qr[4], qn[4];
+      // An angular velocity whose SQUARE is below the smallest normal fp32 (|w| < 1.1e-19 rad/s: a body that has come to rest) is
+      // no rotation: under the fast-math flags v / sqrt(d) becomes v * v_rsq(d), and v_rsq flushes a denormal d to 0 -> inf -> NaN
+      // (the Allegro's ball lying still on the floor, tests/test_gpu_parity.py closed loop; DESIGN.md deliberate deviations)
+      const float w2 = dm::dot3(v, v);
+      float nrm = w2 >= DM_FLT_MIN ? DM_SQRT(w2) : 0.f, axis[3] = {1.f, 0.f, 0.f}, qr[4], qn[4];
       if (nrm > 0.f) { axis[0] = v[0] / nrm; axis[1] = v[1] / nrm; axis[2] = v[2] / nrm; }
       dm::axis_angle_to_quat(qr, axis, dt * nrm);
       float q0[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};

@@ -15,7 +15,10 @@
 //     phase per level;
 //   * leaf-to-root sums (composite inertia, subtree forces) are suffix scans with row_shl.
 // Sums therefore associate differently from forward()'s sequential loops (rounding level; the oracle parity tests cover it).
-// Contacts: plane-sphere / plane-capsule (rows_collide below), one LDS phase after the stage, as in forward().
+// Contacts: one LDS phase after the stage, as in forward() (collide_contact).
+// Second form of the layout (RowsOf::static_root, the Allegro hand): the chains hang off a body WELDED to the world (the palm:
+// constant pose, no velocity, no dofs) and the free body is on its own (the object: lane 15, its six dofs on lanes 8..13) --
+// two kinematic trees, two subtree centres of mass.
 #pragma once
 #include "derived.h"
 #include "dmath.h"
@@ -25,44 +28,12 @@ namespace dial {
 template <class D>
 inline constexpr bool kRowsDims = D::rows_stage;
 
-// one contact of the static list: plane (geom1) against a sphere or one end of a capsule (geom2); forward(): collision_driver
-template <class M>
-DIAL_DEV void rows_collide(const M* m, const Ws& s, int c) {
-  const int g1 = m->con_geom1[c], g2 = m->con_geom2[c], kind = m->con_kind[c];
-  const float n[3] = {s.gaxis[3 * g1], s.gaxis[3 * g1 + 1], s.gaxis[3 * g1 + 2]};
-  float ctr[3] = {s.gpos[3 * g2], s.gpos[3 * g2 + 1], s.gpos[3 * g2 + 2]};
-  const float axis[3] = {s.gaxis[3 * g2], s.gaxis[3 * g2 + 1], s.gaxis[3 * g2 + 2]};
-  const float p1[3] = {s.gpos[3 * g1], s.gpos[3 * g1 + 1], s.gpos[3 * g1 + 2]};
-  const float radius = m->geom_size[g2][0], hl = m->geom_size[g2][1];
-  float* fr = s.cframe + 9 * c;
-  if (kind == DIAL_CON_PLANE_SPHERE) {
-    make_frame(fr, n);
-  } else {   // plane_capsule: frame from the capsule axis projected into the plane, contact at the segment end
-    const float na = dm::dot3(n, axis);
-    float bb[3], cc[3];
-    for (int k = 0; k < 3; k++) bb[k] = axis[k] - n[k] * na;
-    const float bn = DM_SQRT(dm::dot3(bb, bb));
-    if (bn < 0.5f) {
-      bb[0] = 0.f; bb[1] = 0.f; bb[2] = 0.f;
-      if (-0.5f < n[1] && n[1] < 0.5f) bb[1] = 1.f; else bb[2] = 1.f;
-    } else {
-      for (int k = 0; k < 3; k++) bb[k] /= bn;
-    }
-    dm::cross3(cc, n, bb);
-    for (int k = 0; k < 3; k++) { fr[k] = n[k]; fr[3 + k] = bb[k]; fr[6 + k] = cc[k]; }
-    const float sgn = kind == DIAL_CON_PLANE_CAPSULE_P ? 1.f : -1.f;
-    for (int k = 0; k < 3; k++) ctr[k] += sgn * axis[k] * hl;
-  }
-  const float diff[3] = {ctr[0] - p1[0], ctr[1] - p1[1], ctr[2] - p1[2]};
-  const float dist = dm::dot3(diff, n) - radius;
-  s.cdist[c] = dist;
-  for (int k = 0; k < 3; k++) s.cpos[3 * c + k] = ctr[k] - n[k] * (radius + 0.5f * dist);
-}
-
 template <class W, class M>
 DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
   using RT = RowsOf<typename M::D::Topo>;
   constexpr int S = M::D::S, MAXD = RT::maxd;
+  constexpr bool SR = RT::static_root;      // chains under a welded root, the free body on its own lane
+  constexpr int FREE = SR ? 15 : 0;         // the lane whose pose / velocity are the free body's
   static_assert(MAXD >= 1 && MAXD <= 7, "chains of at most 7 bodies below the root (three scan rounds; lanes 8..13 = root dofs)");
   DIAL_MARK(w, 15);
 #if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
@@ -75,7 +46,7 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
   vfloat P[7];   // pos(3) quat(4)
   w.per_lane_n(P, [&](int l, float* o) {
     const int fl = m->rows.flags[l], b = m->rows.body[l];
-    const bool joint = (fl & ROWS_JOINT) != 0, root = (fl & ROWS_BODY) != 0 && (l & 15) == 0;
+    const bool joint = (fl & ROWS_JOINT) != 0, root = SR ? (fl & ROWS_SOLO) != 0 : ((fl & ROWS_BODY) != 0 && (l & 15) == 0);   // the FREE body
     const int ji = joint ? m->body_jntadr[b] : 0, qa = joint ? m->jnt_qposadr[ji] : 7;
     float tq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
     dm::normalize4(tq);
@@ -103,7 +74,7 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     if constexpr (sh <= MAXD) {
       vfloat Q[7], N[7];
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 7; k++) Q[k] = w.template row_shr<sh>(P[k]);
+      for (int k = 0; k < 7; k++) Q[k] = w.template row_shr_lo<sh>(P[k]);
       w.per_lane_n(N, [&](int l, float* o) {
         const int d = l & 15;
         const bool on = d >= sh && d <= MAXD;
@@ -130,7 +101,7 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     vfloat T[31];
     w.per_lane_n(T, [&](int l, float* o) {
       const int fl = m->rows.flags[l], b = m->rows.body[l];
-      const bool owner = (fl & ROWS_OWNER) != 0;
+      const bool owner = (fl & ROWS_OWNER) != 0 && !(SR && (fl & ROWS_SOLO));   // (the solo body is a tree of its own)
       const int si = m->rows.site[l] == 255 ? 0 : m->rows.site[l];
       const float p[3] = {lane_val(P[0], l), lane_val(P[1], l), lane_val(P[2], l)};
       const float q[4] = {lane_val(P[3], l), lane_val(P[4], l), lane_val(P[5], l), lane_val(P[6], l)};
@@ -177,12 +148,14 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     w.vsumN(c4, r4);
     for (int k = 0; k < 3; k++) com[k] = r4[3] < MJ_MINVAL ? bcast(F[k], 0) : r4[k] / r4[3];
   }
-  // the root's pose, rotation matrix and rotational cdofs: the same value in every lane
-  const float tpos[3] = {bcast(P[0], 0), bcast(P[1], 0), bcast(P[2], 0)};
-  const float tquat[4] = {bcast(P[3], 0), bcast(P[4], 0), bcast(P[5], 0), bcast(P[6], 0)};
+  // (static root: the free body's subtree is itself -- its centre of mass is its own xipos)
+  const float comF[3] = {SR ? bcast(F[0], FREE) : com[0], SR ? bcast(F[1], FREE) : com[1], SR ? bcast(F[2], FREE) : com[2]};
+  // the free body's pose, rotation matrix and rotational cdofs: the same value in every lane
+  const float tpos[3] = {bcast(P[0], FREE), bcast(P[1], FREE), bcast(P[2], FREE)};
+  const float tquat[4] = {bcast(P[3], FREE), bcast(P[4], FREE), bcast(P[5], FREE), bcast(P[6], FREE)};
   float Rt[9], cdT[3][6];
   dm::quat_to_mat(Rt, tquat);
-  const float offt[3] = {com[0] - tpos[0], com[1] - tpos[1], com[2] - tpos[2]};
+  const float offt[3] = {comF[0] - tpos[0], comF[1] - tpos[1], comF[2] - tpos[2]};
   for (int i = 0; i < 3; i++) {
     const float a[3] = {Rt[i], Rt[3 + i], Rt[6 + i]};
     float cr[3];
@@ -201,7 +174,9 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       const int ji = joint ? m->body_jntadr[b] : 0, kd = tdof ? m->rows.dof[l] : 3;
       const float R[9] = {lane_val(F[3], l), lane_val(F[4], l), lane_val(F[5], l), lane_val(F[6], l), lane_val(F[7], l),
                           lane_val(F[8], l), lane_val(F[9], l), lane_val(F[10], l), lane_val(F[11], l)};
-      const float off[3] = {lane_val(F[0], l) - com[0], lane_val(F[1], l) - com[1], lane_val(F[2], l) - com[2]};
+      const bool solo = SR && (fl & ROWS_SOLO) != 0;
+      const float off[3] = {lane_val(F[0], l) - (solo ? comF[0] : com[0]), lane_val(F[1], l) - (solo ? comF[1] : com[1]),
+                            lane_val(F[2], l) - (solo ? comF[2] : com[2])};
       const float mb = m->body_mass[b], oo = dm::dot3(off, off);
       const float in0 = m->body_inertia[b][0], in1 = m->body_inertia[b][1], in2 = m->body_inertia[b][2];
       const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
@@ -257,14 +232,14 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
   }
   w.per_lane_n(V, [&](int l, float* o) {
     const int fl = m->rows.flags[l];
-    const bool root = (fl & ROWS_BODY) != 0 && (l & 15) == 0, joint = (fl & ROWS_JOINT) != 0;
-    for (int k = 0; k < 6; k++) o[k] = root ? velT[k] : (joint ? lane_val(CD[k], l) * lane_val(QVL, l) : 0.f);
+    const bool root = SR ? (fl & ROWS_SOLO) != 0 : ((fl & ROWS_BODY) != 0 && (l & 15) == 0), joint = (fl & ROWS_JOINT) != 0;
+    for (int k = 0; k < 6; k++) o[k] = root ? velT[k] : (joint ? lane_val(CD[k], l) * lane_val(QVL, l) : 0.f);   // (a welded root: 0)
   });
   static_for<0, 3>([&](auto IT) {
     constexpr int sh = 1 << decltype(IT)::value;
     if constexpr (sh <= MAXD) {
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) V[k] = V[k] + w.template row_shr<sh>(V[k]);
+      for (int k = 0; k < 6; k++) V[k] = V[k] + w.template row_shr_lo<sh>(V[k]);
     }
   });
   {
@@ -273,19 +248,20 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     for (int k = 0; k < 6; k++) VP[k] = w.template row_shr<1>(V[k]);
     w.per_lane_n(A, [&](int l, float* o) {
       const int fl = m->rows.flags[l];
-      const bool root = (fl & ROWS_BODY) != 0 && (l & 15) == 0, joint = (fl & ROWS_JOINT) != 0;
+      const bool root = SR ? (fl & ROWS_SOLO) != 0 : ((fl & ROWS_BODY) != 0 && (l & 15) == 0), joint = (fl & ROWS_JOINT) != 0;
+      const bool sroot = SR && (fl & ROWS_BODY) != 0 && (l & 15) == 0;   // the welded root: at rest, acceleration = -gravity
       const float vp[6] = {lane_val(VP[0], l), lane_val(VP[1], l), lane_val(VP[2], l), lane_val(VP[3], l), lane_val(VP[4], l), lane_val(VP[5], l)};
       const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
       float cdd[6];
       dm::motion_cross(cdd, vp, cd);
-      for (int k = 0; k < 6; k++) o[k] = root ? accT[k] : (joint ? cdd[k] * lane_val(QVL, l) : 0.f);
+      for (int k = 0; k < 6; k++) o[k] = root ? accT[k] : (joint ? cdd[k] * lane_val(QVL, l) : (sroot && k >= 3 ? -m->gravity[k - 3] : 0.f));
     });
   }
   static_for<0, 3>([&](auto IT) {
     constexpr int sh = 1 << decltype(IT)::value;
     if constexpr (sh <= MAXD) {
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) A[k] = A[k] + w.template row_shr<sh>(A[k]);
+      for (int k = 0; k < 6; k++) A[k] = A[k] + w.template row_shr_lo<sh>(A[k]);
     }
   });
   // the bodies' outputs are complete: stored now, not at the end (32 registers fewer to carry through the dof stage)
@@ -302,10 +278,11 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       const int g = m->rows.geom[l][e];
       if (g != 255) for (int k = 0; k < 3; k++) { s.gpos[3 * g + k] = lane_val(G[3 + 6 * e + k], l); s.gaxis[3 * g + k] = lane_val(G[6 + 6 * e + k], l); }
     }
-    if (l == 0) {
-      for (int k = 0; k < 3; k++) s.com[3 * m->body_rootid[1] + k] = com[k];
+    if (l == 0) {   // subtree centres of mass live at their root body's index (row 0's root lane: the chains' tree)
+      for (int k = 0; k < 3; k++) s.com[3 * m->body_rootid[b] + k] = com[k];
       for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
     }
+    if (SR && l == FREE) for (int k = 0; k < 3; k++) s.com[3 * m->body_rootid[b] + k] = comF[k];
   });
   DIAL_MARK(w, 19);
   // ---- rne: local body forces cfl = cinert cacc + cvel x* (cinert cvel); copies contribute nothing to the subtree sums
@@ -331,11 +308,14 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     constexpr int sh = 1 << decltype(IT)::value;
     if constexpr (sh <= MAXD) {
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 16; k++) X[k] = X[k] + w.template row_shl<sh>(X[k]);
+      for (int k = 0; k < 16; k++) X[k] = X[k] + w.template row_shl_lo<sh>(X[k]);
     }
   });
   float XT[16];
-  for (int k = 0; k < 16; k++) XT[k] = (bcast(X[k], 0) + bcast(X[k], 16)) + (bcast(X[k], 32) + bcast(X[k], 48));
+  for (int k = 0; k < 16; k++) {
+    if constexpr (SR) XT[k] = bcast(X[k], FREE);   // the free body has no children
+    else XT[k] = (bcast(X[k], 0) + bcast(X[k], 16)) + (bcast(X[k], 32) + bcast(X[k], 48));
+  }
   if constexpr (RT::merge_src >= 0) {
     float xm[16];
     for (int k = 0; k < 16; k++) xm[k] = bcast(X[k], RT::merge_src);
@@ -414,8 +394,10 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       const float qf = lane_val(MO[7], l);
       s.qfs[i] = qf;
       s.rhs[i] = qf;
-      for (int j = 0; j < 6; j++) {
-        if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
+      if (tdof || !SR) {   // (under a welded root the chains have no root-dof columns: structural zeros)
+        for (int j = 0; j < 6; j++) {
+          if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
+        }
       }
       if (hinge) {
         s.M[i * S + i] = lane_val(MO[6], l);

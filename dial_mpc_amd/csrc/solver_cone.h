@@ -123,6 +123,11 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     }
 #pragma unroll
     for (int k = 1; k < 6; k++) { const float t2 = tsqr + U[k] * U[k]; tsqr = k < dim ? t2 : tsqr; }
+    // A tangential part below the smallest NORMAL fp32 (a ball that has come to rest: |U_t|^2 decays through 1e-38) counts as
+    // zero: the hardware's sqrt / rcp / rsq flush denormal arguments, so with `tsqr > 0` as the test T came out 0 for a
+    // positive denormal tsqr and the middle zone's -fn / T * U[k] was inf * 0 -- NaN in every rollout of the closed loop once
+    // the ball lay still on the floor (found when the row layout changed the rounding of the decay; the hazard was there before).
+    tsqr = tsqr >= DM_FLT_MIN ? tsqr : 0.f;
     const float N = U[0], T = DM_SQRT(tsqr);
     const bool bottom = (tsqr <= 0.f && N < 0.f) || (tsqr > 0.f && mu * N + T <= 0.f);
     const bool middle = tsqr > 0.f && N < mu * T && mu * N + T > 0.f;
@@ -382,7 +387,8 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       const float u0 = lane_val(L[0], l), v0 = lane_val(L[1], l), uu = lane_val(L[2], l), uv = lane_val(L[3], l), vv = lane_val(L[4], l);
       const float dmc = lane_val(L[5], l);
       const float n = u0 + alpha * v0;
-      const float tsqr = uu + alpha * (2.f * uv + alpha * vv);
+      const float tsqr_raw = uu + alpha * (2.f * uv + alpha * vv);
+      const float tsqr = tsqr_raw >= DM_FLT_MIN ? tsqr_raw : 0.f;   // (denormal = zero, as in unit_cost)
       // T and 1 / T from one v_rsq and a Newton correction each (both then within an ulp of sqrt / divide: the zone
       // tests below sit on the oracle's decisions) instead of a square root and three divisions
       const float rt0 = tsqr > 0.f ? fast_rsqrt(tsqr) : 0.f;

@@ -69,11 +69,23 @@ struct Wave {
   int races = 0;
   int phase = 0;
 
+  // DIAL_EMU_NANCHECK (tests/wave_emu/emu.cpp): report the first phase after which a non-finite value sits in LDS
+  bool nancheck = false, nan_seen = false;
+  void scan_nonfinite() {
+    if (!nancheck || nan_seen) return;
+    for (int k = 0; k < lds_words; k++)
+      if (!std::isfinite(lds[k])) {
+        std::fprintf(stderr, "[wave_emu] first non-finite LDS word after phase #%d: word %d = %g\n", phase, k, (double)lds[k]);
+        nan_seen = true;
+        return;
+      }
+  }
   template <class F>
   void items(int count, F f) {
     phase++;
     if (!check_races) {
       for (int i = 0; i < count; i++) f(i);
+      scan_nonfinite();
       return;
     }
     std::vector<float> snap(lds, lds + lds_words);
@@ -136,6 +148,11 @@ struct Wave {
   vfloat row_shr(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) >= N ? v.x[l - N] : 0.f; return r; }
   template <int N>
   vfloat row_shl(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) + N <= 15 ? v.x[l + N] : 0.f; return r; }
+  // row_shr / row_shl for the lower half of every row only: lanes 0..7 receive, lanes 8..15 read 0 (DPP bank_mask 0x3)
+  template <int N>
+  vfloat row_shr_lo(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = ((l & 15) < 8 && (l & 15) >= N) ? v.x[l - N] : 0.f; return r; }
+  template <int N>
+  vfloat row_shl_lo(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) < 8 ? v.x[l + N] : 0.f; return r; }
   // value of lane N of the own row of 16 lanes (DPP row_newbcast on the GPU)
   template <int N>
   vfloat row_bcast(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~15) + N]; return r; }
@@ -325,6 +342,14 @@ struct Wave {
   template <int N>
   __device__ __forceinline__ vfloat row_shl(vfloat v) {   // DPP row_shl:N
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+  }
+  template <int N>
+  __device__ __forceinline__ vfloat row_shr_lo(vfloat v) {   // bank_mask 0x3: lanes 8..15 of every row keep `old` = 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0x3, true));
+  }
+  template <int N>
+  __device__ __forceinline__ vfloat row_shl_lo(vfloat v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0x3, true));
   }
   template <int N>
   __device__ __forceinline__ vfloat row_bcast(vfloat v) {   // DPP row_newbcast:N (gfx90a+): lane N of the own row

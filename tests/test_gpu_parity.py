@@ -998,36 +998,44 @@ def test_closed_loop_behaviour(example, ticks, N):
     import yaml
     from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
     from dial_mpc_amd.utils.io_utils import get_example_path
-    cfgd = yaml.safe_load(open(get_example_path(example + ".yaml")))
-    cfgd["Nsample"] = N
-    dial_config, env_config, env = load_dial_and_env(cfgd)
-    mbdpi = MBDPI(dial_config, env, kernel_rng=True)
-    state = env.reset(0)
-    Y = torch.zeros((dial_config.Hnode + 1, mbdpi.nu), device=mbdpi.device)
-    xs, zs, rews = [], [], []
-    for t in range(ticks):
-        state = env.step(state, Y[0])
-        Y = mbdpi.shift(Y)
-        n_it = dial_config.Ndiffuse_init if t == 0 else dial_config.Ndiffuse
-        for i in range(n_it):
-            _, Y, info = mbdpi.reverse_once(state, None, Y, mbdpi.sigma_control * dial_config.traj_diffuse_factor ** i,
-                                            want_bars=(i == n_it - 1))
-        q = state.pipeline_state.q.cpu().numpy()
-        xs.append(q[0]); zs.append(q[2]); rews.append(float(state.reward))
-    mbdpi.ctx.status()
-    assert torch.isfinite(Y).all() and np.all(np.isfinite(rews))
-    dt = env_config.dt
-    if example == "unitree_go2_trot":
-        v = (xs[-1] - xs[-51]) / (50 * dt)
-        print(f"go2 trot: forward velocity over the last second {v:.2f} m/s (command 1.0), base height {zs[-1]:.3f} m")
-        assert 0.6 < v < 1.3 and 0.2 < zs[-1] < 0.4
-    elif example == "unitree_h1_jog":
-        v = (xs[-1] - xs[-41]) / (40 * dt)
-        print(f"h1 jog: forward velocity {v:.2f} m/s, pelvis height {zs[-1]:.3f} m")
-        assert v > 0.2 and zs[-1] > 0.8
-    else:
-        print(f"allegro: ball height {zs[-1]:.3f} m after {ticks} ticks, mean reward {np.mean(rews[-10:]):.3f}")
-        assert zs[-1] > 0.08
+    # Allegro: tossing the ball is chaotic -- at N = 512 it leaves the hand in 3-7 % of the runs whatever the build
+    # (profiles/r04_allegro_closed_loop_seeds.txt: 10 of 192 runs over two builds); three seeds, at most one may drop it
+    seeds = (0, 1, 2) if example == "allegro_reorient" else (0,)
+    kept = 0
+    for seed in seeds:
+        cfgd = yaml.safe_load(open(get_example_path(example + ".yaml")))
+        cfgd["Nsample"] = N
+        cfgd["seed"] = seed
+        dial_config, env_config, env = load_dial_and_env(cfgd)
+        mbdpi = MBDPI(dial_config, env, kernel_rng=True)
+        state = env.reset(0)
+        Y = torch.zeros((dial_config.Hnode + 1, mbdpi.nu), device=mbdpi.device)
+        xs, zs, rews = [], [], []
+        for t in range(ticks):
+            state = env.step(state, Y[0])
+            Y = mbdpi.shift(Y)
+            n_it = dial_config.Ndiffuse_init if t == 0 else dial_config.Ndiffuse
+            for i in range(n_it):
+                _, Y, info = mbdpi.reverse_once(state, None, Y, mbdpi.sigma_control * dial_config.traj_diffuse_factor ** i,
+                                                want_bars=(i == n_it - 1))
+            q = state.pipeline_state.q.cpu().numpy()
+            xs.append(q[0]); zs.append(q[2]); rews.append(float(state.reward))
+        mbdpi.ctx.status()
+        assert torch.isfinite(Y).all() and np.all(np.isfinite(rews))
+        dt = env_config.dt
+        if example == "unitree_go2_trot":
+            v = (xs[-1] - xs[-51]) / (50 * dt)
+            print(f"go2 trot: forward velocity over the last second {v:.2f} m/s (command 1.0), base height {zs[-1]:.3f} m")
+            assert 0.6 < v < 1.3 and 0.2 < zs[-1] < 0.4
+        elif example == "unitree_h1_jog":
+            v = (xs[-1] - xs[-41]) / (40 * dt)
+            print(f"h1 jog: forward velocity {v:.2f} m/s, pelvis height {zs[-1]:.3f} m")
+            assert v > 0.2 and zs[-1] > 0.8
+        else:
+            print(f"allegro seed {seed}: ball height {zs[-1]:.3f} m after {ticks} ticks, mean reward {np.mean(rews[-10:]):.3f}")
+            kept += zs[-1] > 0.08
+    if example == "allegro_reorient":
+        assert kept >= len(seeds) - 1, kept
 
 
 def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():

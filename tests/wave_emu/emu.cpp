@@ -12,6 +12,7 @@
 
 #include <cstdlib>
 #include <vector>
+#include <xmmintrin.h>
 
 namespace {
 
@@ -37,6 +38,22 @@ struct Runner {
     w.lds = lds.data();
     w.lds_words = ws_words + ovf_words;
     w.check_races = check_races != 0;
+    // debugging aids: DIAL_EMU_NANCHECK=1 reports the first phase that leaves a non-finite value in LDS; DIAL_EMU_FTZ=1 flushes
+    // fp32 denormals (inputs and results) like the GPU's sqrt / rcp / rsq do -- x / denormal = inf, sqrt(denormal) = 0
+    w.nancheck = std::getenv("DIAL_EMU_NANCHECK") != nullptr;
+    if (std::getenv("DIAL_EMU_FTZ")) _mm_setcsr(_mm_getcsr() | 0x8040);
+    if (w.nancheck) {
+      static bool once = false;
+      if (!once) {
+        once = true;
+#define EMU_OFF(name) std::fprintf(stderr, "[wave_emu] %-8s at word %d\n", #name, (int)(s.name - lds.data()));
+        EMU_OFF(qpos) EMU_OFF(qvel) EMU_OFF(warm) EMU_OFF(info) EMU_OFF(ctrl) EMU_OFF(xpos) EMU_OFF(xquat) EMU_OFF(com) EMU_OFF(cvel) EMU_OFF(cdof)
+        EMU_OFF(M) EMU_OFF(cdist) EMU_OFF(cpos) EMU_OFF(cframe) EMU_OFF(Jc) EMU_OFF(D) EMU_OFF(aref) EMU_OFF(lsign) EMU_OFF(Jaref) EMU_OFF(qfs)
+        EMU_OFF(qas) EMU_OFF(qacc) EMU_OFF(Ma) EMU_OFF(rhs) EMU_OFF(con_on) EMU_OFF(qfc) EMU_OFF(ulist) EMU_OFF(H) EMU_OFF(jv) EMU_OFF(frc)
+        EMU_OFF(cwd) EMU_OFF(cwa) EMU_OFF(cwb) EMU_OFF(ccf) EMU_OFF(vec0) EMU_OFF(vec1) EMU_OFF(gpos) EMU_OFF(gaxis) EMU_OFF(Y)
+#undef EMU_OFF
+      }
+    }
   }
 };
 
