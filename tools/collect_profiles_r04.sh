@@ -45,11 +45,19 @@ python tools/pmc_to_json.py $OUT/pmc_crate $OUT/pmc_unitree_go2_crate_climb.json
 PMC_PASSES="1 2 3 4 6" PMC_BENCH_ARGS="--example unitree_h1_push_crate --steps 8" bash tools/pmc_passes.sh r04/pmc_push > $OUT/pmc_passes_push.log 2>&1
 python tools/pmc_summary.py $OUT/pmc_push > $OUT/pmc_unitree_h1_push_crate.txt 2>&1
 python tools/pmc_to_json.py $OUT/pmc_push $OUT/pmc_unitree_h1_push_crate.json unitree_h1_push_crate 2048 24 > /dev/null 2>&1
-for a in "unitree_go2_trot 2048 16" "unitree_go2_crate_climb 2048 25" "unitree_h1_push_crate 2048 24" "allegro_reorient 2048 20"; do
+for a in "unitree_go2_trot 2048 16" "unitree_h1_jog 2048 25" "unitree_go2_crate_climb 2048 25" "unitree_h1_push_crate 2048 24" "allegro_reorient 2048 20"; do
   set -- $a
   DIAL_HIP_LIB=$ROOT/dial_mpc_amd/csrc/libdialhip_prof.so python tools/profile_sections.py $1 $2 $3 > $OUT/sections_$1_cycles.txt 2>/dev/null
 done
 python tools/transition_survey.py --no-dist > $OUT/transition_parity.txt 2>&1
+DIAL_HIP_LIB=$ROOT/dial_mpc_amd/csrc/libdialhip_prof.so python tools/wave_times.py allegro_reorient 2048 20 9 > $OUT/wave_times.txt 2>&1
+DIAL_HIP_LIB=$ROOT/dial_mpc_amd/csrc/libdialhip_prof.so python tools/wave_times.py allegro_reorient 4096 24 9 >> $OUT/wave_times.txt 2>&1
+for ex in unitree_h1_jog allegro_reorient; do
+  PMC_PASSES="1 2 3 4" PMC_BENCH_ARGS="--example $ex --steps 8" bash tools/pmc_passes.sh r04/pmc_$ex > $OUT/pmc_passes_$ex.log 2>&1
+  python tools/pmc_summary.py $OUT/pmc_$ex > $OUT/pmc_$ex.txt 2>&1
+done
+python tools/pmc_to_json.py $OUT/pmc_unitree_h1_jog $OUT/pmc_unitree_h1_jog.json unitree_h1_jog 2048 25 > /dev/null 2>&1
+python tools/pmc_to_json.py $OUT/pmc_allegro_reorient $OUT/pmc_allegro_reorient.json allegro_reorient 2048 20 > /dev/null 2>&1
 rm -rf $OUT/kstats $OUT/kstats_crate $OUT/kstats_push
 find $OUT -name "*.db" -delete 2>/dev/null; find $OUT -path "*pass*" -name "*kernel_trace.csv" -delete 2>/dev/null; find $OUT -name "*agent_info.csv" -delete 2>/dev/null
 du -sh $OUT; cat $OUT/bench_all_envs.txt; cat $OUT/n_sweep.txt
