@@ -36,6 +36,9 @@ DIAL_KERNELS_ALL(DIAL_X, DIAL_XE)
 
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
+#ifndef DIAL_GO2_SLICE_STEPS
+#define DIAL_GO2_SLICE_STEPS 3   /* control steps per piece of the Go2's time-sliced queue (dial_options.slice_steps overrides) */
+#endif
 #endif
 
 // ------------------------------------------------------------------ kernels (rollout / env.step / env.reset: rollout_kernel.h)
@@ -580,11 +583,16 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
     if (ctx->inst == 4 && !opt.no_lag_priority) HIP_TRY_CREATE(hipMalloc(&ctx->work_stat, 2 * sizeof(int)));
-    // time-sliced queue: models whose rollouts differ in length (the elliptic solver runs to convergence), batches beyond the
-    // resident set
-    if (ctx->inst == 4 && !opt.no_slice && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb) {
+    // time-sliced queue, batches beyond the resident set: models whose rollouts differ in length (the elliptic solver runs to
+    // convergence) -- and the Go2's large-batch kernel, whose batches are k x (resident set) + 1 whenever Nsample is a power of
+    // two (the "+1" = the mean trajectory): as whole rollouts the last one runs alone at the lone-wavefront pace (0.31 ms after
+    // everything else is done: N = 4096 0.76 ms, N = 8192 1.26 ms for 0.49 ms per full round); as pieces the tail is one piece
+    const bool slice_allegro = ctx->inst == 4 && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb;
+    const bool slice_go2 = ctx->inst == 1 && ctx->resident_blocks_large > 0 && ctx->B_cap > ctx->resident_blocks_large * DIAL_GO2_WPB_LARGE;
+    if ((slice_allegro || slice_go2) && !opt.no_slice) {
       ctx->slice_stride = model->nq + 2 * model->nv + DIAL_INFO_N + 4;
       ctx->slice_cap = ctx->B_cap;
+      if (slice_go2) ctx->slice_steps = DIAL_GO2_SLICE_STEPS;
       if (opt.slice_steps >= 1) ctx->slice_steps = opt.slice_steps;
       HIP_TRY_CREATE(hipMalloc(&ctx->slice_buf, sizeof(float) * (size_t)ctx->slice_stride * ctx->B_cap));
       HIP_TRY_CREATE(hipMalloc(&ctx->slice_flag, sizeof(int) * (size_t)ctx->B_cap));

@@ -123,7 +123,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       }
       v = dm::clip(v, -1.f, 1.f);
       s.Y[it] = v;
-      if (io.Y0s) io.Y0s[(size_t)n * Hn1 * nu + it] = v;
+      if (io.Y0s && relay <= 0) io.Y0s[(size_t)n * Hn1 * nu + it] = v;   // (pieces of one rollout rebuild the same nodes: the first writes them)
     });
   }
   float rsum = 0.f;
@@ -174,8 +174,18 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       float u;
       if (io.us) u = io.us[(unsigned)((n * T + st) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
       else {
+        // the examples' node counts with a compile-time trip count: the row of W arrives with one or two scalar loads and every
+        // LDS fetch is issued up front.  (A loop whose length is a run-time value waits for one scalar load + one LDS fetch
+        // per node -- K2 cost a lone Go2 wavefront 2.0 k of its 43.7 k cycles per env.step.)  Same products in the same order.
         u = 0.f;
-        for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
+        const auto k2 = [&](auto HN) {
+          DIAL_UNROLL_FULL
+          for (int k = 0; k < decltype(HN)::value; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
+        };
+        if (Hn1 == 5) k2(std::integral_constant<int, 5>{});
+        else if (Hn1 == 6) k2(std::integral_constant<int, 6>{});
+        else if (Hn1 == 7) k2(std::integral_constant<int, 7>{});
+        else for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
       }
       s.act[a] = u;
     });

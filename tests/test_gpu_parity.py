@@ -537,14 +537,16 @@ def test_rollout_queue_beyond_the_resident_batch():
     assert rep["rollouts"] == len(idx)
 
 
-def test_time_sliced_queue_is_bit_identical():
-    """Allegro batches beyond the resident set run through the TIME-SLICED queue (rollout_kernel.h: (piece, rollout) items in
-    piece-major order, states handed on through global memory): bit-identical to the plain queue of whole rollouts and to the
-    one-wavefront-per-rollout launch, repeatable, for two piece lengths (one that does not divide the horizon)."""
+@pytest.mark.parametrize("example,N,H", [("allegro_reorient", 2500, 7), ("unitree_go2_trot", 4096, 7), ("unitree_go2_trot", 9000, 16)])
+def test_time_sliced_queue_is_bit_identical(example, N, H):
+    """Batches beyond the resident set -- Allegro (rollouts of data-dependent length) and the Go2's large-batch kernel (N + 1 =
+    k x the resident set + 1: as whole rollouts the last one would run alone) -- run through the TIME-SLICED queue
+    (rollout_kernel.h: (piece, rollout) items in piece-major order, states handed on through global memory): bit-identical to
+    the plain queue of whole rollouts and to the one-wavefront-per-rollout launch, repeatable, for two piece lengths (one that
+    does not divide the horizon)."""
     import torch
     from dial_mpc_amd import _lib
-    N, H = 2500, 7
-    dc, env, model, task, cfg = setup_case("allegro_reorient", N, H)
+    dc, env, model, task, cfg = setup_case(example, N, H)
     s0 = None
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=2, Ybar_scale=0.2)
     outs = []
@@ -559,7 +561,7 @@ def test_time_sliced_queue_is_bit_identical():
             torch.cuda.synchronize()
             ctx.status()
             sc = ctx.debug_scratch()
-            outs.append(({k: out[k].clone() for k in ("Ybar", "rews", "qbar", "xbar")}, {k: np.array(sc[k]) for k in ("rewss", "qss", "qdss", "xss")}))
+            outs.append(({k: out[k].clone() for k in ("Ybar", "rews", "qbar", "xbar")}, {k: np.array(sc[k]) for k in ("rewss", "qss", "qdss", "xss", "Y0s")}))
     assert np.isfinite(outs[0][1]["rewss"]).all()
     for o, sc in outs[1:]:
         for k in o:
