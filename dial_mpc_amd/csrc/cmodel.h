@@ -130,6 +130,13 @@ struct Dims {
   static constexpr bool rows_stage = !GEN_ && SQUARE_ && RowsOf<Topo_>::maxd > 0;
 #endif
   static constexpr bool phase_tabs = !quad_stage && !rows_stage;
+  // the quadruped register stage WITHOUT its fused foot contacts, for the generic feature set on the Go2's tree (crate climb:
+  // 17 geoms, 52 candidate contacts): bodies / dofs in registers, then the generic geom frames, collisions and constraint rows
+#if defined(DIAL_NO_QUAD) || defined(DIAL_NO_QUAD_GEN)
+  static constexpr bool quad_gen = false;
+#else
+  static constexpr bool quad_gen = GEN_ && STATIC && !ELL_ && !SQUARE_ && std::is_same<Topo_, TopoGo2>::value;
+#endif
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;
@@ -392,8 +399,9 @@ static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* mer
 // Host: is the model the quadruped this layout assumes (smooth_quad.h; beyond the dof tree dims_match checks)?  World, a free trunk
 // (body 1), four legs of three one-hinge bodies in depth-first order, the floor plane as geom 0, one sphere and one site per calf,
 // the trunk's site first, one plane-sphere contact per foot in leg order.
-static inline bool quad_fits(const dial_model* m) {
-  if (m->nbody != 14 || m->njnt != 13 || m->nv != 18 || m->nq != 19 || m->ngeom != 5 || m->nsite != 5 || m->ncon != 4) return false;
+// the body / joint / dof tree alone: world, a free trunk (body 1), four legs of three one-hinge bodies in depth-first order
+static inline bool quad_tree_fits(const dial_model* m) {
+  if (m->nbody < 14 || m->njnt != 13 || m->nv != 18 || m->nq != 19) return false;
   if (m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
       m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1)
     return false;
@@ -404,6 +412,20 @@ static inline bool quad_fits(const dial_model* m) {
           m->jnt_type[j] != DIAL_JNT_HINGE || m->jnt_qposadr[j] != b + 5 || m->jnt_dofadr[j] != b + 4 || m->body_dofadr[b] != b + 4)
         return false;
     }
+  return true;
+}
+// the generic feature set on that tree (Dims::quad_gen): the trunk's site first, one site per calf in leg order, every further
+// body welded to the world (the crate: a constant pose, written once per kernel)
+static inline bool quad_gen_fits(const dial_model* m) {
+  if (m->nsite != 5 || m->site_bodyid[0] != 1) return false;
+  for (int r = 0; r < 4; r++)
+    if (m->site_bodyid[1 + r] != 4 + 3 * r) return false;
+  for (int b = 14; b < m->nbody; b++)
+    if (m->body_parent[b] != 0 || m->body_jntnum[b] != 0) return false;
+  return true;
+}
+static inline bool quad_fits(const dial_model* m) {
+  if (m->nbody != 14 || m->ngeom != 5 || m->nsite != 5 || m->ncon != 4 || !quad_tree_fits(m)) return false;
   if (m->geom_bodyid[0] != 0 || m->site_bodyid[0] != 1 || (m->nlim & 3) != 0) return false;   // (limit rows fill whole 16-byte groups)
   for (int r = 0; r < 4; r++) {
     const int calf = 4 + 3 * r;
@@ -424,6 +446,7 @@ static inline bool dims_match(const dial_model* m) {
     for (int i = 0; ok && i < D::NV; i++) ok = m->dof_parentid[i] == D::Topo::T.p[i];
   }
   if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
+  if constexpr (D::quad_gen) ok = ok && quad_tree_fits(m) && quad_gen_fits(m);
   if constexpr (!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) {   // smooth_rows.h: the layout must come out as compiled
     using RT = RowsOf<typename D::Topo>;
     RowTab t;

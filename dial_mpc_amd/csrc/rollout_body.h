@@ -1069,6 +1069,43 @@ DIAL_DEV void collide_contact(const M* m, const Ws& s, int c) {
   if constexpr (M::D::ell) s.con_on[c] = (dist - m->con_margin[c]) < 0.f ? 1.f : 0.f;
 }
 
+// The end of forward(): the generic feature set compacts the contacts that touch and, past its LDS cap, moves to the overflow
+// area; then the constraint half.
+template <class W, class M>
+DIAL_DEV void forward_tail(W& w, const M* m, const Ws& s) {
+  const int nv = dim_nv(m), nc = dim_nc(m), ne = dim_ne(m), nl = dim_nl(m);
+  int nca = nc, nea = ne;   // contacts / rows the constraint section works on (generic instantiation: the touching ones)
+  (void)nv; (void)nl;
+  if constexpr (M::D::gen) {
+    // compact the contacts that touch (see con_of above); with more than 64 candidates the list would need a second pass
+    if (nc <= 64) {
+      nca = w.compact(nc, [&](int c) { return s.cdist[c] - m->con_margin[c] < 0.f; }, s.clist);
+    } else {
+      w.items(nc, [&](int c) { s.clist[c] = (float)c; });
+    }
+    nea = nl + dim_nf(m) + 4 * nca;
+  }
+  if constexpr (M::D::gen) {
+    // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
+    // contacts (derived.h: ws_carve).  A sample that touches with more runs the SAME constraint code on its overflow
+    // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
+    if (s.con_cap > 0 && nca > s.con_cap && s.ovf != nullptr) {   // (a capped workspace always comes with its overflow area)
+      Ws sg = s;
+      float* ovf = s.ovf;
+#ifndef DIAL_EMU
+      // (opaque to the optimiser: with the provenance of both workspaces in sight LLVM merges the two copies of the constraint
+      //  code into one over pointer PHIs and trips over its own address-space inference -- "Illegal instruction detected:
+      //  V_CMP_NE_U32 0, $src_shared_base" -- in the capacity-dimension kernel; the overflow copy simply uses flat accesses)
+      asm volatile("" : "+v"(ovf));
+#endif
+      ws_overflow(sg, ovf, nv, nc, ne);
+      forward_constraints(w, m, sg, nca, nea);
+      return;
+    }
+  }
+  forward_constraints(w, m, s, nca, nea);
+}
+
 // ================================================================ mjx.forward
 template <class W, class M>
 DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
@@ -1079,6 +1116,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   if constexpr (kQuadDims<typename M::D>) {   // quadruped topology: the whole position / velocity stage in registers (smooth_quad.h)
     forward_smooth_quad(w, m, s);
     forward_constraints(w, m, s, nca, nea);
+    return;
+  }
+  if constexpr (kQuadGenDims<typename M::D>) {   // the Go2's tree under the generic feature set (crate climb): bodies and dofs in registers
+    forward_smooth_quad<false>(w, m, s);
+    w.items(nc, [&](int c) { collide_contact(m, s, c); });
+    forward_tail(w, m, s);
     return;
   }
   if constexpr (kRowsDims<typename M::D>) {   // one tree under a free root (H1): the same stage on the row layout (smooth_rows.h)
@@ -1563,34 +1606,7 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
       collide_contact(m, s, it - ntri - nv);
     }
   });
-  if constexpr (M::D::gen) {
-    // compact the contacts that touch (see con_of above); with more than 64 candidates the list would need a second pass
-    if (nc <= 64) {
-      nca = w.compact(nc, [&](int c) { return s.cdist[c] - m->con_margin[c] < 0.f; }, s.clist);
-    } else {
-      w.items(nc, [&](int c) { s.clist[c] = (float)c; });
-    }
-    nea = nl + dim_nf(m) + 4 * nca;
-  }
-  if constexpr (M::D::gen) {
-    // The LDS workspace of a rollout wavefront holds the Jacobian and the per-row arrays of at most s.con_cap touching
-    // contacts (derived.h: ws_carve).  A sample that touches with more runs the SAME constraint code on its overflow
-    // area in global memory (a second inlined copy: slower, bit-identical, rare) -- nothing is dropped.
-    if (s.con_cap > 0 && nca > s.con_cap && s.ovf != nullptr) {   // (a capped workspace always comes with its overflow area)
-      Ws sg = s;
-      float* ovf = s.ovf;
-#ifndef DIAL_EMU
-      // (opaque to the optimiser: with the provenance of both workspaces in sight LLVM merges the two copies of the constraint
-      //  code into one over pointer PHIs and trips over its own address-space inference -- "Illegal instruction detected:
-      //  V_CMP_NE_U32 0, $src_shared_base" -- in the capacity-dimension kernel; the overflow copy simply uses flat accesses)
-      asm volatile("" : "+v"(ovf));
-#endif
-      ws_overflow(sg, ovf, nv, nc, ne);
-      forward_constraints(w, m, sg, nca, nea);
-      return;
-    }
-  }
-  forward_constraints(w, m, s, nca, nea);
+  forward_tail(w, m, s);
 }
 
 // Task kinds a kernel instantiation can be asked to run (the dimension-specialised ones are per robot; dial_create checks).
@@ -2067,6 +2083,7 @@ DIAL_DEV void init_square(W& w, const M* m, const Ws& s) {
   (void)m;
   if constexpr (M::D::square) w.items(M::D::NV * M::D::S, [&](int e) { s.M[e] = 0.f; });
   if constexpr (kQuadDims<typename M::D>) init_quad(w, m, s);
+  if constexpr (kQuadGenDims<typename M::D>) init_quad_gen(w, m, s);
 }
 
 }  // namespace dial

@@ -26,11 +26,19 @@ namespace dial {
 
 template <class D>
 inline constexpr bool kQuadDims = D::quad_stage;
+template <class D>
+inline constexpr bool kQuadGenDims = D::quad_gen;
 
-template <class W, class M>
+// FUSED (the Go2's own instantiation): the four plane-sphere foot contacts, their Jacobian and the constraint rows come out of the
+// stage, M in the square layout.  !FUSED (the generic feature set on the Go2's tree, Dims::quad_gen -- crate climb): bodies and
+// dofs only, M as the packed lower triangle, then the geom frames of ALL geoms as one LDS phase; collisions, Jacobians and rows
+// stay the generic feature set's (forward(), forward_constraints()).
+template <bool FUSED = true, class W, class M>
 DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
   constexpr int S = M::D::S;
-  static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "quadruped layout: trunk + 4 legs of 3");
+  static_assert(M::D::NB >= 14 && M::D::NV == 18, "quadruped layout: trunk + 4 legs of 3");
+  static_assert(!FUSED || (M::D::NB == 14 && M::D::NC == 4 && M::D::square), "fused foot contacts: the Go2's own scene");
+  static_assert(FUSED || !M::D::square, "generic feature set: packed M");
   DIAL_MARK(w, 15);
 #if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
   // An opaque copy of the lane id for this stage: its role masks and table addresses are loop invariants of the T-step loop,
@@ -103,14 +111,16 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     const float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
     const float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
     const float sp[3] = {m->site_pos[gs][0], m->site_pos[gs][1], m->site_pos[gs][2]};
-    const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
     const float mass = m->body_mass[b];
-    float t3[3], qi[4], mat[9], ts[3], tg[3];
+    float t3[3], qi[4], mat[9], ts[3], tg[3] = {0.f, 0.f, 0.f};
     dm::rotate(t3, ip, q);
     dm::quat_mul(qi, q, iq);
     dm::quat_to_mat(mat, qi);
     dm::rotate(ts, sp, q);
-    dm::rotate(tg, gp, q);
+    if constexpr (FUSED) {
+      const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
+      dm::rotate(tg, gp, q);
+    }
     for (int k = 0; k < 3; k++) {
       const float xi = p[k] + t3[k];
       o[k] = xi;
@@ -252,6 +262,9 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
     }
     if (d == 3) for (int k = 0; k < 3; k++) s.spos[3 * (1 + r) + k] = lane_val(F[16 + k], l);
+    if constexpr (!FUSED) {   // packed M: the structural zeros (the dof lanes below write the tree's entries only)
+      for (int e = l; e < M::D::NTRI; e += 64) s.M[e] = 0.f;
+    }
   });
   // ---- collision_driver (the four plane-sphere foot contacts), the contact Jacobian and constraint.make_constraint, fused:
   // forward_constraints()'s first two LDS phases (72 (contact, dof) items; 28 rows with an 18-term J qvel each) become
@@ -261,7 +274,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
   //     trunk's dofs against that row's contact): one 16-byte store of J^T[i][4c..4c+3]; the other entries of a leg dof's row
   //     are structural zeros written once per kernel (init_quad);
   //   * leg lanes: their joint's limit row.
-  {
+  if constexpr (FUSED) {
     float pn[3];
     {
       const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
@@ -440,16 +453,43 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       s.rhs[i] = qf;
       // (predicated stores under branches: redirecting the lanes that are off to a dump word instead measured the same,
       //  profiles/r04_ab_smooth_quad.txt)
-      for (int j = 0; j < 6; j++) {
-        if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
-      }
-      if (leg) {
-        s.M[i * S + i] = lane_val(MO[6], l);
-        if (d >= 2) { const float v = lane_val(MO[7], l); s.M[i * S + i - 1] = v; s.M[(i - 1) * S + i] = v; }
-        if (d == 3) { const float v = lane_val(MO[8], l); s.M[i * S + i - 2] = v; s.M[(i - 2) * S + i] = v; }
+      if constexpr (M::D::square) {
+        for (int j = 0; j < 6; j++) {
+          if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
+        }
+        if (leg) {
+          s.M[i * S + i] = lane_val(MO[6], l);
+          if (d >= 2) { const float v = lane_val(MO[7], l); s.M[i * S + i - 1] = v; s.M[(i - 1) * S + i] = v; }
+          if (d == 3) { const float v = lane_val(MO[8], l); s.M[i * S + i - 2] = v; s.M[(i - 2) * S + i] = v; }
+        }
+      } else {   // packed lower triangle (generic feature set)
+        (void)S;
+        for (int j = 0; j < 6; j++) {
+          if (j <= i) s.M[tri_idx(i, j)] = lane_val(MO[j], l);
+        }
+        if (leg) {
+          s.M[tri_idx(i, i)] = lane_val(MO[6], l);
+          if (d >= 2) s.M[tri_idx(i, i - 1)] = lane_val(MO[7], l);
+          if (d == 3) s.M[tri_idx(i, i - 2)] = lane_val(MO[8], l);
+        }
       }
     }
   });
+  if constexpr (!FUSED) {
+    // ---- local_to_global for the geoms (forward(): the geom items of its frames phase), from the poses stored above
+    w.items(M::D::NG, [&](int g) {
+      const int b = m->geom_bodyid[g];
+      const float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      const float gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]};
+      const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
+      float t3[3], qg[4], mat[9];
+      dm::rotate(t3, gp, q);
+      for (int k = 0; k < 3; k++) s.gpos[3 * g + k] = s.xpos[3 * b + k] + t3[k];
+      dm::quat_mul(qg, q, gq);
+      dm::quat_to_mat(mat, qg);
+      s.gaxis[3 * g] = mat[2]; s.gaxis[3 * g + 1] = mat[5]; s.gaxis[3 * g + 2] = mat[8];
+    });
+  }
 #if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
   w.lane = lane_keep;
 #endif
@@ -469,6 +509,17 @@ DIAL_DEV void init_quad(W& w, const M* m, const Ws& s) {
     const float n[3] = {mat[2], mat[5], mat[8]};
     make_frame(fr, n);
     for (int k = 0; k < 9; k++) s.cframe[9 * c + k] = fr[k];
+  });
+}
+
+// Once per kernel, generic feature set on the quadruped tree: the poses of the bodies welded to the world (the crate), which no
+// lane of the stage computes.
+template <class W, class M>
+DIAL_DEV void init_quad_gen(W& w, const M* m, const Ws& s) {
+  w.items(M::D::NB - 14, [&](int e) {
+    const int b = 14 + e;
+    for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = m->body_pos[b][k];
+    for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = m->body_quat[b][k];
   });
 }
 
