@@ -36,9 +36,6 @@ DIAL_KERNELS_ALL(DIAL_X, DIAL_XE)
 
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
-#ifndef DIAL_GO2_SLICE_STEPS
-#define DIAL_GO2_SLICE_STEPS 3   /* control steps per piece of the Go2's time-sliced queue (dial_options.slice_steps overrides) */
-#endif
 #endif
 
 // ------------------------------------------------------------------ kernels (rollout / env.step / env.reset: rollout_kernel.h)
@@ -260,6 +257,7 @@ struct dial_ctx {
   int* err_host = nullptr;     // sticky error word: pinned host memory the kernels can write (relay time-out) ...
   int* err_dev = nullptr;      // ... and its device-side address
   bool relay_ok = false, relay_always = false;
+  bool no_mean_inline = false;   // options: the mean trajectory of a large Go2 batch as an ordinary queue item
   // Allegro split launch (see DIAL_ALLEGRO_WPB_EVEN)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -539,6 +537,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     HIP_TRY_CREATE(hipHostGetDevicePointer((void**)&ctx->err_dev, ctx->err_host, 0));
     ctx->relay_ok = ctx->wpb == 1 && !opt.no_relay;
     ctx->relay_always = opt.relay_always != 0;
+    ctx->no_mean_inline = opt.no_mean_inline != 0;
     ctx->wpb_even = ctx->inst == 4 ? DIAL_ALLEGRO_WPB_EVEN : ctx->inst == 2 ? DIAL_H1_WPB_EVEN : 0;
     if ((opt.no_split_mask >> ctx->inst) & 1) ctx->wpb_even = 0;
     if (ctx->wpb_even > 0) {
@@ -583,16 +582,13 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     ctx->T = cfg->Hsample + 1;
     ctx->Hn1 = cfg->Hnode + 1;
     if (ctx->inst == 4 && !opt.no_lag_priority) HIP_TRY_CREATE(hipMalloc(&ctx->work_stat, 2 * sizeof(int)));
-    // time-sliced queue, batches beyond the resident set: models whose rollouts differ in length (the elliptic solver runs to
-    // convergence) -- and the Go2's large-batch kernel, whose batches are k x (resident set) + 1 whenever Nsample is a power of
-    // two (the "+1" = the mean trajectory): as whole rollouts the last one runs alone at the lone-wavefront pace (0.31 ms after
-    // everything else is done: N = 4096 0.76 ms, N = 8192 1.26 ms for 0.49 ms per full round); as pieces the tail is one piece
-    const bool slice_allegro = ctx->inst == 4 && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb;
-    const bool slice_go2 = ctx->inst == 1 && ctx->resident_blocks_large > 0 && ctx->B_cap > ctx->resident_blocks_large * DIAL_GO2_WPB_LARGE;
-    if ((slice_allegro || slice_go2) && !opt.no_slice) {
+    // time-sliced queue: models whose rollouts differ in length (the elliptic solver runs to convergence), batches beyond the
+    // resident set.  (Not for the Go2's large batches: one hand-over per rollout and piece through global memory -- 4096 release /
+    // acquire pairs per piece level -- cost more than the lone last rollout it would hide: N = 4096 1.34 vs 0.80 ms,
+    // profiles/r04_ab_call_v_sliced_go2_k2_crate_quad.txt; those batches interleave the mean trajectory instead, see launch_rollout.)
+    if (ctx->inst == 4 && !opt.no_slice && ctx->resident_blocks > 0 && ctx->B_cap > ctx->resident_blocks * ctx->wpb) {
       ctx->slice_stride = model->nq + 2 * model->nv + DIAL_INFO_N + 4;
       ctx->slice_cap = ctx->B_cap;
-      if (slice_go2) ctx->slice_steps = DIAL_GO2_SLICE_STEPS;
       if (opt.slice_steps >= 1) ctx->slice_steps = opt.slice_steps;
       HIP_TRY_CREATE(hipMalloc(&ctx->slice_buf, sizeof(float) * (size_t)ctx->slice_stride * ctx->B_cap));
       HIP_TRY_CREATE(hipMalloc(&ctx->slice_flag, sizeof(int) * (size_t)ctx->B_cap));
@@ -714,6 +710,14 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     blocks = resident;
     next = ctx->next;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)next, blocks * wpb, 1, st));
+    // Go2's large batches whose last rollout is the mean trajectory: it is not a queue item -- the first T wavefronts of the
+    // launch run one step of it each between two steps of their own (rollout_driver.h: mean_inline)
+    if (large && !ctx->no_mean_inline && !io.us && io.n_noise == B - 1 && ctx->T <= blocks * wpb && io.relay_stride == 0) {
+      io.mean_inline = 1;
+      io.relay_buf = ctx->relay_buf;
+      io.relay_flag = ctx->relay_flag;
+      io.err_word = ctx->err_dev;
+    }
     if (ctx->slice_buf && B <= ctx->slice_cap && ctx->T > ctx->slice_steps) {   // time-sliced: (piece, rollout) items
       io.relay_buf = ctx->slice_buf;
       io.relay_flag = ctx->slice_flag;

@@ -55,6 +55,11 @@ struct RolloutIO {
   // diagnostics (dial_set_state_trace; nullptr in production): the packed state [qpos|qvel|qacc_warmstart|info] after every
   // env.step, trace:[B,T,nstate] -- what the per-transition parity tests restart the oracle from
   float* trace;
+  // interleaved mean trajectory (rollout-queue launches whose last rollout is the mean trajectory: N + 1 = k x the resident set
+  // + 1 whenever Nsample is a power of two): the mean rollout is NOT a queue item; wavefront q < T of the launch's first round
+  // runs control step q of it between its own steps q and q + 1 (state handed on through relay_buf / relay_flag, T hand-overs
+  // per launch), so that no wavefront slot runs two whole rollouts one after the other -- see rollout_sample
+  int mean_inline;
 };
 
 template <class W, class M>
@@ -88,9 +93,16 @@ DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
 // TRACE (compile time): also write the packed state after every env.step to io.trace -- its own kernel instantiation, because
 // even a null-pointer test costs the production launch (measured +1.4 % on the Go2 headline: one more live kernel argument in a
 // kernel that already spills scalar registers; profiles/r04_ab_trace_hook.txt).
+// `helper` >= 0 (io.mean_inline launches, GPU only): after its own control step `helper` this wavefront parks its rollout's packed
+// state in two registers per lane, takes the mean trajectory's state from its predecessor (wavefront helper - 1 of the same
+// launch, which ran mean step helper - 1 one step earlier: both advance at the same pace, so the wait is short), runs mean
+// step `helper` through the SAME env_step call site, hands the state on and resumes its own rollout.  The mean trajectory
+// advances one step per step of everybody else and ends with them: a batch of k x slots + 1 rollouts takes k rounds and one
+// STEP instead of k rounds and one lone ROLLOUT (Go2, N = 4096: 0.78 ms as a queue item).  Bit-identical: the same steps on
+// the same states.
 template <bool TRACE = false, class W, class M>
 DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_cfg* cfg, const Ws& s,
-                             const RolloutIO& io, int n, int relay = -1) {
+                             const RolloutIO& io, int n, int relay = -1, int helper = -1) {
   const int nq = dim_nq(m), nv = dim_nv(m), nu = dim_nu(m), nx = (dim_nb(m) - 1) * 3, T = io.T, Hn1 = io.Hn1;
 #ifdef DIAL_PROFILE
   w.tprev = __builtin_readcyclecounter();
@@ -159,7 +171,19 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   }
   if (relay >= 0 && io.relay_stride == 0) w.hold_priority(3);   // (the lone relay rollout; the sliced queue keeps the fair sharing)
 #endif
-  for (int st = st_begin; st < st_end; st++) {
+  // element i of the packed state [qpos | qvel | qacc_warmstart | info] in the LDS workspace
+  // (an offset from ONE base pointer, not a select of pointers: keeps the accesses in the LDS address space)
+  const auto packed = [&](int i) -> float* {
+    const int off = i < nq ? i : (i < nq + nv ? (int)(s.qvel - s.qpos) + (i - nq)
+                    : (i < nq + 2 * nv ? (int)(s.warm - s.qpos) + (i - nq - nv) : (int)(s.info - s.qpos) + (i - nq - 2 * nv)));
+    return s.qpos + off;
+  };
+  bool mean_now = false;   // this pass of the loop runs the mean trajectory's step `helper`, not an own step
+  float keep0 = 0.f, keep1 = 0.f, msum = 0.f;
+  (void)packed; (void)keep0; (void)keep1; (void)msum;
+  for (int st_own = st_begin; mean_now || st_own < st_end;) {
+    const int st = mean_now ? helper : st_own;    // control step this pass runs ...
+    const int row = mean_now ? io.n_noise : n;    // ... of this rollout (the mean trajectory is rollout n_noise)
     w.redraw_priority();
 #ifndef DIAL_EMU
     // generic feature set: lane-derived LDS addresses and masks are loop invariants of this T-step loop; hoisted, they are
@@ -173,7 +197,10 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     w.items(nu, [&](int a) {
       float u;
       if (io.us) u = io.us[(unsigned)((n * T + st) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
-      else {
+      else if (mean_now) {   // the mean trajectory's nodes are clip(Ybar): not in this wavefront's LDS (s.Y holds its own rollout's)
+        u = 0.f;
+        for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * dm::clip(io.Ybar[k * nu + a], -1.f, 1.f);
+      } else {
         // the examples' node counts with a compile-time trip count: the row of W arrives with one or two scalar loads and every
         // LDS fetch is issued up front.  (A loop whose length is a run-time value waits for one scalar load + one LDS fetch
         // per node -- K2 cost a lone Go2 wavefront 2.0 k of its 43.7 k cycles per env.step.)  Same products in the same order.
@@ -192,7 +219,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     DIAL_MARK(w, 11);
     const int work0 = w.work;
     float rew = env_step<false>(w, m, tg, s);
-    rsum += rew;
+    if (mean_now) msum += rew; else rsum += rew;
 #ifndef DIAL_EMU
     if constexpr (M::D::ell) {
       if (io.work_stat && relay < 0) {   // once per control step: add own work to the launch totals, compare rates, set the level
@@ -215,7 +242,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #endif
     // per-step outputs: wave-uniform row pointers (scalar address arithmetic), one pass -- lane i stores element i
     // of each row that is that long
-    const size_t o = (size_t)n * T + st;
+    const size_t o = (size_t)row * T + st;
     float* const qrow = io.qss ? io.qss + o * nq : nullptr;
     float* const qdrow = io.qdss ? io.qdss + o * nv : nullptr;
     float* const xrow = io.xss ? io.xss + o * nx : nullptr;
@@ -231,6 +258,62 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     if constexpr (TRACE) { if (io.trace) store_state(w, m, s, io.trace + o * nstate); }
 #endif
     DIAL_MARK(w, 24);
+#ifndef DIAL_EMU
+    if (mean_now) {
+      // hand the mean trajectory on (or finish it), then resume the own rollout from the parked state
+      if (helper + 1 < T) {
+        store_state(w, m, s, io.relay_buf);
+        w.items(1, [&](int) { io.relay_buf[nstate] = msum; });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (w.lane == 0) __hip_atomic_store(io.relay_flag, helper + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (io.rews) { const float mean = msum / (float)T; w.items(1, [&](int) { io.rews[row] = mean; }); }
+        if (w.lane == 0) __hip_atomic_store(io.relay_flag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+      }
+      w.items(64, [&](int l) {
+        if (l < nstate) *packed(l) = keep0;
+        if (l + 64 < nstate) *packed(l + 64) = keep1;
+      });
+      mean_now = false;
+      continue;
+    }
+#endif
+    st_own++;
+#ifndef DIAL_EMU
+    if (helper >= 0 && st == helper && relay < 0) {   // own step `helper` is done: the mean trajectory's step `helper` comes next
+      keep0 = w.lane < nstate ? *packed(w.lane) : 0.f;
+      keep1 = w.lane + 64 < nstate ? *packed(w.lane + 64) : 0.f;
+      w.sync();
+      bool ok = true;
+      if (helper == 0) {
+        load_state(w, m, s, io.state);
+        msum = 0.f;
+        if (io.Y0s) w.items(Hn1 * nu, [&](int it) { io.Y0s[(size_t)io.n_noise * Hn1 * nu + it] = dm::clip(io.Ybar[it], -1.f, 1.f); });
+      } else {
+        int timed_out = 0;
+        if (w.lane == 0) {   // (bounded like the relay's wait: give up, raise the sticky error, never run on a stale state)
+          unsigned spins = 0;
+          while (__hip_atomic_load(io.relay_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != helper && ++spins < (1u << 20))
+            __builtin_amdgcn_s_sleep(2);
+          timed_out = spins >= (1u << 20);
+        }
+        timed_out = __builtin_amdgcn_readfirstlane(timed_out);
+        if (timed_out) {
+          if (w.lane == 0) {
+            if (io.err_word) __hip_atomic_store(io.err_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (io.rews) reinterpret_cast<uint32_t*>(io.rews)[io.n_noise] = 0x7fc00000u;
+          }
+          ok = false;
+        } else {
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          load_state(w, m, s, io.relay_buf);
+          msum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      mean_now = ok;   // (!ok: the predecessor never came -- the own rollout resumes, its state is still in the workspace)
+    }
+#endif
   }
 #ifdef DIAL_PROFILE
   DIAL_MARK(w, 11);

@@ -53,6 +53,13 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   if constexpr (WPB == 1 && !QUEUE) {
     if (io.relay_flag && (int)blockIdx.x >= io.relay_base) { relay = (int)blockIdx.x - io.relay_base; n = B - 1; }
   }
+  int helper = -1;   // interleaved mean trajectory (RolloutIO::mean_inline): the queue holds the B - 1 noisy rollouts only
+  if constexpr (QUEUE) {
+    if (io.mean_inline) {
+      if (n >= B - 1) return;
+      if (n - io.n_first < io.T) helper = n - io.n_first;   // wavefront q < T of the first round also runs mean step q
+    }
+  }
   if (n >= B) return;
   Wave w;
   w.lane = threadIdx.x & 63;
@@ -83,7 +90,8 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
     if constexpr (QUEUE) {
       if (io.slice_pieces > 0) { relay = q / B; n = q - relay * B; }
     }
-    dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay);
+    dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay, QUEUE ? helper : -1);
+    helper = -1;
 #ifdef DIAL_PROFILE
     if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
       unsigned long long* p = io.prof + 32 + 6 * (size_t)n;
@@ -97,7 +105,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
     if (w.lane == 0) nn = atomicAdd(next, 1);
     n = __builtin_amdgcn_readfirstlane(nn);
     q = n;
-    if (n >= (io.slice_pieces > 0 ? io.slice_pieces * B : B)) break;
+    if (n >= (io.slice_pieces > 0 ? io.slice_pieces * B : B - io.mean_inline)) break;
 #ifdef DIAL_PROFILE
     t_start = wall_clock64();
 #endif

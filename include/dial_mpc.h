@@ -328,12 +328,14 @@ typedef struct dial_options {
   int32_t no_split_mask;      /* bit i: no split launch for kernel instantiation i (2 = H1, 4 = Allegro); -1: never split   */
   int32_t debug_relay_stall;  /* TEST HOOK k >= 1: relay piece k - 1 never hands over (its successors time out; dial_status) */
   int32_t no_slice;           /* 1: batches beyond the resident set of a model with data-dependent rollout lengths (elliptic
-                                 cones: the Allegro hand) or of the Go2 (N + 1 = k x the resident set + 1: the last rollout
-                                 would run alone) go through the plain rollout queue (whole rollouts) instead of the
+                                 cones: the Allegro hand) go through the plain rollout queue (whole rollouts) instead of the
                                  time-sliced one (pieces of `slice_steps` control steps, handed on through global memory)   */
   int32_t slice_steps;        /* control steps per piece of the time-sliced queue, 1 .. 16 (0: default 3)                    */
   int32_t no_lag_priority;    /* 1: pseudo-random fair SIMD sharing also for models with data-dependent rollout lengths
                                  (default there: the rollouts that are behind get the higher issue priority)                */
+  int32_t no_mean_inline;     /* 1: Go2 batches beyond the resident set run the mean trajectory as an ordinary queue item (the
+                                 last one: alone at the lone-wavefront pace) instead of interleaving its steps with the first
+                                 T wavefronts' own                                                                          */
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for

@@ -539,18 +539,22 @@ def test_rollout_queue_beyond_the_resident_batch():
 
 @pytest.mark.parametrize("example,N,H", [("allegro_reorient", 2500, 7), ("unitree_go2_trot", 4096, 7), ("unitree_go2_trot", 9000, 16)])
 def test_time_sliced_queue_is_bit_identical(example, N, H):
-    """Batches beyond the resident set -- Allegro (rollouts of data-dependent length) and the Go2's large-batch kernel (N + 1 =
-    k x the resident set + 1: as whole rollouts the last one would run alone) -- run through the TIME-SLICED queue
+    """Batches beyond the resident set.  Allegro (rollouts of data-dependent length) runs through the TIME-SLICED queue
     (rollout_kernel.h: (piece, rollout) items in piece-major order, states handed on through global memory): bit-identical to
     the plain queue of whole rollouts and to the one-wavefront-per-rollout launch, repeatable, for two piece lengths (one that
-    does not divide the horizon)."""
+    does not divide the horizon).  The Go2's large-batch kernel (N + 1 = k x the resident set + 1: as a queue item the mean
+    trajectory would run alone at the end) INTERLEAVES the mean trajectory: wavefront q < T runs its step q between two steps
+    of its own rollout -- bit-identical to the plain queue and to one wavefront per rollout."""
     import torch
     from dial_mpc_amd import _lib
     dc, env, model, task, cfg = setup_case(example, N, H)
     s0 = None
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=2, Ybar_scale=0.2)
     outs = []
-    for opts in (dict(), dict(slice_steps=2), dict(no_slice=1), dict(no_queue=1)):
+    # (Go2: its large batches interleave the mean trajectory with the first T wavefronts' own steps instead of slicing -- rollout_driver.h
+    #  mean_inline; no_mean_inline runs it as the queue's last item)
+    go2 = example.startswith("unitree_go2")
+    for opts in (dict(), dict(no_mean_inline=1) if go2 else dict(slice_steps=2), dict(no_slice=1), dict(no_queue=1)):
         ctx = _lib.Context(model, task, cfg, options=opts)
         slots = ctx.lib.dial_debug_resident_rollouts(ctx.h, N + 1)
         assert (slots == 0) if opts.get("no_queue") else (0 < slots < N + 1), (opts, slots)

@@ -51,3 +51,19 @@ def test_an_h1_shaped_model_with_three_geoms_on_a_body_falls_back():
     m2.geom_bodyid[3] = 6                           # three capsules on the left ankle, one on the right
     emu = emu_lib.Emu(m2, task, cfg)
     assert emu.sizes()[0] == 0
+
+
+def test_crate_climb_runs_the_quadruped_stage_and_another_site_layout_falls_back():
+    """The generic feature set on the Go2's tree (crate climb, Dims::quad_gen): bodies and dofs in registers (smooth_quad.h without
+    the fused foot contacts), geom frames / collisions / rows generic.  cmodel.h: quad_tree_fits && quad_gen_fits inside dims_match;
+    with the foot sites on the thighs the same model runs on the capacity-dimension instantiation -- same physics."""
+    dc, env, model, task, cfg = setup_case("unitree_go2_crate_climb", 8, 8, per_rollout=True)
+    got, err = _rollout_err("unitree_go2_crate_climb", model, task, cfg, env)
+    assert got == 5, got
+    assert max(err.values()) <= 1.0, err
+    m2 = type(model).from_buffer_copy(model)
+    for r in range(4):
+        m2.site_bodyid[1 + r] = 3 + 3 * r
+    got2, err2 = _rollout_err("unitree_go2_crate_climb", m2, task, cfg, env)
+    assert got2 == 0, got2
+    assert max(err2.values()) <= 1.0, err2
