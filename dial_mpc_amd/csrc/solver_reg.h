@@ -80,14 +80,38 @@ struct AncList {
 };
 
 // TopoT: the fill pattern of A -- the robot's dof tree for M (and M + dt B), TopoDense for a matrix that couples all dofs
-template <class D, class TopoT = typename D::Topo, class W, class M>
-DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch) {
+// dinv_io: where the pivots' reciprocals go (lane = reversed dof), for a later REUSE solve.
+// REUSE: a second right-hand side on the factor the previous call left in `scratch` (nothing has written there since) and the
+// reciprocals it returned: the unit columns are re-read from the LDS copy (N strided fetches per lane), forward substitution in
+// the same order with the same operands -- bit for bit what a second factorisation of the same matrix gives -- then the shared
+// backward pass.  (The Newton solver's second iteration when the active set did not change: H is the same matrix.)
+template <class D, class TopoT = typename D::Topo, bool REUSE = false, class W, class M>
+DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, float* scratch, vfloat* dinv_io = nullptr) {
   constexpr int N = D::NV, S = kCholStride<N>;
   using Topo = TopoT;
   w.begin_region();
   vfloat a[N];
   static_assert(D::square, "the register solver reads M / H from the square LDS layout");
   const auto own_i = [&](int l) { return N - 1 - l; };   // the lane's dof
+  (void)m;
+  vfloat b = w.lane_reverse(bvec, N);
+  vfloat dinv = vsplat(0.f);
+  constexpr ElimOrder<Topo, N> EO{};
+  if constexpr (REUSE) {
+    (void)A;
+    dinv = *dinv_io;
+    // column k' of L' (unit lower, 0 in lanes <= k') sits in row N-1-k' of the LDS copy, this lane's entry at its own dof
+    static_for<0, N>([&](auto KP) {
+      constexpr int kp = KP;
+      a[kp] = w.per_lane([&](int l) { return scratch[(N - 1 - kp) * S + (l < N ? own_i(l) : 0)]; });
+    });
+    static_for<0, EO.nlevel>([&](auto LV) {
+      constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
+      float bk[l1 - l0 > 0 ? l1 - l0 : 1];
+      static_for<l0, l1>([&](auto STEP) { bk[STEP - l0] = bcast(b, EO.seq[STEP]); });
+      static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
+    });
+  } else {
   // A is a full symmetric square with exact zeros off the sparsity pattern: lane l fetches row N-1-l with
   // S/4 ds_read_b128.  Entries above the diagonal of A' (and everything in lanes >= N) are never used: a
   // column is masked when it is finalised, broadcasts only read lanes k' <= l < N.
@@ -100,10 +124,6 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
       if constexpr (j < N) a[N - 1 - j] = t[E];
     });
   });
-  (void)m;
-  vfloat b = w.lane_reverse(bvec, N);
-  vfloat dinv = vsplat(0.f);
-  constexpr ElimOrder<Topo, N> EO{};
   static_for<0, EO.nlevel>([&](auto LV) {
     constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
     float bk[l1 - l0 > 0 ? l1 - l0 : 1];
@@ -135,6 +155,8 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   w.items(N, [&](int l) {
     static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
   });
+  if (dinv_io) *dinv_io = dinv;
+  }   // (!REUSE)
   vfloat x = b * dinv;
   // backward substitution L'^T x = D^-1 z: lane i' needs u[j'] = L'[j'][i'] = scratch[i * S + j] (0 unless j' > i'):
   // its row of the LDS copy, fetched into the registers the factor no longer needs; steps in reverse elimination
@@ -244,6 +266,12 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   unsigned long long prof_prev_act = 0;
 #endif
   int niter = 0;
+  // H = M + J^T diag(D act) J depends on the iterate through the active set alone: when the second Newton iteration finds the
+  // set of the first (27 % of the Go2's control steps at N = 2048, profiles/r04_sections_unitree_go2_trot_cycles.txt), its H is
+  // the same matrix -- assembly and factorisation are skipped, the factor left in s.H by the first solve is used again
+  unsigned long long act_prev = 0;
+  vfloat h_dinv = vzero;
+  bool h_valid = false;
   for (;;) {
     // ---- _update_constraint: forces; _update_gradient: grad = Ma - qfrc_smooth - J^T f
     const vbool act = vlt0(vJa);
@@ -289,6 +317,22 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
 
     // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
     const vfloat vwgt = vsel(act, vD, vzero);
+#ifdef DIAL_NO_FACTOR_REUSE
+    const bool reuse = false;
+#else
+    const unsigned long long act_now = w.mask(vlt0(vzero - vwgt));   // rows that carry weight: active and D > 0
+    // (also in the 128-VGPR large-batch build, where the reciprocals kept across the line search cost 29 more spilled VGPRs: it
+    //  is VALU-issue-bound, and the instructions saved weigh more -- N = 65536 9.38 -> 9.17 ms, N = 8192 unchanged,
+    //  profiles/r04_ab_call_x_factor_reuse.txt)
+    const bool reuse = h_valid && act_now == act_prev;
+    act_prev = act_now;
+    h_valid = true;
+#endif
+    vfloat vsearch;
+    if (reuse) {
+      vsearch = vzero - reg_chol_solve_v<typename M::D, typename M::D::Topo, true>(w, m, s.H, vgrad, s.H, &h_dinv);
+      DIAL_MARK(w, 5);
+    } else {
     {
       // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC), then a zero word
       constexpr int S = M::D::S, T = M::D::T, NLP = M::D::NLP, NP = M::D::NHI / 64;
@@ -349,7 +393,8 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
       });
     }
     DIAL_MARK(w, 5);
-    const vfloat vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, s.H);
+    vsearch = vzero - reg_chol_solve_v<typename M::D>(w, m, s.H, vgrad, s.H, &h_dinv);
+    }
     DIAL_MARK(w, 6);
 
     // ---- solver._linesearch

@@ -156,6 +156,8 @@ struct Wave {
   // value of lane N of the own row of 16 lanes (DPP row_newbcast on the GPU)
   template <int N>
   vfloat row_bcast(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~15) + N]; return r; }
+  // the lanes where a predicate holds, as a bit mask (GPU: ballot)
+  unsigned long long mask(const vbool& c) const { unsigned long long b = 0; for (int l = 0; l < 64; l++) b |= (unsigned long long)(c.x[l] ? 1 : 0) << l; return b; }
   vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l > k; return r; }
   vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l == k; return r; }
   vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = l < k; return r; }
@@ -405,6 +407,7 @@ struct Wave {
     else __builtin_amdgcn_s_setprio(3);
 #endif
   }
+  __device__ __forceinline__ unsigned long long mask(vbool c) const { return __builtin_amdgcn_ballot_w64(c); }
   __device__ __forceinline__ vbool lane_gt(int k) const { return lane_r > k; }
   __device__ __forceinline__ vbool lane_eq(int k) const { return lane_r == k; }
   __device__ __forceinline__ vbool lane_lt(int k) const { return lane_r < k; }
