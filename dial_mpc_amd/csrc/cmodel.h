@@ -59,6 +59,8 @@ struct RowsOf { static constexpr int maxd = 0, merge_src = -1, merge_dst = -1; s
 template <>
 struct RowsOf<TopoH1> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; static constexpr bool static_root = false; };       // torso: row 2 owns it, row 3 copies it
 template <>
+struct RowsOf<TopoH1PushCrate> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; static constexpr bool static_root = false; };   // (+ the crate: a tree of its own, outside the rows)
+template <>
 struct RowsOf<TopoH1Loco> { static constexpr int maxd = 5, merge_src = 49, merge_dst = 33; static constexpr bool static_root = false; };   // (arms welded: chain members without dofs)
 // Allegro: the free object on its own (body 1), four fingers of four hinges + a welded tip under the palm, which is welded to the world
 template <>
@@ -129,7 +131,14 @@ struct Dims {
 #else
   static constexpr bool rows_stage = !GEN_ && SQUARE_ && RowsOf<Topo_>::maxd > 0;
 #endif
-  static constexpr bool phase_tabs = !quad_stage && !rows_stage;
+  // the row layout under the GENERIC feature set (push crate: the H1's tree in registers; the crate on its slide joint -- a second
+  // tree of one body -- as a one-lane phase; geom frames / collisions / rows generic), M as the packed lower triangle
+#if defined(DIAL_NO_ROWS) || defined(DIAL_NO_ROWS_GEN)
+  static constexpr bool rows_gen = false;
+#else
+  static constexpr bool rows_gen = GEN_ && STATIC && !ELL_ && !SQUARE_ && RowsOf<Topo_>::maxd > 0;
+#endif
+  static constexpr bool phase_tabs = !quad_stage && !rows_stage && !rows_gen;
   // the quadruped register stage WITHOUT its fused foot contacts, for the generic feature set on the Go2's tree (crate climb:
   // 17 geoms, 52 candidate contacts): bodies / dofs in registers, then the generic geom frames, collisions and constraint rows
 #if defined(DIAL_NO_QUAD) || defined(DIAL_NO_QUAD_GEN)
@@ -252,7 +261,7 @@ struct CModel : CModelGeneric<D_> {
   float cmd_vel[3], cmd_ang_vel[3], ramp_up_time, done_height, jump_dt, init_pos_tar[3], init_ang_vel_tar[3];
   float kp[D::NU], kd[D::NU], joint_range[D::NU][2], phys_range[D::NU][2], tau_range[D::NU][2], joint_offset[D::NU];
   // ---- lane layout of the register-resident position / velocity stage (smooth_rows.h), robots that use it
-  typename std::conditional<(!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0), RowTab, RowTabNone>::type rows;
+  typename std::conditional<((!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) || D::rows_gen), RowTab, RowTabNone>::type rows;
 };
 
 // ---- runtime / compile-time dimension accessors
@@ -289,7 +298,11 @@ CM_HD constexpr int dim_nf(const M* m) {
 // Host: the row layout of smooth_rows.h for a model (false: the model is not one tree of hinge / welded bodies under a free
 // root with at most four chains of <= maxd bodies, at most one body shared by two chains (directly below the root), at most two
 // geoms and one site per body, plane-sphere / plane-capsule contacts).
-static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* merge_src, int* merge_dst, bool static_root = false) {
+// extra_trees (the generic feature set's use of the layout): bodies that are roots of their own -- a slide joint on the world, no
+// children, no sites (the push-crate scene's crate) -- stay outside the rows (smooth_rows.h runs them as a one-lane phase); geoms are
+// not assigned to lanes at all (the generic geom phase computes every frame) and any contact kind is allowed.
+static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* merge_src, int* merge_dst, bool static_root = false,
+                              bool extra_trees = false) {
   for (int l = 0; l < 64; l++) { t->body[l] = 0; t->flags[l] = 0; t->dof[l] = 0; t->geom[l][0] = 255; t->geom[l][1] = 255; t->site[l] = 255; }
   *merge_src = -1; *merge_dst = -1;
   if (maxd < 1 || maxd > 7 || m->nbody < 2 || m->nbody > 64) return false;
@@ -346,14 +359,24 @@ static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* mer
   if (m->body_parent[1] != 0 || m->body_jntnum[1] != 1 || m->body_jntadr[1] != 0 || m->jnt_type[0] != DIAL_JNT_FREE ||
       m->jnt_qposadr[0] != 0 || m->jnt_dofadr[0] != 0 || m->body_dofadr[1] != 0 || m->body_rootid[1] != 1)
     return false;
-  for (int b = 2; b < m->nbody; b++) {
+  int nb_tree = m->nbody;   // bodies [1, nb_tree) form the tree under the free root
+  if (extra_trees) {
+    while (nb_tree > 2 && m->body_parent[nb_tree - 1] == 0) {
+      const int b = nb_tree - 1;
+      if (m->body_jntnum[b] != 1 || m->jnt_type[m->body_jntadr[b]] != DIAL_JNT_SLIDE || m->body_rootid[b] != b || m->body_dofnum[b] != 1) return false;
+      nb_tree--;
+    }
+    if (m->nbody - nb_tree > 1) return false;   // (one such body: smooth_rows.h's solo phase)
+    for (int si = 0; si < m->nsite; si++) if (m->site_bodyid[si] >= nb_tree) return false;
+  }
+  for (int b = 2; b < nb_tree; b++) {
     if (m->body_parent[b] < 1 || m->body_rootid[b] != 1 || m->body_jntnum[b] > 1) return false;
     if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] != DIAL_JNT_HINGE) return false;
   }
   int owner[64];
   for (int b = 0; b < 64; b++) owner[b] = -1;
   int row = 0;
-  for (int b = 1; b < m->nbody; b++) {
+  for (int b = 1; b < nb_tree; b++) {
     bool leaf = true;
     for (int c2 = b + 1; c2 < m->nbody; c2++) leaf = leaf && m->body_parent[c2] != b;
     if (!leaf) continue;
@@ -378,7 +401,7 @@ static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* mer
     row++;
   }
   for (int k = 0; k < 6; k++) { t->flags[8 + k] = ROWS_TDOF; t->dof[8 + k] = (uint8_t)k; }
-  for (int g = 0; g < m->ngeom; g++) {
+  for (int g = 0; g < m->ngeom && !extra_trees; g++) {
     const int b = m->geom_bodyid[g], l = b == 0 ? 14 : owner[b];   // lane 14: the world's geoms (identity pose)
     if (l < 0) return false;
     if (t->geom[l][0] == 255) t->geom[l][0] = (uint8_t)g;
@@ -390,7 +413,7 @@ static inline bool rows_build(const dial_model* m, RowTab* t, int maxd, int* mer
     if (b == 0 || owner[b] < 0 || t->site[owner[b]] != 255) return false;
     t->site[owner[b]] = (uint8_t)si;
   }
-  for (int c = 0; c < m->ncon; c++) {
+  for (int c = 0; c < m->ncon && !extra_trees; c++) {
     const int k = m->con_kind[c];
     if (k != DIAL_CON_PLANE_SPHERE && k != DIAL_CON_PLANE_CAPSULE_P && k != DIAL_CON_PLANE_CAPSULE_N) return false;
   }
@@ -447,11 +470,12 @@ static inline bool dims_match(const dial_model* m) {
   }
   if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
   if constexpr (D::quad_gen) ok = ok && quad_tree_fits(m) && quad_gen_fits(m);
-  if constexpr (!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) {   // smooth_rows.h: the layout must come out as compiled
+  if constexpr ((!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) || D::rows_gen) {   // smooth_rows.h: the layout must come out as compiled
     using RT = RowsOf<typename D::Topo>;
     RowTab t;
     int ms, md;
-    ok = ok && rows_build(m, &t, RT::maxd, &ms, &md, RT::static_root) && ms == RT::merge_src && md == RT::merge_dst;
+    ok = ok && rows_build(m, &t, RT::maxd, &ms, &md, RT::static_root, D::rows_gen) && ms == RT::merge_src && md == RT::merge_dst;
+    if constexpr (D::rows_gen) ok = ok && m->nbody == D::NB && m->body_parent[D::NB - 1] == 0 && m->body_rootid[D::NB - 1] == D::NB - 1;   // exactly one solo body, the last
   }
   return ok;
 }

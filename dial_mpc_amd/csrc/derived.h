@@ -242,9 +242,9 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
       if (fits) o.nshared = ns;
     }
   }
-  if constexpr (!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) {
+  if constexpr ((!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) || D::rows_gen) {
     int ms, md;
-    rows_build(m, &o.rows, RowsOf<typename D::Topo>::maxd, &ms, &md, RowsOf<typename D::Topo>::static_root);   // (dims_match<D> has checked that it succeeds)
+    rows_build(m, &o.rows, RowsOf<typename D::Topo>::maxd, &ms, &md, RowsOf<typename D::Topo>::static_root, D::rows_gen);   // (dims_match<D> has checked that it succeeds)
   }
   for (int j = 0; j < m->njnt; j++) {
     o.jnt_type[j] = m->jnt_type[j]; o.jnt_qposadr[j] = m->jnt_qposadr[j]; o.jnt_dofadr[j] = m->jnt_dofadr[j];

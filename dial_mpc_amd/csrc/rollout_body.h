@@ -1124,6 +1124,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
     forward_tail(w, m, s);
     return;
   }
+  if constexpr (kRowsGenDims<typename M::D>) {   // the H1's tree under the generic feature set (push crate): the row layout + the solo crate
+    forward_smooth_rows<true>(w, m, s);
+    w.items(nc, [&](int c) { collide_contact(m, s, c); });
+    forward_tail(w, m, s);
+    return;
+  }
   if constexpr (kRowsDims<typename M::D>) {   // one tree under a free root (H1): the same stage on the row layout (smooth_rows.h)
     forward_smooth_rows(w, m, s);
     w.items(nc, [&](int c) { collide_contact(m, s, c); });

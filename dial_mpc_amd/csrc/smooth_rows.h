@@ -27,11 +27,79 @@ namespace dial {
 
 template <class D>
 inline constexpr bool kRowsDims = D::rows_stage;
+template <class D>
+inline constexpr bool kRowsGenDims = D::rows_gen;
 
-template <class W, class M>
+// A body that is a kinematic tree of its own: one SLIDE joint on the world, no children (the push-crate scene's crate).  One lane,
+// forward()'s formulas for that body alone: pose, subtree centre of mass (its own), cinert, cdof = [0, axis], cvel = cdof qvel,
+// cacc = [0, -g] (no velocity-dependent cdof_dot: the parent is at rest), cfl = cinert cacc + cvel x* (cinert cvel), M = cdof .
+// (cinert cdof) + armature, qfrc_smooth = passive - cdof . cfl + actuator.
+template <class M>
+DIAL_DEV void solo_slide_body(const M* m, const Ws& s, int b) {
+  const int ji = m->body_jntadr[b], qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+  const float lq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+  const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+  float ax[3], pos[3], t3[3], qi[4], R[9], xi[3], cm[3], off[3];
+  dm::rotate(ax, ja, lq);
+  const float disp = s.qpos[qa] - m->qpos0[qa];
+  for (int k = 0; k < 3; k++) pos[k] = m->body_pos[b][k] + ax[k] * disp;
+  const float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
+  const float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+  dm::rotate(t3, ip, lq);
+  dm::quat_mul(qi, lq, iq);
+  dm::quat_to_mat(R, qi);
+  const float mb = m->body_mass[b];
+  for (int k = 0; k < 3; k++) {
+    xi[k] = pos[k] + t3[k];
+    cm[k] = mb < MJ_MINVAL ? xi[k] : (xi[k] * mb) / mb;   // smooth.com_pos of a one-body tree
+    off[k] = xi[k] - cm[k];
+  }
+  float ci[10];
+  {
+    const float oo = dm::dot3(off, off);
+    const float in0 = m->body_inertia[b][0], in1 = m->body_inertia[b][1], in2 = m->body_inertia[b][2];
+    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+    for (int e = 0; e < 6; e++) {
+      const int i = ii[e], j = jj[e];
+      const float v = R[3 * i] * in0 * R[3 * j] + R[3 * i + 1] * in1 * R[3 * j + 1] + R[3 * i + 2] * in2 * R[3 * j + 2];
+      const float hh = (i == j ? oo : 0.f) - off[i] * off[j];
+      ci[e] = v + hh * mb;
+    }
+    for (int k = 0; k < 3; k++) ci[6 + k] = off[k] * mb;
+    ci[9] = mb;
+  }
+  const float qv = s.qvel[da];
+  const float cd[6] = {0.f, 0.f, 0.f, ax[0], ax[1], ax[2]};
+  float cv[6], ca[6], f1[6], f2[6], f3[6], fd[6];
+  for (int k = 0; k < 6; k++) { cv[k] = cd[k] * qv; ca[k] = k >= 3 ? -m->gravity[k - 3] : 0.f; }
+  dm::inert_mul(f1, ci, ca);
+  dm::inert_mul(f2, ci, cv);
+  dm::motion_cross_force(f3, cv, f2);
+  dm::inert_mul(fd, ci, cd);
+  float mdd = 0.f, bias = 0.f;
+  for (int k = 0; k < 6; k++) { mdd += fd[k] * cd[k]; bias += cd[k] * (f1[k] + f3[k]); }
+  const float passive = -m->dof_damping[da] * qv;
+  const int a = m->dof_act[da], aa = a >= 0 ? a : 0;
+  const float c0 = s.ctrl[aa];
+  const float c = m->act_ctrllimited[aa] ? dm::clip(c0, m->act_ctrlrange[aa][0], m->act_ctrlrange[aa][1]) : c0;
+  const float force = m->act_isposition[aa] ? m->act_kp[aa] * (c - s.qpos[m->act_qposadr[aa]]) : c;
+  const float qf = passive - bias + (a >= 0 ? m->act_gear[aa] * force : 0.f);
+  for (int k = 0; k < 3; k++) { s.xpos[3 * b + k] = pos[k]; s.com[3 * m->body_rootid[b] + k] = cm[k]; }
+  for (int k = 0; k < 4; k++) s.xquat[4 * b + k] = lq[k];
+  for (int k = 0; k < 6; k++) { s.cvel[6 * b + k] = cv[k]; s.cdof[6 * da + k] = cd[k]; }
+  s.qfs[da] = qf;
+  s.rhs[da] = qf;
+  s.M[tri_idx(da, da)] = mdd + m->dof_armature[da];
+}
+
+// GEN (Dims::rows_gen, the generic feature set on the layout -- push crate): M as the packed lower triangle, no geoms in the lanes
+// (every geom frame comes out of one LDS phase at the end, from the stored poses), the solo slide body on lane 15 of the dofs'
+// output phase; collisions / Jacobians / rows stay the generic feature set's.
+template <bool GEN = false, class W, class M>
 DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
   using RT = RowsOf<typename M::D::Topo>;
   constexpr int S = M::D::S, MAXD = RT::maxd;
+  static_assert(GEN != M::D::square, "square layout: the robots' own instantiations; packed M: the generic feature set");
   constexpr bool SR = RT::static_root;      // chains under a welded root, the free body on its own lane
   constexpr int FREE = SR ? 15 : 0;         // the lane whose pose / velocity are the free body's
   static_assert(MAXD >= 1 && MAXD <= 7, "chains of at most 7 bodies below the root (three scan rounds; lanes 8..13 = root dofs)");
@@ -123,6 +191,8 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       for (int k = 0; k < 9; k++) o[3 + k] = mat[k];
       o[15] = owner ? mass : 0.f;
       for (int e = 0; e < 2; e++) {
+        if constexpr (GEN) { for (int k = 0; k < 6; k++) o[19 + 6 * e + k] = 0.f; }
+        else {
         const int g = m->rows.geom[l][e] == 255 ? 0 : m->rows.geom[l][e];
         const float gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]};
         const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
@@ -132,6 +202,7 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
         dm::quat_to_mat(gm, qg);
         for (int k = 0; k < 3; k++) o[19 + 6 * e + k] = p[k] + tg[k];
         o[22 + 6 * e] = gm[2]; o[23 + 6 * e] = gm[5]; o[24 + 6 * e] = gm[8];
+        }
       }
     });
     DIAL_UNROLL_FULL
@@ -274,6 +345,9 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       const int si = m->rows.site[l];
       if (si != 255) for (int k = 0; k < 3; k++) s.spos[3 * si + k] = lane_val(G[k], l);
     }
+    if constexpr (GEN) {   // packed M: the structural zeros (the dof lanes below write the tree's entries only)
+      for (int e = l; e < M::D::NTRI; e += 64) s.M[e] = 0.f;
+    } else
     for (int e = 0; e < 2; e++) {
       const int g = m->rows.geom[l][e];
       if (g != 255) for (int k = 0; k < 3; k++) { s.gpos[3 * g + k] = lane_val(G[3 + 6 * e + k], l); s.gaxis[3 * g + k] = lane_val(G[6 + 6 * e + k], l); }
@@ -394,6 +468,7 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
       const float qf = lane_val(MO[7], l);
       s.qfs[i] = qf;
       s.rhs[i] = qf;
+      if constexpr (!GEN) {
       if (tdof || !SR) {   // (under a welded root the chains have no root-dof columns: structural zeros)
         for (int j = 0; j < 6; j++) {
           if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
@@ -407,8 +482,38 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
           if (d - k >= 1 && ja >= 0.f) { const int j = (int)ja; const float v = lane_val(MA[k], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
         });
       }
+      } else {   // packed lower triangle (an ancestor's dof index is smaller than the own)
+        (void)S;
+        for (int j = 0; j < 6; j++) {
+          if (j <= i) s.M[tri_idx(i, j)] = lane_val(MO[j], l);
+        }
+        if (hinge) {
+          s.M[tri_idx(i, i)] = lane_val(MO[6], l);
+          static_for<1, MAXD>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            const float ja = lane_val(AD[k], l);
+            if (d - k >= 1 && ja >= 0.f) s.M[tri_idx(i, (int)ja)] = lane_val(MA[k], l);
+          });
+        }
+      }
     }
+    if constexpr (GEN) { if (l == 15) solo_slide_body(m, s, M::D::NB - 1); }
   });
+  if constexpr (GEN) {
+    // ---- local_to_global for the geoms (forward(): the geom items of its frames phase), from the poses stored above
+    w.items(M::D::NG, [&](int g) {
+      const int b = m->geom_bodyid[g];
+      const float q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      const float gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]};
+      const float gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
+      float t3[3], qg[4], mat[9];
+      dm::rotate(t3, gp, q);
+      for (int k = 0; k < 3; k++) s.gpos[3 * g + k] = s.xpos[3 * b + k] + t3[k];
+      dm::quat_mul(qg, q, gq);
+      dm::quat_to_mat(mat, qg);
+      s.gaxis[3 * g] = mat[2]; s.gaxis[3 * g + 1] = mat[5]; s.gaxis[3 * g + 2] = mat[8];
+    });
+  }
 #if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
   w.lane = lane_keep;
 #endif

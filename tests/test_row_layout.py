@@ -67,3 +67,16 @@ def test_crate_climb_runs_the_quadruped_stage_and_another_site_layout_falls_back
     got2, err2 = _rollout_err("unitree_go2_crate_climb", m2, task, cfg, env)
     assert got2 == 0, got2
     assert max(err2.values()) <= 1.0, err2
+
+
+def test_push_crate_runs_the_row_layout_and_a_site_on_the_crate_falls_back():
+    """The generic feature set on the H1's tree (push crate, Dims::rows_gen): the row layout for the robot, the crate -- a slide
+    joint on the world, a tree of its own -- as a one-lane phase (smooth_rows.h: solo_slide_body), geom frames / collisions / rows
+    generic.  rows_build(extra_trees) inside dims_match; a site on the crate does not fit -> capacity-dimension instantiation."""
+    dc, env, model, task, cfg = setup_case("unitree_h1_push_crate", 8, 8, per_rollout=True)
+    got, err = _rollout_err("unitree_h1_push_crate", model, task, cfg, env)
+    assert got == 6, got
+    assert max(err.values()) <= 1.0, err
+    m2 = type(model).from_buffer_copy(model)
+    m2.site_bodyid[2] = model.nbody - 1
+    assert emu_lib.Emu(m2, task, cfg).sizes()[0] == 0
