@@ -138,7 +138,6 @@ struct Dims {
 #else
   static constexpr bool rows_gen = GEN_ && STATIC && !ELL_ && !SQUARE_ && RowsOf<Topo_>::maxd > 0;
 #endif
-  static constexpr bool phase_tabs = !quad_stage && !rows_stage && !rows_gen;
   // the quadruped register stage WITHOUT its fused foot contacts, for the generic feature set on the Go2's tree (crate climb:
   // 17 geoms, 52 candidate contacts): bodies / dofs in registers, then the generic geom frames, collisions and constraint rows
 #if defined(DIAL_NO_QUAD) || defined(DIAL_NO_QUAD_GEN)
@@ -146,6 +145,7 @@ struct Dims {
 #else
   static constexpr bool quad_gen = GEN_ && STATIC && !ELL_ && !SQUARE_ && std::is_same<Topo_, TopoGo2>::value;
 #endif
+  static constexpr bool phase_tabs = !quad_stage && !rows_stage && !rows_gen && !quad_gen;
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;

@@ -257,6 +257,7 @@ struct dial_ctx {
   int* err_host = nullptr;     // sticky error word: pinned host memory the kernels can write (relay time-out) ...
   int* err_dev = nullptr;      // ... and its device-side address
   bool relay_ok = false, relay_always = false;
+  bool no_spread = false;        // options: batches below the large-batch kernel's resident set fill workgroup after workgroup
   bool no_mean_inline = false;   // options: the mean trajectory of a large Go2 batch as an ordinary queue item
   // Allegro split launch (see DIAL_ALLEGRO_WPB_EVEN)
   hipStream_t side = nullptr;
@@ -538,6 +539,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     ctx->relay_ok = ctx->wpb == 1 && !opt.no_relay;
     ctx->relay_always = opt.relay_always != 0;
     ctx->no_mean_inline = opt.no_mean_inline != 0;
+    ctx->no_spread = opt.no_spread != 0;
     ctx->wpb_even = ctx->inst == 4 ? DIAL_ALLEGRO_WPB_EVEN : ctx->inst == 2 ? DIAL_H1_WPB_EVEN : 0;
     if ((opt.no_split_mask >> ctx->inst) & 1) ctx->wpb_even = 0;
     if (ctx->wpb_even > 0) {
@@ -704,6 +706,12 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
     }
   }
   int blocks = io.relay_flag ? io.relay_base + (ctx->T + io.relay_steps - 1) / io.relay_steps : (B + wpb - 1) / wpb;
+  // Go2's large-batch kernel below its resident set (2304 < B <= 4096): the whole resident grid is launched and the rollouts are
+  // dealt round-robin over the workgroups, so that every CU carries the same number of wavefronts
+  if (large && !io.relay_flag && resident > 0 && blocks <= resident && B > resident && !ctx->no_spread) {
+    blocks = resident;
+    io.spread = 1;
+  }
   int* next = nullptr;
   const bool has_queue_variant = large || ctx->inst != 1;   // Go2's small-batch kernel never exceeds the resident set (B <= DIAL_GO2_LARGE_B)
   if (has_queue_variant && resident > 0 && blocks > resident && ctx->next && !tracing) {

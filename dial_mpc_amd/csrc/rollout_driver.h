@@ -60,6 +60,7 @@ struct RolloutIO {
   // runs control step q of it between its own steps q and q + 1 (state handed on through relay_buf / relay_flag, T hand-overs
   // per launch), so that no wavefront slot runs two whole rollouts one after the other -- see rollout_sample
   int mean_inline;
+  int spread;   // rollout_kernel.h: the spread launch (rollout index = wavefront-in-workgroup x grid + workgroup)
 };
 
 template <class W, class M>

@@ -49,6 +49,12 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   if constexpr (D::gen)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
     s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
   int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
+  // spread launch (a batch that fits the resident grid of multi-wavefront workgroups without filling it): wavefront w of workgroup b
+  // runs rollout w x gridDim + b, so that EVERY workgroup -- every CU -- carries ceil(B / gridDim) rollouts instead of the first
+  // B / WPB workgroups being full and the rest empty (Go2, N = 3000 in workgroups of 8: 119 CUs with 16 wavefronts, 137 with 8)
+  if constexpr (WPB > 1 && QUEUE) {
+    if (io.spread) n = (int)(threadIdx.x >> 6) * (int)gridDim.x + (int)blockIdx.x + io.n_first;
+  }
   int relay = -1;
   if constexpr (WPB == 1 && !QUEUE) {
     if (io.relay_flag && (int)blockIdx.x >= io.relay_base) { relay = (int)blockIdx.x - io.relay_base; n = B - 1; }

@@ -336,6 +336,9 @@ typedef struct dial_options {
   int32_t no_mean_inline;     /* 1: Go2 batches beyond the resident set run the mean trajectory as an ordinary queue item (the
                                  last one: alone at the lone-wavefront pace) instead of interleaving its steps with the first
                                  T wavefronts' own                                                                          */
+  int32_t no_spread;          /* 1: a Go2 batch between the small-batch limit and the large-batch kernel's resident set fills
+                                 workgroup after workgroup (some CUs with 16 wavefronts, some with 8) instead of being dealt
+                                 round-robin over the whole resident grid                                                     */
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for

@@ -575,6 +575,33 @@ def test_time_sliced_queue_is_bit_identical(example, N, H):
 
 
 
+@pytest.mark.parametrize("N", [2400, 3000, 4095])
+def test_spread_launch_is_bit_identical(N):
+    """Go2 batches between the small-batch limit (2304 rollouts) and the large-batch kernel's resident set (4096): the whole
+    resident grid is launched and the rollouts are dealt round-robin over the workgroups (rollout_kernel.h: spread) so that every CU
+    carries the same number of wavefronts -- same results as filling workgroup after workgroup (dial_options.no_spread)."""
+    import torch
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case("unitree_go2_trot", N, 7)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=5, Ybar_scale=0.2)
+    outs, s0 = [], None
+    for opts in (dict(), dict(no_spread=1)):
+        ctx = _lib.Context(model, task, cfg, options=opts)
+        assert ctx.lib.dial_debug_resident_rollouts(ctx.h, N + 1) >= N + 1            # everything resident: no queue
+        if s0 is None:
+            s0, _, _ = ctx.env_reset(_dev(env._init_q), _dev(np.zeros(model.nv)))
+        out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+        torch.cuda.synchronize()
+        ctx.status()
+        sc = ctx.debug_scratch()
+        outs.append(({k: out[k].clone() for k in ("Ybar", "rews", "qbar", "xbar")}, {k: np.array(sc[k]) for k in ("rewss", "qss", "qdss", "xss", "Y0s")}))
+    assert np.isfinite(outs[0][1]["rewss"]).all()
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
 @pytest.mark.parametrize("example,N,H", [("unitree_go2_trot", 2048, 16), ("unitree_go2_seq_jump", 1024, 20), ("unitree_go2_trot", 100, 7)])
 def test_mean_trajectory_relay_is_bit_identical(example, N, H):
     """The mean-trajectory rollout cut into pieces that different wavefronts run one after the other (state handed over
