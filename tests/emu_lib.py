@@ -14,24 +14,26 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_HERE, "libwave_emu.so")
 
 
-def build():
+def build(defines=(), tag=""):
+    """defines / tag: a VARIANT of the emulator (e.g. ("-DDIAL_NO_FACTOR_REUSE",), "_noreuse") next to the default one."""
+    so = _SO if not tag else _SO.replace(".so", f"{tag}.so")
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     srcs.append(_abi.HEADER)
-    if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(f) for f in srcs):
-        return
-    tmp = f"{_SO}.{os.getpid()}.tmp"     # atomic: parallel test workers may all find the library stale at once
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(f) for f in srcs):
+        return so
+    tmp = f"{so}.{os.getpid()}.tmp"     # atomic: parallel test workers may all find the library stale at once
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fno-strict-aliasing",
-                           "-ffp-contract=off", "-o", tmp, os.path.join(_HERE, "emu.cpp")])
-    os.replace(tmp, _SO)
+                           "-ffp-contract=off", *defines, "-o", tmp, os.path.join(_HERE, "emu.cpp")])
+    os.replace(tmp, so)
+    return so
 
 
 class Emu:
-    def __init__(self, model, task, cfg=None, path=0):
+    def __init__(self, model, task, cfg=None, path=0, defines=(), tag=""):
         """path 0: dimension-specialised instantiation when the model matches one (like the HIP library);
-        path 1: force the generic instantiation."""
-        build()
+        path 1: force the generic instantiation.  defines / tag: a variant build of the emulator (see build)."""
         self.path = int(path)
-        self.lib = ctypes.CDLL(_SO)
+        self.lib = ctypes.CDLL(build(defines, tag))
         self.model, self.task, self.cfg = model, task, cfg
         self.nq, self.nv, self.nu, self.nbody = model.nq, model.nv, model.nu, model.nbody
         self.nx = (model.nbody - 1) * 3

@@ -179,3 +179,25 @@ def test_emulated_kernel_randomize_tasks_across_the_500_step_boundary(example):
     # steps 494 .. 499 use the default command in both runs; step 500 (index 6) is the redraw
     assert np.array_equal(outs[True][:, :6], outs[False][:, :6])
     assert np.all(np.abs(outs[True][:, 6] - outs[False][:, 6]) > 1e-4)
+
+
+@pytest.mark.parametrize("example", ["unitree_go2_trot", "unitree_h1_jog"])
+def test_factor_reuse_is_bit_identical_to_a_second_factorisation(example):
+    """solver_reg.h: when the second Newton iteration finds the active set of the first, H is the same matrix and the factor
+    the first solve left in LDS is used again (unit columns re-read, same forward substitution).  The claim is "bit for bit
+    what a second factorisation gives": the emulated kernel built with -DDIAL_NO_FACTOR_REUSE (always assembles and
+    factorises) must produce IDENTICAL rollouts, from the rest pose and from perturbed states, under both line-search rules."""
+    for per_rollout in (True, False):
+        dc, env, model, task, cfg = setup_case(example, 8, 10, per_rollout=per_rollout)
+        emu = emu_lib.Emu(model, task, cfg)
+        ref = emu_lib.Emu(model, task, cfg, defines=("-DDIAL_NO_FACTOR_REUSE",), tag="_noreuse")
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        rng = np.random.default_rng(3)
+        for seed in range(3):
+            q, qd = perturbed_state(env, seed) if seed else (env._init_q, np.zeros(model.nv))
+            s0, _, _ = o32.env_reset(q, qd)
+            us = rng.uniform(-0.8, 0.8, (8, 11, model.nu)).astype(np.float32)
+            a = emu.rollout(s0, us, check_races=False)
+            b = ref.rollout(s0, us, check_races=False)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
