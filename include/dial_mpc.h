@@ -276,7 +276,10 @@ typedef struct dial_task {
   /* crate climb (unitree_go2_env.py:741-766): reward_contact counts the feet whose contact with the crate lies inside
    * the box `crate_region` = (x0, x1, y0, y1, z0, z1) -- upstream's cond on contact.pos[contact_indices[i]].  Upstream
    * hard-codes the indices [16, 17, 18, 19] of ITS MJX release's contact array; here the env class looks the four
-   * foot-sphere / crate contacts up by geom identity (`crate_contact`, indices into this model's static contact list). */
+   * foot-sphere / crate contacts up by geom identity (`crate_contact`, indices into this model's static contact list).
+   * The device evaluates the four terms of :770-783 that carry a non-zero weight (head position, upright, yaw, feet on the
+   * crate); the seven others (pitch, roll, vel, ang_vel, height, energy, penalty_contact) are multiplied by 0.0 upstream and
+   * are not computed: identical rewards as long as they are finite, which the oracle -- it restates all eleven -- checks. */
   int32_t crate_contact[DIAL_MAX_FEET];
   float crate_region[6];
   float head_vec[3];           /* head_pos = torso pos + R head_vec (:717-718)                                         */
