@@ -76,6 +76,16 @@ DIAL_DEV void plane_box(const float* n, const float* ppos, const BoxG& b, int su
   const float rel[3] = {b.c[0] - ppos[0], b.c[1] - ppos[1], b.c[2] - ppos[2]};
   const float base = dm::dot3(rel, n);
   for (int k = 0; k < 3; k++) e[k] = b.h[k] * dm::dot3(n, ax[k]);
+  {   // broad phase: the LOWEST vertex more than 1 cm above the plane -- all four candidates parked (dist >= margin: no rows; nothing
+      // reads the position of a box-plane contact that does not touch).  The trunk over the floor: every step of a standing robot.
+    const float lowest = base - (dm::absf(e[0]) + dm::absf(e[1]) + dm::absf(e[2]));
+    if (lowest > 0.01f) {
+      dist = lowest;
+      for (int k = 0; k < 3; k++) pos[k] = b.c[k];
+      make_frame(fr, n);
+      return;
+    }
+  }
   float hv[8];
   DIAL_UNROLL_FULL
   for (int i = 0; i < 8; i++) hv[i] = base + ((i & 1) ? e[0] : -e[0]) + ((i & 2) ? e[1] : -e[1]) + ((i & 4) ? e[2] : -e[2]);
@@ -166,6 +176,22 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
   for (int k = 0; k < 3; k++) { e0[k] = ctr[k] - axis[k] * hl; e1[k] = ctr[k] + axis[k] * hl; r0[k] = e0[k] - b.c[k]; r1[k] = e1[k] - b.c[k]; }
   dm::inv_rotate(l0, r0, b.q);
   dm::inv_rotate(l1, r1, b.q);
+  {   // second broad phase, in the box's frame: the capsule more than 1 cm outside one of the box's three slabs (a separating
+      // FACE axis: the true distance is at least that gap).  The bounding spheres above overlap whenever the robot stands next to
+      // the box; the slabs separate all but the capsules that are about to touch.
+    float sep = -1.f;
+    for (int k = 0; k < 3; k++) {
+      const float lo = dm::fminf_(l0[k], l1[k]) - r, hi = dm::fmaxf_(l0[k], l1[k]) + r;
+      sep = dm::fmaxf_(sep, dm::fmaxf_(lo - b.h[k], -b.h[k] - hi));
+    }
+    if (sep > 0.01f) {
+      dist = sub == 0 ? sep : 1.f;
+      for (int k = 0; k < 3; k++) pos[k] = 0.5f * (ctr[k] + b.c[k]);
+      const float tw[3] = {b.c[0] - ctr[0], b.c[1] - ctr[1], b.c[2] - ctr[2]};
+      make_frame(fr, tw);
+      return;
+    }
+  }
   // interior stretch [ta, tb] of the axis (intersection of the three slabs) and the slabs that bound it
   float ta = 0.f, tb = 1.f;
   int ka = -1, kb = -1;
@@ -232,6 +258,15 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
     const float tb = t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j];
     const float sep = dm::absf(tb) - (B.h[j] + A.h[0] * Q[0][j] + A.h[1] * Q[1][j] + A.h[2] * Q[2][j]);
     if (sep > sbest) { best = 3 + j; sbest = sep; }
+  }
+  // second broad phase: a FACE axis separates the boxes by more than 1 cm (the true distance is at least that): all candidates
+  // parked before the nine edge axes and the clipping.  The bounding spheres above overlap whenever the robot is near the crate
+  // (its half-diagonal is 0.63 m); the trunk over the crate's top face, or the torso beside it, is separated on a face axis.
+  if (sbest > 0.01f) {
+    dist = sub == 0 ? sbest : 1.f;
+    for (int k = 0; k < 3; k++) pos[k] = 0.5f * (A.c[k] + B.c[k]);
+    make_frame(fr, tw);
+    return;
   }
   float nedge[3] = {0.f, 0.f, 0.f};       // world direction of the winning edge axis
   DIAL_UNROLL_FULL

@@ -264,8 +264,9 @@ def test_kernel_narrow_phase_matches_the_oracle(kind, nsub):
             do, po, fo = o32.box_contact(kind, sub, (c1, _q2m(q1), size1), (c2, R2, h2))
             de, pe, fe = emu.box_contact(kind, sub, (c1, q1, size1), (c2, q2, h2))
             same = abs(do - de) < 2e-5 and np.allclose(fo[0], fe[0], atol=2e-4) and (do > 0.5 or np.allclose(po, pe, atol=2e-5))
-            if kind == KIND_CAPSULE_BOX and do > 0.01 and de > 0.01:
-                same = True     # the kernel's broad phase parks candidates whose bounding spheres are > 1 cm apart (no rows either way)
+            if kind != KIND_SPHERE_BOX and do > 0.01 and de > 0.01:
+                same = True     # the kernel's broad phases (bounding spheres, then a separating face axis / slab / lowest vertex) park candidates
+                                # that are > 1 cm apart: no rows either way, and nothing reads the position of a contact that does not touch
             if not same:
                 ties += 1
     assert ties <= n * nsub * 0.01, (kind, ties)
