@@ -217,6 +217,8 @@ DIAL_DEV void make_frame(float* fr, const float* a_in) {
 #include "solver_cone.h"
 #include "smooth_quad.h"
 #include "smooth_rows.h"
+#include "solver_reg2.h"
+#include "smooth_quad2.h"
 namespace dial {
 
 // Generic instantiation: x = A^-1 rhs for the packed SPD matrix A (M or H) with the register-resident L D L^T of
@@ -452,7 +454,10 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
-  if constexpr (!M::D::gen) {
+  if constexpr (W::half2) {   // two samples per wavefront: the 32-lane solver (solver_reg2.h)
+    const vfloat vq = reg_chol_solve2<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
+    w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
+  } else if constexpr (!M::D::gen) {
     const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
@@ -467,7 +472,10 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
     w.items(nv, [&](int i) { s.qacc[i] = s.qas[i]; });
     return;
   }
-  if constexpr (M::D::ell) {
+  if constexpr (W::half2) {
+    solver_reg2(w, m, s);
+    return;
+  } else if constexpr (M::D::ell) {
     solver_cone(w, m, s);  // elliptic cones: per-contact Newton solver (solver_cone.h)
     return;
   } else if constexpr (!M::D::gen) {
@@ -1113,6 +1121,12 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   const int ne = dim_ne(m), nl = dim_nl(m), ntri = m->ntri;   // ntri: structurally non-zero entries of M / H
   int nca = nc, nea = ne;   // contacts / rows the constraint section works on (generic instantiation: the touching ones)
 
+  if constexpr (W::half2) {   // two samples per wavefront (wave.h: WaveH): the quadruped stage on 32 lanes (smooth_quad2.h)
+    static_assert(kQuadDims<typename M::D>, "the half-wave kernel exists for the Go2's own instantiation");
+    forward_smooth_quad2(w, m, s);
+    forward_constraints(w, m, s, nca, nea);
+    return;
+  } else
   if constexpr (kQuadDims<typename M::D>) {   // quadruped topology: the whole position / velocity stage in registers (smooth_quad.h)
     forward_smooth_quad(w, m, s);
     forward_constraints(w, m, s, nca, nea);
@@ -2089,6 +2103,7 @@ DIAL_DEV void init_square(W& w, const M* m, const Ws& s) {
   (void)m;
   if constexpr (M::D::square) w.items(M::D::NV * M::D::S, [&](int e) { s.M[e] = 0.f; });
   if constexpr (kQuadDims<typename M::D>) init_quad(w, m, s);
+  if constexpr (W::half2) init_quad2(w, m, s);
   if constexpr (kQuadGenDims<typename M::D>) init_quad_gen(w, m, s);
 }
 

@@ -1,0 +1,442 @@
+// smooth_quad2.h -- the quadruped position / velocity stage of smooth_quad.h on 32 LANES, for the kernel that runs TWO samples
+// per wavefront (wave.h: WaveH -- every 32-lane half owns one sample).
+//
+// smooth_quad.h gives every leg a DPP row of 16 lanes and uses 10 of them; here a leg is a group of EIGHT lanes, two legs per row:
+//
+//   lane 8 g + d  (g = leg):  d = 0      the trunk (every group keeps its own copy; only lane 0 stores / counts it)
+//                             d = 1..3   hip, thigh, calf of leg g  (body 3 g + d + 1, dof 3 g + d + 5)
+//                             d = 4..6   the trunk's ROTATIONAL dof d - 1 against leg g's foot contact (Jacobian entries);
+//                                        in group 0 also row d - 1 of M and of qfrc_smooth
+//                             d = 7      (g < 3) the trunk's TRANSLATIONAL dof g: row g of M and of qfrc_smooth
+//
+// "My parent" is still the lane below (row_shr:1), "my child" the lane above (row_shl:1); the sweeps never cross a group (the
+// lane that would read across is a trunk copy, which keeps its own value).  The translational trunk dofs' Jacobian entries
+// against the four plane-sphere contacts are CONSTANTS (cdof = [0, e_k]: the frame's k-th column, times mu): written once per
+// kernel (init_quad2) instead of by six lanes per leg and step.  Everything else is the same arithmetic in the same order as
+// smooth_quad.h -- sums over the four legs associate as (leg 0 + leg 1) + (leg 2 + leg 3) in both layouts -- so the two stages
+// agree BIT FOR BIT (tests/test_half_wave.py compares them on the emulator, the GPU test on the device).
+#pragma once
+#include "derived.h"
+#include "dmath.h"
+
+namespace dial {
+
+template <class W, class M>
+DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
+  constexpr int S = M::D::S;
+  static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "the Go2's own scene");
+  static_assert(W::half2, "32-lane layout: the half-wave execution model");
+  // lane roles (functions of the logical lane id)
+  //   leg:  d in 1..3      rot: d in 4..6 (trunk dof d - 1)      tr: d == 7 && g < 3 (trunk dof g)
+  //   mrow: the lanes that own a row of M / an entry of qfrc_smooth for a trunk dof: rot of group 0, tr
+  // ---- smooth.kinematics: local transforms (leg lanes), absolute pose (trunk lanes)
+  vfloat PL[14];   // [0..7): world pose pos(3) quat(4); [7..14): leg lanes' transform relative to the parent l_p(3) l_q(4)
+  w.per_lane_n(PL, [&](int l, float* o) {
+    const int d = l & 7, g = l >> 3;
+    const bool leg = d >= 1 && d <= 3;
+    const int b = leg ? 3 * g + d + 1 : 1, ji = b - 1, qa = leg ? b + 5 : 7;
+    float tq[4] = {s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+    dm::normalize4(tq);
+    const int bflags = m->body_flags[b];
+    float lq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+    float lp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
+    const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+    const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+    float qloc[4], qb[4], t0[3], t1[3];
+    dm::axis_angle_to_quat(qloc, ja, s.qpos[qa] - m->qpos0[qa]);
+    if (bflags & 1) { qb[0] = qloc[0]; qb[1] = qloc[1]; qb[2] = qloc[2]; qb[3] = qloc[3]; }
+    else dm::quat_mul(qb, lq, qloc);
+    if (!(bflags & 2)) {
+      if (bflags & 1) { t0[0] = jp[0]; t0[1] = jp[1]; t0[2] = jp[2]; }
+      else dm::rotate(t0, jp, lq);
+      dm::rotate(t1, jp, qb);
+      for (int k = 0; k < 3; k++) lp[k] += t0[k] - t1[k];
+    }
+    for (int k = 0; k < 3; k++) { o[k] = leg ? 0.f : s.qpos[k]; o[7 + k] = lp[k]; }
+    for (int k = 0; k < 4; k++) { o[3 + k] = leg ? (k == 0 ? 1.f : 0.f) : tq[k]; o[10 + k] = qb[k]; }
+  });
+  // root-to-leaf: a lane at depth d is final after round d (its parent, the lane below, after round d - 1)
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 3; it++) {
+    vfloat Q[7], N[7];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 7; k++) Q[k] = w.template row_shr<1>(PL[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const int d = l & 7;
+      const bool leg = d >= 1 && d <= 3;
+      const float pp[3] = {lane_val(Q[0], l), lane_val(Q[1], l), lane_val(Q[2], l)};
+      const float pq[4] = {lane_val(Q[3], l), lane_val(Q[4], l), lane_val(Q[5], l), lane_val(Q[6], l)};
+      const float lp[3] = {lane_val(PL[7], l), lane_val(PL[8], l), lane_val(PL[9], l)};
+      const float lq[4] = {lane_val(PL[10], l), lane_val(PL[11], l), lane_val(PL[12], l), lane_val(PL[13], l)};
+      float pos[3], quat[4];
+      dm::rotate(pos, lp, pq);
+      for (int k = 0; k < 3; k++) pos[k] += pp[k];
+      dm::quat_mul(quat, pq, lq);
+      for (int k = 0; k < 3; k++) o[k] = leg ? pos[k] : lane_val(PL[k], l);
+      for (int k = 0; k < 4; k++) o[3 + k] = leg ? quat[k] : lane_val(PL[3 + k], l);
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 7; k++) PL[k] = N[k];
+  }
+  // ---- local_to_global: inertial frames (all bodies), the foot geom and site (calf lanes), the trunk's site (trunk lanes)
+  vfloat F[22];   // xipos(3) ximat(9) | mass-weighted xipos(3), mass | site(3) | foot geom centre(3)
+  w.per_lane_n(F, [&](int l, float* o) {
+    const int d = l & 7, g = l >> 3;
+    const bool leg = d >= 1 && d <= 3, counted = leg || l == 0;
+    const int b = leg ? 3 * g + d + 1 : 1, gs = d == 3 ? 1 + g : 0;
+    const float p[3] = {lane_val(PL[0], l), lane_val(PL[1], l), lane_val(PL[2], l)};
+    const float q[4] = {lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l)};
+    const float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
+    const float iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+    const float sp[3] = {m->site_pos[gs][0], m->site_pos[gs][1], m->site_pos[gs][2]};
+    const float mass = m->body_mass[b];
+    float t3[3], qi[4], mat[9], ts[3], tg[3];
+    dm::rotate(t3, ip, q);
+    dm::quat_mul(qi, q, iq);
+    dm::quat_to_mat(mat, qi);
+    dm::rotate(ts, sp, q);
+    const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
+    dm::rotate(tg, gp, q);
+    for (int k = 0; k < 3; k++) {
+      const float xi = p[k] + t3[k];
+      o[k] = xi;
+      o[12 + k] = counted ? xi * mass : 0.f;
+      o[16 + k] = p[k] + ts[k];
+      o[19 + k] = p[k] + tg[k];
+    }
+    for (int k = 0; k < 9; k++) o[3 + k] = mat[k];
+    o[15] = counted ? mass : 0.f;
+  });
+  // ---- smooth.com_pos: one reduction over the half (the 13 bodies form one kinematic tree)
+  float com[3];
+  {
+    vfloat c4[4] = {F[12], F[13], F[14], F[15]};
+    float r4[4];
+    w.vsumN(c4, r4);
+    for (int k = 0; k < 3; k++) com[k] = r4[3] < MJ_MINVAL ? w.template bc<0>(F[k]) : r4[k] / r4[3];
+  }
+  // the trunk's pose, rotation matrix and rotational cdofs: the same value in every lane of the half
+  const float tpos[3] = {w.template bc<0>(PL[0]), w.template bc<0>(PL[1]), w.template bc<0>(PL[2])};
+  const float tquat[4] = {w.template bc<0>(PL[3]), w.template bc<0>(PL[4]), w.template bc<0>(PL[5]), w.template bc<0>(PL[6])};
+  float Rt[9], cdT[3][6];
+  dm::quat_to_mat(Rt, tquat);
+  const float offt[3] = {com[0] - tpos[0], com[1] - tpos[1], com[2] - tpos[2]};
+  for (int i = 0; i < 3; i++) {
+    const float a[3] = {Rt[i], Rt[3 + i], Rt[6 + i]};
+    float cr[3];
+    dm::cross3(cr, a, offt);
+    for (int k = 0; k < 3; k++) { cdT[i][k] = a[k]; cdT[i][3 + k] = cr[k]; }
+  }
+  // ---- cinert (body lanes) and cdof (dof lanes)
+  vfloat X[16];   // cinert(10) | local force cfl(6): the quantities summed over subtrees
+  vfloat CD[6];
+  {
+    vfloat T[16];
+    w.per_lane_n(T, [&](int l, float* o) {
+      const int d = l & 7, g = l >> 3;
+      const bool leg = d >= 1 && d <= 3, body = d <= 3, rot = d >= 4 && d <= 6, tr = d == 7 && g < 3, tdof = rot || tr;
+      const int b = leg ? 3 * g + d + 1 : 1, ji = b - 1, kd = rot ? d - 1 : (tr ? g : 3);
+      const float R[9] = {lane_val(F[3], l), lane_val(F[4], l), lane_val(F[5], l), lane_val(F[6], l), lane_val(F[7], l),
+                          lane_val(F[8], l), lane_val(F[9], l), lane_val(F[10], l), lane_val(F[11], l)};
+      const float off[3] = {lane_val(F[0], l) - com[0], lane_val(F[1], l) - com[1], lane_val(F[2], l) - com[2]};
+      const float mb = m->body_mass[b], oo = dm::dot3(off, off);
+      const float in0 = m->body_inertia[b][0], in1 = m->body_inertia[b][1], in2 = m->body_inertia[b][2];
+      const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+      for (int e = 0; e < 6; e++) {
+        const int i = ii[e], j = jj[e];
+        const float v = R[3 * i] * in0 * R[3 * j] + R[3 * i + 1] * in1 * R[3 * j + 1] + R[3 * i + 2] * in2 * R[3 * j + 2];
+        const float hh = (i == j ? oo : 0.f) - off[i] * off[j];
+        o[e] = body ? v + hh * mb : 0.f;
+      }
+      for (int k = 0; k < 3; k++) o[6 + k] = body ? off[k] * mb : 0.f;
+      o[9] = body ? mb : 0.f;
+      // cdof: hinge = [axis, axis x (com - anchor)]; trunk dof k < 3: [0, e_k], k >= 3: column k - 3 of the trunk's xmat
+      const float bq[4] = {lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l)};
+      const float jp[3] = {m->jnt_pos[ji][0], m->jnt_pos[ji][1], m->jnt_pos[ji][2]};
+      const float ja[3] = {m->jnt_axis[ji][0], m->jnt_axis[ji][1], m->jnt_axis[ji][2]};
+      float anchor[3], jaxis[3], cr[3];
+      if (m->body_flags[b] & 2) { anchor[0] = 0.f; anchor[1] = 0.f; anchor[2] = 0.f; }
+      else dm::rotate(anchor, jp, bq);
+      for (int k = 0; k < 3; k++) anchor[k] += lane_val(PL[k], l);
+      dm::rotate(jaxis, ja, bq);
+      const float offj[3] = {com[0] - anchor[0], com[1] - anchor[1], com[2] - anchor[2]};
+      dm::cross3(cr, jaxis, offj);
+      // (blended with 0 / 1 weights, not selected: see smooth_quad.h)
+      const float w0 = kd == 3 ? 1.f : 0.f, w1 = kd == 4 ? 1.f : 0.f, w2 = kd == 5 ? 1.f : 0.f;
+      for (int k = 0; k < 3; k++) {
+        const float ta = w0 * cdT[0][k] + w1 * cdT[1][k] + w2 * cdT[2][k];
+        const float tl = (k == kd ? 1.f : 0.f) + (w0 * cdT[0][3 + k] + w1 * cdT[1][3 + k] + w2 * cdT[2][3 + k]);
+        o[10 + k] = leg ? jaxis[k] : (tdof ? ta : 0.f);
+        o[13 + k] = leg ? cr[k] : (tdof ? tl : 0.f);
+      }
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 10; k++) X[k] = T[k];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) CD[k] = T[10 + k];
+  }
+  // ---- smooth.com_vel + cdof_dot + rne forward: the trunk's velocity / acceleration (every lane the same), then root-to-leaf
+  vfloat VA[12];   // cvel(6) | cacc(6)
+  {
+    const float qv[6] = {s.qvel[0], s.qvel[1], s.qvel[2], s.qvel[3], s.qvel[4], s.qvel[5]};
+    const float vs[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};   // the rotational dofs see the velocity after the translational ones
+    float velT[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};
+    float accT[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
+    for (int j = 0; j < 3; j++) {
+      float cdd[6];
+      dm::motion_cross(cdd, vs, cdT[j]);
+      for (int k = 0; k < 6; k++) { accT[k] += cdd[k] * qv[3 + j]; velT[k] += cdT[j][k] * qv[3 + j]; }
+    }
+    w.per_lane_n(VA, [&](int l, float* o) {
+      const bool trunk = (l & 7) == 0;
+      for (int k = 0; k < 6; k++) { o[k] = trunk ? velT[k] : 0.f; o[6 + k] = trunk ? accT[k] : 0.f; }
+    });
+  }
+  const vfloat QVL = w.per_lane([&](int l) {
+    const int d = l & 7, g = l >> 3;
+    const bool leg = d >= 1 && d <= 3, mrow = (g == 0 && d >= 4 && d <= 6) || (d == 7 && g < 3);
+    return s.qvel[leg ? 3 * g + d + 5 : (mrow ? (d == 7 ? g : d - 1) : 0)];   // this dof lane's velocity
+  });
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 3; it++) {
+    vfloat Q[12], N[12];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 12; k++) Q[k] = w.template row_shr<1>(VA[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const int d = l & 7;
+      const bool leg = d >= 1 && d <= 3;
+      const float vp[6] = {lane_val(Q[0], l), lane_val(Q[1], l), lane_val(Q[2], l), lane_val(Q[3], l), lane_val(Q[4], l), lane_val(Q[5], l)};
+      const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
+      const float qv = lane_val(QVL, l);
+      float cdd[6];
+      dm::motion_cross(cdd, vp, cd);
+      for (int k = 0; k < 6; k++) {
+        const float a = lane_val(Q[6 + k], l) + cdd[k] * qv, v = vp[k] + cd[k] * qv;
+        o[k] = leg ? v : lane_val(VA[k], l);
+        o[6 + k] = leg ? a : lane_val(VA[6 + k], l);
+      }
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 12; k++) VA[k] = N[k];
+  }
+  // the bodies' outputs are complete: stored now
+  w.items(32, [&](int l) {
+    const int d = l & 7, g = l >> 3;
+    const bool leg = d >= 1 && d <= 3;
+    const int b = leg ? 3 * g + d + 1 : 1;
+    if (leg || l == 0) {
+      for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(PL[k], l);
+      store4(s.xquat + 4 * b, lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l));
+      for (int k = 0; k < 3; k++) store2(s.cvel + 6 * b + 2 * k, lane_val(VA[2 * k], l), lane_val(VA[2 * k + 1], l));
+    }
+    if (l == 0) {
+      for (int k = 0; k < 3; k++) { s.com[3 * m->body_rootid[1] + k] = com[k]; s.spos[k] = lane_val(F[16 + k], l); }
+      for (int k = 0; k < 4; k++) s.qpos[3 + k] = tquat[k];   // (kinematics normalises the free joint's quaternion in place)
+    }
+    if (d == 3) for (int k = 0; k < 3; k++) s.spos[3 * (1 + g) + k] = lane_val(F[16 + k], l);
+  });
+  // ---- collision_driver (the four plane-sphere foot contacts), the contact Jacobian and constraint.make_constraint, fused
+  {
+    float pn[3];
+    {
+      const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
+      float mat[9];
+      dm::quat_to_mat(mat, gq);
+      pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
+    }
+    const float fr[9] = {s.cframe[0], s.cframe[1], s.cframe[2], s.cframe[3], s.cframe[4], s.cframe[5], s.cframe[6], s.cframe[7], s.cframe[8]};
+    vfloat CP[4];   // contact point (3), distance
+    w.per_lane_n(CP, [&](int l, float* o) {
+      const int g = l >> 3, g2 = 1 + g;
+      const float ctr[3] = {lane_val(F[19], l), lane_val(F[20], l), lane_val(F[21], l)};
+      const float radius = m->geom_size[g2][0];
+      const float diff[3] = {ctr[0] - m->geom_pos[0][0], ctr[1] - m->geom_pos[0][1], ctr[2] - m->geom_pos[0][2]};
+      const float dist = dm::dot3(diff, pn) - radius;
+      for (int k = 0; k < 3; k++) o[k] = ctr[k] - pn[k] * (radius + 0.5f * dist);
+      o[3] = dist;
+    });
+    vfloat PC[3];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 3; k++) PC[k] = w.grp8_bcast3(CP[k]);   // the calf lane's contact point, to its whole group
+    w.items(32, [&](int l) {   // -- Jacobian of contact g with respect to this lane's dof (leg dofs and the trunk's rotational dofs)
+      const int d = l & 7, g = l >> 3;
+      const bool leg = d >= 1 && d <= 3, rot = d >= 4 && d <= 6;
+      if (!(leg || rot)) return;
+      const int i = leg ? 3 * g + d + 5 : d - 1;
+      const float mu1 = m->con_friction[g][0], mu2 = m->con_friction[g][1];
+      const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
+      const float off[3] = {lane_val(PC[0], l) - com[0], lane_val(PC[1], l) - com[1], lane_val(PC[2], l) - com[2]};
+      float cr[3];
+      dm::cross3(cr, cd, off);
+      const float diff[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]};
+      const float jn = dm::dot3(fr, diff), t1 = dm::dot3(fr + 3, diff) * mu1, t2 = dm::dot3(fr + 6, diff) * mu2;
+      store4(s.Jc + i * M::D::T + 4 * g, jn + t1, jn - t1, jn + t2, jn - t2);
+    });
+    w.items(32, [&](int l) {   // -- the contact's four pyramid rows (calf lanes)
+      const int d = l & 7, g = l >> 3;
+      if (d != 3) return;
+      const float mu1 = m->con_friction[g][0], mu2 = m->con_friction[g][1];
+      const float pos = lane_val(CP[3], l) - m->con_margin[g];
+      const float t = m->body_invweight0[m->con_body1[g]] + m->body_invweight0[m->con_body2[g]];
+      float invweight = t + mu1 * mu1 * t;
+      invweight = invweight * 2.f * mu1 * mu1 / m->impratio;
+      float k_, b_, imp;
+      kbi(m, m->con_solref[g], m->con_solimp[g], pos, k_, b_, imp);
+      const float Rr = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
+      const float va[3] = {lane_val(VA[0], l), lane_val(VA[1], l), lane_val(VA[2], l)};
+      const float off[3] = {lane_val(CP[0], l) - com[0], lane_val(CP[1], l) - com[1], lane_val(CP[2], l) - com[2]};
+      float cr[3];
+      dm::cross3(cr, va, off);
+      const float vp[3] = {lane_val(VA[3], l) + cr[0], lane_val(VA[4], l) + cr[1], lane_val(VA[5], l) + cr[2]};
+      const float vn = dm::dot3(fr, vp), v1 = dm::dot3(fr + 3, vp) * mu1, v2 = dm::dot3(fr + 6, vp) * mu2;
+      const bool on = pos < 0.f;
+      const float dd = on ? 1.f / Rr : 0.f, ar = -k_ * imp * pos;
+      constexpr int NL = M::D::NL;
+      store4(s.D + NL + 4 * g, dd, dd, dd, dd);
+      store4(s.aref + NL + 4 * g, on ? ar - b_ * (vn + v1) : 0.f, on ? ar - b_ * (vn - v1) : 0.f, on ? ar - b_ * (vn + v2) : 0.f, on ? ar - b_ * (vn - v2) : 0.f);
+      s.cdist[g] = lane_val(CP[3], l);
+      for (int k = 0; k < 3; k++) s.cpos[3 * g + k] = lane_val(CP[k], l);
+    });
+    w.items(32, [&](int l) {   // -- the joint's limit row (leg lanes)
+      const int d = l & 7, g = l >> 3;
+      if (!(d >= 1 && d <= 3)) return;
+      const int b = 3 * g + d + 1, ji = b - 1, i = b + 4, qa = b + 5, lr = m->dof_limrow[i];
+      if (lr < 0) return;
+      const float q = s.qpos[qa];
+      const float dist_min = q - m->jnt_range[ji][0], dist_max = m->jnt_range[ji][1] - q;
+      const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
+      const float sgn = dist_min < dist_max ? 1.f : -1.f;
+      float k_, b_, imp;
+      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      const float Rr = dm::fmaxf_(m->dof_invweight0[i] * (1.f - imp) / imp, MJ_MINVAL);
+      const bool on = pos < 0.f;
+      s.lsign[lr] = sgn;
+      s.D[lr] = on ? 1.f / Rr : 0.f;
+      s.aref[lr] = on ? -b_ * (sgn * lane_val(QVL, l)) - k_ * imp * pos : 0.f;
+    });
+  }
+  // ---- rne: local body forces cfl = cinert cacc + cvel x* (cinert cvel)
+  {
+    vfloat T[6];
+    w.per_lane_n(T, [&](int l, float* o) {
+      const bool body = (l & 7) <= 3;
+      float ci[10], ca[6], cv[6], f1[6], f2[6], f3[6];
+      for (int k = 0; k < 10; k++) ci[k] = lane_val(X[k], l);
+      for (int k = 0; k < 6; k++) { cv[k] = lane_val(VA[k], l); ca[k] = lane_val(VA[6 + k], l); }
+      dm::inert_mul(f1, ci, ca);
+      dm::inert_mul(f2, ci, cv);
+      dm::motion_cross_force(f3, cv, f2);
+      for (int k = 0; k < 6; k++) o[k] = body ? f1[k] + f3[k] : 0.f;
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) X[10 + k] = T[k];
+  }
+  // ---- subtree sums (smooth.crb, rne backward): leaf-to-root along the legs, then the trunk = own + the four hips
+  DIAL_UNROLL_FULL
+  for (int it = 0; it < 2; it++) {
+    vfloat Q[16], N[16];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 16; k++) Q[k] = w.template row_shl<1>(X[k]);
+    w.per_lane_n(N, [&](int l, float* o) {
+      const bool on = (l & 7) == 2 - it;
+      for (int k = 0; k < 16; k++) o[k] = on ? lane_val(X[k], l) + lane_val(Q[k], l) : lane_val(X[k], l);
+    });
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 16; k++) X[k] = N[k];
+  }
+  float XT[16];   // the trunk's composite inertia and subtree force
+  {
+    vfloat H[16];
+    w.per_lane_n(H, [&](int l, float* o) {
+      const bool hip = (l & 7) == 1;
+      for (int k = 0; k < 16; k++) o[k] = hip ? lane_val(X[k], l) : 0.f;
+    });
+    float hs[16];
+    w.vsumN(H, hs);
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 16; k++) XT[k] = w.template bc<0>(X[k]) + hs[k];
+  }
+  // ---- F_i = crb cdof_i, M = F . cdof over the ancestors (support.make_m), qfrc_smooth = passive - bias + actuator
+  vfloat MO[11];   // columns 0..5 (trunk dofs) | own diagonal | parent dof | grandparent dof | qfrc_smooth | (unused)
+  {
+    vfloat P1[6], P2[6];
+    DIAL_UNROLL_FULL
+    for (int k = 0; k < 6; k++) { P1[k] = w.template row_shr<1>(CD[k]); P2[k] = w.template row_shr<2>(CD[k]); }
+    w.per_lane_n(MO, [&](int l, float* o) {
+      const int d = l & 7, g = l >> 3;
+      const bool leg = d >= 1 && d <= 3, mrow = (g == 0 && d >= 4 && d <= 6) || (d == 7 && g < 3);
+      const int b = leg ? 3 * g + d + 1 : 1, i = leg ? b + 4 : (mrow ? (d == 7 ? g : d - 1) : 0);
+      float crb[10], cfrc[6], cd[6], f[6];
+      for (int k = 0; k < 10; k++) crb[k] = leg ? lane_val(X[k], l) : XT[k];
+      for (int k = 0; k < 6; k++) { cfrc[k] = leg ? lane_val(X[10 + k], l) : XT[10 + k]; cd[k] = lane_val(CD[k], l); }
+      dm::inert_mul(f, crb, cd);
+      const float arm = m->dof_armature[i];
+      for (int j = 0; j < 6; j++) {
+        float v = 0.f;
+        if (j < 3) v = f[3 + j];
+        else for (int k = 0; k < 6; k++) v += f[k] * cdT[j - 3][k];
+        o[j] = (mrow && j == i) ? v + arm : v;
+      }
+      float own = 0.f, p1 = 0.f, p2 = 0.f, bias = 0.f;
+      for (int k = 0; k < 6; k++) {
+        own += f[k] * cd[k];
+        p1 += f[k] * lane_val(P1[k], l);
+        p2 += f[k] * lane_val(P2[k], l);
+        bias += cd[k] * cfrc[k];
+      }
+      o[6] = own + arm; o[7] = p1; o[8] = p2;
+      const float passive = -m->dof_damping[i] * lane_val(QVL, l);
+      const int a = m->dof_act[i];
+      const int aa = a >= 0 ? a : 0;
+      const float c0 = s.ctrl[aa], lo = m->act_ctrlrange[aa][0], hi = m->act_ctrlrange[aa][1], kp = m->act_kp[aa];
+      const float qp = s.qpos[m->act_qposadr[aa]], gear = m->act_gear[aa];
+      const float c = m->act_ctrllimited[aa] ? dm::clip(c0, lo, hi) : c0;
+      const float force = m->act_isposition[aa] ? kp * (c - qp) : c;
+      const float actf = a >= 0 ? gear * force : 0.f;
+      o[9] = passive - bias + actf;
+      o[10] = 0.f;
+    });
+  }
+  // ---- the dofs' outputs
+  w.items(32, [&](int l) {
+    const int d = l & 7, g = l >> 3;
+    const bool leg = d >= 1 && d <= 3, mrow = (g == 0 && d >= 4 && d <= 6) || (d == 7 && g < 3);
+    const int b = leg ? 3 * g + d + 1 : 1;
+    if (leg || mrow) {
+      const int i = leg ? b + 4 : (d == 7 ? g : d - 1);
+      for (int k = 0; k < 3; k++) store2(s.cdof + 6 * i + 2 * k, lane_val(CD[2 * k], l), lane_val(CD[2 * k + 1], l));
+      const float qf = lane_val(MO[9], l);
+      s.qfs[i] = qf;
+      s.rhs[i] = qf;
+      for (int j = 0; j < 6; j++) {
+        if (j <= i) { const float v = lane_val(MO[j], l); s.M[i * S + j] = v; s.M[j * S + i] = v; }
+      }
+      if (leg) {
+        s.M[i * S + i] = lane_val(MO[6], l);
+        if (d >= 2) { const float v = lane_val(MO[7], l); s.M[i * S + i - 1] = v; s.M[(i - 1) * S + i] = v; }
+        if (d == 3) { const float v = lane_val(MO[8], l); s.M[i * S + i - 2] = v; s.M[(i - 2) * S + i] = v; }
+      }
+    }
+  });
+}
+
+// Once per kernel, on top of init_quad (smooth_quad.h): the Jacobian entries of the trunk's three TRANSLATIONAL dofs against the
+// four foot contacts.  cdof = [0, e_k] and the frame of a plane contact is fixed, so J^T[k][4 c + e] = fr_n[k] +- mu fr_t[k]: the
+// same expressions smooth_quad.h evaluates per step (a cross product with a zero angular part adds an exact zero).
+template <class W, class M>
+DIAL_DEV void init_quad2(W& w, const M* m, const Ws& s) {
+  w.items(3 * M::D::NC, [&](int it) {
+    const int k = it / M::D::NC, c = it - k * M::D::NC;
+    const float* fr = s.cframe + 9 * c;
+    const float mu1 = m->con_friction[c][0], mu2 = m->con_friction[c][1];
+    const float cd[6] = {0.f, 0.f, 0.f, k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
+    const float off[3] = {0.f, 0.f, 0.f};
+    float cr[3];
+    dm::cross3(cr, cd, off);
+    const float diff[3] = {cd[3] + cr[0], cd[4] + cr[1], cd[5] + cr[2]};
+    const float jn = dm::dot3(fr, diff), t1 = dm::dot3(fr + 3, diff) * mu1, t2 = dm::dot3(fr + 6, diff) * mu2;
+    store4(s.Jc + k * M::D::T + 4 * c, jn + t1, jn - t1, jn + t2, jn - t2);
+  });
+}
+
+}  // namespace dial

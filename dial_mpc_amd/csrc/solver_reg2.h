@@ -1,0 +1,429 @@
+// solver_reg2.h -- the register-resident Newton solver of solver_reg.h on 32 LANES, for the kernel that runs TWO samples per
+// wavefront (wave.h: WaveH).  Same iterates, same arithmetic in the same order -- the one-sample solver is the reference the
+// emulator and the GPU tests compare against bit for bit -- on a layout that never leaves the half:
+//
+//   lanes [0, NV)      dof i: row i of M in R[NV]; its joint-limit row, if it has one               ("limit slot")
+//   lanes [0, 4 NC)    ALSO pyramid edge e of contact c (lane 4 c + e), in registers of their own   ("contact slot"):
+//                      the row is kept COMPACT -- the six trunk columns and the three columns of the contact's own leg
+//                      (a foot contact's Jacobian has no other non-zeros: solver_reg.h multiplies the rest by exact zeros)
+//
+// Broadcasts are VGPR operands: dup_rows (one v_permlane16_swap) makes the half's even / odd row visible in both rows, DPP
+// row_newbcast picks the lane -- where solver_reg.h pays v_readlane + the SGPR-operand hazard per pivot, this layout pays one
+// swap per VECTOR and a DPP mov per use, and serves two samples.  The leg columns of a contact row are a lane-indexed gather
+// (ds_bpermute).  Wave-uniform scalars of solver_reg.h (costs, step sizes, the bracket of the line search, loop exits) are
+// per-lane values that agree within the half; where the two samples disagree (one has converged, one re-uses its factor) the
+// EXEC mask serialises the two paths like any divergent code.
+// The line search evaluates TWO trial points per pass in two 16-lane groups (solver_reg.h: three in three groups): an iteration
+// is one pass for (lo_next, hi_next) and one for the mid-point; the rows keep their positions inside the 16-lane groups, so the
+// sums associate identically.  The bracket update runs lane-wise on the integer keys of ls_bracket.h (ls_update).
+#pragma once
+// (included from rollout_body.h after solver_reg.h)
+
+namespace dial {
+
+// x = A^-1 b, the sparse L D L^T of solver_reg.h (same elimination order, same operations) with DPP broadcasts.
+template <class D, class TopoT = typename D::Topo, bool REUSE = false, class W, class M>
+DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, float* scratch, vfloat* dinv_io = nullptr) {
+  constexpr int N = D::NV, S = kCholStride<N>;
+  using Topo = TopoT;
+  static_assert(N <= 32 && D::square, "one 32-lane half holds the rows");
+  w.begin_region();
+  vfloat a[N];
+  const auto own_i = [&](int l) { return N - 1 - l; };   // the lane's dof
+  (void)m;
+  vfloat b = w.lane_reverse(bvec, N);
+  vfloat dinv = vsplat(0.f);
+  constexpr ElimOrder<Topo, N> EO{};
+  // lane K of the half from its duplicated rows
+  const auto pick = [&](auto KK, const vfloat& X, const vfloat& Y) {
+    constexpr int K = decltype(KK)::value;
+    if constexpr (K < 16) return w.template row_bcast<K>(X);
+    else return w.template row_bcast<K - 16>(Y);
+  };
+  if constexpr (REUSE) {
+    (void)A;
+    dinv = *dinv_io;
+    static_for<0, N>([&](auto KP) {
+      constexpr int kp = KP;
+      a[kp] = w.per_lane([&](int l) { return scratch[(N - 1 - kp) * S + (l < N ? own_i(l) : 0)]; });
+    });
+    static_for<0, EO.nlevel>([&](auto LV) {
+      constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
+      vfloat bX, bY;
+      w.dup_rows(b, bX, bY);
+      vfloat bk[l1 - l0 > 0 ? l1 - l0 : 1];
+      static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; bk[STEP - l0] = pick(std::integral_constant<int, kp>{}, bX, bY); });
+      static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
+    });
+  } else {
+  static_for<0, S / 4>([&](auto Q) {
+    constexpr int q = Q;
+    vfloat t[4];
+    w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    static_for<0, 4>([&](auto E) {
+      constexpr int j = 4 * q + E;
+      if constexpr (j < N) a[N - 1 - j] = t[E];
+    });
+  });
+  static_for<0, EO.nlevel>([&](auto LV) {
+    constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
+    vfloat bX, bY;
+    w.dup_rows(b, bX, bY);   // (the columns of one depth do not touch each other's b entries: one swap per level)
+    vfloat bk[l1 - l0 > 0 ? l1 - l0 : 1];
+    static_for<l0, l1>([&](auto STEP) {
+      constexpr int kp = EO.seq[STEP];
+      const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
+      vfloat cX, cY;
+      w.dup_rows(col, cX, cY);
+      const vfloat rinv = vrcp(pick(std::integral_constant<int, kp>{}, cX, cY));
+      const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
+      a[kp] = lik;
+      dinv = vsel(w.lane_eq(kp), rinv, dinv);
+      bk[STEP - l0] = pick(std::integral_constant<int, kp>{}, bX, bY);
+      constexpr AncList<Topo, N, kp> L{};
+      static_for<0, L.n>([&](auto IDX) {
+        constexpr int jp = L.jp[IDX];
+        a[jp] = a[jp] - lik * pick(std::integral_constant<int, jp>{}, cX, cY);
+      });
+    });
+    static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
+  });
+  w.items(N, [&](int l) {
+    static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
+  });
+  if (dinv_io) *dinv_io = dinv;
+  }   // (!REUSE)
+  vfloat x = b * dinv;
+  static_for<0, S / 4>([&](auto Q) {
+    constexpr int q = Q;
+    vfloat t[4];
+    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    static_for<0, 4>([&](auto E) {
+      constexpr int j = 4 * q + E;
+      if constexpr (j < N) a[N - 1 - j] = t[E];
+    });
+  });
+  static_for<0, EO.nlevel>([&](auto LVR) {
+    constexpr int lv = EO.nlevel - 1 - LVR, l0 = EO.lvl[lv], l1 = EO.lvl[lv + 1];
+    vfloat xX, xY;
+    w.dup_rows(x, xX, xY);
+    vfloat xk[l1 - l0 > 0 ? l1 - l0 : 1];
+    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; xk[STEP - l0] = pick(std::integral_constant<int, kp>{}, xX, xY); });
+    static_for<l0, l1>([&](auto STEP) { x = x - a[EO.seq[STEP]] * xk[STEP - l0]; });
+  });
+  return w.lane_reverse(x, N);
+}
+
+template <class W, class M>
+DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
+  constexpr int NV = M::D::NV, NC = M::D::NC, NL = M::D::NL;
+  static_assert(W::half2, "32-lane layout: the half-wave execution model");
+  static_assert(NV <= 32 && 4 * NC <= 16 && NV == 6 + 3 * NC, "free trunk + one three-dof leg per contact; contact rows in one DPP row");
+  w.begin_region();
+  const vbool isdof = w.lane_lt(NV), iscon = w.lane_lt(4 * NC);
+  const vfloat vzero = vsplat(0.f);
+  const auto lim_of = [&](int l) -> int { return l < NV ? m->dof_limrow[l] : -1; };
+
+  // ---- persistent registers
+  vfloat R[NV];      // dof lane i: row i of M
+  vfloat RJt[6];     // contact lane r = 4 c + e: the trunk columns of J_r = Jn +- mu Jt ...
+  vfloat RJl[3];     // ... and the columns of leg c's dofs 6 + 3 c + q
+  {
+    // (offsets from ONE base pointer rather than a select of pointers: keeps the accesses in the LDS address space; idle lanes
+    //  re-read a word that holds 0 -- lsign of a contact row)
+    constexpr int S = M::D::S, T = M::D::T;
+    const int ojc = (int)(s.Jc - s.M), ozero = (int)(s.lsign - s.M) + NL;
+#pragma unroll
+    for (int j = 0; j < NV; j++) R[j] = w.per_lane([&](int l) { return s.M[l < NV ? l * S + j : ozero]; });
+#pragma unroll
+    for (int j = 0; j < 6; j++) RJt[j] = w.per_lane([&](int l) { return s.M[l < 4 * NC ? ojc + j * T + l : ozero]; });
+#pragma unroll
+    for (int q = 0; q < 3; q++) RJl[q] = w.per_lane([&](int l) { return s.M[l < 4 * NC ? ojc + (6 + 3 * (l >> 2) + q) * T + l : ozero]; });
+  }
+  const vfloat vD = w.per_lane([&](int l) { const int r = lim_of(l); return r >= 0 ? s.D[r] : 0.f; });
+  const vfloat varef = w.per_lane([&](int l) { const int r = lim_of(l); return r >= 0 ? s.aref[r] : 0.f; });
+  const vfloat vls = w.per_lane([&](int l) { const int r = lim_of(l); return r >= 0 ? s.lsign[r] : 0.f; });
+  const vfloat cD = w.per_lane([&](int l) { return l < 4 * NC ? s.D[NL + l] : 0.f; });
+  const vfloat caref = w.per_lane([&](int l) { return l < 4 * NC ? s.aref[NL + l] : 0.f; });
+  const vfloat vqfs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] : 0.f; });
+  const vfloat vqas = w.per_lane([&](int l) { return l < NV ? s.qas[l] : 0.f; });
+  const vfloat vwarm = w.per_lane([&](int l) { return l < NV ? s.warm[l] : 0.f; });
+
+  // pM[dof lane i] = (M v)_i, pJ[contact lane r] = (J v)_r.  Three partial sums each, column j in chain j % 3, in ascending j:
+  // exactly the chains of solver_reg.h's sweep minus its exact-zero terms.
+  auto dotR = [&](const vfloat& v, vfloat& pM, vfloat& pJ) {
+    vfloat vX, vY;
+    w.dup_rows(v, vX, vY);
+    vfloat accM[3] = {vzero, vzero, vzero}, accJ[3] = {vzero, vzero, vzero};
+    static_for<0, NV>([&](auto JJ) {
+      constexpr int j = JJ;
+      vfloat bj;
+      if constexpr (j < 16) bj = w.template row_bcast<j>(vX);
+      else bj = w.template row_bcast<j - 16>(vY);
+      accM[j % 3] = accM[j % 3] + R[j] * bj;
+      if constexpr (j < 6) accJ[j % 3] = accJ[j % 3] + RJt[j] * bj;
+    });
+    static_for<0, 3>([&](auto QQ) {
+      constexpr int q = QQ;
+      const vfloat vl = w.gather(v, [&](int l) { return l < 4 * NC ? 6 + 3 * (l >> 2) + q : 0; });
+      accJ[q] = accJ[q] + RJl[q] * vl;
+    });
+    pM = (accM[0] + accM[1]) + accM[2];
+    pJ = (accJ[0] + accJ[1]) + accJ[2];
+  };
+  auto cost_terms = [&](const vfloat& D_, const vfloat& ja) { return vsel(vlt0(ja), D_ * ja * ja, vzero); };
+  // the sum over all rows as solver_reg.h's 64-lane reduction forms it: (contact rows) + (limit rows)
+  auto sum_rows = [&](float rc, float rl) { return rc + rl; };
+
+  // ---- warm-start selection (solver.solve): cost at qacc_warmstart vs cost at qacc_smooth
+  vfloat pW, jW, pS, jS;
+  dotR(vwarm, pW, jW);
+  dotR(vqas, pS, jS);
+  const vfloat jaW = vls * vwarm - varef, jaS = vls * vqas - varef;          // limit slot
+  const vfloat cjaW = vsel(iscon, jW, vzero) - caref, cjaS = vsel(iscon, jS, vzero) - caref;   // contact slot
+  const vfloat maW = vsel(isdof, pW, vzero), maS = vsel(isdof, pS, vzero);
+  float cw, gw, cs, gs;
+  {
+    vfloat t[6] = {cost_terms(vD, jaW), cost_terms(cD, cjaW), (maW - vqfs) * (vwarm - vqas),
+                   cost_terms(vD, jaS), cost_terms(cD, cjaS), (maS - vqfs) * (vqas - vqas)};
+    float r[6];
+    w.vsumN(t, r);
+    cw = sum_rows(r[1], r[0]); gw = r[2]; cs = sum_rows(r[4], r[3]); gs = r[5];
+  }
+  const float cost_w = 0.5f * cw + 0.5f * gw, cost_s = 0.5f * cs + 0.5f * gs;
+  const bool use_warm = cost_w < cost_s;
+  vfloat vqacc = use_warm ? vwarm : vqas;
+  vfloat vMa = use_warm ? maW : maS;
+  vfloat vJa = use_warm ? jaW : jaS;      // limit slot
+  vfloat cJa = use_warm ? cjaW : cjaS;    // contact slot
+  float cost = use_warm ? cost_w : cost_s;
+  float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
+  float prev_cost = INFINITY;
+  const float scale = 1.f / (m->meaninertia * (float)(NV > 1 ? NV : 1));
+  const bool rule_swap = m->ls_rule == DIAL_LS_SWAP;
+  const int max_iter = DM_UNIFORM_I(m->iterations), max_ls = DM_UNIFORM_I(m->ls_iterations);
+  const float tol = m->tolerance, ls_tol = m->ls_tolerance, meaninertia = m->meaninertia;
+
+  int niter = 0;
+  unsigned long long act_prev_l = 0, act_prev_c = 0;
+  vfloat h_dinv = vzero;
+  bool h_valid = false;
+  for (;;) {
+    // ---- _update_constraint: forces; _update_gradient: grad = Ma - qfrc_smooth - J^T f
+    const vbool act = vlt0(vJa), cact = vlt0(cJa);
+    const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
+    const vfloat cf = vsel(cact, cD * (vzero - cJa), vzero);
+    vfloat qfc = vls * vf;  // limit row of the own dof
+    {
+      vfloat fX, fY;
+      w.dup_rows(cf, fX, fY);   // (the contact rows sit in the half's even row)
+      static_for<0, NC>([&](auto Cc) {   // J^T f from the dof-major pyramid rows: one 16-byte fetch per contact
+        constexpr int c = Cc;
+        vfloat jr[4];
+        w.per_lane4([&](int l) { return s.Jc + (l < NV ? l : 0) * M::D::T + 4 * c; }, jr[0], jr[1], jr[2], jr[3]);
+        qfc = qfc + ((jr[0] * w.template row_bcast<4 * c>(fX) + jr[1] * w.template row_bcast<4 * c + 1>(fX)) +
+                     (jr[2] * w.template row_bcast<4 * c + 2>(fX) + jr[3] * w.template row_bcast<4 * c + 3>(fX)));
+      });
+    }
+    const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
+    float gn = 0.f;
+    if (niter > 0) {
+      vfloat t[4] = {cost_terms(vD, vJa), cost_terms(cD, cJa), (vMa - vqfs) * (vqacc - vqas), vgrad * vgrad};
+      float r[4];
+      w.vsumN(t, r);
+      gauss = 0.5f * r[2];
+      prev_cost = cost;
+      cost = 0.5f * sum_rows(r[1], r[0]) + gauss;
+      gn = r[3];
+    } else if (max_iter != 1) {
+      gn = w.vsum(vgrad * vgrad);
+    }
+    bool done;
+    if (max_iter != 1) {
+      const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
+      done = niter >= max_iter || improvement < tol || gradient < tol;
+    } else {
+      done = niter >= 1;
+    }
+    if (done) break;
+
+    // ---- Newton direction: H = M + J^T diag(D*active) J in LDS (lane per entry), Cholesky in registers
+    const vfloat vwgt = vsel(act, vD, vzero), cwgt = vsel(cact, cD, vzero);
+#ifdef DIAL_NO_FACTOR_REUSE
+    const bool reuse = false;
+#else
+    const unsigned long long act_l = w.mask(vlt0(vzero - vwgt)), act_c = w.mask(vlt0(vzero - cwgt));   // rows that carry weight
+    const bool reuse = h_valid && act_l == act_prev_l && act_c == act_prev_c;
+    act_prev_l = act_l;
+    act_prev_c = act_c;
+    h_valid = true;
+#endif
+    vfloat vsearch;
+    if (reuse) {
+      vsearch = vzero - reg_chol_solve2<typename M::D, typename M::D::Topo, true>(w, m, s.H, vgrad, s.H, &h_dinv);
+    } else {
+    {
+      // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC), then a zero word
+      constexpr int NLP = M::D::NLP, NP = M::D::NHI / 32;   // passes of 32 work-list records (solver_reg.h: of 64)
+      w.items(32, [&](int l) {
+        const int r = lim_of(l);
+        if (r >= 0) s.frc[r] = lane_val(vwgt, l);
+        if (l < 4 * NC) s.frc[NLP + l] = lane_val(cwgt, l);
+        if (l == 31) s.frc[NLP + 4 * NC] = 0.f;
+      });
+      // the work list of solver_reg.h, record p * 32 + lane in pass p: the same items, the same quads.  Three passes at a time:
+      // every lane accumulates its item of every pass of the batch (the LDS latencies of the passes overlap), partial sums of
+      // split entries are combined inside quads, then one phase writes the batch's entries.
+      constexpr int NB = 3;
+      static_assert(NP % NB == 0, "work-list capacity: a multiple of 96 records");
+      static_for<0, NP / NB>([&](auto BATCH) {
+        constexpr int p0 = BATCH * NB;
+        vfloat part[NB], tot[NB];
+        static_for<0, 4>([&](auto Qq) {
+          constexpr int q = Qq;
+          bool any = false;
+          static_for<0, NB>([&](auto PP) { any = any || q < m->hpass_n[(p0 + PP) / 2]; });
+          if (any) {   // wave-uniform: round q of the contact lists (Go2: one round)
+            vfloat ji[NB][4], jj[NB][4], dd[NB][4];
+            static_for<0, NB>([&](auto PP) {
+              constexpr int pp = PP, pass = p0 + PP;
+              const auto c4 = [&](int l) { return (int)((m->hrec[pass * 32 + l][0] >> (20 + 3 * q)) & 7u) * 4; };
+              w.per_lane4([&](int l) { return s.Jc + (m->hrec[pass * 32 + l][0] & 1023u) + c4(l); }, ji[pp][0], ji[pp][1], ji[pp][2], ji[pp][3]);
+              w.per_lane4([&](int l) { return s.Jc + ((m->hrec[pass * 32 + l][0] >> 10) & 1023u) + c4(l); }, jj[pp][0], jj[pp][1], jj[pp][2], jj[pp][3]);
+              w.per_lane4([&](int l) { return s.frc + NLP + c4(l); }, dd[pp][0], dd[pp][1], dd[pp][2], dd[pp][3]);
+            });
+            static_for<0, NB>([&](auto PP) {
+              constexpr int pp = PP, pass = p0 + PP;
+              const vfloat t = ((ji[pp][0] * dd[pp][0]) * jj[pp][0] + (ji[pp][1] * dd[pp][1]) * jj[pp][1]) +
+                               ((ji[pp][2] * dd[pp][2]) * jj[pp][2] + (ji[pp][3] * dd[pp][3]) * jj[pp][3]);
+              const vfloat tq = w.per_lane([&](int l) { return q < (int)(m->hrec[pass * 32 + l][1] >> 29) ? lane_val(t, l) : 0.f; });
+              if constexpr (q == 0) part[pp] = tq; else part[pp] = part[pp] + tq;
+            });
+          }
+        });
+        static_for<0, NB>([&](auto PP) {
+          constexpr int pp = PP, pass = p0 + PP;
+          const vfloat pair = part[pp] + w.quad_xor1(part[pp]);
+          const vfloat quad = pair + w.quad_xor2(pair);
+          tot[pp] = w.per_lane([&](int l) {
+            const float t1 = lane_val(part[pp], l), t2 = lane_val(pair, l), t4 = lane_val(quad, l);
+            const uint32_t pc = (m->hrec[pass * 32 + l][1] >> 26) & 3u;
+            return pc == 0 ? t1 : (pc == 1 ? t2 : t4);
+          });
+        });
+        w.items(32, [&](int l) {
+          static_for<0, NB>([&](auto PP) {
+            constexpr int pp = PP, pass = p0 + PP;
+            const uint32_t w1 = m->hrec[pass * 32 + l][1];
+            const float v = (s.M[w1 & 1023u] + lane_val(tot[pp], l)) + s.frc[(w1 >> 20) & 63u];
+            if ((w1 >> 28) & 1u) {
+              s.H[w1 & 1023u] = v;
+              s.H[(w1 >> 10) & 1023u] = v;
+            }
+          });
+        });
+      });
+    }
+    vsearch = vzero - reg_chol_solve2<typename M::D>(w, m, s.H, vgrad, s.H, &h_dinv);
+    }
+
+    // ---- solver._linesearch
+    w.begin_region();
+    vfloat pv, cjv;
+    dotR(vsearch, pv, cjv);
+    const vfloat vmv = vsel(isdof, pv, vzero);
+    const vfloat vjv = vls * vsearch;          // limit slot
+    cjv = vsel(iscon, cjv, vzero);             // contact slot
+    float sn2, s1, s2;
+    {
+      vfloat t[3] = {vsearch * vsearch, vsearch * vMa - vsearch * vqfs, vsearch * vmv};
+      float r[3];
+      w.vsumN(t, r);
+      sn2 = r[0]; s1 = r[1]; s2 = r[2];
+    }
+    const float smag = DM_SQRT(sn2) * meaninertia * (float)(NV > 1 ? NV : 1);
+    const float gtol = tol * ls_tol * smag;
+    const float qg0 = gauss, qg1 = s1, qg2 = 0.5f * s2;
+    // Line-search layout: lane (g, l) = (lane >> 4, lane & 15) owns rows l, l + 16 for the trial point of group g.
+    // Re-layout through LDS (rows are indexed by r there).
+    w.items(32, [&](int l) {
+      const int r = lim_of(l);
+      if (r >= 0) { s.Jaref[r] = lane_val(vJa, l); s.jv[r] = lane_val(vjv, l); }
+      if (l < 4 * NC) { s.Jaref[NL + l] = lane_val(cJa, l); s.jv[NL + l] = lane_val(cjv, l); }
+    });
+    constexpr int NE = M::D::NE, RPL = (NE + 15) / 16;   // rows per line-search lane (Go2: 2)
+    const vbool g0 = w.lane_lt(16);
+    vfloat lJa[RPL], ljv[RPL], Q0[RPL], Q1[RPL], Q2[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      lJa[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return r < NE ? s.Jaref[r] : 0.f; });
+      ljv[q] = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return r < NE ? s.jv[r] : 0.f; });
+      const vfloat lD = w.per_lane([&](int l) { const int r = (l & 15) + 16 * q; return r < NE ? s.D[r] : 0.f; });
+      const vfloat dja = lD * lJa[q], djv = lD * ljv[q];
+      Q0[q] = (lJa[q] * 0.5f) * dja;
+      Q1[q] = ljv[q] * dja;
+      Q2[q] = (ljv[q] * 0.5f) * djv;
+    }
+    // evaluate the points a0 (group 0) and a1 (group 1): every lane of a group finishes its point -- cost, slope, the point's
+    // own Newton step, the integer keys of ls_bracket.h -- and the four words reach the rest of the half by dup_rows
+    auto ls_eval2 = [&](float a0, float a1, LsPt& p0_, LsPt& p1_) {
+      const vfloat va = vsel(g0, vsplat(a0), vsplat(a1));
+      vfloat s0 = vzero, s1v = vzero, s2v = vzero;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const vfloat act_ = vsel(vlt0(lJa[q] + ljv[q] * va), vsplat(1.f), vzero);
+        s0 = s0 + act_ * Q0[q];
+        s1v = s1v + act_ * Q1[q];
+        s2v = s2v + act_ * Q2[q];
+      }
+      w.row16_sum3(s0, s1v, s2v);
+      const vfloat q0 = s0 + vsplat(qg0), q1 = s1v + vsplat(qg1), q2 = s2v + vsplat(qg2);
+      const vfloat vcost = (va * va) * q2 + va * q1 + q0;
+      const vfloat vd0 = vfma(va * 2.f, q2, q1);   // single rounding: see the line search of rollout_body.h
+      const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
+      vfloat pk[4];
+      w.per_lane_n(pk, [&](int l, float* o) {
+        ls_pack(lane_val(va, l), lane_val(vcost, l), lane_val(vd0, l), lane_val(vd1, l), o[0], o[1], o[2], o[3]);
+      });
+      vfloat X[4], Y[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w.dup_rows(pk[k], X[k], Y[k]);   // (rows are constant: no lane select needed)
+      p0_.alpha = fbits(lane_val(X[0], 0)); p0_.nalpha = fbits(lane_val(X[1], 0)); p0_.cost = fbits(lane_val(X[2], 0)); p0_.d0 = fbits(lane_val(X[3], 0));
+      p1_.alpha = fbits(lane_val(Y[0], 0)); p1_.nalpha = fbits(lane_val(Y[1], 0)); p1_.cost = fbits(lane_val(Y[2], 0)); p1_.d0 = fbits(lane_val(Y[3], 0));
+    };
+    LsPt p0, pdummy, p1;
+    ls_eval2(0.f, 0.f, p0, pdummy);
+    ls_eval2(bitsf(p0.nalpha), bitsf(p0.nalpha), p1, pdummy);
+    LsPt lo, hi;
+    ls_open(p0, p1, lo, hi);
+    const int kg = fkey(gtol), kng = fkey(-gtol);
+    bool swap = true;
+    int ls_iter = 0;
+    for (;;) {
+      const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
+      if (ls_done) break;
+      LsPt lo_next, hi_next, mid;
+      ls_eval2(bitsf(lo.nalpha), bitsf(hi.nalpha), lo_next, hi_next);
+      const float amid = 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha));
+      ls_eval2(amid, amid, mid, pdummy);
+      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
+      ls_iter++;
+    }
+    float alpha;
+    const bool improved = ls_result(p0, lo, hi, alpha);
+    if (improved) {
+      vqacc = vqacc + vsearch * alpha;
+      vMa = vMa + vmv * alpha;
+      vJa = vJa + vjv * alpha;
+      cJa = cJa + cjv * alpha;
+    }
+    niter++;
+  }
+  w.items(NV, [&](int i) {
+    const float q = lane_val(vqacc, i);
+    s.qacc[i] = q;
+    s.warm[i] = q;
+  });
+}
+
+}  // namespace dial

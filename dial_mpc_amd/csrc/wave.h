@@ -59,9 +59,30 @@ inline void store2(float* p, float a, float b) { p[0] = a; p[1] = b; }
 inline void store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+inline vfloat vrcp(const vfloat& a) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = 1.0f / a.x[l]; return r; }   // lane-wise fast_rcp
+
+// The GPU's wave reductions are DPP butterflies with a fixed association (HIP section below: wave_sum_dpp).  The emulator sums
+// sequentially by default (its results are compared with the oracle at tolerance); with `tree_sums` it reproduces the GPU's
+// association bit for bit -- that is what lets a test compare two LANE LAYOUTS of the same arithmetic for exact equality.
+inline float emu_row_tree(const float* v) {   // one row of 16 lanes: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+  float s1[16], s2[16], s3[16];
+  for (int l = 0; l < 16; l++) s1[l] = v[l] + v[l ^ 1];
+  for (int l = 0; l < 16; l++) s2[l] = s1[l] + s1[l ^ 2];
+  for (int l = 0; l < 16; l++) s3[l] = s2[l] + s2[(l & 8) | (7 - (l & 7))];
+  return s3[15] + s3[0];
+}
+inline float emu_tree64(const float* v) {     // ... row_bcast15 (rows 1, 3 += rows 0, 2), row_bcast31 (rows 2, 3 += row 1): lane 63
+  const float r0 = emu_row_tree(v), r1 = emu_row_tree(v + 16), r2 = emu_row_tree(v + 32), r3 = emu_row_tree(v + 48);
+  return (r3 + r2) + (r1 + r0);
+}
+inline float emu_tree32(const float* v) {     // half-wave sum (WaveH): the two rows combined through v_permlane16_swap
+  return emu_row_tree(v) + emu_row_tree(v + 16);
+}
 
 #define DIAL_MARK(w, id)
 struct Wave {
+  static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront, this object is one 32-lane half)
+  bool tree_sums = false;                // wave sums in the GPU's association (see emu_row_tree)
   bool launder = false;   // (GPU only: opaque lane id per step, see the HIP Wave)
   float* lds = nullptr;
   int lds_words = 0;
@@ -105,6 +126,11 @@ struct Wave {
   }
   template <class F>
   float sum(int count, F f) {
+    if (tree_sums) {   // lane-strided partial sums first, as the GPU does (HIP Wave::sum)
+      float v[64];
+      for (int l = 0; l < 64; l++) { v[l] = l < count ? f(l) : 0.f; for (int i = l + 64; i < count; i += 64) v[l] += f(i); }
+      return emu_tree64(v);
+    }
     float s = 0.f;
     for (int i = 0; i < count; i++) s += f(i);
     return s;
@@ -112,6 +138,16 @@ struct Wave {
   // three sums at once; f(i, a, b, c) adds its contribution to a, b, c
   template <class F>
   void sum3(int count, F f, float& a, float& b, float& c) {
+    if (tree_sums) {
+      float va[64], vb[64], vc[64];
+      for (int l = 0; l < 64; l++) {
+        va[l] = vb[l] = vc[l] = 0.f;
+        if (l < count) f(l, va[l], vb[l], vc[l]);
+        for (int i = l + 64; i < count; i += 64) { float x = 0.f, y = 0.f, z = 0.f; f(i, x, y, z); va[l] += x; vb[l] += y; vc[l] += z; }
+      }
+      a = emu_tree64(va); b = emu_tree64(vb); c = emu_tree64(vc);
+      return;
+    }
     a = b = c = 0.f;
     for (int i = 0; i < count; i++) {
       float x = 0.f, y = 0.f, z = 0.f;
@@ -192,9 +228,64 @@ struct Wave {
   template <int K>
   void row16_sumN(vfloat (&v)[K]) { for (int k = 0; k < K; k++) v[k] = row16_sum(v[k]); }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
-  float vsum(const vfloat& v) { float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
+  float vsum(const vfloat& v) { if (tree_sums) return emu_tree64(v.x); float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
   template <int K>
   void vsumN(vfloat (&v)[K], float (&out)[K]) { for (int k = 0; k < K; k++) out[k] = vsum(v[k]); }
+  // value of lane K, as a wave-uniform scalar (same as the free function bcast; WaveH: of the own half)
+  template <int K>
+  float bc(const vfloat& v) { return v.x[K]; }
+};
+
+// ---- WaveH: TWO samples per wavefront, one per 32-lane half (HIP section below).  The emulator runs ONE half: logical lanes
+// 0..31 (lanes 32..63 of a vfloat mirror them), so that the 32-lane layouts of smooth_quad2.h / solver_reg2.h can be compared
+// with the oracle -- and bit for bit with the 64-lane layouts -- without a GPU.  Sums are always in the GPU's association.
+struct WaveH : Wave {
+  static constexpr bool half2 = true;
+  template <class F>
+  float sum(int count, F f) {
+    float v[32];
+    for (int l = 0; l < 32; l++) { v[l] = l < count ? f(l) : 0.f; for (int i = l + 32; i < count; i += 32) v[l] += f(i); }
+    return emu_tree32(v);
+  }
+  template <class F>
+  void sum3(int count, F f, float& a, float& b, float& c) {
+    float va[32], vb[32], vc[32];
+    for (int l = 0; l < 32; l++) {
+      va[l] = vb[l] = vc[l] = 0.f;
+      if (l < count) f(l, va[l], vb[l], vc[l]);
+      for (int i = l + 32; i < count; i += 32) { float x = 0.f, y = 0.f, z = 0.f; f(i, x, y, z); va[l] += x; vb[l] += y; vc[l] += z; }
+    }
+    a = emu_tree32(va); b = emu_tree32(vb); c = emu_tree32(vc);
+  }
+  template <class F>
+  vfloat per_lane(F f) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = f(l & 31); return r; }
+  template <class F>
+  vfloat per_lane_r(F f) { return per_lane(f); }
+  template <int K, class F>
+  void per_lane_n(vfloat (&out)[K], F f) {
+    for (int l = 0; l < 64; l++) { float o[K]; f(l & 31, o); for (int k = 0; k < K; k++) out[k].x[l] = o[k]; }
+  }
+  template <class F>
+  void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
+    for (int l = 0; l < 64; l++) { const float* p = f(l & 31); a.x[l] = p[0]; b.x[l] = p[1]; c.x[l] = p[2]; d.x[l] = p[3]; }
+  }
+  unsigned long long mask(const vbool& c) const { unsigned long long b = 0; for (int l = 0; l < 32; l++) b |= (unsigned long long)(c.x[l] ? 1 : 0) << l; return b; }
+  vbool lane_gt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = (l & 31) > k; return r; }
+  vbool lane_eq(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = (l & 31) == k; return r; }
+  vbool lane_lt(int k) const { vbool r; for (int l = 0; l < 64; l++) r.x[l] = (l & 31) < k; return r; }
+  vfloat lane_reverse(const vfloat& v, int n) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 31) < n ? v.x[(l & 32) + n - 1 - (l & 31)] : 0.f; return r; }
+  float vsum(const vfloat& v) { return emu_tree32(v.x); }
+  template <int K>
+  void vsumN(vfloat (&v)[K], float (&out)[K]) { for (int k = 0; k < K; k++) out[k] = vsum(v[k]); }
+  // X = the half's even row in both of its rows, Y = its odd row in both (GPU: one v_permlane16_swap)
+  void dup_rows(const vfloat& v, vfloat& X, vfloat& Y) {
+    for (int l = 0; l < 64; l++) { X.x[l] = v.x[(l & 32) | (l & 15)]; Y.x[l] = v.x[(l & 32) | 16 | (l & 15)]; }
+  }
+  // value of (logical) lane src(l) of the own half, per lane (GPU: ds_bpermute)
+  template <class F>
+  vfloat gather(const vfloat& v, F src) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & 32) | (src(l & 31) & 31)]; return r; }
+  // lane 3 of the own group of 8 lanes, to the whole group (GPU: two row_newbcast + select)
+  vfloat grp8_bcast3(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~7) | 3]; return r; }
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -252,6 +343,7 @@ __device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpre
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ vfloat vrcp(vfloat a) { return __builtin_amdgcn_rcpf(a); }
 
 #ifdef DIAL_PROFILE
 #define DIAL_NSEC 32
@@ -260,6 +352,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 #define DIAL_MARK(w, id)
 #endif
 struct Wave {
+  static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront)
   int lane;
 #ifdef DIAL_PROFILE
   // accumulators live in LDS (written by lane 0) so that the profiling build does not eat the scalar
@@ -469,5 +562,107 @@ struct Wave {
     a = dialwave::dpp_add<0x141>(a); b = dialwave::dpp_add<0x141>(b); c = dialwave::dpp_add<0x141>(c);
     a = dialwave::dpp_add<0x140>(a); b = dialwave::dpp_add<0x140>(b); c = dialwave::dpp_add<0x140>(c);
   }
+  template <int K>
+  __device__ __forceinline__ float bc(vfloat v) { return bcast(v, K); }
+};
+
+// ---- WaveH: TWO samples per wavefront.  Each 32-lane half owns one sample; the kernel body is the same per-lane program,
+// `lane` is the LOGICAL lane 0..31 inside the half and every value the one-sample kernel keeps wave-uniform (reduction results,
+// broadcast pivots, the solver's control flow) is simply a per-lane value that agrees within a half: where the two samples
+// take different branches the hardware's EXEC mask does what it does for any divergent SIMT code.  What that needs is that no
+// cross-lane operation leaves the half:
+//   * reductions: the DPP butterfly inside each row of 16 lanes, then ONE v_permlane16_swap (gfx950) that puts the half's
+//     even row next to its odd row in every lane -- no v_readlane, no SGPR;
+//   * broadcasts: dup_rows (the same swap: X = the half's even row in both rows, Y = its odd row) + DPP row_newbcast, i.e. a
+//     broadcast is a VGPR operand of the consuming instruction's DPP mov instead of a v_readlane -> SGPR -> VALU hazard chain;
+//   * ballots are split per half; the LDS workspace base and every global row pointer are per-lane values.
+// The lane layouts that need more than 32 lanes per sample in the one-sample kernel (smooth_quad.h: four DPP rows; solver_reg.h:
+// dof lanes + contact lanes + three line-search groups) have 32-lane versions in smooth_quad2.h / solver_reg2.h.
+struct WaveH : Wave {
+  static constexpr bool half2 = true;
+  int half;     // 0 / 1: which half of the wavefront this lane belongs to (a VGPR value)
+  __device__ __forceinline__ void init(int tid) { lane = tid & 31; lane_r = lane; half = (tid >> 5) & 1; }
+  template <class F>
+  __device__ __forceinline__ void items(int count, F f) {
+    for (int i = lane; i < count; i += 32) f(i);
+    sync();
+  }
+  // even row + odd row of the own half, in every lane of the half
+  static __device__ __forceinline__ float half_combine(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned r0 = r[0], r1 = r[1];   // (element temporaries: bit_cast straight from r[k] folds both to element 0, clang 22)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  }
+  __device__ __forceinline__ void dup_rows(vfloat v, vfloat& X, vfloat& Y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    X = __builtin_bit_cast(float, r0);
+    Y = __builtin_bit_cast(float, r1);
+  }
+  template <int K>
+  __device__ __forceinline__ float bc(vfloat v) {
+    static_assert(K >= 0 && K < 32, "logical lane");
+    vfloat X, Y;
+    dup_rows(v, X, Y);
+    if constexpr (K < 16) return row_bcast<K>(X);
+    else return row_bcast<K - 16>(Y);
+  }
+  template <class F>
+  __device__ __forceinline__ vfloat gather(vfloat v, F src) { return __shfl(v, (src(lane) & 31) + 32 * half, 64); }   // ds_bpermute_b32
+  __device__ __forceinline__ vfloat grp8_bcast3(vfloat v) {
+    const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
+    return (lane & 8) ? b : a;
+  }
+  __device__ __forceinline__ float vsum(vfloat v) { return half_combine(row16_sum(v)); }
+  template <int K>
+  __device__ __forceinline__ void vsumN(vfloat (&v)[K], float (&out)[K]) {
+    row16_sumN(v);
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = half_combine(v[k]);
+  }
+  template <class F>
+  __device__ __forceinline__ float sum(int count, F f) {
+    float v = lane < count ? f(lane) : 0.f;
+    for (int i = lane + 32; i < count; i += 32) v += f(i);
+    return vsum(v);
+  }
+  template <class F>
+  __device__ __forceinline__ void sum3(int count, F f, float& a, float& b, float& c) {
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (lane < count) f(lane, x, y, z);
+    for (int i = lane + 32; i < count; i += 32) {
+      float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+      f(i, x2, y2, z2);
+      x += x2; y += y2; z += z2;
+    }
+    vfloat t3[3] = {x, y, z};
+    float r3[3];
+    vsumN(t3, r3);
+    a = r3[0]; b = r3[1]; c = r3[2];
+  }
+  // ballot of the own half, in the low 32 bits
+  __device__ __forceinline__ unsigned long long mask(vbool c) const {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
+    return half ? (unsigned)(b >> 32) : (unsigned)b;
+  }
+  __device__ __forceinline__ vfloat lane_reverse(vfloat v, int n) {
+    const float r = __shfl(v, ((n - 1 - lane) & 31) + 32 * half, 64);
+    return lane < n ? r : 0.f;
+  }
+  // issue priority is a property of the wavefront: keyed by the pair's first rollout
+  __device__ __forceinline__ void set_rollout(int n) { Wave::set_rollout(__builtin_amdgcn_readfirstlane(n)); }
+  __device__ __forceinline__ void redraw_priority() {
+#ifndef DIAL_FIXED_PRIORITY
+    prio_ctr++;
+    const unsigned h = __builtin_amdgcn_readfirstlane((prio_seed + prio_ctr * 0x9E3779B1u) >> 30);
+    if (h == 0) __builtin_amdgcn_s_setprio(0);
+    else if (h == 1) __builtin_amdgcn_s_setprio(1);
+    else if (h == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#endif
+  }
+#ifdef DIAL_PROFILE
+  __device__ __forceinline__ void mark(int) {}
+#endif
 };
 #endif

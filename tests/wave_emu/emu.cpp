@@ -57,17 +57,21 @@ struct Runner {
   }
 };
 
-template <class D>
+// WV: Wave (one sample per wavefront, the 64-lane layouts) or WaveH (one half of the two-samples-per-wavefront kernel: the
+// 32-lane layouts of smooth_quad2.h / solver_reg2.h).  tree: wave sums in the GPU's association (wave.h: emu_row_tree) -- what
+// lets the two layouts be compared bit for bit.
+template <class D, class WV = Wave>
 int run_rollout(const dial_model* m, const dial_task* t, const dial_derived* dv, const dial_cfg* cfg,
-                const dial::RolloutIO& io, int B, int check_races) {
+                const dial::RolloutIO& io, int B, int check_races, bool tree = false) {
   Runner<D> r(m, t, dv);
   int races = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : races)
   for (int n = 0; n < B; n++) {
     std::vector<float> lds;
     Ws s;
-    Wave w;
+    WV w;
     r.setup(lds, s, w, check_races);
+    w.tree_sums = tree;
     dial::rollout_sample<true>(w, &r.cm, t, cfg, s, io, n);
     races += w.races;
   }
@@ -122,6 +126,13 @@ int emu_rollout(const dial_model* m, const dial_task* t, const dial_cfg* cfg, co
   if (rc) return rc;
   dial::RolloutIO io{state, us, eps, Ybar, noise_scale, ns, n_noise, T, Hn1, Y0s, rewss, rews, qss, qdss, xss, nullptr, 0, 0u, 0u, 0u, 0};
   io.trace = trace;   // [B,T,nstate] packed state after every env.step, or nullptr
+  // path 2: the Go2's 32-lane (half-wave) layouts; path 3: its 64-lane layouts with the GPU's summation order (the reference
+  // path 2 must equal bit for bit)
+  if (path == 2 || path == 3) {
+    if (!dims_match<DimsGo2>(m)) return DIAL_ERR_UNSUPPORTED;
+    if (path == 2) return run_rollout<DimsGo2, WaveH>(m, t, &dv, cfg, io, B, check_races, true);
+    return run_rollout<DimsGo2, Wave>(m, t, &dv, cfg, io, B, check_races, true);
+  }
 #define CALL(D) run_rollout<D>(m, t, &dv, cfg, io, B, check_races)
   DISPATCH(path, m, CALL)
 #undef CALL
