@@ -26,7 +26,7 @@ class DialHipError(RuntimeError):
 IEEE_LIB_PATH = os.path.join(_CSRC, "libdialhip_ieee.so")
 
 
-N_FAMILIES = 7     # robot families of csrc/kernel_list.h, one translation unit each (kern_family.hip -DDIAL_FAMILY=k)
+N_FAMILIES = 8     # robot families of csrc/kernel_list.h (7: the Go2's two-samples-per-wavefront kernels), one translation unit each (kern_family.hip -DDIAL_FAMILY=k)
 # device fast-math flags of the product build (the IEEE measurement variant drops them):
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: fp32 divide / sqrt via v_rcp / v_sqrt sequences (<= 2.5 ulp)
 # instead of the IEEE fix-up chains; well inside the fp32 parity tolerance.
@@ -38,6 +38,11 @@ _FAST = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-freci
          "-Xarch_device", "-fno-honor-nans"]
 # -fno-slp-vectorize (both variants): the SLP pass packs pairs of scalar fp32 ops into v_pk_* and pays for it in v_mov
 # shuffles -- measured 5-6% slower on this issue-bound kernel.
+# the IEEE measurement variant: none of the fast-math flags and NO fused multiply-add contraction either -- every fp32 operation
+# rounded on its own, as the CPU oracle computes.  Which a * b + c pairs the compiler fuses depends on the basic-block structure around
+# them, i.e. differs between two kernels that run the same arithmetic on different lane layouts: this variant is where the Go2's
+# two-samples-per-wavefront kernel is compared BIT FOR BIT with the one-sample kernel (tests/test_gpu_parity.py).
+_IEEE = ["-Xarch_device", "-ffp-contract=off"]
 _COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_device", "-fno-slp-vectorize"]
 
 
@@ -46,7 +51,8 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
     kernels) and csrc/kern_family.hip once per robot family, the translation units IN PARALLEL, then one link.
 
     ieee=True builds the MEASUREMENT variant libdialhip_ieee.so: the same sources without the device fast-math flags
-    (correctly rounded divide / sqrt, no reciprocal-math, no approximate functions, NaNs honoured).  It is never the product
+    (correctly rounded divide / sqrt, no reciprocal-math, no approximate functions, NaNs honoured) and without fused
+    multiply-add contraction (_IEEE above).  It is never the product
     path; the GPU suite loads it next to the product library to show how much of the knife-edge witness traffic is the
     fast-math rounding (tests/test_gpu_parity.py: test_ieee_build_needs_no_more_witnesses)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -56,7 +62,7 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = _COMMON + ([] if ieee else _FAST) + ([] if ieee else os.environ.get("DIAL_HIPCC_EXTRA", "").split())
+    flags = _COMMON + (_IEEE if ieee else _FAST) + ([] if ieee else os.environ.get("DIAL_HIPCC_EXTRA", "").split())
     objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", "obj_" + os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]

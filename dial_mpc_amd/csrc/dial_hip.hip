@@ -29,6 +29,10 @@
   extern template __global__ void env_step_kernel<D>(const CModel<D>*, const dial_task*, float*, const float*, float*, float*, float*); \
   extern template __global__ void env_reset_kernel<D>(const CModel<D>*, const float*, const float*, float*, float*, float*);
 DIAL_KERNELS_ALL(DIAL_X, DIAL_XE)
+#define DIAL_X2(D, WPB, OCC, Q) \
+  extern template __global__ void rollout_kernel2<D, WPB, OCC, Q>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
+DIAL_KERNELS2_GO2(DIAL_X2)
+#undef DIAL_X2
 #undef DIAL_X
 #undef DIAL_XE
 
@@ -269,6 +273,11 @@ struct dial_ctx {
   int debug_stall_piece1 = 0;  // DIAL_DEBUG_RELAY_STALL=k (tests): relay piece k - 1 never hands over
   int relay_steps = 3;         // control steps per relay piece (measured: 1 -> no gain, 2 -4.9 %, 3 -5.3 %, 4 -5.0 %, 6 -4.0 %)
   int resident_blocks = 0, resident_blocks_large = 0;   // workgroups of the rollout kernel the whole chip holds at once
+  // Go2, two rollouts per wavefront (rollout_kernel2): LDS of the one-wavefront / DIAL_GO2_PAIR_WPB-wavefront workgroups and how
+  // many of each the chip keeps resident; pair_ok: the context launches them (dial_options::pair_mode)
+  bool pair_ok = false;
+  size_t lds_pair = 0, lds_pair_large = 0;
+  int resident_pair = 0, resident_pair_large = 0;
   bool timing = false;
   dial_options opt{};          // launch-shape / measurement options (dial_create_ex); all zero = shipped behaviour
   float* trace = nullptr;      // diagnostics: per-step packed states of the rollouts (dial_set_state_trace), caller-owned
@@ -504,6 +513,18 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
 #undef DIAL_BIG_LDS
     if (e == hipSuccess && ctx->inst == 1 && ctx->lds_large > 64 * 1024)
       e = hipFuncSetAttribute((const void*)rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_large);
+    if (ctx->inst == 1 && cfg) {
+      ctx->pair_ok = opt.pair_mode != 1;
+      ctx->lds_pair = ctx->cm_bytes + (size_t)2 * ctx->ws_words * sizeof(float);
+      ctx->lds_pair_large = ctx->cm_bytes + (size_t)2 * DIAL_GO2_PAIR_WPB * ctx->ws_words * sizeof(float);
+#ifdef DIAL_PROFILE
+      ctx->lds_pair += 16 + 32 * sizeof(unsigned long long);
+      ctx->lds_pair_large += 16 + (size_t)DIAL_GO2_PAIR_WPB * 32 * sizeof(unsigned long long);
+#endif
+      if (ctx->lds_pair_large > 160 * 1024) ctx->pair_ok = false;
+      if (e == hipSuccess && ctx->pair_ok && ctx->lds_pair_large > 64 * 1024)
+        e = hipFuncSetAttribute((const void*)rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_pair_large);
+    }
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
   {   // how many workgroups of the rollout kernel the chip keeps resident (larger batches go through the rollout queue)
@@ -526,6 +547,14 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel<DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true>,
                                                        64 * DIAL_GO2_WPB_LARGE, ctx->lds_large);
       if (e == hipSuccess) ctx->resident_blocks_large = nb * prop.multiProcessorCount;
+    }
+    if (e == hipSuccess && ctx->pair_ok) {
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false>, 64, ctx->lds_pair);
+      if (e == hipSuccess) ctx->resident_pair = nb * prop.multiProcessorCount;
+      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>,
+                                                                            64 * DIAL_GO2_PAIR_WPB, ctx->lds_pair_large);
+      if (e == hipSuccess) ctx->resident_pair_large = nb * prop.multiProcessorCount;
+      if (e == hipSuccess && (ctx->resident_pair <= 0 || ctx->resident_pair_large <= 0)) ctx->pair_ok = false;
     }
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: occupancy query: ") + hipGetErrorString(e)); }
     if (opt.no_queue) ctx->resident_blocks = ctx->resident_blocks_large = 0;   // options: one wavefront per rollout at any batch size
@@ -665,6 +694,7 @@ int dial_get_rollout_ms(dial_ctx* ctx, double* total_ms, int* launches) {
   return DIAL_OK;
 }
 
+static bool opt_no_queue(const dial_ctx* ctx) { return ctx->opt.no_queue != 0; }
 static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hipStream_t st) {
   if (int rc = check_sticky(ctx)) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -683,6 +713,25 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // batches beyond what the chip keeps resident: launch exactly the resident grid and let the wavefronts draw the
   // remaining rollouts from a queue (see rollout_kernel); the queue head starts behind the grid's own first rollouts
   const bool tracing = ctx->trace != nullptr;   // diagnostics: the TRACE instantiation on the plain grid (no queue / split / large-batch variant)
+  // Go2: two rollouts per wavefront.  Up to the resident set of one-wavefront workgroups the grid covers the batch (wavefront p:
+  // rollouts 2 p, 2 p + 1); beyond it the resident grid of DIAL_GO2_PAIR_WPB-wavefront workgroups draws pairs from the queue.
+  if (ctx->pair_ok && !tracing) {
+    dial::RolloutIO io = io_in;
+    const int pairs = (B + 1) / 2;
+    if (pairs <= ctx->resident_pair || opt_no_queue(ctx)) {
+      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false>), dim3(pairs), dim3(64), ctx->lds_pair, st,
+                         (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, (int*)nullptr);
+    } else {
+      const int blocks = ctx->resident_pair_large;
+      HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->next, blocks * DIAL_GO2_PAIR_WPB, 1, st));
+      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>), dim3(blocks), dim3(64 * DIAL_GO2_PAIR_WPB),
+                         ctx->lds_pair_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B,
+                         ctx->ws_words, ctx->next);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(e1, st));
+    return DIAL_OK;
+  }
   const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B && !tracing;
   const int wpb = large ? DIAL_GO2_WPB_LARGE : ctx->wpb;
   const int resident = large ? ctx->resident_blocks_large : ctx->resident_blocks;
@@ -1054,6 +1103,7 @@ int dial_debug_set_stall(dial_ctx* ctx, int piece1) { if (!ctx) return DIAL_ERR_
 // wavefront slots of the rollout kernel on the whole chip for a batch of B rollouts (B > slots: the rollout queue runs)
 int dial_debug_resident_rollouts(dial_ctx* ctx, int B) {
   if (!ctx) return -1;
+  if (ctx->pair_ok) return (B + 1) / 2 <= ctx->resident_pair ? 2 * ctx->resident_pair : 2 * DIAL_GO2_PAIR_WPB * ctx->resident_pair_large;
   const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B;
   return large ? ctx->resident_blocks_large * DIAL_GO2_WPB_LARGE : ctx->resident_blocks * ctx->wpb;
 }

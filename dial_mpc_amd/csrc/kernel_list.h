@@ -17,6 +17,16 @@
 #ifndef DIAL_GO2_OCC_LARGE
 #define DIAL_GO2_OCC_LARGE 4
 #endif
+// Round 5: TWO samples per wavefront (rollout_kernel2, wave.h: WaveH).  Small batches: one wavefront per workgroup (7.3 KB of
+// constants + 2 x 8.9 KB), N + 1 = 2049 rollouts = 1025 wavefronts = ONE per SIMD; large ones: the rollout queue over workgroups
+// of DIAL_GO2_PAIR_WPB wavefronts (78.5 KB: two per CU = two wavefronts = four rollouts per SIMD).  Compiled for two wavefronts
+// per SIMD (<= 256 VGPRs; the kernel uses ~236, no scratch).
+#ifndef DIAL_GO2_PAIR_WPB
+#define DIAL_GO2_PAIR_WPB 4
+#endif
+#ifndef DIAL_GO2_PAIR_OCC
+#define DIAL_GO2_PAIR_OCC 2
+#endif
 // Allegro: 15.3 KB of workspace per wavefront + 10.5 KB of shared constants.  9 wavefronts per workgroup = 148 KB = one
 // workgroup per CU = 2304 resident rollouts: the example's N + 1 = 2049 run in ONE round (8 per CU would leave the
 // 2049th rollout for a second round and double the launch time), BASELINE config 4 (4097) in two instead of three.
@@ -47,6 +57,8 @@
 // X(Dims, wavefronts per workgroup, occupancy target, rollout-queue variant, state-trace variant); XE(Dims): env.step / env.reset
 #define DIAL_KERNELS_GO2(X, XE) \
   X(DimsGo2, 1, 3, false, false) X(DimsGo2, 1, 3, false, true) X(DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true, false) XE(DimsGo2)
+// X2(Dims, wavefronts per workgroup, occupancy target, rollout-queue variant): the two-samples-per-wavefront kernels
+#define DIAL_KERNELS2_GO2(X2) X2(DimsGo2, 1, DIAL_GO2_PAIR_OCC, false) X2(DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true)
 #define DIAL_KERNELS_H1(X, XE) \
   X(DimsH1, 3, 3, false, false) X(DimsH1, 3, 3, true, false) X(DimsH1, 3, 3, false, true) \
   X(DimsH1, DIAL_H1_WPB_EVEN, DIAL_EVEN_OCC_H1, false, false) X(DimsH1, 1, 3, false, false) XE(DimsH1)
@@ -64,4 +76,4 @@
 #define DIAL_KERNELS_ALL(X, XE) \
   DIAL_KERNELS_GO2(X, XE) DIAL_KERNELS_H1(X, XE) DIAL_KERNELS_H1LOCO(X, XE) DIAL_KERNELS_ALLEGRO(X, XE) DIAL_KERNELS_GENERIC(X, XE) \
   DIAL_KERNELS_GO2CRATE(X, XE) DIAL_KERNELS_H1PUSHCRATE(X, XE)
-#define DIAL_N_FAMILIES 7
+#define DIAL_N_FAMILIES 8

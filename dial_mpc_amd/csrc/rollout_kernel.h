@@ -118,6 +118,51 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   }
 }
 
+// TWO samples per wavefront (wave.h: WaveH): every 32-lane half owns one rollout -- its own workspace in LDS, its own rows in the
+// output tensors -- and the staged constants are shared by the 2 x WPB rollouts of the workgroup.  Wavefront p of the launch runs
+// rollouts 2 p and 2 p + 1 (an odd batch leaves the last wavefront's upper half idle: it returns, the EXEC mask does the rest).
+// QUEUE: the grid is what the chip keeps resident and every wavefront draws its next PAIR from `next`.
+// The body is rollout_sample -- the same per-lane program as the one-sample kernel with the 32-lane layouts of smooth_quad2.h /
+// solver_reg2.h -- and produces the same bits per rollout (GPU test: test_two_samples_per_wavefront_is_bit_identical).
+template <class D, int WPB, int OCC = 2, bool QUEUE = false>
+__global__ void __launch_bounds__(64 * WPB, OCC)
+rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
+                const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
+  static_assert(D::is_static && dial::kQuadDims<D>, "the half-wave layouts exist for the Go2's own instantiation");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspaces 16-B aligned
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
+    __syncthreads();   // (the only workgroup-level barrier: phase boundaries are wavefront-scope fences, wave.h)
+  }
+  const CModel<D>* m = reinterpret_cast<const CModel<D>*>(smem);
+  WaveH w;
+  w.init((int)threadIdx.x);
+  Ws s;
+  ws_carve(s, smem + CMW + (int)(threadIdx.x >> 5) * ws_words, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m),
+           dim_ns(m), dim_nc(m), dim_ne(m), io.Hn1, false, true, 0, 0, D::NVP);
+#ifdef DIAL_PROFILE
+  w.acc = reinterpret_cast<unsigned long long*>(smem + (CMW + 2 * WPB * ws_words + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
+  if ((threadIdx.x & 63) < 32) w.acc[threadIdx.x & 63] = 0;
+  __syncthreads();
+#endif
+  int pair = (WPB > 1 ? (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
+  for (;;) {
+    const int n = 2 * pair + w.half + io.n_first;
+    // (measured and not kept: the highest issue priority for the odd wavefront of a batch -- N + 1 = 2049 is 1024 full
+    //  wavefronts and the mean trajectory alone in the 1025th, which shares a SIMD -- starves its SIMD-mate: 0.408 -> 0.440 ms)
+    if (n < B) dial::rollout_sample<false>(w, m, tg, cfg, s, io, n);
+    if constexpr (!QUEUE) break;
+    if (!next) break;
+    int nn = 0;
+    if ((threadIdx.x & 63) == 0) nn = atomicAdd(next, 1);
+    pair = __builtin_amdgcn_readfirstlane(nn);
+    if (2 * pair + io.n_first >= B) break;
+  }
+}
+
 template <class D>
 __global__ void __launch_bounds__(64)
 env_step_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg, float* state,

@@ -26,6 +26,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
   constexpr int S = M::D::S;
   static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "the Go2's own scene");
   static_assert(W::half2, "32-lane layout: the half-wave execution model");
+  DIAL_MARK(w, 15);
   // lane roles (functions of the logical lane id)
   //   leg:  d in 1..3      rot: d in 4..6 (trunk dof d - 1)      tr: d == 7 && g < 3 (trunk dof g)
   //   mrow: the lanes that own a row of M / an entry of qfrc_smooth for a trunk dof: rot of group 0, tr
@@ -78,6 +79,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     DIAL_UNROLL_FULL
     for (int k = 0; k < 7; k++) PL[k] = N[k];
   }
+  DIAL_MARK(w, 0);
   // ---- local_to_global: inertial frames (all bodies), the foot geom and site (calf lanes), the trunk's site (trunk lanes)
   vfloat F[22];   // xipos(3) ximat(9) | mass-weighted xipos(3), mass | site(3) | foot geom centre(3)
   w.per_lane_n(F, [&](int l, float* o) {
@@ -107,6 +109,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     for (int k = 0; k < 9; k++) o[3 + k] = mat[k];
     o[15] = counted ? mass : 0.f;
   });
+  DIAL_MARK(w, 16);
   // ---- smooth.com_pos: one reduction over the half (the 13 bodies form one kinematic tree)
   float com[3];
   {
@@ -127,6 +130,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     dm::cross3(cr, a, offt);
     for (int k = 0; k < 3; k++) { cdT[i][k] = a[k]; cdT[i][3 + k] = cr[k]; }
   }
+  DIAL_MARK(w, 17);
   // ---- cinert (body lanes) and cdof (dof lanes)
   vfloat X[16];   // cinert(10) | local force cfl(6): the quantities summed over subtrees
   vfloat CD[6];
@@ -175,6 +179,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     DIAL_UNROLL_FULL
     for (int k = 0; k < 6; k++) CD[k] = T[10 + k];
   }
+  DIAL_MARK(w, 18);
   // ---- smooth.com_vel + cdof_dot + rne forward: the trunk's velocity / acceleration (every lane the same), then root-to-leaf
   vfloat VA[12];   // cvel(6) | cacc(6)
   {
@@ -235,6 +240,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     }
     if (d == 3) for (int k = 0; k < 3; k++) s.spos[3 * (1 + g) + k] = lane_val(F[16 + k], l);
   });
+  DIAL_MARK(w, 20);   // (smooth_quad.h counts the sweep and the fused contact stage together as section 19)
   // ---- collision_driver (the four plane-sphere foot contacts), the contact Jacobian and constraint.make_constraint, fused
   {
     float pn[3];
@@ -315,6 +321,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
       s.aref[lr] = on ? -b_ * (sgn * lane_val(QVL, l)) - k_ * imp * pos : 0.f;
     });
   }
+  DIAL_MARK(w, 19);
   // ---- rne: local body forces cfl = cinert cacc + cvel x* (cinert cvel)
   {
     vfloat T[6];
@@ -356,6 +363,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     DIAL_UNROLL_FULL
     for (int k = 0; k < 16; k++) XT[k] = w.template bc<0>(X[k]) + hs[k];
   }
+  DIAL_MARK(w, 22);
   // ---- F_i = crb cdof_i, M = F . cdof over the ancestors (support.make_m), qfrc_smooth = passive - bias + actuator
   vfloat MO[11];   // columns 0..5 (trunk dofs) | own diagonal | parent dof | grandparent dof | qfrc_smooth | (unused)
   {
@@ -397,6 +405,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
       o[10] = 0.f;
     });
   }
+  DIAL_MARK(w, 23);
   // ---- the dofs' outputs
   w.items(32, [&](int l) {
     const int d = l & 7, g = l >> 3;
@@ -418,6 +427,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
       }
     }
   });
+  DIAL_MARK(w, 1);
 }
 
 // Once per kernel, on top of init_quad (smooth_quad.h): the Jacobian entries of the trunk's three TRANSLATIONAL dofs against the

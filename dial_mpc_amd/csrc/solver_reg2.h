@@ -238,6 +238,7 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
     } else if (max_iter != 1) {
       gn = w.vsum(vgrad * vgrad);
     }
+    DIAL_MARK(w, 4);
     bool done;
     if (max_iter != 1) {
       const float improvement = scale * (prev_cost - cost), gradient = scale * DM_SQRT(gn);
@@ -261,6 +262,7 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
     vfloat vsearch;
     if (reuse) {
       vsearch = vzero - reg_chol_solve2<typename M::D, typename M::D::Topo, true>(w, m, s.H, vgrad, s.H, &h_dinv);
+      DIAL_MARK(w, 5);
     } else {
     {
       // row weights: limit rows at frc[0, NL), contact rows 16-byte aligned at frc[NLP, NLP + 4 NC), then a zero word
@@ -324,8 +326,10 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
         });
       });
     }
+    DIAL_MARK(w, 5);
     vsearch = vzero - reg_chol_solve2<typename M::D>(w, m, s.H, vgrad, s.H, &h_dinv);
     }
+    DIAL_MARK(w, 6);
 
     // ---- solver._linesearch
     w.begin_region();
@@ -364,36 +368,43 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
       Q1[q] = ljv[q] * dja;
       Q2[q] = (ljv[q] * 0.5f) * djv;
     }
-    // evaluate the points a0 (group 0) and a1 (group 1): every lane of a group finishes its point -- cost, slope, the point's
-    // own Newton step, the integer keys of ls_bracket.h -- and the four words reach the rest of the half by dup_rows
-    auto ls_eval2 = [&](float a0, float a1, LsPt& p0_, LsPt& p1_) {
-      const vfloat va = vsel(g0, vsplat(a0), vsplat(a1));
-      vfloat s0 = vzero, s1v = vzero, s2v = vzero;
-#pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const vfloat act_ = vsel(vlt0(lJa[q] + ljv[q] * va), vsplat(1.f), vzero);
-        s0 = s0 + act_ * Q0[q];
-        s1v = s1v + act_ * Q1[q];
-        s2v = s2v + act_ * Q2[q];
-      }
-      w.row16_sum3(s0, s1v, s2v);
+    // One pass evaluates up to THREE trial points: every lane the point of its group (`a_ab`: group 0 lo_next, group 1 hi_next) AND
+    // the mid-point (`a_c`, by both groups redundantly) -- per row and point one FMA, one compare and three selected adds into the
+    // sums (0.5 D Jaref^2, D jv Jaref, 0.5 D jv^2 over the active rows), six interleaved 16-lane DPP reductions, and every lane
+    // finishes both of its points: cost, slope, the point's own Newton step and the integer keys of ls_bracket.h.  Each point's
+    // sums associate exactly as in solver_reg.h (rows l and l + 16 in lane l of a 16-lane group).
+    auto finish = [&](const vfloat& va, vfloat s0, vfloat s1v, vfloat s2v, vfloat (&pk)[4]) {
       const vfloat q0 = s0 + vsplat(qg0), q1 = s1v + vsplat(qg1), q2 = s2v + vsplat(qg2);
       const vfloat vcost = (va * va) * q2 + va * q1 + q0;
       const vfloat vd0 = vfma(va * 2.f, q2, q1);   // single rounding: see the line search of rollout_body.h
       const vfloat vd1 = q2 * 2.f + vsel(veq0(q2), vsplat(MJ_MINVAL), vzero);
-      vfloat pk[4];
       w.per_lane_n(pk, [&](int l, float* o) {
         ls_pack(lane_val(va, l), lane_val(vcost, l), lane_val(vd0, l), lane_val(vd1, l), o[0], o[1], o[2], o[3]);
       });
-      vfloat X[4], Y[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) w.dup_rows(pk[k], X[k], Y[k]);   // (rows are constant: no lane select needed)
-      p0_.alpha = fbits(lane_val(X[0], 0)); p0_.nalpha = fbits(lane_val(X[1], 0)); p0_.cost = fbits(lane_val(X[2], 0)); p0_.d0 = fbits(lane_val(X[3], 0));
-      p1_.alpha = fbits(lane_val(Y[0], 0)); p1_.nalpha = fbits(lane_val(Y[1], 0)); p1_.cost = fbits(lane_val(Y[2], 0)); p1_.d0 = fbits(lane_val(Y[3], 0));
     };
-    LsPt p0, pdummy, p1;
-    ls_eval2(0.f, 0.f, p0, pdummy);
-    ls_eval2(bitsf(p0.nalpha), bitsf(p0.nalpha), p1, pdummy);
+    auto to_pt = [&](const vfloat (&pk)[4]) {
+      LsPt p;
+      p.alpha = fbits(lane_val(pk[0], 0)); p.nalpha = fbits(lane_val(pk[1], 0)); p.cost = fbits(lane_val(pk[2], 0)); p.d0 = fbits(lane_val(pk[3], 0));
+      return p;
+    };
+    auto ls_eval1 = [&](float a) {   // one point, evaluated by both groups (identical results): every lane of the half has it
+      const vfloat va = vsplat(a);
+      vfloat t[3] = {vzero, vzero, vzero};
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const vfloat act_ = vsel(vlt0(lJa[q] + ljv[q] * va), vsplat(1.f), vzero);
+        t[0] = t[0] + act_ * Q0[q];
+        t[1] = t[1] + act_ * Q1[q];
+        t[2] = t[2] + act_ * Q2[q];
+      }
+      w.row16_sumN(t);
+      vfloat pk[4];
+      finish(va, t[0], t[1], t[2], pk);
+      return to_pt(pk);
+    };
+    DIAL_MARK(w, 26);   // line-search set-up (J v, M v, sums, re-layout)
+    const LsPt p0 = ls_eval1(0.f);
+    const LsPt p1 = ls_eval1(bitsf(p0.nalpha));
     LsPt lo, hi;
     ls_open(p0, p1, lo, hi);
     const int kg = fkey(gtol), kng = fkey(-gtol);
@@ -402,11 +413,32 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
     for (;;) {
       const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
-      LsPt lo_next, hi_next, mid;
-      ls_eval2(bitsf(lo.nalpha), bitsf(hi.nalpha), lo_next, hi_next);
-      const float amid = 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha));
-      ls_eval2(amid, amid, mid, pdummy);
-      swap = ls_update(rule_swap, lo, hi, lo_next, hi_next, mid);
+      const vfloat va = vsel(g0, vsplat(bitsf(lo.nalpha)), vsplat(bitsf(hi.nalpha)));   // groups: lo_next, hi_next
+      const vfloat vc = vsplat(0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));             // both groups: mid
+      vfloat t[6] = {vzero, vzero, vzero, vzero, vzero, vzero};
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const vfloat act_a = vsel(vlt0(lJa[q] + ljv[q] * va), vsplat(1.f), vzero);
+        const vfloat act_c = vsel(vlt0(lJa[q] + ljv[q] * vc), vsplat(1.f), vzero);
+        t[0] = t[0] + act_a * Q0[q];
+        t[1] = t[1] + act_a * Q1[q];
+        t[2] = t[2] + act_a * Q2[q];
+        t[3] = t[3] + act_c * Q0[q];
+        t[4] = t[4] + act_c * Q1[q];
+        t[5] = t[5] + act_c * Q2[q];
+      }
+      w.row16_sumN(t);
+      vfloat pkab[4], pkc[4], pkA[4], pkB[4];
+      finish(va, t[0], t[1], t[2], pkab);
+      finish(vc, t[3], t[4], t[5], pkc);
+#pragma unroll
+      for (int k = 0; k < 4; k++) w.dup_rows(pkab[k], pkA[k], pkB[k]);   // group 0's point / group 1's point, to the whole half
+      // the bracket update on the slope keys alone (ls_bracket.h: ls_update_lazy); `lane` 0 / 1 / 2 names the winner: lo_next, hi_next, mid
+      swap = ls_update_lazy(rule_swap, lo, hi, fbits(lane_val(pkA[3], 0)), fbits(lane_val(pkB[3], 0)), fbits(lane_val(pkc[3], 0)), 0, 1, 2,
+                            [&](int word, int which) {
+                              const int a_ = fbits(lane_val(pkA[word], 0)), b_ = fbits(lane_val(pkB[word], 0)), c_ = fbits(lane_val(pkc[word], 0));
+                              return which == 0 ? a_ : (which == 1 ? b_ : c_);
+                            });
       ls_iter++;
     }
     float alpha;
@@ -418,12 +450,14 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
       cJa = cJa + cjv * alpha;
     }
     niter++;
+    DIAL_MARK(w, 7);
   }
   w.items(NV, [&](int i) {
     const float q = lane_val(vqacc, i);
     s.qacc[i] = q;
     s.warm[i] = q;
   });
+  DIAL_MARK(w, 8);
 }
 
 }  // namespace dial

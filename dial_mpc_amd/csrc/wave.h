@@ -613,6 +613,21 @@ struct WaveH : Wave {
     const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
     return (lane & 8) ? b : a;
   }
+  // Reductions whose result every lane USES (there is no v_readlane to make it wave-uniform): all lanes of the half must end
+  // up with the same bits.  The butterfly is symmetric -- lane l forms v[l] + v[l ^ 1], lane l ^ 1 the same two operands the other
+  // way round -- unless hipcc contracts the multiply that produced v into the first add: fma(a_l, b_l, round(a_l' b_l')) in one
+  // lane and fma(a_l', b_l', round(a_l b_l)) in the other differ in the last bit, the lanes of a half then take different
+  // branches of the solver and the rollout is garbage (the first GPU run of the product build; the build without contraction was
+  // bit-identical to the one-sample kernel).  So the summands enter the butterfly through an opaque copy: no fusion across it.
+  static __device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
+  __device__ __forceinline__ vfloat row16_sum(vfloat v) { return Wave::row16_sum(opaque(v)); }
+  template <int K>
+  __device__ __forceinline__ void row16_sumN(vfloat (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = opaque(v[k]);
+    Wave::row16_sumN(v);
+  }
+  __device__ __forceinline__ void row16_sum3(vfloat& a, vfloat& b, vfloat& c) { a = opaque(a); b = opaque(b); c = opaque(c); Wave::row16_sum3(a, b, c); }
   __device__ __forceinline__ float vsum(vfloat v) { return half_combine(row16_sum(v)); }
   template <int K>
   __device__ __forceinline__ void vsumN(vfloat (&v)[K], float (&out)[K]) {
@@ -650,9 +665,11 @@ struct WaveH : Wave {
     return lane < n ? r : 0.f;
   }
   // issue priority is a property of the wavefront: keyed by the pair's first rollout
-  __device__ __forceinline__ void set_rollout(int n) { Wave::set_rollout(__builtin_amdgcn_readfirstlane(n)); }
+  // (a priority held by the kernel -- rollout_kernel2: the odd wavefront of a batch -- survives the start of the rollout)
+  __device__ __forceinline__ void set_rollout(int n) { const bool held = prio_held; Wave::set_rollout(__builtin_amdgcn_readfirstlane(n)); prio_held = held; }
   __device__ __forceinline__ void redraw_priority() {
 #ifndef DIAL_FIXED_PRIORITY
+    if (prio_held) return;
     prio_ctr++;
     const unsigned h = __builtin_amdgcn_readfirstlane((prio_seed + prio_ctr * 0x9E3779B1u) >> 30);
     if (h == 0) __builtin_amdgcn_s_setprio(0);
@@ -662,7 +679,11 @@ struct WaveH : Wave {
 #endif
   }
 #ifdef DIAL_PROFILE
-  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void mark(int id) {   // the lower half's lane 0 keeps the wavefront's section clock
+    unsigned long long t = __builtin_readcyclecounter();
+    if (lane == 0 && half == 0 && acc) acc[id] += t - tprev;
+    tprev = t;
+  }
 #endif
 };
 #endif

@@ -11,7 +11,23 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _suite_option_defaults():
+    """Measurement aid of the TEST HARNESS (not of the library): DIAL_TEST_OPTIONS="pair_mode=1,no_queue=1" makes every Context the
+    suite creates start from these dial_options (a test's own options win) -- e.g. the whole GPU suite on the Go2's one-sample kernels."""
+    spec = os.environ.get("DIAL_TEST_OPTIONS", "")
+    if not spec:
+        return
+    defaults = {k.strip(): int(v) for k, v in (kv.split("=") for kv in spec.split(",") if kv.strip())}
+    from dial_mpc_amd import _lib
+    init = _lib.Context.__init__
+
+    def patched(self, model, task, cfg, device=None, n_local_cap=None, lib_path=None, options=None):
+        init(self, model, task, cfg, device=device, n_local_cap=n_local_cap, lib_path=lib_path, options={**defaults, **(options or {})})
+    _lib.Context.__init__ = patched
+
+
 def pytest_configure(config):
+    _suite_option_defaults()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 

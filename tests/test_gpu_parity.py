@@ -575,6 +575,51 @@ def test_time_sliced_queue_is_bit_identical(example, N, H):
 
 
 
+@pytest.mark.parametrize("example,N,H,per_rollout", [("unitree_go2_trot", 2048, 16, False), ("unitree_go2_trot", 2048, 16, True),
+                                                     ("unitree_go2_seq_jump", 1024, 16, False), ("unitree_go2_trot", 63, 5, False),
+                                                     ("unitree_go2_trot", 8192, 16, False), ("unitree_go2_trot", 5000, 9, False)])
+def test_two_samples_per_wavefront_is_bit_identical(example, N, H, per_rollout):
+    """The Go2's round-5 kernel runs TWO rollouts per wavefront, one per 32-lane half (rollout_kernel2: wave.h WaveH, the 32-lane
+    layouts of smooth_quad2.h / solver_reg2.h): every rollout must come out bit for bit as from the one-rollout-per-wavefront
+    kernel (dial_options.pair_mode = 1) -- shipped line-search rule and the per-rollout-comparable one, an odd batch (the last
+    wavefront's upper half idle), batches beyond the resident set (the pair queue), from the rest pose and a perturbed state,
+    in-kernel noise and noise as data.
+    Compared on the build WITHOUT fused multiply-add contraction (libdialhip_ieee.so): the two kernels are the same arithmetic in
+    the same order on different lane layouts, but which a * b + c pairs hipcc fuses depends on the basic blocks around them, so in
+    the product build they differ at rounding level (measured: first differences of 2 .. 9e-7 in qvel, tools/pair_diff.py); there the
+    pair kernel -- the default for every Go2 context -- is held to the oracle by all the parity gates of this file."""
+    import os
+    import torch
+    from dial_mpc_amd import _lib
+    if not os.path.exists(_lib.IEEE_LIB_PATH):
+        pytest.skip("libdialhip_ieee.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    dc, env, model, task, cfg = setup_case(example, N, H, per_rollout=per_rollout)
+    eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=3, Ybar_scale=0.2)
+    ctxs = [_lib.Context(model, task, cfg, options=dict(pair_mode=1), lib_path=_lib.IEEE_LIB_PATH),
+            _lib.Context(model, task, cfg, lib_path=_lib.IEEE_LIB_PATH)]
+    assert ctxs[1].lib.dial_debug_resident_rollouts(ctxs[1].h, N + 1) % 2 == 0
+    q1, qd1 = perturbed_state(env, 1)
+    for q, qd, rng in ((env._init_q, np.zeros(model.nv), False), (q1, qd1, True)):
+        outs = []
+        for ctx in ctxs:
+            s0, _, _ = ctx.env_reset(_dev(q), _dev(qd))
+            for rep in range(2):
+                if rng:
+                    out = ctx.reverse_once_rng(s0, _dev(Ybar), _dev(sigma), seed=1234, counter=7)
+                else:
+                    out = ctx.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps))
+                torch.cuda.synchronize()
+                ctx.status()
+                sc = ctx.debug_scratch()
+                outs.append(({k: out[k].clone() for k in ("Ybar", "rews", "qbar", "xbar")}, {k: np.array(sc[k]) for k in ("rewss", "qss", "qdss", "xss", "Y0s")}))
+        assert np.isfinite(outs[0][1]["rewss"]).all()
+        for o, sc in outs[1:]:
+            for k in sc:
+                assert np.array_equal(sc[k].view(np.uint32), outs[0][1][k].view(np.uint32)), (k, rng, float(np.abs(sc[k] - outs[0][1][k]).max()))
+            for k in o:
+                assert torch.equal(o[k], outs[0][0][k]), (k, rng)
+
+
 @pytest.mark.parametrize("N", [2400, 3000, 4095])
 def test_spread_launch_is_bit_identical(N):
     """Go2 batches between the small-batch limit (2304 rollouts) and the large-batch kernel's resident set (4096): the whole

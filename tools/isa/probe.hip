@@ -15,3 +15,8 @@
 #endif
 template __global__ void rollout_kernel<PROBE_D, PROBE_WPB, PROBE_OCC, PROBE_QUEUE>(const CModel<PROBE_D>*, const dial_task*, const dial_cfg*,
                                                                                     dial::RolloutIO, int, int, int*);
+
+#ifdef PROBE_PAIR
+template __global__ void rollout_kernel2<PROBE_D, PROBE_WPB, PROBE_OCC, PROBE_QUEUE>(const CModel<PROBE_D>*, const dial_task*, const dial_cfg*,
+                                                                                     dial::RolloutIO, int, int, int*);
+#endif
