@@ -63,7 +63,13 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = _COMMON + (_IEEE if ieee else _FAST) + ([] if ieee else os.environ.get("DIAL_HIPCC_EXTRA", "").split())
-    objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", "obj_" + os.path.basename(out))
+    # objects go to a directory of THIS call (flags hashed into its name, pid-suffixed), the library is linked next to its final
+    # place and moved there atomically: concurrent callers (ranks of a multi-process launch, pytest-xdist workers that all find
+    # a stale tree) never see each other's half-written files
+    import hashlib
+    import shutil
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:8]
+    objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", f"obj_{os.path.basename(out)}_{tag}_{os.getpid()}")
     os.makedirs(objdir, exist_ok=True)
     units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
     units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"], os.path.join(objdir, f"kern_family_{k}.o"))
@@ -78,10 +84,13 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
         return obj
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_unit, units))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    tmp_out = f"{out}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp_out, out)
+    shutil.rmtree(objdir, ignore_errors=True)
     return out
 
 

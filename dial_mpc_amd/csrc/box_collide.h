@@ -8,6 +8,12 @@
 // Only the generic instantiation carries this code (rollout_body.h: `if constexpr (!is_static)`).
 #pragma once
 
+// distance beyond which the second broad phases park a box candidate (a lower bound of the true distance is enough then: no
+// rows, nothing reads the position); dial_create rejects box contacts whose margin reaches it
+#ifndef DIAL_BOX_PARK_DIST
+#define DIAL_BOX_PARK_DIST 0.01f
+#endif
+
 namespace dial {
 
 struct BoxG {
@@ -79,7 +85,7 @@ DIAL_DEV void plane_box(const float* n, const float* ppos, const BoxG& b, int su
   {   // broad phase: the LOWEST vertex more than 1 cm above the plane -- all four candidates parked (dist >= margin: no rows; nothing
       // reads the position of a box-plane contact that does not touch).  The trunk over the floor: every step of a standing robot.
     const float lowest = base - (dm::absf(e[0]) + dm::absf(e[1]) + dm::absf(e[2]));
-    if (lowest > 0.01f) {
+    if (lowest > DIAL_BOX_PARK_DIST) {
       dist = lowest;
       for (int k = 0; k < 3; k++) pos[k] = b.c[k];
       make_frame(fr, n);
@@ -165,7 +171,7 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
       // lanes of a wavefront take this exit while the robot is away from the box, and the ~600-instruction routine is skipped.
     const float tw[3] = {b.c[0] - ctr[0], b.c[1] - ctr[1], b.c[2] - ctr[2]};
     const float gap = DM_SQRT(dm::dot3(tw, tw)) - (hl + r) - DM_SQRT(dm::dot3(b.h, b.h));
-    if (gap > 0.01f) {
+    if (gap > DIAL_BOX_PARK_DIST) {
       dist = sub == 0 ? gap : 1.f;
       for (int k = 0; k < 3; k++) pos[k] = 0.5f * (ctr[k] + b.c[k]);
       make_frame(fr, tw);
@@ -184,7 +190,7 @@ DIAL_DEV void capsule_box(const float* ctr, const float* axis, float hl, float r
       const float lo = dm::fminf_(l0[k], l1[k]) - r, hi = dm::fmaxf_(l0[k], l1[k]) + r;
       sep = dm::fmaxf_(sep, dm::fmaxf_(lo - b.h[k], -b.h[k] - hi));
     }
-    if (sep > 0.01f) {
+    if (sep > DIAL_BOX_PARK_DIST) {
       dist = sub == 0 ? sep : 1.f;
       for (int k = 0; k < 3; k++) pos[k] = 0.5f * (ctr[k] + b.c[k]);
       const float tw[3] = {b.c[0] - ctr[0], b.c[1] - ctr[1], b.c[2] - ctr[2]};
@@ -230,7 +236,7 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
   const float tw[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
   {   // bounding spheres more than 1 cm apart: nothing to do (all candidates parked; the normal is the centre line)
     const float gap = DM_SQRT(dm::dot3(tw, tw)) - DM_SQRT(dm::dot3(A.h, A.h)) - DM_SQRT(dm::dot3(B.h, B.h));
-    if (gap > 0.01f) {
+    if (gap > DIAL_BOX_PARK_DIST) {
       dist = sub == 0 ? gap : 1.f;
       for (int k = 0; k < 3; k++) pos[k] = 0.5f * (A.c[k] + B.c[k]);
       make_frame(fr, tw);
@@ -262,7 +268,7 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
   // second broad phase: a FACE axis separates the boxes by more than 1 cm (the true distance is at least that): all candidates
   // parked before the nine edge axes and the clipping.  The bounding spheres above overlap whenever the robot is near the crate
   // (its half-diagonal is 0.63 m); the trunk over the crate's top face, or the torso beside it, is separated on a face axis.
-  if (sbest > 0.01f) {
+  if (sbest > DIAL_BOX_PARK_DIST) {
     dist = sub == 0 ? sbest : 1.f;
     for (int k = 0; k < 3; k++) pos[k] = 0.5f * (A.c[k] + B.c[k]);
     make_frame(fr, tw);
@@ -298,7 +304,7 @@ DIAL_DEV void box_box(const BoxG& A, const BoxG& B, int sub, float& dist, float*
     for (int k = 0; k < 3; k++) n[k] = bb[k] * sg;
   } else { const float sg = dm::dot3(tw, nedge) >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = nedge[k] * sg; }
   make_frame(fr, n);
-  if (sbest > 0.01f) {                    // clearly apart
+  if (sbest > DIAL_BOX_PARK_DIST) {                    // clearly apart
     dist = sub == 0 ? sbest : 1.f;
     for (int k = 0; k < 3; k++) pos[k] = mid[k];
     return;

@@ -470,6 +470,16 @@ static inline bool dims_match(const dial_model* m) {
   }
   if constexpr (std::is_same<D, DimsGo2>::value) ok = ok && quad_fits(m);   // its position / velocity stage is laid out for this tree
   if constexpr (D::quad_gen) ok = ok && quad_tree_fits(m) && quad_gen_fits(m);
+  if constexpr (D::gen && D::is_static && !D::h_dense) {
+    // H = M + J^T D J is factorised in the dof TREE's elimination order: valid only while every contact has one static side
+    // (world or a body welded to it) -- a contact between two moving bodies fills H across branches.  Such a model falls
+    // through to the capacity-dimension kernel (dense order).
+    const auto is_static_body = [&](int b) {
+      while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parent[b];
+      return b == 0;
+    };
+    for (int c = 0; ok && c < m->ncon; c++) ok = is_static_body(m->con_body1[c]) || is_static_body(m->con_body2[c]);
+  }
   if constexpr ((!D::gen && D::square && RowsOf<typename D::Topo>::maxd > 0) || D::rows_gen) {   // smooth_rows.h: the layout must come out as compiled
     using RT = RowsOf<typename D::Topo>;
     RowTab t;

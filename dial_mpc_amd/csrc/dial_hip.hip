@@ -41,6 +41,9 @@ DIAL_KERNELS2_GO2(DIAL_X2)
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
 #endif
+#ifndef DIAL_GO2_PAIR_MIN_B
+#define DIAL_GO2_PAIR_MIN_B 2304   /* batches above this many rollouts run two per wavefront (rollout_kernel2); see launch_rollout */
+#endif
 
 // ------------------------------------------------------------------ kernels (rollout / env.step / env.reset: rollout_kernel.h)
 // Deterministic block reductions (1024 threads = 16 wavefronts): DPP butterfly inside each wavefront, then a
@@ -381,6 +384,12 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     if (nbb * DIAL_BOX_POLY_WORDS > 6 * model->nv + 12 * model->nbody)
       return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: too many box-box candidate contacts for the polygon scratch");
   }
+  // The box narrow phases park a candidate whose shapes are provably more than DIAL_BOX_PARK_DIST apart (box_collide.h: second
+  // broad phases) -- with a lower BOUND of the distance, a centre-line frame and a midpoint position.  A contact is active while
+  // dist < margin, so a box contact whose margin reaches that distance would be activated with those placeholder values.
+  for (int c = 0; c < model->ncon; c++)
+    if (model->con_kind[c] >= DIAL_CON_PLANE_BOX && !(model->con_margin[c] < DIAL_BOX_PARK_DIST))
+      return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: box contacts need margin < 0.01 m (the box narrow phases park candidates that are further apart)");
   if (model->cone != DIAL_CONE_PYRAMIDAL && model->cone != DIAL_CONE_ELLIPTIC)
     return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: unknown friction cone type");
   if (model->ls_rule != DIAL_LS_SWAP && model->ls_rule != DIAL_LS_IN_BRACKET)
@@ -715,14 +724,30 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   const bool tracing = ctx->trace != nullptr;   // diagnostics: the TRACE instantiation on the plain grid (no queue / split / large-batch variant)
   // Go2: two rollouts per wavefront.  Up to the resident set of one-wavefront workgroups the grid covers the batch (wavefront p:
   // rollouts 2 p, 2 p + 1); beyond it the resident grid of DIAL_GO2_PAIR_WPB-wavefront workgroups draws pairs from the queue.
-  if (ctx->pair_ok && !tracing) {
+  // Which batches: the pair kernel executes ~1.1 x the instructions of the one-sample kernel for TWO rollouts, so it wins wherever
+  // the SIMDs are short of issue slots -- N = 8192: 1.25 -> 1.10 ms, N = 65536: 8.96 -> 6.75 ms (7.15 -> 9.4 M rollouts/s) -- and
+  // loses where the launch is one rollout's dependence chain long: a lone pair wavefront needs 46.7 k cycles per env.step against
+  // 42.7 k (the DPP / permlane broadcasts sit on the chain, and it waits for the slower of its two rollouts' line searches):
+  // N = 2048 0.380 -> 0.408 ms.  Default: above DIAL_GO2_PAIR_MIN_B rollouts; dial_options.pair_mode 1 = never, 2 = always.
+  // (profiles/r05_ab_pair_kernel.txt, profiles/r05_sections_pair_cycles.txt)
+  if (ctx->pair_ok && !tracing && (ctx->opt.pair_mode == 2 || B > DIAL_GO2_PAIR_MIN_B)) {
     dial::RolloutIO io = io_in;
-    const int pairs = (B + 1) / 2;
-    if (pairs <= ctx->resident_pair || opt_no_queue(ctx)) {
+    if ((B + 1) / 2 <= ctx->resident_pair || opt_no_queue(ctx)) {
+      const int pairs = (B + 1) / 2;   // plain grid: wavefront p runs rollouts 2 p, 2 p + 1 (the mean trajectory alone in the last one)
       hipLaunchKernelGGL((rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false>), dim3(pairs), dim3(64), ctx->lds_pair, st,
                          (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, (int*)nullptr);
     } else {
+      // beyond the resident set: the queue -- and the mean trajectory rides along with the first T wavefronts (rollout_kernel2)
+      // whenever it is the batch's last rollout and the noisy ones pair up exactly, so that N = 4096 / 8192 are one / two full
+      // rounds of the resident grid (0.70 -> 0.48 ms, 1.24 -> 0.90 ms) instead of "+ 1 pair"
       const int blocks = ctx->resident_pair_large;
+      if (!ctx->no_mean_inline && !io.us && io.n_noise == B - 1 && ((B - 1) & 1) == 0 && ctx->T <= blocks * DIAL_GO2_PAIR_WPB &&
+          ctx->relay_buf && ctx->relay_flag) {
+        io.mean_inline = 1;
+        io.relay_buf = ctx->relay_buf;
+        io.relay_flag = ctx->relay_flag;
+        io.err_word = ctx->err_dev;
+      }
       HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->next, blocks * DIAL_GO2_PAIR_WPB, 1, st));
       hipLaunchKernelGGL((rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>), dim3(blocks), dim3(64 * DIAL_GO2_PAIR_WPB),
                          ctx->lds_pair_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B,
@@ -757,7 +782,8 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   int blocks = io.relay_flag ? io.relay_base + (ctx->T + io.relay_steps - 1) / io.relay_steps : (B + wpb - 1) / wpb;
   // Go2's large-batch kernel below its resident set (2304 < B <= 4096): the whole resident grid is launched and the rollouts are
   // dealt round-robin over the workgroups, so that every CU carries the same number of wavefronts
-  if (large && !io.relay_flag && resident > 0 && blocks <= resident && B > resident && !ctx->no_spread) {
+  // (blocks and resident count workgroups: the batch fits the resident grid without filling it)
+  if (large && !io.relay_flag && resident > 0 && blocks < resident && !ctx->no_spread) {
     blocks = resident;
     io.spread = 1;
   }
@@ -1103,7 +1129,10 @@ int dial_debug_set_stall(dial_ctx* ctx, int piece1) { if (!ctx) return DIAL_ERR_
 // wavefront slots of the rollout kernel on the whole chip for a batch of B rollouts (B > slots: the rollout queue runs)
 int dial_debug_resident_rollouts(dial_ctx* ctx, int B) {
   if (!ctx) return -1;
-  if (ctx->pair_ok) return (B + 1) / 2 <= ctx->resident_pair ? 2 * ctx->resident_pair : 2 * DIAL_GO2_PAIR_WPB * ctx->resident_pair_large;
+  if (ctx->pair_ok && (ctx->opt.pair_mode == 2 || B > DIAL_GO2_PAIR_MIN_B)) {
+    if (ctx->opt.no_queue) return 0;
+    return (B + 1) / 2 <= ctx->resident_pair ? 2 * ctx->resident_pair : 2 * DIAL_GO2_PAIR_WPB * ctx->resident_pair_large;
+  }
   const bool large = ctx->inst == 1 && B > DIAL_GO2_LARGE_B;
   return large ? ctx->resident_blocks_large * DIAL_GO2_WPB_LARGE : ctx->resident_blocks * ctx->wpb;
 }

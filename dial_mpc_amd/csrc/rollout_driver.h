@@ -180,8 +180,10 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     return s.qpos + off;
   };
   bool mean_now = false;   // this pass of the loop runs the mean trajectory's step `helper`, not an own step
-  float keep0 = 0.f, keep1 = 0.f, msum = 0.f;
-  (void)packed; (void)keep0; (void)keep1; (void)msum;
+  // the parked state: element l + k * KSTRIDE of the packed state in register k of (logical) lane l
+  constexpr int KSTRIDE = W::half2 ? 32 : 64, NKEEP = W::half2 ? 4 : 2;
+  float keep[NKEEP] = {}, msum = 0.f;
+  (void)packed; (void)keep; (void)msum;
   for (int st_own = st_begin; mean_now || st_own < st_end;) {
     const int st = mean_now ? helper : st_own;    // control step this pass runs ...
     const int row = mean_now ? io.n_noise : n;    // ... of this rollout (the mean trajectory is rollout n_noise)
@@ -271,9 +273,9 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
         if (io.rews) { const float mean = msum / (float)T; w.items(1, [&](int) { io.rews[row] = mean; }); }
         if (w.lane == 0) __hip_atomic_store(io.relay_flag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
       }
-      w.items(64, [&](int l) {
-        if (l < nstate) *packed(l) = keep0;
-        if (l + 64 < nstate) *packed(l + 64) = keep1;
+      w.items(KSTRIDE, [&](int l) {
+#pragma unroll
+        for (int k = 0; k < NKEEP; k++) if (l + k * KSTRIDE < nstate) *packed(l + k * KSTRIDE) = keep[k];
       });
       mean_now = false;
       continue;
@@ -282,8 +284,8 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     st_own++;
 #ifndef DIAL_EMU
     if (helper >= 0 && st == helper && relay < 0) {   // own step `helper` is done: the mean trajectory's step `helper` comes next
-      keep0 = w.lane < nstate ? *packed(w.lane) : 0.f;
-      keep1 = w.lane + 64 < nstate ? *packed(w.lane + 64) : 0.f;
+#pragma unroll
+      for (int k = 0; k < NKEEP; k++) keep[k] = w.lane + k * KSTRIDE < nstate ? *packed(w.lane + k * KSTRIDE) : 0.f;
       w.sync();
       bool ok = true;
       if (helper == 0) {

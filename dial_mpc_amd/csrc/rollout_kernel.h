@@ -122,6 +122,11 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
 // output tensors -- and the staged constants are shared by the 2 x WPB rollouts of the workgroup.  Wavefront p of the launch runs
 // rollouts 2 p and 2 p + 1 (an odd batch leaves the last wavefront's upper half idle: it returns, the EXEC mask does the rest).
 // QUEUE: the grid is what the chip keeps resident and every wavefront draws its next PAIR from `next`.
+// io.mean_inline (a batch whose last rollout is the mean trajectory, i.e. every reverse_once: N + 1 rollouts, N even): the mean
+// trajectory is not a rollout of the grid -- N / 2 wavefronts hold the noisy pairs, and wavefront q < T of the launch's first round
+// runs control step q of the mean trajectory between its own steps q and q + 1 (rollout_driver.h: helper; here BOTH halves run
+// it, redundantly, on their own workspaces: same state in, same bits out, the stores coincide).  N = 2048 is then 1024
+// wavefronts, one per SIMD, and N = 4096 / 8192 are one / two full rounds of the resident grid instead of "+ 1 pair".
 // The body is rollout_sample -- the same per-lane program as the one-sample kernel with the 32-lane layouts of smooth_quad2.h /
 // solver_reg2.h -- and produces the same bits per rollout (GPU test: test_two_samples_per_wavefront_is_bit_identical).
 template <class D, int WPB, int OCC = 2, bool QUEUE = false>
@@ -149,17 +154,22 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   __syncthreads();
 #endif
   int pair = (WPB > 1 ? (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
+  // (the interleaved mean trajectory exists in the QUEUE variant only: its hand-over code costs the body 20 VGPRs and a lone
+  //  wavefront 12 % -- 0.366 -> 0.41 ms at N = 256 --, which the plain grid's small batches would pay for nothing)
+  const int Bq = QUEUE ? B - io.mean_inline : B;                  // rollouts the grid / the queue holds
+  int helper = QUEUE && io.mean_inline && pair < io.T ? pair : -1;   // (first round only)
   for (;;) {
     const int n = 2 * pair + w.half + io.n_first;
     // (measured and not kept: the highest issue priority for the odd wavefront of a batch -- N + 1 = 2049 is 1024 full
     //  wavefronts and the mean trajectory alone in the 1025th, which shares a SIMD -- starves its SIMD-mate: 0.408 -> 0.440 ms)
-    if (n < B) dial::rollout_sample<false>(w, m, tg, cfg, s, io, n);
+    if (n < Bq) dial::rollout_sample<false>(w, m, tg, cfg, s, io, n, -1, helper);
+    helper = -1;
     if constexpr (!QUEUE) break;
     if (!next) break;
     int nn = 0;
     if ((threadIdx.x & 63) == 0) nn = atomicAdd(next, 1);
     pair = __builtin_amdgcn_readfirstlane(nn);
-    if (2 * pair + io.n_first >= B) break;
+    if (2 * pair + io.n_first >= Bq) break;
   }
 }
 

@@ -19,6 +19,10 @@
 #pragma once
 // (included from rollout_body.h after solver_reg.h)
 
+#ifndef DIAL_PAIR_HBATCH
+#define DIAL_PAIR_HBATCH 3   // work-list passes of 32 records whose LDS fetches are in flight together (H assembly below)
+#endif
+
 namespace dial {
 
 // x = A^-1 b, the sparse L D L^T of solver_reg.h (same elimination order, same operations) with DPP broadcasts.
@@ -276,7 +280,7 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
       // the work list of solver_reg.h, record p * 32 + lane in pass p: the same items, the same quads.  Three passes at a time:
       // every lane accumulates its item of every pass of the batch (the LDS latencies of the passes overlap), partial sums of
       // split entries are combined inside quads, then one phase writes the batch's entries.
-      constexpr int NB = 3;
+      constexpr int NB = DIAL_PAIR_HBATCH;
       static_assert(NP % NB == 0, "work-list capacity: a multiple of 96 records");
       static_for<0, NP / NB>([&](auto BATCH) {
         constexpr int p0 = BATCH * NB;

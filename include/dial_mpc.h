@@ -342,8 +342,11 @@ typedef struct dial_options {
   int32_t no_spread;          /* 1: a Go2 batch between the small-batch limit and the large-batch kernel's resident set fills
                                  workgroup after workgroup (some CUs with 16 wavefronts, some with 8) instead of being dealt
                                  round-robin over the whole resident grid                                                     */
-  int32_t pair_mode;          /* Go2: 0 = default (two rollouts per wavefront, one per 32-lane half: rollout_kernel2), 1 = one
-                                 rollout per wavefront at any batch size (the round-1..4 kernels).  Bit-identical per rollout.  */
+  int32_t pair_mode;          /* Go2: TWO rollouts per wavefront, one per 32-lane half (rollout_kernel2).  0 = for batches beyond
+                                 4608 rollouts, where the SIMDs are short of issue slots (N = 65536: 7.15 -> 9.4 M rollouts/s);
+                                 1 = never (the one-rollout-per-wavefront kernels at any batch size); 2 = always.  The same
+                                 arithmetic in the same order per rollout: bit-identical on the build without fused multiply-add
+                                 contraction, at rounding level (which products the compiler fuses) on the product build.       */
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for

@@ -62,6 +62,21 @@ def test_compiled_scene(case):
     assert md["iterations"] == 2 and md["ls_iterations"] == 5 and md["cone"] == 0 and md["eulerdamp"] == 0
 
 
+def test_robot_robot_contact_falls_back_to_the_capacity_dimension_kernel(case):
+    """DimsGo2Crate factorises H = M + J^T D J in the dof TREE's elimination order, which is only valid while every contact has a
+    static side (world, or the crate welded to it).  A model with the same counts and one contact between two MOVING bodies
+    (two legs: cross-branch fill in H) must not select that instantiation (cmodel.h: dims_match) -- it runs on the generic one."""
+    import copy
+    dc, env, model, task, cfg = case
+    assert emu_lib.Emu(model, task, cfg).sizes()[0] == 5
+    m2 = copy.deepcopy(model)
+    c = next(c for c in range(m2.ncon) if m2.con_body1[c] == 0)         # a floor contact ...
+    other_leg = next(b for b in range(1, m2.nbody) if m2.body_dofnum[b] > 0 and b != m2.con_body2[c] and m2.body_parent[b] != m2.con_body2[c]
+                     and m2.body_parent[m2.con_body2[c]] != b and b > 1)
+    m2.con_body1[c] = other_leg                                          # ... becomes a contact between two robot bodies
+    assert emu_lib.Emu(m2, task, cfg).sizes()[0] == 0
+
+
 def test_oracle_robot_stands_on_the_crate_and_the_contact_reward_counts_its_feet(case):
     dc, env, model, task, cfg = case
     o64 = O.Oracle(model, task, cfg, np.float64)

@@ -49,6 +49,19 @@ def test_crate_context_runs_on_the_generic_instantiation():
     assert model.nefc == 220 and model.ncon == 52
 
 
+def test_box_contacts_with_a_wide_margin_are_rejected():
+    """The box narrow phases park candidates that are provably more than 1 cm apart with a placeholder distance / frame
+    (csrc/box_collide.h); a box contact whose margin reaches that distance would be activated on those values: dial_create refuses it."""
+    import copy
+    from dial_mpc_amd import _lib
+    dc, env, model, task, cfg = setup_case(EX, 64, 8)
+    m2 = copy.deepcopy(model)
+    c = next(c for c in range(m2.ncon) if m2.con_kind[c] >= 5)
+    m2.con_margin[c] = 0.02
+    with pytest.raises(_lib.DialHipError, match="margin"):
+        _lib.Context(m2, task, cfg)
+
+
 def test_crate_env_step_and_rollouts_match_oracle():
     import oracle as O
     from dial_mpc_amd import _lib

@@ -596,7 +596,7 @@ def test_two_samples_per_wavefront_is_bit_identical(example, N, H, per_rollout):
     dc, env, model, task, cfg = setup_case(example, N, H, per_rollout=per_rollout)
     eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=3, Ybar_scale=0.2)
     ctxs = [_lib.Context(model, task, cfg, options=dict(pair_mode=1), lib_path=_lib.IEEE_LIB_PATH),
-            _lib.Context(model, task, cfg, lib_path=_lib.IEEE_LIB_PATH)]
+            _lib.Context(model, task, cfg, options=dict(pair_mode=2), lib_path=_lib.IEEE_LIB_PATH)]
     assert ctxs[1].lib.dial_debug_resident_rollouts(ctxs[1].h, N + 1) % 2 == 0
     q1, qd1 = perturbed_state(env, 1)
     for q, qd, rng in ((env._init_q, np.zeros(model.nv), False), (q1, qd1, True)):
@@ -618,6 +618,34 @@ def test_two_samples_per_wavefront_is_bit_identical(example, N, H, per_rollout):
                 assert np.array_equal(sc[k].view(np.uint32), outs[0][1][k].view(np.uint32)), (k, rng, float(np.abs(sc[k] - outs[0][1][k]).max()))
             for k in o:
                 assert torch.equal(o[k], outs[0][0][k]), (k, rng)
+
+
+@pytest.mark.parametrize("gate", ["rollout", "stagewise", "full_size", "stress", "converged", "distribution"])
+def test_pair_kernel_passes_the_oracle_gates(gate, monkeypatch):
+    """By default the Go2 runs two rollouts per wavefront only for batches beyond 4608 rollouts; here the oracle gates of this file
+    run on that kernel at THEIR sizes (dial_options.pair_mode = 2 for every context they create): per rollout and step under the
+    per-rollout-comparable rule, the full BASELINE sizes, perturbed states, the converged solver and the distribution-level gate
+    of the shipped rule."""
+    from dial_mpc_amd import _lib
+    init = _lib.Context.__init__
+
+    def forced(self, model, task, cfg, device=None, n_local_cap=None, lib_path=None, options=None):
+        init(self, model, task, cfg, device=device, n_local_cap=n_local_cap, lib_path=lib_path, options={**(options or {}), "pair_mode": 2})
+    monkeypatch.setattr(_lib.Context, "__init__", forced)
+    if gate == "rollout":
+        test_rollout_matches_oracle("unitree_go2_trot", 64, 8)
+        test_rollout_matches_oracle("unitree_go2_seq_jump", 48, 16)
+    elif gate == "stagewise":
+        test_reverse_once_matches_oracle_stagewise("unitree_go2_trot", 256, 16)
+        test_reverse_once_matches_oracle_stagewise("unitree_go2_seq_jump", 48, 16)
+    elif gate == "full_size":
+        test_full_size_oracle_parity("unitree_go2_trot", 2048, 16)
+    elif gate == "stress":
+        test_stress_parity_perturbed_states("unitree_go2_seq_jump", 20)
+    elif gate == "converged":
+        test_in_bracket_rule_converged_at_full_size("unitree_go2_seq_jump", 1024, 16)
+    else:
+        test_default_rule_distribution_parity_full_size("unitree_go2_trot", 2048, 16)
 
 
 @pytest.mark.parametrize("N", [2400, 3000, 4095])
