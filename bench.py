@@ -40,6 +40,10 @@ FLOP_PER_STEP_FALLBACK = {"unitree_go2_trot": 62794.0, "unitree_go2_seq_jump": 6
                           "unitree_h1_loco": 65119.0, "allegro_reorient": 755832.0}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3
+SHADER_CLOCK_HZ = 2.4e9           # nominal; the chip clocks to its power budget (MI355X_MICROARCH.md: DVFS), issue fractions are at nominal
+# cycles per wave64 VALU instruction of the rollout kernels' instruction mix with 1 / 2 / 3 / 4 wavefronts on a SIMD
+# (tools/ubench/issue.hip -> profiles/r05_ubench_issue.txt, "rollout-kernel mix" row)
+UBENCH_MIX_CYCLES = [5.00, 3.75, 3.54, 3.36]
 
 
 def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_s: float = 2.0):
@@ -303,6 +307,16 @@ def main():
                "ms_per_step_plan_pattern": p_el / s_steps * 1e3, "value_plan_pattern": (n_total + 1) * s_steps / p_el,
                "collectives_per_iteration": {"full": 2 if sharded else 0, "lean": 1 if sharded else 0},
                "avg_rollout_kernel_ms": s_kms / max(s_nl, 1)}
+        # the VALU-issue fraction of this launch (see `roofline.valu_issue` below), when a PMC pass of exactly this batch is committed
+        pj = os.path.join(ROOT, "profiles", f"r05_pmc_unitree_go2_trot_N{pls.n_local}.json")
+        if os.path.exists(pj) and s_kms > 0:
+            pc = json.load(open(pj)).get("counters", {})
+            n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+            wps = min(4.0, max(1.0, pc.get("SQ_WAVES", n_simd) / n_simd))
+            cyc = float(np.interp(wps, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
+            if pc.get("SQ_INSTS_VALU"):
+                rec["valu_issue_frac"] = pc["SQ_INSTS_VALU"] * cyc / (n_simd * (s_kms / max(s_nl, 1)) * 1e-3 * SHADER_CLOCK_HZ)
+                rec["valu_issue_source"] = f"profiles/{os.path.basename(pj)} x {cyc:.2f} cycles per VALU instruction (profiles/r05_ubench_issue.txt, {wps:.0f} wavefronts per SIMD)"
         del pls
         return rec
 
@@ -335,10 +349,11 @@ def main():
     # HBM traffic / instruction counters of THIS configuration from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same command, tools/pmc_passes.sh -> tools/pmc_to_json.py); null when the batch measured there is not the one run here
     traffic, traffic_src, valu_per_step, lane_util, stall = None, None, None, None, None
-    pmc_path = os.path.join(ROOT, "profiles", f"r04_pmc_{args.example}.json")
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.example}.json")
-    if os.path.exists(pmc_path) and world == 1:
+    valu_issue = None
+    cands = [f"r05_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r05_pmc_{args.example}.json",
+             f"r04_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r04_pmc_{args.example}.json", f"r03_pmc_{args.example}.json"]
+    pmc_path = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
+    if pmc_path is not None and world == 1:
         pmc = json.load(open(pmc_path))
         if pmc.get("Nsample") == args.nsample_per_gpu and pmc.get("Hsample") == args.hsample:
             traffic = pmc.get("hbm_bytes_per_launch")
@@ -346,6 +361,21 @@ def main():
             valu_per_step = pmc.get("valu_insts_per_wave_env_step")
             lane_util = pmc.get("valu_active_lanes_per_inst")
             stall = pmc.get("wave_time_breakdown")
+            # What bounds the large batches and nearly bounds the headline: VALU ISSUE.  SQ_INSTS_VALU of the committed PMC pass x the
+            # measured issue cost of this kernel's instruction mix / the SIMD-cycles of the launch timed HERE.  The cost per wave64 VALU
+            # instruction is NOT the 2 cycles of the fp32 peak: tools/ubench/issue.hip (profiles/r05_ubench_issue.txt) measures 3.9
+            # cycles for v_fma_f32 with three VGPR sources, 4.2 for compares / DPP / v_readlane, 8.1 for transcendentals and
+            # v_permlane16_swap, 2.25 for two-source mul / mov, and for the kernels' mix 5.0 / 3.75 / 3.54 / 3.36 cycles with 1 / 2 / 3 / 4
+            # wavefronts on the SIMD.
+            insts = (pmc.get("counters") or {}).get("SQ_INSTS_VALU")
+            if insts and avg_kernel_s > 0:
+                n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+                waves_per_simd = min(4.0, max(1.0, (pmc.get("counters") or {}).get("SQ_WAVES", n_simd) / n_simd))
+                cyc = float(np.interp(waves_per_simd, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
+                valu_issue = {"frac": insts * cyc / (n_simd * avg_kernel_s * SHADER_CLOCK_HZ), "valu_insts_per_launch_pmc": insts,
+                              "cycles_per_valu_inst": cyc, "wavefronts_per_simd": waves_per_simd, "simds": n_simd, "clock_hz": SHADER_CLOCK_HZ,
+                              "source": f"profiles/{os.path.basename(pmc_path)} (SQ_INSTS_VALU) x profiles/r05_ubench_issue.txt (mix row) "
+                                        f"/ (SIMDs x this run's average kernel time x nominal clock)"}
     out = {
         "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"
         else f"sample-rollouts/sec (N x H env.steps), {args.example}", "value": value,
@@ -376,7 +406,8 @@ def main():
                      "valu_tflops_counted": valu_tflops,
                      "valu_frac_counted": (valu_tflops / VALU_PEAK_TFLOPS) if valu_tflops is not None else None,
                      "valu_insts_per_wave_env_step_pmc": valu_per_step, "valu_active_lanes_per_inst_pmc": lane_util,
-                     "wave_time_breakdown_pmc": stall},
+                     "wave_time_breakdown_pmc": stall,
+                     "valu_issue_frac": valu_issue["frac"] if valu_issue else None, "valu_issue": valu_issue},
         "plan_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
                             "ticks": len(lat), "tick_budget_ms": 20.0,
                             "plan": f"env.step + shift + {dial_config.Ndiffuse} x reverse_once"},

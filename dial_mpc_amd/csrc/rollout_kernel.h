@@ -48,12 +48,16 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap);
   if constexpr (D::gen)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
     s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
-  int n = (WPB > 1 ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x) + io.n_first;
+  // (the wavefront's index in its workgroup as a SCALAR: the rollout index and every row pointer derived from it are wave-uniform;
+  //  left in a VGPR, the 64-bit row offsets n * T * nq ... become VGPR pairs that live through the whole kernel -- the H1's
+  //  three-wavefront kernel spilled five of them to scratch, ISA probe round 5)
+  const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  int n = (WPB > 1 ? (int)blockIdx.x * WPB + wv : (int)blockIdx.x) + io.n_first;
   // spread launch (a batch that fits the resident grid of multi-wavefront workgroups without filling it): wavefront w of workgroup b
   // runs rollout w x gridDim + b, so that EVERY workgroup -- every CU -- carries ceil(B / gridDim) rollouts instead of the first
   // B / WPB workgroups being full and the rest empty (Go2, N = 3000 in workgroups of 8: 119 CUs with 16 wavefronts, 137 with 8)
   if constexpr (WPB > 1 && QUEUE) {
-    if (io.spread) n = (int)(threadIdx.x >> 6) * (int)gridDim.x + (int)blockIdx.x + io.n_first;
+    if (io.spread) n = wv * (int)gridDim.x + (int)blockIdx.x + io.n_first;
   }
   int relay = -1;
   if constexpr (WPB == 1 && !QUEUE) {
@@ -73,7 +77,10 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
 #ifndef DIAL_LAUNDER_STATIC
 #define DIAL_LAUNDER_STATIC 0   // A/B switch: the opaque lane id per step for EVERY instantiation
 #endif
-  w.launder = D::gen || OCC >= 4 || DIAL_LAUNDER_STATIC;   // (see wave.h)
+#ifndef DIAL_LAUNDER_H1
+#define DIAL_LAUNDER_H1 0       // A/B switch: the opaque lane id per step for the H1's 25-dof kernels (10 spilled VGPRs without it, 1 with)
+#endif
+  w.launder = D::gen || OCC >= 4 || DIAL_LAUNDER_STATIC || (DIAL_LAUNDER_H1 && std::is_same<typename D::Topo, TopoH1>::value);   // (see wave.h)
 #ifdef DIAL_PROFILE
   w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
   if (w.lane < 32) w.acc[w.lane] = 0;

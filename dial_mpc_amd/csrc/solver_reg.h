@@ -118,7 +118,10 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   static_for<0, S / 4>([&](auto Q) {
     constexpr int q = Q;
     vfloat t[4];
-    w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    // (large models: the row addresses from the region's own copy of the lane id -- hoisted out of the T-step loop they are
+    //  S / 4 more VGPRs that live through the whole kernel; the H1's kernel spilled them)
+    if constexpr (N > 20) w.per_lane4_r([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    else w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
     static_for<0, 4>([&](auto E) {
       constexpr int j = 4 * q + E;
       if constexpr (j < N) a[N - 1 - j] = t[E];
@@ -164,7 +167,8 @@ DIAL_DEV vfloat reg_chol_solve_v(W& w, const M* m, const float* A, vfloat bvec, 
   static_for<0, S / 4>([&](auto Q) {
     constexpr int q = Q;
     vfloat t[4];
-    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    if constexpr (N > 20) w.per_lane4_r([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
+    else w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
     static_for<0, 4>([&](auto E) {
       constexpr int j = 4 * q + E;
       if constexpr (j < N) a[N - 1 - j] = t[E];

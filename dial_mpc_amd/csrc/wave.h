@@ -179,6 +179,8 @@ struct Wave {
   void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
     for (int l = 0; l < 64; l++) { const float* p = f(l); a.x[l] = p[0]; b.x[l] = p[1]; c.x[l] = p[2]; d.x[l] = p[3]; }
   }
+  template <class F>
+  void per_lane4_r(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) { per_lane4(f, a, b, c, d); }
   // value of the lane N below / above inside the aligned row of 16 lanes (0 where the row ends; DPP row_shr / row_shl on the GPU)
   template <int N>
   vfloat row_shr(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = (l & 15) >= N ? v.x[l - N] : 0.f; return r; }
@@ -453,6 +455,12 @@ struct Wave {
   template <class F>
   __device__ __forceinline__ void per_lane4(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
     const float4 t = *reinterpret_cast<const float4*>(f(lane));
+    a = t.x; b = t.y; c = t.z; d = t.w;
+  }
+  // (address from the region-laundered lane id, see per_lane_r)
+  template <class F>
+  __device__ __forceinline__ void per_lane4_r(F f, vfloat& a, vfloat& b, vfloat& c, vfloat& d) {
+    const float4 t = *reinterpret_cast<const float4*>(f(lane_r));
     a = t.x; b = t.y; c = t.z; d = t.w;
   }
   // Lane-index predicates compare against `lane_r`, a copy of the lane id that begin_region() launders

@@ -819,7 +819,9 @@ def test_default_rule_distribution_parity_full_size(example, N, H):
               f"{trep['witness_ulp']}, unwitnessed {len(trep['unwitnessed'])}")
         # (2) what a caller consumes: the aggregates against the oracle's own 1-ulp jitter envelope
         prod = {k: out[k].cpu().numpy() for k in ("Ybar", "qbar", "qdbar", "xbar")}
-        rep = distribution_parity(o32, s0, us, sc["Y0s"], got, prod, cfg.temp_sample)
+        # (the Allegro's ensemble is 12 members instead of 32: every member is 4097 rollouts x 100 converged sub-steps on the CPU --
+        #  231 s of the suite's 499 s in round 5's first run; the envelope is the p95 of the members either way)
+        rep = distribution_parity(o32, s0, us, sc["Y0s"], got, prod, cfg.temp_sample, members=12 if example == "allegro_reorient" else 32)
         print(f"   distribution level: ESS oracle {rep['ess_oracle']:.1f} / GPU {rep['ess_gpu']:.1f}\n"
               f"   GPU vs oracle   {rep['gpu']}\n   jitter envelope (p95 of {rep['members']}) {rep['envelope']}\n   ratio {rep['ratio']}")
 
@@ -1052,9 +1054,10 @@ def test_mean_action_only_iteration_is_bit_identical(example, N, H):
 
 
 def test_config5_batch_on_one_gpu_matches_small_batch_kernel_and_oracle():
-    """BASELINE config 5's batch (unitree_go2_trot N = 65536, H = 16) on ONE GPU: the large-batch instantiation (4 wavefronts
-    per workgroup, rollout queue) against (1) the small-batch kernel -- three 2048-sample slices of the same noise rows
-    give bit-identical mean rewards, (2) the oracle -- 96 rollouts drawn from the whole batch, per step, witness gate,
+    """BASELINE config 5's batch (unitree_go2_trot N = 65536, H = 16) on ONE GPU: the large-batch launch (round 5: two rollouts
+    per wavefront, four wavefronts per workgroup, the pair queue with the interleaved mean trajectory) against (1) the same
+    kernel body on the plain grid -- three 2048-sample slices of the same noise rows give bit-identical mean rewards --,
+    (2) the oracle -- 96 rollouts drawn from the whole batch, per step, witness gate,
     (3) K4 in fp64 on the device's own rewards / nodes.  (The 8-GPU run shards this batch 8192 per rank.)"""
     import torch
     import oracle as O
@@ -1072,7 +1075,7 @@ def test_config5_batch_on_one_gpu_matches_small_batch_kernel_and_oracle():
     rews = out["rews"].cpu().numpy()
     # (1) slices through the small-batch kernel
     dc2, _, model2, task2, cfg2 = setup_case("unitree_go2_trot", 2048, H, per_rollout=True)
-    small = _lib.Context(model2, task2, cfg2)
+    small = _lib.Context(model2, task2, cfg2, options=dict(pair_mode=2))
     for a in (0, 30000, N - 2048):
         r2 = small.reverse_once(s0, _dev(Ybar), _dev(sigma), _dev(eps[a:a + 2048]))["rews"].cpu().numpy()
         assert np.array_equal(r2[:-1], rews[a:a + 2048]) and r2[-1] == rews[-1], a
