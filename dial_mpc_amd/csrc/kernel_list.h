@@ -4,13 +4,13 @@
 #pragma once
 #include "rollout_kernel.h"
 
-// wavefronts per workgroup (they share one staged copy of the constants) / occupancy target of the Go2 instantiations:
-// small batches (every sample co-resident at 1 wavefront per workgroup, 168 VGPRs, 2 wavefronts per SIMD at N = 2048) and
-// large ones, where wavefront slots are what counts.  Round 4: EIGHT wavefronts per workgroup (78 KB: two workgroups = 16
-// wavefronts per CU) compiled for FOUR wavefronts per SIMD -- possible without spills since the opaque lane id per step
-// (wave.h: launder) took the kernel from 168 VGPRs + 15 spilled to 125 -- instead of round 2's 4 per workgroup / 3 per SIMD:
-// 4096 resident rollouts instead of 3072; N = 4096 +14.6 %, 8192 +3 %, 16384 +9 %, 65536 +11.4 % (one box, alternating runs,
-// profiles/r04_go2_large_batch_ab.txt).
+// wavefronts per workgroup (they share one staged copy of the constants) / occupancy target of the Go2's ONE-rollout-per-wavefront
+// instantiations: small batches (every sample co-resident at 1 wavefront per workgroup, 168 VGPRs, 0 scratch, 2 wavefronts per SIMD
+// at N = 2048) and, since round 4, a large-batch variant of EIGHT wavefronts per workgroup (78 KB: two workgroups = 16 wavefronts per
+// CU) compiled for FOUR wavefronts per SIMD (128 VGPRs; ISA probe of round 5: 13 spilled VGPRs / 32 B of scratch after the
+// wavefront index became a scalar, 47 / 104 B before).  Since round 5 the default launch for batches beyond 2304 rollouts is the
+// two-rollouts-per-wavefront kernel below (N = 65536: 7.15 -> 9.3 M rollouts/s); this variant is what dial_options.pair_mode = 1
+// selects (the A/B arm of profiles/r05_ab_pair_kernel.txt).
 #ifndef DIAL_GO2_WPB_LARGE
 #define DIAL_GO2_WPB_LARGE 8
 #endif
