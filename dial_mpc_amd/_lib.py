@@ -34,7 +34,9 @@ N_FAMILIES = 8     # robot families of csrc/kernel_list.h (7: the Go2's two-samp
 # (native v_sqrt / v_rsq / v_exp / v_log without denormal fix-ups); finite-math is NOT assumed (+-inf
 # control ranges are compared against).  -fno-honor-nans: min / max / clip become single v_min / v_max instead of
 # compare + select chains.
-_FAST = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
+# -DDIAL_FUSED_DPP: the pair kernel's broadcast-multiply-adds as single v_fmac_f32_dpp instructions (csrc/wave.h: WaveH::fma_pick);
+# product build only -- the fused form IS a contraction.
+_FAST = ["-DDIAL_FUSED_DPP", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Xarch_device", "-freciprocal-math", "-Xarch_device", "-fapprox-func",
          "-Xarch_device", "-fno-honor-nans"]
 # -fno-slp-vectorize (both variants): the SLP pass packs pairs of scalar fp32 ops into v_pk_* and pays for it in v_mov
 # shuffles -- measured 5-6% slower on this issue-bound kernel.

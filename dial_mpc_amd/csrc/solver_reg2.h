@@ -38,12 +38,6 @@ DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, f
   vfloat b = w.lane_reverse(bvec, N);
   vfloat dinv = vsplat(0.f);
   constexpr ElimOrder<Topo, N> EO{};
-  // lane K of the half from its duplicated rows
-  const auto pick = [&](auto KK, const vfloat& X, const vfloat& Y) {
-    constexpr int K = decltype(KK)::value;
-    if constexpr (K < 16) return w.template row_bcast<K>(X);
-    else return w.template row_bcast<K - 16>(Y);
-  };
   if constexpr (REUSE) {
     (void)A;
     dinv = *dinv_io;
@@ -55,9 +49,7 @@ DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, f
       constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
       vfloat bX, bY;
       w.dup_rows(b, bX, bY);
-      vfloat bk[l1 - l0 > 0 ? l1 - l0 : 1];
-      static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; bk[STEP - l0] = pick(std::integral_constant<int, kp>{}, bX, bY); });
-      static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
+      static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; b = w.template fnma_pick<kp>(b, bX, bY, a[kp]); });
     });
   } else {
   static_for<0, S / 4>([&](auto Q) {
@@ -73,24 +65,23 @@ DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, f
     constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
     vfloat bX, bY;
     w.dup_rows(b, bX, bY);   // (the columns of one depth do not touch each other's b entries: one swap per level)
-    vfloat bk[l1 - l0 > 0 ? l1 - l0 : 1];
     static_for<l0, l1>([&](auto STEP) {
       constexpr int kp = EO.seq[STEP];
       const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
       vfloat cX, cY;
       w.dup_rows(col, cX, cY);
-      const vfloat rinv = vrcp(pick(std::integral_constant<int, kp>{}, cX, cY));
+      const vfloat rinv = w.template rcp_pick<kp>(cX, cY);
       const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
       a[kp] = lik;
       dinv = vsel(w.lane_eq(kp), rinv, dinv);
-      bk[STEP - l0] = pick(std::integral_constant<int, kp>{}, bX, bY);
       constexpr AncList<Topo, N, kp> L{};
       static_for<0, L.n>([&](auto IDX) {
         constexpr int jp = L.jp[IDX];
-        a[jp] = a[jp] - lik * pick(std::integral_constant<int, jp>{}, cX, cY);
+        a[jp] = w.template fnma_pick<jp>(a[jp], cX, cY, lik);
       });
     });
-    static_for<l0, l1>([&](auto STEP) { b = b - a[EO.seq[STEP]] * bk[STEP - l0]; });
+    // forward substitution L' z = b: the level's pivots' entries of b were duplicated before its columns were touched
+    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; b = w.template fnma_pick<kp>(b, bX, bY, a[kp]); });
   });
   w.items(N, [&](int l) {
     static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
@@ -111,9 +102,7 @@ DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, f
     constexpr int lv = EO.nlevel - 1 - LVR, l0 = EO.lvl[lv], l1 = EO.lvl[lv + 1];
     vfloat xX, xY;
     w.dup_rows(x, xX, xY);
-    vfloat xk[l1 - l0 > 0 ? l1 - l0 : 1];
-    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; xk[STEP - l0] = pick(std::integral_constant<int, kp>{}, xX, xY); });
-    static_for<l0, l1>([&](auto STEP) { x = x - a[EO.seq[STEP]] * xk[STEP - l0]; });
+    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; x = w.template fnma_pick<kp>(x, xX, xY, a[kp]); });
   });
   return w.lane_reverse(x, N);
 }
@@ -161,11 +150,8 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
     vfloat accM[3] = {vzero, vzero, vzero}, accJ[3] = {vzero, vzero, vzero};
     static_for<0, NV>([&](auto JJ) {
       constexpr int j = JJ;
-      vfloat bj;
-      if constexpr (j < 16) bj = w.template row_bcast<j>(vX);
-      else bj = w.template row_bcast<j - 16>(vY);
-      accM[j % 3] = accM[j % 3] + R[j] * bj;
-      if constexpr (j < 6) accJ[j % 3] = accJ[j % 3] + RJt[j] * bj;
+      accM[j % 3] = w.template fma_pick<j>(accM[j % 3], vX, vY, R[j]);
+      if constexpr (j < 6) accJ[j % 3] = w.template fma_pick<j>(accJ[j % 3], vX, vY, RJt[j]);
     });
     static_for<0, 3>([&](auto QQ) {
       constexpr int q = QQ;

@@ -288,6 +288,16 @@ struct WaveH : Wave {
   vfloat gather(const vfloat& v, F src) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & 32) | (src(l & 31) & 31)]; return r; }
   // lane 3 of the own group of 8 lanes, to the whole group (GPU: two row_newbcast + select)
   vfloat grp8_bcast3(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~7) | 3]; return r; }
+  // acc +- other * (lane K of the half, from its duplicated rows X | Y) and 1 / that lane: on the GPU's product build ONE instruction
+  // each -- the DPP row broadcast is an operand modifier of v_fmac_f32 / v_rcp_f32 (HIP WaveH below)
+  template <int K>
+  vfloat pick(const vfloat& X, const vfloat& Y) { if constexpr (K < 16) return row_bcast<K>(X); else return row_bcast<K - 16>(Y); }
+  template <int K>
+  vfloat fma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc + other * pick<K>(X, Y); }
+  template <int K>
+  vfloat fnma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc - other * pick<K>(X, Y); }
+  template <int K>
+  vfloat rcp_pick(const vfloat& X, const vfloat& Y) { return vrcp(pick<K>(X, Y)); }
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -606,6 +616,9 @@ struct WaveH : Wave {
     const unsigned r0 = r[0], r1 = r[1];
     X = __builtin_bit_cast(float, r0);
     Y = __builtin_bit_cast(float, r1);
+#ifdef DIAL_FUSED_DPP
+    asm("s_nop 1" : "+v"(X), "+v"(Y));   // (the hand-written DPP consumers of X | Y: see fma_pick)
+#endif
   }
   template <int K>
   __device__ __forceinline__ float bc(vfloat v) {
@@ -621,6 +634,43 @@ struct WaveH : Wave {
     const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
     return (lane & 8) ? b : a;
   }
+  template <int K>
+  __device__ __forceinline__ vfloat pick(vfloat X, vfloat Y) { if constexpr (K < 16) return row_bcast<K>(X); else return row_bcast<K - 16>(Y); }
+  // acc +- other * (lane K of the half) and 1 / (lane K of the half).  hipcc keeps `v_mov_b32_dpp` + `v_fma_f32` apart (its DPP
+  // combine does not see through the three-address FMA), so the product build (-DDIAL_FUSED_DPP) spells the fused instruction:
+  // v_fmac_f32_dpp dst, src0 (the DPP operand, with its neg modifier), src1 -- the same single-rounding fma the compiler's
+  // contraction produces, one VALU issue slot instead of two.  Inline asm is opaque to the hazard recogniser: a DPP source must not
+  // have been written by one of the two preceding VALU instructions.  The sources are always the X | Y of dup_rows, which (in this
+  // build) ends in an `s_nop 1` that every later use depends on; tools/isa/check_dpp_hazards.py verifies the emitted ISA.  The build without
+  // contraction (libdialhip_ieee.so) keeps the plain expression: there the multiply and the add round separately, as in the
+  // one-sample kernel it is compared with bit for bit.
+#ifdef DIAL_FUSED_DPP
+#define DIAL_DPP_TAIL " row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+  template <int K>
+  __device__ __forceinline__ vfloat fma_pick(vfloat acc, vfloat X, vfloat Y, vfloat other) {
+    asm("v_fmac_f32_dpp %0, %1, %2" DIAL_DPP_TAIL : "+v"(acc) : "v"(K < 16 ? X : Y), "v"(other), "n"(K & 15));
+    return acc;
+  }
+  template <int K>
+  __device__ __forceinline__ vfloat fnma_pick(vfloat acc, vfloat X, vfloat Y, vfloat other) {
+    asm("v_fmac_f32_dpp %0, -%1, %2" DIAL_DPP_TAIL : "+v"(acc) : "v"(K < 16 ? X : Y), "v"(other), "n"(K & 15));
+    return acc;
+  }
+  template <int K>
+  __device__ __forceinline__ vfloat rcp_pick(vfloat X, vfloat Y) {
+    vfloat r;
+    asm("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(K < 16 ? X : Y), "n"(K & 15));
+    return r;
+  }
+#undef DIAL_DPP_TAIL
+#else
+  template <int K>
+  __device__ __forceinline__ vfloat fma_pick(vfloat acc, vfloat X, vfloat Y, vfloat other) { return acc + other * pick<K>(X, Y); }
+  template <int K>
+  __device__ __forceinline__ vfloat fnma_pick(vfloat acc, vfloat X, vfloat Y, vfloat other) { return acc - other * pick<K>(X, Y); }
+  template <int K>
+  __device__ __forceinline__ vfloat rcp_pick(vfloat X, vfloat Y) { return vrcp(pick<K>(X, Y)); }
+#endif
   // Reductions whose result every lane USES (there is no v_readlane to make it wave-uniform): all lanes of the half must end
   // up with the same bits.  The butterfly is symmetric -- lane l forms v[l] + v[l ^ 1], lane l ^ 1 the same two operands the other
   // way round -- unless hipcc contracts the multiply that produced v into the first add: fma(a_l, b_l, round(a_l' b_l')) in one
