@@ -152,6 +152,10 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   const CModel<D>* m = reinterpret_cast<const CModel<D>*>(smem);
   WaveH w;
   w.init((int)threadIdx.x);
+#ifndef DIAL_PAIR_LAUNDER
+#define DIAL_PAIR_LAUNDER 0   // A/B switch: the opaque lane id per control step / physics frame (wave.h: launder) for the pair kernels
+#endif
+  w.launder = DIAL_PAIR_LAUNDER;
   Ws s;
   ws_carve(s, smem + CMW + (int)(threadIdx.x >> 5) * ws_words, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m),
            dim_ns(m), dim_nc(m), dim_ne(m), io.Hn1, false, true, 0, 0, D::NVP);

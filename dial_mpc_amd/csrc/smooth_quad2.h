@@ -27,6 +27,12 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
   static_assert(M::D::NB == 14 && M::D::NV == 18 && M::D::NC == 4 && M::D::square, "the Go2's own scene");
   static_assert(W::half2, "32-lane layout: the half-wave execution model");
   DIAL_MARK(w, 15);
+#if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
+  // an opaque copy of the lane id for this stage (as in smooth_quad.h): its role masks and table addresses are loop invariants of
+  // the T-step loop; hoisted they are dozens of 64-bit SGPR masks / address VGPRs that live through the solver and get spilled
+  const int lane_keep = w.lane;
+  { int lq = w.lane; asm volatile("" : "+v"(lq)); w.lane = lq; }
+#endif
   // lane roles (functions of the logical lane id)
   //   leg:  d in 1..3      rot: d in 4..6 (trunk dof d - 1)      tr: d == 7 && g < 3 (trunk dof g)
   //   mrow: the lanes that own a row of M / an entry of qfrc_smooth for a trunk dof: rot of group 0, tr
@@ -116,11 +122,13 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     vfloat c4[4] = {F[12], F[13], F[14], F[15]};
     float r4[4];
     w.vsumN(c4, r4);
-    for (int k = 0; k < 3; k++) com[k] = r4[3] < MJ_MINVAL ? w.template bc<0>(F[k]) : r4[k] / r4[3];
+    for (int k = 0; k < 3; k++) com[k] = r4[3] < MJ_MINVAL ? w.template rowbc<0>(F[k]) : r4[k] / r4[3];
   }
-  // the trunk's pose, rotation matrix and rotational cdofs: the same value in every lane of the half
-  const float tpos[3] = {w.template bc<0>(PL[0]), w.template bc<0>(PL[1]), w.template bc<0>(PL[2])};
-  const float tquat[4] = {w.template bc<0>(PL[3]), w.template bc<0>(PL[4]), w.template bc<0>(PL[5]), w.template bc<0>(PL[6])};
+  // the trunk's pose, rotation matrix and rotational cdofs: the same value in every lane of the half.  (Every group of eight lanes
+  // keeps its own copy of the trunk in its lane 0, so lane 0 of the own ROW already holds the value: one DPP row broadcast, no
+  // cross-row swap -- v_permlane16_swap issues at quarter rate.)
+  const float tpos[3] = {w.template rowbc<0>(PL[0]), w.template rowbc<0>(PL[1]), w.template rowbc<0>(PL[2])};
+  const float tquat[4] = {w.template rowbc<0>(PL[3]), w.template rowbc<0>(PL[4]), w.template rowbc<0>(PL[5]), w.template rowbc<0>(PL[6])};
   float Rt[9], cdT[3][6];
   dm::quat_to_mat(Rt, tquat);
   const float offt[3] = {com[0] - tpos[0], com[1] - tpos[1], com[2] - tpos[2]};
@@ -361,7 +369,7 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     float hs[16];
     w.vsumN(H, hs);
     DIAL_UNROLL_FULL
-    for (int k = 0; k < 16; k++) XT[k] = w.template bc<0>(X[k]) + hs[k];
+    for (int k = 0; k < 16; k++) XT[k] = w.template rowbc<0>(X[k]) + hs[k];
   }
   DIAL_MARK(w, 22);
   // ---- F_i = crb cdof_i, M = F . cdof over the ancestors (support.make_m), qfrc_smooth = passive - bias + actuator
@@ -427,6 +435,9 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
       }
     }
   });
+#if !defined(DIAL_EMU) && !defined(DIAL_QUAD_HOIST)
+  w.lane = lane_keep;
+#endif
   DIAL_MARK(w, 1);
 }
 

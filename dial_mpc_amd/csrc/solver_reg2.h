@@ -31,6 +31,9 @@ DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, f
   constexpr int N = D::NV, S = kCholStride<N>;
   using Topo = TopoT;
   static_assert(N <= 32 && D::square, "one 32-lane half holds the rows");
+#ifdef DIAL_PAIR_SOLVER_SCOPE
+  DIAL_LANE_SCOPE(w);
+#endif
   w.begin_region();
   vfloat a[N];
   const auto own_i = [&](int l) { return N - 1 - l; };   // the lane's dof
@@ -112,6 +115,9 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
   constexpr int NV = M::D::NV, NC = M::D::NC, NL = M::D::NL;
   static_assert(W::half2, "32-lane layout: the half-wave execution model");
   static_assert(NV <= 32 && 4 * NC <= 16 && NV == 6 + 3 * NC, "free trunk + one three-dof leg per contact; contact rows in one DPP row");
+#ifdef DIAL_PAIR_SOLVER_SCOPE
+  DIAL_LANE_SCOPE(w);
+#endif
   w.begin_region();
   const vbool isdof = w.lane_lt(NV), iscon = w.lane_lt(4 * NC);
   const vfloat vzero = vsplat(0.f);

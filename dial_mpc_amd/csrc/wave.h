@@ -80,6 +80,7 @@ inline float emu_tree32(const float* v) {     // half-wave sum (WaveH): the two 
 }
 
 #define DIAL_MARK(w, id)
+#define DIAL_LANE_SCOPE(w)
 struct Wave {
   static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront, this object is one 32-lane half)
   bool tree_sums = false;                // wave sums in the GPU's association (see emu_row_tree)
@@ -288,6 +289,9 @@ struct WaveH : Wave {
   vfloat gather(const vfloat& v, F src) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & 32) | (src(l & 31) & 31)]; return r; }
   // lane 3 of the own group of 8 lanes, to the whole group (GPU: two row_newbcast + select)
   vfloat grp8_bcast3(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~7) | 3]; return r; }
+  // lane K of the own ROW, as a (half-uniform) scalar -- for values every row holds a copy of (GPU: one DPP row_newbcast)
+  template <int K>
+  float rowbc(const vfloat& v) { return v.x[K]; }
   // acc +- other * (lane K of the half, from its duplicated rows X | Y) and 1 / that lane: on the GPU's product build ONE instruction
   // each -- the DPP row broadcast is an operand modifier of v_fmac_f32 / v_rcp_f32 (HIP WaveH below)
   template <int K>
@@ -357,6 +361,21 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_r
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ vfloat vrcp(vfloat a) { return __builtin_amdgcn_rcpf(a); }
 
+// An opaque copy of the lane id for the enclosing scope (restored at its end): what is derived from it -- role masks, table
+// addresses -- stays inside the scope instead of being hoisted out of the T-step loop as long-lived SGPR masks / address VGPRs.
+template <class W>
+struct LaneScope {
+  W& w;
+  int keep, keep_r;
+  __device__ __forceinline__ explicit LaneScope(W& w_) : w(w_), keep(w_.lane), keep_r(w_.lane_r) {
+    int lq = w.lane;
+    asm volatile("" : "+v"(lq));
+    w.lane = lq;
+    w.lane_r = lq;
+  }
+  __device__ __forceinline__ ~LaneScope() { w.lane = keep; w.lane_r = keep_r; }
+};
+#define DIAL_LANE_SCOPE(w) LaneScope<std::remove_reference_t<decltype(w)>> dial_lane_scope_(w)
 #ifdef DIAL_PROFILE
 #define DIAL_NSEC 32
 #define DIAL_MARK(w, id) (w).mark(id)
@@ -634,6 +653,8 @@ struct WaveH : Wave {
     const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
     return (lane & 8) ? b : a;
   }
+  template <int K>
+  __device__ __forceinline__ float rowbc(vfloat v) { return row_bcast<K>(v); }
   template <int K>
   __device__ __forceinline__ vfloat pick(vfloat X, vfloat Y) { if constexpr (K < 16) return row_bcast<K>(X); else return row_bcast<K - 16>(Y); }
   // acc +- other * (lane K of the half) and 1 / (lane K of the half).  hipcc keeps `v_mov_b32_dpp` + `v_fma_f32` apart (its DPP
