@@ -29,8 +29,8 @@
   extern template __global__ void env_step_kernel<D>(const CModel<D>*, const dial_task*, float*, const float*, float*, float*, float*); \
   extern template __global__ void env_reset_kernel<D>(const CModel<D>*, const float*, const float*, float*, float*, float*);
 DIAL_KERNELS_ALL(DIAL_X, DIAL_XE)
-#define DIAL_X2(D, WPB, OCC, Q) \
-  extern template __global__ void rollout_kernel2<D, WPB, OCC, Q>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
+#define DIAL_X2(D, WPB, OCC, Q, MI) \
+  extern template __global__ void rollout_kernel2<D, WPB, OCC, Q, MI>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
 DIAL_KERNELS2_GO2(DIAL_X2)
 #undef DIAL_X2
 #undef DIAL_X
@@ -532,7 +532,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
 #endif
       if (ctx->lds_pair_large > 160 * 1024) ctx->pair_ok = false;
       if (e == hipSuccess && ctx->pair_ok && ctx->lds_pair_large > 64 * 1024)
-        e = hipFuncSetAttribute((const void*)rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_pair_large);
+        e = hipFuncSetAttribute((const void*)rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_pair_large);
     }
     if (e != hipSuccess) { dial_destroy(ctx); return fail(nullptr, DIAL_ERR_HIP, std::string("dial_create: hipFuncSetAttribute: ") + hipGetErrorString(e)); }
   }
@@ -558,9 +558,9 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       if (e == hipSuccess) ctx->resident_blocks_large = nb * prop.multiProcessorCount;
     }
     if (e == hipSuccess && ctx->pair_ok) {
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false>, 64, ctx->lds_pair);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false, false>, 64, ctx->lds_pair);
       if (e == hipSuccess) ctx->resident_pair = nb * prop.multiProcessorCount;
-      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>,
+      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true, true>,
                                                                             64 * DIAL_GO2_PAIR_WPB, ctx->lds_pair_large);
       if (e == hipSuccess) ctx->resident_pair_large = nb * prop.multiProcessorCount;
       if (e == hipSuccess && (ctx->resident_pair <= 0 || ctx->resident_pair_large <= 0)) ctx->pair_ok = false;
@@ -732,24 +732,27 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // (profiles/r05_ab_pair_kernel.txt, profiles/r05_sections_pair_cycles.txt)
   if (ctx->pair_ok && !tracing && (ctx->opt.pair_mode == 2 || B > DIAL_GO2_PAIR_MIN_B)) {
     dial::RolloutIO io = io_in;
+    const bool mean_last = !io.us && io.n_noise == B - 1 && ((B - 1) & 1) == 0 && ctx->relay_buf && ctx->relay_flag && !ctx->no_mean_inline;
     if ((B + 1) / 2 <= ctx->resident_pair || opt_no_queue(ctx)) {
-      const int pairs = (B + 1) / 2;   // plain grid: wavefront p runs rollouts 2 p, 2 p + 1 (the mean trajectory alone in the last one)
-      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false>), dim3(pairs), dim3(64), ctx->lds_pair, st,
+      // plain grid: wavefront p runs rollouts 2 p, 2 p + 1 (the mean trajectory alone in the last one).  The interleaved mean
+      // trajectory was measured here as well (N = 2048 as exactly 1024 wavefronts, one per SIMD): 0.418 ms against 0.389 ms with
+      // the 1025th wavefront -- the hand-over code slows every wavefront more than the odd one costs (profiles/r05_ab_pair_n2048.txt)
+      const int pairs = (B + 1) / 2;
+      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, 1, DIAL_GO2_PAIR_OCC, false, false>), dim3(pairs), dim3(64), ctx->lds_pair, st,
                          (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B, ctx->ws_words, (int*)nullptr);
     } else {
       // beyond the resident set: the queue -- and the mean trajectory rides along with the first T wavefronts (rollout_kernel2)
       // whenever it is the batch's last rollout and the noisy ones pair up exactly, so that N = 4096 / 8192 are one / two full
       // rounds of the resident grid (0.70 -> 0.48 ms, 1.24 -> 0.90 ms) instead of "+ 1 pair"
       const int blocks = ctx->resident_pair_large;
-      if (!ctx->no_mean_inline && !io.us && io.n_noise == B - 1 && ((B - 1) & 1) == 0 && ctx->T <= blocks * DIAL_GO2_PAIR_WPB &&
-          ctx->relay_buf && ctx->relay_flag) {
+      if (mean_last && ctx->T <= blocks * DIAL_GO2_PAIR_WPB) {
         io.mean_inline = 1;
         io.relay_buf = ctx->relay_buf;
         io.relay_flag = ctx->relay_flag;
         io.err_word = ctx->err_dev;
       }
       HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->next, blocks * DIAL_GO2_PAIR_WPB, 1, st));
-      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true>), dim3(blocks), dim3(64 * DIAL_GO2_PAIR_WPB),
+      hipLaunchKernelGGL((rollout_kernel2<DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true, true>), dim3(blocks), dim3(64 * DIAL_GO2_PAIR_WPB),
                          ctx->lds_pair_large, st, (const CModel<DimsGo2>*)ctx->dcm, (const dial_task*)ctx->dtask, (const dial_cfg*)ctx->dcfg, io, B,
                          ctx->ws_words, ctx->next);
     }

@@ -5,8 +5,8 @@
 #define DIAL_XE(D)                                                                                                       \
   template __global__ void env_step_kernel<D>(const CModel<D>*, const dial_task*, float*, const float*, float*, float*, float*); \
   template __global__ void env_reset_kernel<D>(const CModel<D>*, const float*, const float*, float*, float*, float*);
-#define DIAL_X2(D, WPB, OCC, Q) \
-  template __global__ void rollout_kernel2<D, WPB, OCC, Q>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
+#define DIAL_X2(D, WPB, OCC, Q, MI) \
+  template __global__ void rollout_kernel2<D, WPB, OCC, Q, MI>(const CModel<D>*, const dial_task*, const dial_cfg*, dial::RolloutIO, int, int, int*);
 #if DIAL_FAMILY == 0
 DIAL_KERNELS_GO2(DIAL_X, DIAL_XE)
 #elif DIAL_FAMILY == 7

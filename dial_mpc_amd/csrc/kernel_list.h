@@ -57,8 +57,8 @@
 // X(Dims, wavefronts per workgroup, occupancy target, rollout-queue variant, state-trace variant); XE(Dims): env.step / env.reset
 #define DIAL_KERNELS_GO2(X, XE) \
   X(DimsGo2, 1, 3, false, false) X(DimsGo2, 1, 3, false, true) X(DimsGo2, DIAL_GO2_WPB_LARGE, DIAL_GO2_OCC_LARGE, true, false) XE(DimsGo2)
-// X2(Dims, wavefronts per workgroup, occupancy target, rollout-queue variant): the two-samples-per-wavefront kernels
-#define DIAL_KERNELS2_GO2(X2) X2(DimsGo2, 1, DIAL_GO2_PAIR_OCC, false) X2(DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true)
+// X2(Dims, wavefronts per workgroup, occupancy target, rollout-queue variant, interleaved mean trajectory): the two-samples-per-wavefront kernels
+#define DIAL_KERNELS2_GO2(X2) X2(DimsGo2, 1, DIAL_GO2_PAIR_OCC, false, false) X2(DimsGo2, DIAL_GO2_PAIR_WPB, DIAL_GO2_PAIR_OCC, true, true)
 #define DIAL_KERNELS_H1(X, XE) \
   X(DimsH1, 3, 3, false, false) X(DimsH1, 3, 3, true, false) X(DimsH1, 3, 3, false, true) \
   X(DimsH1, DIAL_H1_WPB_EVEN, DIAL_EVEN_OCC_H1, false, false) X(DimsH1, 1, 3, false, false) XE(DimsH1)

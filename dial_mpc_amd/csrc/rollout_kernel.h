@@ -136,7 +136,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
 // wavefronts, one per SIMD, and N = 4096 / 8192 are one / two full rounds of the resident grid instead of "+ 1 pair".
 // The body is rollout_sample -- the same per-lane program as the one-sample kernel with the 32-lane layouts of smooth_quad2.h /
 // solver_reg2.h -- and produces the same bits per rollout (GPU test: test_two_samples_per_wavefront_is_bit_identical).
-template <class D, int WPB, int OCC = 2, bool QUEUE = false>
+template <class D, int WPB, int OCC = 2, bool QUEUE = false, bool INLINE = QUEUE>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ tg,
                 const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
@@ -165,10 +165,10 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   __syncthreads();
 #endif
   int pair = (WPB > 1 ? (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
-  // (the interleaved mean trajectory exists in the QUEUE variant only: its hand-over code costs the body 20 VGPRs and a lone
-  //  wavefront 12 % -- 0.366 -> 0.41 ms at N = 256 --, which the plain grid's small batches would pay for nothing)
-  const int Bq = QUEUE ? B - io.mean_inline : B;                  // rollouts the grid / the queue holds
-  int helper = QUEUE && io.mean_inline && pair < io.T ? pair : -1;   // (first round only)
+  // (INLINE: the instantiation carries the interleaved mean trajectory's hand-over code -- the queue variant always, the plain grid as
+  //  a second instantiation: the code costs registers and a lone wavefront's pace, which batches that do not need it should not pay)
+  const int Bq = INLINE ? B - io.mean_inline : B;                  // rollouts the grid / the queue holds
+  int helper = INLINE && io.mean_inline && pair < io.T ? pair : -1;   // (first round only)
   for (;;) {
     const int n = 2 * pair + w.half + io.n_first;
     // (measured and not kept: the highest issue priority for the odd wavefront of a batch -- N + 1 = 2049 is 1024 full
