@@ -243,7 +243,7 @@ DIAL_DEV void solve_spd_reg(W& w, const M* m, const Ws& s, const float* A, const
     s.sq[e] = v;
   });
   const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
-  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
+  const vfloat xv = reg_chol<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
   w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
 }
 // the same with the square already in s.sq (the Hessian's accumulator tile is written straight into it)
@@ -252,7 +252,7 @@ DIAL_DEV void solve_sq_reg(W& w, const M* m, const Ws& s, const float* rhs, floa
   constexpr int NP = M::D::NVP;
   const int nv = dim_nv(m);
   const vfloat b = w.per_lane([&](int l) { return l < nv ? rhs[l] : 0.f; });
-  const vfloat xv = reg_chol_solve_v<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
+  const vfloat xv = reg_chol<DimsPadV<NP>, TopoT>(w, m, s.sq, b, s.sq);
   w.items(nv, [&](int i) { x[i] = lane_val(xv, i); });
 }
 
@@ -454,11 +454,8 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
-  if constexpr (W::half2) {   // two samples per wavefront: the 32-lane solver (solver_reg2.h)
-    const vfloat vq = reg_chol_solve2<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
-    w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
-  } else if constexpr (!M::D::gen) {
-    const vfloat vq = reg_chol_solve_v<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
+  if constexpr (!M::D::gen) {
+    const vfloat vq = reg_chol<typename M::D>(w, m, s.M, w.per_lane([&](int l) { return l < M::D::NV ? s.rhs[l] : 0.f; }), s.H);
     w.items(M::D::NV, [&](int i) { s.qas[i] = lane_val(vq, i); });
   } else {
 #ifdef DIAL_LDS_CHOL
@@ -1694,7 +1691,7 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
         s.H[e] = s.M[e] + (i == j ? dt * m->dof_damping[i] : 0.f);
       });
       const vfloat rhs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] + s.qfc[l] : 0.f; });
-      const vfloat x = reg_chol_solve_v<typename M::D>(w, m, s.H, rhs, s.H);
+      const vfloat x = reg_chol<typename M::D>(w, m, s.H, rhs, s.H);
       w.items(NV, [&](int i) { s.qvel[i] += lane_val(x, i) * dt; });
     } else {
       w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });

@@ -316,7 +316,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       });
     }
     DIAL_MARK(w, 5);
-    const vfloat vsearch = vzero - reg_chol_solve_v<D, TopoDense>(w, m, s.H, vgrad, s.H);
+    const vfloat vsearch = vzero - reg_chol<D, TopoDense>(w, m, s.H, vgrad, s.H);
     DIAL_MARK(w, 6);
 
     // ---- solver._linesearch

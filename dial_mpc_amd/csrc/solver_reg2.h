@@ -25,91 +25,6 @@
 
 namespace dial {
 
-// x = A^-1 b, the sparse L D L^T of solver_reg.h (same elimination order, same operations) with DPP broadcasts.
-template <class D, class TopoT = typename D::Topo, bool REUSE = false, class W, class M>
-DIAL_DEV vfloat reg_chol_solve2(W& w, const M* m, const float* A, vfloat bvec, float* scratch, vfloat* dinv_io = nullptr) {
-  constexpr int N = D::NV, S = kCholStride<N>;
-  using Topo = TopoT;
-  static_assert(N <= 32 && D::square, "one 32-lane half holds the rows");
-#ifdef DIAL_PAIR_SOLVER_SCOPE
-  DIAL_LANE_SCOPE(w);
-#endif
-  w.begin_region();
-  vfloat a[N];
-  const auto own_i = [&](int l) { return N - 1 - l; };   // the lane's dof
-  (void)m;
-  vfloat b = w.lane_reverse(bvec, N);
-  vfloat dinv = vsplat(0.f);
-  constexpr ElimOrder<Topo, N> EO{};
-  if constexpr (REUSE) {
-    (void)A;
-    dinv = *dinv_io;
-    static_for<0, N>([&](auto KP) {
-      constexpr int kp = KP;
-      a[kp] = w.per_lane([&](int l) { return scratch[(N - 1 - kp) * S + (l < N ? own_i(l) : 0)]; });
-    });
-    static_for<0, EO.nlevel>([&](auto LV) {
-      constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
-      vfloat bX, bY;
-      w.dup_rows(b, bX, bY);
-      static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; b = w.template fnma_pick<kp>(b, bX, bY, a[kp]); });
-    });
-  } else {
-  static_for<0, S / 4>([&](auto Q) {
-    constexpr int q = Q;
-    vfloat t[4];
-    w.per_lane4([&](int l) { return A + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
-    static_for<0, 4>([&](auto E) {
-      constexpr int j = 4 * q + E;
-      if constexpr (j < N) a[N - 1 - j] = t[E];
-    });
-  });
-  static_for<0, EO.nlevel>([&](auto LV) {
-    constexpr int l0 = EO.lvl[LV], l1 = EO.lvl[LV + 1];
-    vfloat bX, bY;
-    w.dup_rows(b, bX, bY);   // (the columns of one depth do not touch each other's b entries: one swap per level)
-    static_for<l0, l1>([&](auto STEP) {
-      constexpr int kp = EO.seq[STEP];
-      const vfloat col = a[kp];                                   // d_k l_ik (unscaled column, lanes >= k')
-      vfloat cX, cY;
-      w.dup_rows(col, cX, cY);
-      const vfloat rinv = w.template rcp_pick<kp>(cX, cY);
-      const vfloat lik = vsel(w.lane_gt(kp), col * rinv, vsplat(0.f));   // unit lower column: 0 in lanes <= k'
-      a[kp] = lik;
-      dinv = vsel(w.lane_eq(kp), rinv, dinv);
-      constexpr AncList<Topo, N, kp> L{};
-      static_for<0, L.n>([&](auto IDX) {
-        constexpr int jp = L.jp[IDX];
-        a[jp] = w.template fnma_pick<jp>(a[jp], cX, cY, lik);
-      });
-    });
-    // forward substitution L' z = b: the level's pivots' entries of b were duplicated before its columns were touched
-    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; b = w.template fnma_pick<kp>(b, bX, bY, a[kp]); });
-  });
-  w.items(N, [&](int l) {
-    static_for<0, N>([&](auto KP) { constexpr int kp = KP; scratch[(N - 1 - kp) * S + own_i(l)] = lane_val(a[kp], l); });
-  });
-  if (dinv_io) *dinv_io = dinv;
-  }   // (!REUSE)
-  vfloat x = b * dinv;
-  static_for<0, S / 4>([&](auto Q) {
-    constexpr int q = Q;
-    vfloat t[4];
-    w.per_lane4([&](int l) { return scratch + (l < N ? own_i(l) : 0) * S + 4 * q; }, t[0], t[1], t[2], t[3]);
-    static_for<0, 4>([&](auto E) {
-      constexpr int j = 4 * q + E;
-      if constexpr (j < N) a[N - 1 - j] = t[E];
-    });
-  });
-  static_for<0, EO.nlevel>([&](auto LVR) {
-    constexpr int lv = EO.nlevel - 1 - LVR, l0 = EO.lvl[lv], l1 = EO.lvl[lv + 1];
-    vfloat xX, xY;
-    w.dup_rows(x, xX, xY);
-    static_for<l0, l1>([&](auto STEP) { constexpr int kp = EO.seq[STEP]; x = w.template fnma_pick<kp>(x, xX, xY, a[kp]); });
-  });
-  return w.lane_reverse(x, N);
-}
-
 template <class W, class M>
 DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
   constexpr int NV = M::D::NV, NC = M::D::NC, NL = M::D::NL;
@@ -257,7 +172,7 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
 #endif
     vfloat vsearch;
     if (reuse) {
-      vsearch = vzero - reg_chol_solve2<typename M::D, typename M::D::Topo, true>(w, m, s.H, vgrad, s.H, &h_dinv);
+      vsearch = vzero - reg_chol<typename M::D, typename M::D::Topo, true>(w, m, s.H, vgrad, s.H, &h_dinv);
       DIAL_MARK(w, 5);
     } else {
     {
@@ -323,7 +238,7 @@ DIAL_DEV void solver_reg2(W& w, const M* m, const Ws& s) {
       });
     }
     DIAL_MARK(w, 5);
-    vsearch = vzero - reg_chol_solve2<typename M::D>(w, m, s.H, vgrad, s.H, &h_dinv);
+    vsearch = vzero - reg_chol<typename M::D>(w, m, s.H, vgrad, s.H, &h_dinv);
     }
     DIAL_MARK(w, 6);
 

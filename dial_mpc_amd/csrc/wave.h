@@ -237,6 +237,24 @@ struct Wave {
   // value of lane K, as a wave-uniform scalar (same as the free function bcast; WaveH: of the own half)
   template <int K>
   float bc(const vfloat& v) { return v.x[K]; }
+  // ---- DPP-operand broadcasts (used by the 32-lane layouts of WaveH and by the register L D L^T of every robot: solver_reg2.h)
+  // X = the half's even row in both of its rows, Y = its odd row in both (GPU: one v_permlane16_swap)
+  void dup_rows(const vfloat& v, vfloat& X, vfloat& Y) {
+    for (int l = 0; l < 64; l++) { X.x[l] = v.x[(l & 32) | (l & 15)]; Y.x[l] = v.x[(l & 32) | 16 | (l & 15)]; }
+  }
+  // lane K of the own ROW, as a (half-uniform) scalar -- for values every row holds a copy of (GPU: one DPP row_newbcast)
+  template <int K>
+  float rowbc(const vfloat& v) { return v.x[K]; }
+  // acc +- other * (lane K of the half, from its duplicated rows X | Y) and 1 / that lane: on the GPU's product build ONE instruction
+  // each -- the DPP row broadcast is an operand modifier of v_fmac_f32 / v_rcp_f32 (HIP WaveH below)
+  template <int K>
+  vfloat pick(const vfloat& X, const vfloat& Y) { if constexpr (K < 16) return row_bcast<K>(X); else return row_bcast<K - 16>(Y); }
+  template <int K>
+  vfloat fma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc + other * pick<K>(X, Y); }
+  template <int K>
+  vfloat fnma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc - other * pick<K>(X, Y); }
+  template <int K>
+  vfloat rcp_pick(const vfloat& X, const vfloat& Y) { return vrcp(pick<K>(X, Y)); }
 };
 
 // ---- WaveH: TWO samples per wavefront, one per 32-lane half (HIP section below).  The emulator runs ONE half: logical lanes
@@ -280,28 +298,11 @@ struct WaveH : Wave {
   float vsum(const vfloat& v) { return emu_tree32(v.x); }
   template <int K>
   void vsumN(vfloat (&v)[K], float (&out)[K]) { for (int k = 0; k < K; k++) out[k] = vsum(v[k]); }
-  // X = the half's even row in both of its rows, Y = its odd row in both (GPU: one v_permlane16_swap)
-  void dup_rows(const vfloat& v, vfloat& X, vfloat& Y) {
-    for (int l = 0; l < 64; l++) { X.x[l] = v.x[(l & 32) | (l & 15)]; Y.x[l] = v.x[(l & 32) | 16 | (l & 15)]; }
-  }
   // value of (logical) lane src(l) of the own half, per lane (GPU: ds_bpermute)
   template <class F>
   vfloat gather(const vfloat& v, F src) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & 32) | (src(l & 31) & 31)]; return r; }
   // lane 3 of the own group of 8 lanes, to the whole group (GPU: two row_newbcast + select)
   vfloat grp8_bcast3(const vfloat& v) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[(l & ~7) | 3]; return r; }
-  // lane K of the own ROW, as a (half-uniform) scalar -- for values every row holds a copy of (GPU: one DPP row_newbcast)
-  template <int K>
-  float rowbc(const vfloat& v) { return v.x[K]; }
-  // acc +- other * (lane K of the half, from its duplicated rows X | Y) and 1 / that lane: on the GPU's product build ONE instruction
-  // each -- the DPP row broadcast is an operand modifier of v_fmac_f32 / v_rcp_f32 (HIP WaveH below)
-  template <int K>
-  vfloat pick(const vfloat& X, const vfloat& Y) { if constexpr (K < 16) return row_bcast<K>(X); else return row_bcast<K - 16>(Y); }
-  template <int K>
-  vfloat fma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc + other * pick<K>(X, Y); }
-  template <int K>
-  vfloat fnma_pick(const vfloat& acc, const vfloat& X, const vfloat& Y, const vfloat& other) { return acc - other * pick<K>(X, Y); }
-  template <int K>
-  vfloat rcp_pick(const vfloat& X, const vfloat& Y) { return vrcp(pick<K>(X, Y)); }
 };
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
@@ -601,35 +602,7 @@ struct Wave {
   }
   template <int K>
   __device__ __forceinline__ float bc(vfloat v) { return bcast(v, K); }
-};
-
-// ---- WaveH: TWO samples per wavefront.  Each 32-lane half owns one sample; the kernel body is the same per-lane program,
-// `lane` is the LOGICAL lane 0..31 inside the half and every value the one-sample kernel keeps wave-uniform (reduction results,
-// broadcast pivots, the solver's control flow) is simply a per-lane value that agrees within a half: where the two samples
-// take different branches the hardware's EXEC mask does what it does for any divergent SIMT code.  What that needs is that no
-// cross-lane operation leaves the half:
-//   * reductions: the DPP butterfly inside each row of 16 lanes, then ONE v_permlane16_swap (gfx950) that puts the half's
-//     even row next to its odd row in every lane -- no v_readlane, no SGPR;
-//   * broadcasts: dup_rows (the same swap: X = the half's even row in both rows, Y = its odd row) + DPP row_newbcast, i.e. a
-//     broadcast is a VGPR operand of the consuming instruction's DPP mov instead of a v_readlane -> SGPR -> VALU hazard chain;
-//   * ballots are split per half; the LDS workspace base and every global row pointer are per-lane values.
-// The lane layouts that need more than 32 lanes per sample in the one-sample kernel (smooth_quad.h: four DPP rows; solver_reg.h:
-// dof lanes + contact lanes + three line-search groups) have 32-lane versions in smooth_quad2.h / solver_reg2.h.
-struct WaveH : Wave {
-  static constexpr bool half2 = true;
-  int half;     // 0 / 1: which half of the wavefront this lane belongs to (a VGPR value)
-  __device__ __forceinline__ void init(int tid) { lane = tid & 31; lane_r = lane; half = (tid >> 5) & 1; }
-  template <class F>
-  __device__ __forceinline__ void items(int count, F f) {
-    for (int i = lane; i < count; i += 32) f(i);
-    sync();
-  }
-  // even row + odd row of the own half, in every lane of the half
-  static __device__ __forceinline__ float half_combine(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    const unsigned r0 = r[0], r1 = r[1];   // (element temporaries: bit_cast straight from r[k] folds both to element 0, clang 22)
-    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
-  }
+  // ---- DPP-operand broadcasts: X = every 32-lane half's even row in both of its rows, Y = its odd row (one v_permlane16_swap, gfx950)
   __device__ __forceinline__ void dup_rows(vfloat v, vfloat& X, vfloat& Y) {
     const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
     const unsigned r0 = r[0], r1 = r[1];
@@ -638,20 +611,6 @@ struct WaveH : Wave {
 #ifdef DIAL_FUSED_DPP
     asm("s_nop 1" : "+v"(X), "+v"(Y));   // (the hand-written DPP consumers of X | Y: see fma_pick)
 #endif
-  }
-  template <int K>
-  __device__ __forceinline__ float bc(vfloat v) {
-    static_assert(K >= 0 && K < 32, "logical lane");
-    vfloat X, Y;
-    dup_rows(v, X, Y);
-    if constexpr (K < 16) return row_bcast<K>(X);
-    else return row_bcast<K - 16>(Y);
-  }
-  template <class F>
-  __device__ __forceinline__ vfloat gather(vfloat v, F src) { return __shfl(v, (src(lane) & 31) + 32 * half, 64); }   // ds_bpermute_b32
-  __device__ __forceinline__ vfloat grp8_bcast3(vfloat v) {
-    const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
-    return (lane & 8) ? b : a;
   }
   template <int K>
   __device__ __forceinline__ float rowbc(vfloat v) { return row_bcast<K>(v); }
@@ -692,6 +651,50 @@ struct WaveH : Wave {
   template <int K>
   __device__ __forceinline__ vfloat rcp_pick(vfloat X, vfloat Y) { return vrcp(pick<K>(X, Y)); }
 #endif
+};
+
+// ---- WaveH: TWO samples per wavefront.  Each 32-lane half owns one sample; the kernel body is the same per-lane program,
+// `lane` is the LOGICAL lane 0..31 inside the half and every value the one-sample kernel keeps wave-uniform (reduction results,
+// broadcast pivots, the solver's control flow) is simply a per-lane value that agrees within a half: where the two samples
+// take different branches the hardware's EXEC mask does what it does for any divergent SIMT code.  What that needs is that no
+// cross-lane operation leaves the half:
+//   * reductions: the DPP butterfly inside each row of 16 lanes, then ONE v_permlane16_swap (gfx950) that puts the half's
+//     even row next to its odd row in every lane -- no v_readlane, no SGPR;
+//   * broadcasts: dup_rows (the same swap: X = the half's even row in both rows, Y = its odd row) + DPP row_newbcast, i.e. a
+//     broadcast is a VGPR operand of the consuming instruction's DPP mov instead of a v_readlane -> SGPR -> VALU hazard chain;
+//   * ballots are split per half; the LDS workspace base and every global row pointer are per-lane values.
+// The lane layouts that need more than 32 lanes per sample in the one-sample kernel (smooth_quad.h: four DPP rows; solver_reg.h:
+// dof lanes + contact lanes + three line-search groups) have 32-lane versions in smooth_quad2.h / solver_reg2.h.
+struct WaveH : Wave {
+  static constexpr bool half2 = true;
+  int half;     // 0 / 1: which half of the wavefront this lane belongs to (a VGPR value)
+  __device__ __forceinline__ void init(int tid) { lane = tid & 31; lane_r = lane; half = (tid >> 5) & 1; }
+  template <class F>
+  __device__ __forceinline__ void items(int count, F f) {
+    for (int i = lane; i < count; i += 32) f(i);
+    sync();
+  }
+  // even row + odd row of the own half, in every lane of the half
+  static __device__ __forceinline__ float half_combine(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned r0 = r[0], r1 = r[1];   // (element temporaries: bit_cast straight from r[k] folds both to element 0, clang 22)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  }
+  template <int K>
+  __device__ __forceinline__ float bc(vfloat v) {
+    static_assert(K >= 0 && K < 32, "logical lane");
+    vfloat X, Y;
+    dup_rows(v, X, Y);
+    if constexpr (K < 16) return row_bcast<K>(X);
+    else return row_bcast<K - 16>(Y);
+  }
+  template <class F>
+  __device__ __forceinline__ vfloat gather(vfloat v, F src) { return __shfl(v, (src(lane) & 31) + 32 * half, 64); }   // ds_bpermute_b32
+  __device__ __forceinline__ vfloat grp8_bcast3(vfloat v) {
+    const vfloat a = row_bcast<3>(v), b = row_bcast<11>(v);
+    return (lane & 8) ? b : a;
+  }
+
   // Reductions whose result every lane USES (there is no v_readlane to make it wave-uniform): all lanes of the half must end
   // up with the same bits.  The butterfly is symmetric -- lane l forms v[l] + v[l ^ 1], lane l ^ 1 the same two operands the other
   // way round -- unless hipcc contracts the multiply that produced v into the first add: fma(a_l, b_l, round(a_l' b_l')) in one
