@@ -903,14 +903,17 @@ def test_async_planner_replay_matches_oracle_restatement():
         last_plan_time = rec["t"]
 
 
-@pytest.mark.parametrize("N,world", [(2048, 2), (2048, 4), (1001, 4), (37, 4), (5, 4), (2048, 1)])
+@pytest.mark.parametrize("N,world", [(2048, 2), (2048, 4), (1001, 4), (37, 4), (5, 4), (2048, 1), (16384, 2)])
 def test_sharded_kernels_at_world_2_and_4_on_one_gpu(N, world):
     """The HIP kernels of the sharded path at world > 1, driven on ONE GPU: one dial_create_sharded context per pseudo-rank
     (threads, tests/local_group.py), the production `sharded_reverse_once` on each, collectives as device-side copies /
     rank-ordered sums.  Against the fused dial_reverse_once[_rng] on the same inputs: the gathered rewards are bit-equal
     (a rollout's result does not depend on which shard ran it), every rank holds bit-identical Ybar / bars, and they
     agree with the fused sums to summation-order rounding (the fused K4b sums 64 row chunks over all samples, the
-    sharded one world x 64 over the shards; world = 1: bit-equal).  1001 / 37 / 5 samples: ragged and EMPTY shards."""
+    sharded one world x 64 over the shards; world = 1: bit-equal).  1001 / 37 / 5 samples: ragged and EMPTY shards; 16384 over
+    two ranks: a rank's shard of BASELINE config 5 (8192 rollouts) -- the two-rollouts-per-wavefront queue with the interleaved
+    mean trajectory, fused and sharded alike.  (Bit-equality across the sharding holds where both sides launch the same kernel
+    family; a batch above and shards below the 2304-rollout switch differ at fused-multiply-add rounding level on the product build.)"""
     import torch
     from dial_mpc_amd import _lib
     from dial_mpc_amd.core.sharding import ShardPlan, partition, sharded_reverse_once
@@ -1107,9 +1110,14 @@ def test_closed_loop_behaviour(example, ticks, N):
     import yaml
     from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
     from dial_mpc_amd.utils.io_utils import get_example_path
-    # Allegro: tossing the ball is chaotic -- at N = 512 it leaves the hand in 3-7 % of the runs whatever the build
-    # (profiles/r04_allegro_closed_loop_seeds.txt: 10 of 192 runs over two builds); three seeds, at most one may drop it
-    seeds = (0, 1, 2) if example == "allegro_reorient" else (0,)
+    # Allegro: the planner sometimes tosses the ball out of the hand.  What round 5 established (profiles/r05_allegro_closed_loop.txt,
+    # tools/allegro_closed_loop_study.py / allegro_closed_loop_parity.py): 4 of 64 seeds lose it within 40 ticks at N = 512 AND at the
+    # reference's N = 2048 alike (it is not the reduced sample count); along the closed loop -- the drops included -- 99.96 % of 115 200
+    # sampled transitions of the device's rollouts are reproduced by the oracle within 1 x TOL from the device's own state (it is not the
+    # kernel's physics in some unusual contact regime); the CPU oracle as plant and planner on the same Philox noise kept the ball in
+    # all of its runs, which at a true rate of 1 / 16 happens by chance one time in eight.  The gate is therefore a RATE over 16
+    # fixed seeds: at most 4 may drop the ball (measured 2; P(>= 5 of 16) at the measured rate of 6.25 % is 0.3 %).
+    seeds = tuple(range(16)) if example == "allegro_reorient" else (0,)
     kept = 0
     for seed in seeds:
         cfgd = yaml.safe_load(open(get_example_path(example + ".yaml")))
@@ -1144,7 +1152,8 @@ def test_closed_loop_behaviour(example, ticks, N):
             print(f"allegro seed {seed}: ball height {zs[-1]:.3f} m after {ticks} ticks, mean reward {np.mean(rews[-10:]):.3f}")
             kept += zs[-1] > 0.08
     if example == "allegro_reorient":
-        assert kept >= len(seeds) - 1, kept
+        print(f"allegro: the ball stayed in the hand in {kept} of {len(seeds)} runs")
+        assert kept >= len(seeds) - 4, kept
 
 
 def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():
