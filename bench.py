@@ -46,6 +46,15 @@ SHADER_CLOCK_HZ = 2.4e9           # nominal; the chip clocks to its power budget
 UBENCH_MIX_CYCLES = [5.00, 3.75, 3.54, 3.36]
 
 
+def resident_waves_per_simd(example, rollouts, n_simd):
+    """Wavefronts that share a SIMD while a launch of `rollouts` rollouts runs (what the issue ceiling of profiles/r05_ubench_issue.txt
+    is looked up at): one wavefront per rollout -- the Go2 beyond 2304 rollouts: per PAIR of rollouts, at most two per SIMD (256 VGPRs,
+    16 rollouts of LDS per CU) -- up to the kernels' occupancy of three to four."""
+    pair = example in ("unitree_go2_trot", "unitree_go2_seq_jump") and rollouts > 2304
+    waves = (rollouts + 1) // 2 if pair else rollouts
+    return float(min(2.0 if pair else 4.0, max(1.0, waves / n_simd)))
+
+
 def cpu_baseline(example: str, N: int, H: int, budget_s: float = 16.0, min_wall_s: float = 2.0):
     """Time the CPU oracle (kind = "port") on this box's host cores.  Test-infrastructure code is used
     here ONLY as the reported baseline, never on the timed GPU path."""
@@ -312,7 +321,7 @@ def main():
         if os.path.exists(pj) and s_kms > 0:
             pc = json.load(open(pj)).get("counters", {})
             n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-            wps = min(4.0, max(1.0, pc.get("SQ_WAVES", n_simd) / n_simd))
+            wps = resident_waves_per_simd("unitree_go2_trot", pls.n_local + 1, n_simd)
             cyc = float(np.interp(wps, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
             if pc.get("SQ_INSTS_VALU"):
                 rec["valu_issue_frac"] = pc["SQ_INSTS_VALU"] * cyc / (n_simd * (s_kms / max(s_nl, 1)) * 1e-3 * SHADER_CLOCK_HZ)
@@ -370,7 +379,7 @@ def main():
             insts = (pmc.get("counters") or {}).get("SQ_INSTS_VALU")
             if insts and avg_kernel_s > 0:
                 n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-                waves_per_simd = min(4.0, max(1.0, (pmc.get("counters") or {}).get("SQ_WAVES", n_simd) / n_simd))
+                waves_per_simd = resident_waves_per_simd(args.example, n_local, n_simd)
                 cyc = float(np.interp(waves_per_simd, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
                 valu_issue = {"frac": insts * cyc / (n_simd * avg_kernel_s * SHADER_CLOCK_HZ), "valu_insts_per_launch_pmc": insts,
                               "cycles_per_valu_inst": cyc, "wavefronts_per_simd": waves_per_simd, "simds": n_simd, "clock_hz": SHADER_CLOCK_HZ,
