@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--nsample", type=int, default=512)
     ap.add_argument("--ticks", type=int, default=40)
     ap.add_argument("--rollouts", type=int, default=24, help="rollouts of each tick's last annealing iteration that are checked")
+    ap.add_argument("--dump", default=None, help="directory: every transition that misses the gate by more than 5 x is saved there (.npz: the tick's "
+                                                 "start state, the rollout's controls and the device's per-step states) and replayed in isolation")
     args = ap.parse_args()
     import torch
     import oracle as O
@@ -65,6 +67,22 @@ def main():
         except AssertionError as e:
             rep = e.args[0] if e.args and isinstance(e.args[0], dict) else dict(transitions=0, direct_worst=float("nan"), needed_witness=0, unwitnessed=[None])
             unw = len(rep["unwitnessed"])
+        if args.dump and rep.get("unwitnessed"):
+            os.makedirs(args.dump, exist_ok=True)
+            for (n_, t_, err_) in [u for u in rep["unwitnessed"] if u is not None and u[2] > 5.0]:
+                nq, nv = model.nq, model.nv
+                st = np.array(s0, dtype=np.float32)
+                st[:nq], st[nq:nq + nv], st[nq + nv:nq + 2 * nv], st[nq + 2 * nv] = got[1][n_, t_], got[2][n_, t_], 0.0, t_ + 1
+                f = os.path.join(args.dump, f"bad_seed{args.seed}_tick{t + 1}_r{n_}_t{t_}.npz")
+                np.savez(f, state=st, action=us[n_, t_ + 1], q_next=got[1][n_, t_ + 1], qd_next=got[2][n_, t_ + 1], rew_next=got[0][n_, t_ + 1], err=err_,
+                         s0=s0, us=us[n_], qss=got[1][n_], qdss=got[2][n_], rewss=got[0][n_])
+                # replay in isolation: the device's env.step kernel from that state (warm start 0, as the oracle's restart) vs the oracle
+                dev = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=mbdpi.device)  # noqa: E731
+                g_next = mbdpi.ctx.env_step(dev(st), dev(us[n_, t_ + 1]))[0].cpu().numpy()
+                o_next = o32.env_step(st, us[n_, t_ + 1])[0]
+                print(f"   saved {f}: rollout's own next qd vs oracle {np.abs(got[2][n_, t_ + 1] - o_next[nq:nq + nv]).max():.3g}; "
+                      f"device env.step replay vs oracle {np.abs(g_next[nq:nq + nv] - o_next[nq:nq + nv]).max():.3g}; "
+                      f"replay vs the rollout's own {np.abs(g_next[nq:nq + nv] - got[2][n_, t_ + 1]).max():.3g}", flush=True)
         z = float(state.pipeline_state.q[2])
         print(f"seed {args.seed} tick {t + 1:3d}: ball z {z:+.3f}  transitions {rep['transitions']}  direct worst {rep['direct_worst']:.2f} x gate  "
               f"needed a witness {rep['needed_witness']}  UNWITNESSED {unw}" + (f"  {rep['unwitnessed'][:3]}" if unw else ""), flush=True)

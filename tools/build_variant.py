@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build a MEASUREMENT variant of the HIP library for A/B runs (never the product path):
-     tools/build_variant.py NAME [--rev GITREV] [-- extra hipcc flags]
+     tools/build_variant.py NAME [--rev GITREV] [--no-fast] [-- extra hipcc flags]
    -> dial_mpc_amd/csrc/ab_NAME.so, from the working tree's sources or from those of a git revision (exported to build/src_NAME),
    with the product flags plus the extra ones.  Run an A/B with DIAL_HIP_LIB=.../ab_NAME.so python bench.py ..."""
 import os
@@ -29,7 +29,8 @@ def main():
     out = os.path.join(ROOT, "dial_mpc_amd", "csrc", f"ab_{name}.so")
     objdir = os.path.join(ROOT, "build", "obj_ab_" + name)
     os.makedirs(objdir, exist_ok=True)
-    flags = _lib._COMMON + _lib._FAST + extra
+    fast = [] if "--no-fast" in args else _lib._FAST      # --no-fast: without the product's fast-math flags (and without -DDIAL_FUSED_DPP)
+    flags = _lib._COMMON + fast + extra
     nfam = int(subprocess.check_output(f"grep -h 'define DIAL_N_FAMILIES' {csrc}/kernel_list.h", shell=True).split()[-1])
     units = [(os.path.join(csrc, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
     units += [(os.path.join(csrc, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"], os.path.join(objdir, f"kern_family_{k}.o")) for k in range(nfam)]
