@@ -1110,13 +1110,14 @@ def test_closed_loop_behaviour(example, ticks, N):
     import yaml
     from dial_mpc_amd.core.dial_core import MBDPI, load_dial_and_env
     from dial_mpc_amd.utils.io_utils import get_example_path
-    # Allegro: the planner sometimes tosses the ball out of the hand.  What round 5 established (profiles/r05_allegro_closed_loop.txt,
-    # tools/allegro_closed_loop_study.py / allegro_closed_loop_parity.py): 4 of 64 seeds lose it within 40 ticks at N = 512 AND at the
-    # reference's N = 2048 alike (it is not the reduced sample count); along the closed loop -- the drops included -- 99.96 % of 115 200
-    # sampled transitions of the device's rollouts are reproduced by the oracle within 1 x TOL from the device's own state (it is not the
-    # kernel's physics in some unusual contact regime); the CPU oracle as plant and planner on the same Philox noise kept the ball in
-    # all of its runs, which at a true rate of 1 / 16 happens by chance one time in eight.  The gate is therefore a RATE over 16
-    # fixed seeds: at most 4 may drop the ball (measured 2; P(>= 5 of 16) at the measured rate of 6.25 % is 0.3 %).
+    # Allegro: the planner sometimes tosses the ball out of the hand.  What round 5 established (profiles/r05_allegro/):
+    # 2-3 % of the runs lose it within 40 ticks (34 of 1408 at N = 512 over product build, arithmetic variants, plant / planner hybrids and
+    # the strict build under a 1-ulp disturbance of the plant; 4 of 64 at the reference's N = 2048); only the two UNDISTURBED strict loops (CPU
+    # oracle as plant and planner, libdialhip_ieee.so) kept it in all 320 runs, and the strict build loses it at the common rate once its plant
+    # state is moved by one ulp, once.  Through four recorded drops the plant's steps and the planner's per-rollout rewards are the oracle's,
+    # and the oracle's own loop continued from the recorded state tosses the ball the same way (tools/allegro_drop_autopsy.py): the toss is
+    # decided by the softmax average of ~25-65 samples, i.e. by the algorithm.  The gate is a RATE over 16 fixed seeds: at most 3 may
+    # lose the ball (this build: 2; P(>= 4 of 16) at 2.4 % is 4e-4) -- a kernel that breaks the hand's physics loses it nearly always.
     seeds = tuple(range(16)) if example == "allegro_reorient" else (0,)
     kept = 0
     for seed in seeds:
@@ -1153,7 +1154,7 @@ def test_closed_loop_behaviour(example, ticks, N):
             kept += zs[-1] > 0.08
     if example == "allegro_reorient":
         print(f"allegro: the ball stayed in the hand in {kept} of {len(seeds)} runs")
-        assert kept >= len(seeds) - 4, kept
+        assert kept >= len(seeds) - 3, kept
 
 
 def test_relay_timeout_raises_a_sticky_error_instead_of_hanging():

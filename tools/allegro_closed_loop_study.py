@@ -66,22 +66,50 @@ def setup(nsample, seed):
     return load_dial_and_env(d)
 
 
+PLANT_JITTER = 0     # --plant-jitter K: the plant's (q, qd) moved by up to K ulp (random sign per element) after every env.step
+JITTER_TICKS = 10 ** 9   # --jitter-ticks K: only on the first K ticks (1: a one-off perturbation, the loop is self-consistent afterwards)
+BITCHECK = False     # --bitcheck: per run, on how many ticks the plant's step equals the planner's own first predicted step BIT FOR BIT
+PLANT_LIB = None     # --plant-lib: another build of the library for the PLANT's env.step only (hybrid runs: which side matters?)
+
+
 def loop_gpu(nsample, seed, ticks):
     import torch
+    from dial_mpc_amd import _lib
     from dial_mpc_amd.core.dial_core import MBDPI
     dc, ec, env = setup(nsample, seed)
     mbdpi = MBDPI(dc, env, kernel_rng=True)
+    if PLANT_LIB:
+        env._ctx = _lib.Context(env.make_model(), env.make_task(), None, mbdpi.ctx.device, lib_path=PLANT_LIB)
     state = env.reset(0)
     Y = torch.zeros((dc.Hnode + 1, mbdpi.nu), device=mbdpi.device)
     zs = []
+    nqv = env.sys.nq + env.sys.nv
+    gen = torch.Generator(device="cpu").manual_seed(4242 + seed)
+    pred, same, worst = None, 0, 0.0
     for t in range(ticks):
         state = env.step(state, Y[0])
+        if BITCHECK and pred is not None:
+            got = state.packed[:nqv].cpu().numpy()
+            same += int(np.array_equal(got, pred))
+            worst = max(worst, float(np.abs(got - pred).max()))
+        if PLANT_JITTER and t < JITTER_TICKS:
+            x = state.packed[:nqv]
+            ulp = torch.nextafter(x.abs(), torch.full_like(x, float("inf"))) - x.abs()
+            k = torch.randint(-PLANT_JITTER, PLANT_JITTER + 1, (nqv,), generator=gen).to(x.device, x.dtype)
+            state.packed[:nqv] = x + k * ulp
         Y = mbdpi.shift(Y)
         n_it = dc.Ndiffuse_init if t == 0 else dc.Ndiffuse
         for i in range(n_it):
             _, Y, _ = mbdpi.reverse_once(state, None, Y, mbdpi.sigma_control * dc.traj_diffuse_factor ** i, want_bars=(i == n_it - 1))
+        if BITCHECK:   # the mean trajectory's rollout (row Nsample) of the last iteration started with Ybar[0], which the update leaves in place:
+            sc = mbdpi.ctx.debug_scratch()    # its first step is the planner's prediction of the plant's next step
+            pred = np.concatenate([sc["qss"][-1, 0], sc["qdss"][-1, 0]])
+            pred_u0 = float(np.abs(Y[0].cpu().numpy() - sc["Y0s"][-1, 0]).max())
+            worst = max(worst, 0.0 if pred_u0 == 0.0 else worst)
         zs.append(float(state.pipeline_state.q[2]))
     mbdpi.ctx.status()
+    if BITCHECK:
+        print(f"   bitcheck seed {seed}: plant step == the planner's predicted first step bit for bit on {same} of {ticks - 1} ticks; largest |difference| {worst:.3g}", flush=True)
     return zs
 
 
@@ -95,8 +123,13 @@ def loop_oracle(nsample, seed, ticks):
     sigma = (dc.horizon_diffuse_factor ** np.arange(Hn1)[::-1] * dc.sigma_scale).astype(np.float32)
     Y = np.zeros((Hn1, nu), np.float32)
     counter, zs = 0, []
+    rng = np.random.default_rng(4242 + seed)
+    nqv = model.nq + model.nv
     for t in range(ticks):
         state = o32.env_step(state, Y[0])[0]
+        if PLANT_JITTER and t < JITTER_TICKS:     # as in loop_gpu: the plant's (q, qd) moved by up to K ulp
+            state = np.array(state, np.float32)
+            state[:nqv] += (rng.integers(-PLANT_JITTER, PLANT_JITTER + 1, nqv) * np.spacing(np.abs(state[:nqv]))).astype(np.float32)
         Y = np.asarray(o32.shift(Y), np.float32)
         n_it = dc.Ndiffuse_init if t == 0 else dc.Ndiffuse
         for i in range(n_it):
@@ -114,7 +147,13 @@ def main():
     ap.add_argument("--seeds", default="0:8", help="a:b or a comma-separated list")
     ap.add_argument("--ticks", type=int, default=40)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--plant-jitter", type=int, default=0, help="move the plant's (q, qd) by up to this many ulp after every env.step")
+    ap.add_argument("--jitter-ticks", type=int, default=10 ** 9, help="apply --plant-jitter only on the first K ticks")
+    ap.add_argument("--bitcheck", action="store_true", help="gpu mode: count the ticks on which the plant's step equals the planner's predicted first step bitwise")
+    ap.add_argument("--plant-lib", default=None, help="gpu mode: the plant's env.step from this build of the library (the planner's: DIAL_HIP_LIB)")
     args = ap.parse_args()
+    global PLANT_LIB, PLANT_JITTER, BITCHECK, JITTER_TICKS
+    PLANT_LIB, PLANT_JITTER, BITCHECK, JITTER_TICKS = args.plant_lib, args.plant_jitter, args.bitcheck, args.jitter_ticks
     seeds = list(range(*map(int, args.seeds.split(":")))) if ":" in args.seeds else [int(s) for s in args.seeds.split(",")]
     if args.mode == "philox-check":   # the NumPy restatement against dial_rng_fill (needs a GPU)
         from dial_mpc_amd import _lib
