@@ -804,7 +804,9 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
       io.relay_flag = ctx->relay_flag;
       io.err_word = ctx->err_dev;
     }
-    if (ctx->slice_buf && B <= ctx->slice_cap && ctx->T > ctx->slice_steps) {   // time-sliced: (piece, rollout) items
+    // (one hand-over protocol per launch: the slices exist for the elliptic models only, the interleaved mean trajectory for the Go2 only;
+    //  the test keeps it that way should either condition widen -- both drive io.relay_buf / io.relay_flag)
+    if (!io.mean_inline && ctx->slice_buf && B <= ctx->slice_cap && ctx->T > ctx->slice_steps) {   // time-sliced: (piece, rollout) items
       io.relay_buf = ctx->slice_buf;
       io.relay_flag = ctx->slice_flag;
       io.relay_stride = ctx->slice_stride;
