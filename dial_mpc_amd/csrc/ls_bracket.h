@@ -87,10 +87,15 @@ DIAL_DEV bool ls_update(bool rule_swap, LsPt& lo, LsPt& hi, const LsPt& lo_next,
 // with; the winner's other three words are fetched afterwards with a lane-indexed v_readlane.  (Carrying all 12 words
 // of the three candidates through the select chain cost ~28 live SGPRs and four s_cselect per pick: the kernels sit at
 // the SGPR limit, and every SGPR spilled to a VGPR lane is a v_writelane / v_readlane pair on the VALU.)
-template <class BC>
+// MINMAX = false keeps the boolean form of `_in_bracket` (the same decisions): the capacity-dimension kernel's translation unit trips an
+// LLVM address-space bug ("Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base", cf. rollout_body.h: the overflow workspace)
+// whenever this function's shape changes; its call sites pass !D::gen.
+template <bool MINMAX = true, class BC>
 DIAL_DEV bool ls_update_lazy(bool rule_swap, LsPt& lo, LsPt& hi, int k_lo_next, int k_hi_next, int k_mid, int lane_lo_next,
                              int lane_hi_next, int lane_mid, BC&& fetch /* (word 0..2, lane) -> int */) {
-  int lo_d0 = lo.d0, hi_d0 = hi.d0, lo_sel = -1, hi_sel = -1;
+  // ("none" is -2, not -1: `taken ? 0 : -1` is a sign extension of the condition, which the compiler routes through the VALU --
+  //  s_cselect_b64, v_cndmask, v_readfirstlane -- where `taken ? 0 : -2` is one s_cselect_b32)
+  int lo_d0 = lo.d0, hi_d0 = hi.d0, lo_sel = -2, hi_sel = -2;
   bool any;
   if (rule_swap) {   // MJX <= 3.1.3
     const bool swap_lo_next = (lo_d0 > 0) | (lo_d0 < k_lo_next);
@@ -102,9 +107,7 @@ DIAL_DEV bool ls_update_lazy(bool rule_swap, LsPt& lo, LsPt& hi, int k_lo_next, 
     const bool swap_hi_mid = (k_mid > 0) & (hi_d0 > k_mid);
     hi_sel = swap_hi_mid ? lane_mid : hi_sel; hi_d0 = swap_hi_mid ? k_mid : hi_d0;
     any = swap_lo_next | swap_lo_mid | swap_hi_next | swap_hi_mid;
-  } else {
-    // MJX >= 3.1.4 `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer
-    // to it; each end is offered its own Newton step, the mid-point and the other end's Newton step
+  } else if constexpr (!MINMAX) {
     const auto in_bracket = [](int x, int y) { return ((x < y) & (y < 0)) | ((x > y) & (y > 0)); };
     const bool s1 = in_bracket(lo_d0, k_lo_next);
     lo_sel = s1 ? lane_lo_next : lo_sel; lo_d0 = s1 ? k_lo_next : lo_d0;
@@ -119,6 +122,31 @@ DIAL_DEV bool ls_update_lazy(bool rule_swap, LsPt& lo, LsPt& hi, int k_lo_next, 
     const bool s6 = in_bracket(hi_d0, k_lo_next);
     hi_sel = s6 ? lane_lo_next : hi_sel; hi_d0 = s6 ? k_lo_next : hi_d0;
     any = s1 | s2 | s3 | s4 | s5 | s6;
+  } else {
+    // MJX >= 3.1.4 `_in_bracket`: y replaces the bracket end x only if it lies on the same side of the minimum and closer
+    // to it -- ((x < y) & (y < 0)) | ((x > y) & (y > 0)); each end is offered its own Newton step, the mid-point and the other end's
+    // Newton step, in that order.  On the integer keys "x after the offer" is max(x, y) for y < 0, min(x, y) for y > 0 and x for
+    // y = 0, i.e. min(max(x, a), b) with a = y < 0 ? y : INT_MIN, b = y > 0 ? y : INT_MAX (neither sentinel is the key of a
+    // non-NaN float), and the offer was taken exactly when that differs from x: two compares + two selects per CANDIDATE and
+    // s_max / s_min / s_cmp_lg / s_cselect per offer -- 39 scalar instructions for the six offers where the boolean form (every
+    // compare materialised as a 64-bit mask, two s_and and an s_or per offer) took 85 (build/isa/DimsAllegro_9_3_false.s, round 5).
+    // The decisions are the same for every triple of keys (tests/test_ls_bracket.py runs both forms over edge and random keys).
+    constexpr int KMIN = (int)0x80000000u, KMAX = 0x7fffffff;
+    const int a1 = k_lo_next < 0 ? k_lo_next : KMIN, b1 = k_lo_next > 0 ? k_lo_next : KMAX;
+    const int a2 = k_mid < 0 ? k_mid : KMIN, b2 = k_mid > 0 ? k_mid : KMAX;
+    const int a3 = k_hi_next < 0 ? k_hi_next : KMIN, b3 = k_hi_next > 0 ? k_hi_next : KMAX;
+    const auto offer = [](int& x, int& sel, int a, int b, int lane) {
+      const int m = x > a ? x : a, n = m < b ? m : b;
+      sel = n != x ? lane : sel;
+      x = n;
+    };
+    offer(lo_d0, lo_sel, a1, b1, lane_lo_next);
+    offer(lo_d0, lo_sel, a2, b2, lane_mid);
+    offer(lo_d0, lo_sel, a3, b3, lane_hi_next);
+    offer(hi_d0, hi_sel, a3, b3, lane_hi_next);
+    offer(hi_d0, hi_sel, a2, b2, lane_mid);
+    offer(hi_d0, hi_sel, a1, b1, lane_lo_next);
+    any = (lo_sel >= 0) | (hi_sel >= 0);
   }
   const bool lo_new = lo_sel >= 0, hi_new = hi_sel >= 0;
   const int ll = lo_new ? lo_sel : 0, hl = hi_new ? hi_sel : 0;

@@ -855,7 +855,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
         if (done) break;
         ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-        swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+        swap = ls_update_lazy<!M::D::gen>(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
                               [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
         ls_iter++;
       }

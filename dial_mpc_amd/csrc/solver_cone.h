@@ -471,7 +471,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
       if (ls_done) break;
       ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-      swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(res[3], 0)), fbits(bcast(res[3], 16)), fbits(bcast(res[3], 32)), 0, 16, 32,
+      swap = ls_update_lazy<!D::gen>(rule_swap, lo, hi, fbits(bcast(res[3], 0)), fbits(bcast(res[3], 16)), fbits(bcast(res[3], 32)), 0, 16, 32,
                             [&](int word, int lane) { return fbits(bcast(res[word], lane)); });
       ls_iter++;
     }

@@ -188,4 +188,24 @@ int emu_box_contact(int kind, int sub, const float* g1, const float* g2, float* 
   else return -1;
   return 0;
 }
+// the bracket update of the line search on integer slope keys (csrc/ls_bracket.h: ls_update_lazy): n cases of
+// (lo.d0, hi.d0, k_lo_next, k_hi_next, k_mid) -> (lo.d0', hi.d0', lo_sel, hi_sel, any); sel = 0 / 1 / 2 names the winner
+// (lo_next / hi_next / mid), negative: the end kept its point
+int emu_ls_update(int rule_swap, int n, const int* in5, int* out5) {
+  for (int i = 0; i < n; i++) {
+    dial::LsPt lo{0, 0, 0, in5[5 * i]}, hi{0, 0, 0, in5[5 * i + 1]};
+    int lo_lane = -1, hi_lane = -1, calls = 0;
+    const auto fetch = [&](int word, int lane) { if (word == 0) (calls++ == 0 ? lo_lane : hi_lane) = lane; return 1000 + lane; };
+    // rule_swap 2: `_in_bracket` in the boolean form the capacity-dimension kernel keeps (ls_bracket.h: MINMAX = false)
+    const bool any = rule_swap == 2 ? dial::ls_update_lazy<false>(false, lo, hi, in5[5 * i + 2], in5[5 * i + 3], in5[5 * i + 4], 0, 1, 2, fetch)
+                                    : dial::ls_update_lazy<true>(rule_swap != 0, lo, hi, in5[5 * i + 2], in5[5 * i + 3], in5[5 * i + 4], 0, 1, 2, fetch);
+    // (the fetches run for both ends whether they moved or not; which lane each END took is read off its new alpha word)
+    out5[5 * i] = lo.d0; out5[5 * i + 1] = hi.d0;
+    out5[5 * i + 2] = lo.alpha >= 1000 ? lo.alpha - 1000 : -1;
+    out5[5 * i + 3] = hi.alpha >= 1000 ? hi.alpha - 1000 : -1;
+    out5[5 * i + 4] = any ? 1 : 0;
+    (void)lo_lane; (void)hi_lane;
+  }
+  return 0;
+}
 }
