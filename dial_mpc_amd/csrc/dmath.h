@@ -15,6 +15,7 @@
 #define DM_RINT(x) std::nearbyint(x)
 #define DM_FMA(a, b, c) std::fma((float)(a), (float)(b), (float)(c))
 #define DM_OPAQUE(x) ((void)0)
+#define DM_NOFOLD() ((void)0)
 #define DM_UNIFORM_I(x) (x)
 #else
 #define DM_SQRT(x) sqrtf(x)
@@ -28,6 +29,9 @@
 #define DM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 // hides a VGPR value's provenance from the optimiser (stops select chains from becoming scratch-array lookups)
 #define DM_OPAQUE(x) asm("" : "+v"(x))
+// between two `if (uniform condition) break;`: keeps them two s_cmp + s_cbranch_scc pairs (SimplifyCFG folds consecutive exits into one
+// condition, and every term of that becomes a 64-bit lane mask: s_cselect_b64 per compare, s_or_b64 per term)
+#define DM_NOFOLD() asm volatile("")
 // a wave-uniform int that the compiler holds in a VGPR (loaded from LDS / computed by the VALU): move it to an SGPR
 #define DM_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 #endif

@@ -49,6 +49,20 @@ DIAL_DEV bool ls_converged(const LsPt& lo, const LsPt& hi, int kg, int kng) {
   return ((lo.d0 < 0) & (lo.d0 > kng)) | ((hi.d0 > 0) & (hi.d0 < kg));
 }
 
+// The same test as two unsigned range compares (s_sub + s_cmp_lt_u32 each, straight into a branch), where the form above
+// materialises four compares as 64-bit masks: lo.d0 in (kng, 0)  <=>  lo.d0 - (kng + 1) <u -(kng + 1),  hi.d0 in (0, kg)  <=>
+// hi.d0 - 1 <u kg - 1; an empty interval (gtol = 0) gets range 0.
+struct LsGate { int lo_off; unsigned lo_rng, hi_rng; };
+DIAL_DEV LsGate ls_gate(int kg, int kng) {
+  LsGate g;
+  g.lo_off = kng + 1;
+  g.lo_rng = kng < 0 ? (unsigned)(-(kng + 1)) : 0u;
+  g.hi_rng = kg > 0 ? (unsigned)(kg - 1) : 0u;
+  return g;
+}
+DIAL_DEV bool ls_converged_lo(const LsPt& lo, const LsGate& g) { return (unsigned)lo.d0 - (unsigned)g.lo_off < g.lo_rng; }
+DIAL_DEV bool ls_converged_hi(const LsPt& hi, const LsGate& g) { return (unsigned)hi.d0 - 1u < g.hi_rng; }
+
 // one bracket update; returns whether any end moved (`swap` of the reference)
 DIAL_DEV bool ls_update(bool rule_swap, LsPt& lo, LsPt& hi, const LsPt& lo_next, const LsPt& hi_next, const LsPt& mid) {
   if (rule_swap) {   // MJX <= 3.1.3

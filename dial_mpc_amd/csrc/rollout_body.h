@@ -849,15 +849,32 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       ls_eval3(bitsf(p0.nalpha), bitsf(p0.nalpha), bitsf(p0.nalpha));
       LsPt lo, hi;
       ls_open(p0, point_at(0), lo, hi);
-      bool swap = true;
-      int ls_iter = 0;
-      for (;;) {
-        const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
-        if (done) break;
-        ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-        swap = ls_update_lazy<!M::D::gen>(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
-                              [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
-        ls_iter++;
+      if constexpr (M::D::gen) {   // (the capacity-dimension kernel keeps the combined flag: its translation unit trips LLVM's address-space
+        bool swap = true;          //  bug when this loop changes shape, see ls_bracket.h)
+        int ls_iter = 0;
+        for (;;) {
+          const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
+          if (done) break;
+          ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
+          swap = ls_update_lazy<false>(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+                                       [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
+          ls_iter++;
+        }
+      } else {
+        const LsGate gate = ls_gate(kg, kng);   // (one scalar compare + branch per loop condition, see solver_reg.h)
+        const int max_ls = DM_UNIFORM_I(m->ls_iterations);
+        int ls_iter = 0;
+        while (ls_iter < max_ls) {
+          DM_NOFOLD();
+          if (ls_converged_lo(lo, gate)) break;
+          DM_NOFOLD();
+          if (ls_converged_hi(hi, gate)) break;
+          ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
+          const bool swap = ls_update_lazy<true>(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+                                                       [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
+          ls_iter++;
+          if (!swap) break;
+        }
       }
       improved = ls_result(p0, lo, hi, alpha);
     } else {

@@ -465,15 +465,18 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     ls_open(p0, ls_point(bitsf(p0.nalpha)), lo, hi);
     const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
     DIAL_MARK(w, 26);
-    bool swap = true;
+    const LsGate gate = ls_gate(kg, kng);   // (one scalar compare + branch per loop condition, see solver_reg.h)
     int ls_iter = 0;
-    for (;;) {
-      const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
-      if (ls_done) break;
+    while (ls_iter < max_ls) {
+      DM_NOFOLD();
+      if (ls_converged_lo(lo, gate)) break;
+      DM_NOFOLD();
+      if (ls_converged_hi(hi, gate)) break;
       ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-      swap = ls_update_lazy<!D::gen>(rule_swap, lo, hi, fbits(bcast(res[3], 0)), fbits(bcast(res[3], 16)), fbits(bcast(res[3], 32)), 0, 16, 32,
-                            [&](int word, int lane) { return fbits(bcast(res[word], lane)); });
+      const bool swap = ls_update_lazy<!D::gen>(rule_swap, lo, hi, fbits(bcast(res[3], 0)), fbits(bcast(res[3], 16)), fbits(bcast(res[3], 32)), 0, 16, 32,
+                                                [&](int word, int lane) { return fbits(bcast(res[word], lane)); });
       ls_iter++;
+      if (!swap) break;
     }
     float alpha;
     const bool improved = ls_result(p0, lo, hi, alpha);

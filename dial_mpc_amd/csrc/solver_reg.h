@@ -578,15 +578,20 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
     LsPt lo, hi;
     ls_open(p0, point_at(0), lo, hi);
     const int kg = DM_UNIFORM_I(fkey(gtol)), kng = DM_UNIFORM_I(fkey(-gtol));
-    bool swap = true;
+    // the reference's `while (ls_iter < max) & swap & !converged`, as one scalar compare + branch per condition (a combined
+    // `done` flag cost 18 scalar instructions per iteration: every compare became a 64-bit mask)
+    const LsGate gate = ls_gate(kg, kng);
     int ls_iter = 0;
-    for (;;) {
-      const bool ls_done = (ls_iter >= max_ls) | !swap | ls_converged(lo, hi, kg, kng);
-      if (ls_done) break;
+    while (ls_iter < max_ls) {
+      DM_NOFOLD();
+      if (ls_converged_lo(lo, gate)) break;
+      DM_NOFOLD();
+      if (ls_converged_hi(hi, gate)) break;
       ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-      swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
-                            [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
+      const bool swap = ls_update_lazy(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
+                                       [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
       ls_iter++;
+      if (!swap) break;
     }
     float alpha;
     const bool improved = ls_result(p0, lo, hi, alpha);
