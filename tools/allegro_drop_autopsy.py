@@ -83,7 +83,7 @@ def analyse(path, nsample):
     while tt > 1 and std[tt - 1] < 0.04:
         tt -= 1
     print(f"(2) the reward spread of the rollouts collapses at tick {tt + 1} (std {std[tt - 1]:.3f} -> {std[tt]:.3f}): the ball is in flight from there on")
-    for t in range(max(0, tt - 4), min(ticks - 7, tt + 2)):
+    for t in range(max(0, tt - 4), min(ticks - 7, tt + 2)) if not os.environ.get("AUTOPSY_SKIP3") else ():
         us = np.einsum("tk,nka->nta", W, p["Y0s"][t]).astype(np.float32)
         g, o = p["rewss"][t].mean(1), np.asarray(o32.rollout(S[t], us)[0]).mean(1)
         w = p["weights"][t]
@@ -97,7 +97,8 @@ def analyse(path, nsample):
               f"the plan's mean reward {np.asarray(rew)[0].mean():+.3f} (best sample {g.max():+.3f}); ball z it predicts {np.asarray(qs)[0][:6, 2].round(3)} "
               f"realised {np.round([S[t + k + 1][2] for k in range(6)], 3)}")
     sigma = (dc.horizon_diffuse_factor ** np.arange(Hn1)[::-1] * dc.sigma_scale).astype(np.float32)
-    for back in (1, 2, 3, 4, 6):
+    backs = tuple(int(b) for b in os.environ.get("AUTOPSY_BACKS", "1,2,3,4,6").split(","))   # how many ticks before the flight the oracle takes over
+    for back in backs:
         k0 = tt - back          # the oracle takes over after tick k0 (1-based): state S[k0 - 1], plan Yo[k0 - 1]
         if k0 < 1:
             continue
