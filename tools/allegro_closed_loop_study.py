@@ -69,6 +69,7 @@ def setup(nsample, seed):
 PLANT_JITTER = 0     # --plant-jitter K: the plant's (q, qd) moved by up to K ulp (random sign per element) after every env.step
 JITTER_TICKS = 10 ** 9   # --jitter-ticks K: only on the first K ticks (1: a one-off perturbation, the loop is self-consistent afterwards)
 BITCHECK = False     # --bitcheck: per run, on how many ticks the plant's step equals the planner's own first predicted step BIT FOR BIT
+DRIFT = {}            # gpu mode: per seed, the ball's distance from its tick-1 position in the palm's plane, per tick
 PLANT_LIB = None     # --plant-lib: another build of the library for the PLANT's env.step only (hybrid runs: which side matters?)
 
 
@@ -107,6 +108,9 @@ def loop_gpu(nsample, seed, ticks):
             pred_u0 = float(np.abs(Y[0].cpu().numpy() - sc["Y0s"][-1, 0]).max())
             worst = max(worst, 0.0 if pred_u0 == 0.0 else worst)
         zs.append(float(state.pipeline_state.q[2]))
+        xy = state.pipeline_state.q[:2].cpu().numpy()
+        xy0 = xy if t == 0 else xy0
+        DRIFT.setdefault(seed, []).append(float(np.hypot(*(xy - xy0))))
     mbdpi.ctx.status()
     if BITCHECK:
         print(f"   bitcheck seed {seed}: plant step == the planner's predicted first step bit for bit on {same} of {ticks - 1} ticks; largest |difference| {worst:.3g}", flush=True)
@@ -172,6 +176,10 @@ def main():
         zs = loop(args.nsample, seed, args.ticks)
         dropped = min(zs) < 0.08 or not np.isfinite(zs).all()
         res.append(dict(seed=seed, dropped=bool(dropped), z=[round(zs[k], 4) for k in marks], z_min=round(float(np.nanmin(zs)), 4)))
+        if seed in DRIFT:   # sideways drift while the ball is still in the hand (z >= 0.08), in cm
+            dr = [d for d, zz in zip(DRIFT[seed], zs) if zz >= 0.08]
+            res[-1]["drift_cm"] = [round(100 * d, 2) for d in DRIFT[seed]]
+            res[-1]["drift_max_in_hand_cm"] = round(100 * max(dr), 2)
         print(f"{args.mode} N={args.nsample} seed {seed}: ball z at ticks {[k + 1 for k in marks]} = {[round(zs[k], 3) for k in marks]}"
               f"{'  DROPPED' if dropped else ''}  ({time.time() - t0:.0f} s)", flush=True)
     nd = sum(r["dropped"] for r in res)
