@@ -208,4 +208,14 @@ int emu_ls_update(int rule_swap, int n, const int* in5, int* out5) {
   }
   return 0;
 }
+// the loop's done-test in both forms (ls_bracket.h): n cases of (lo.d0, hi.d0, kg, kng) -> out[i] = ls_converged | (lo / hi range-compare form) << 1
+int emu_ls_converged(int n, const int* in4, int* out) {
+  for (int i = 0; i < n; i++) {
+    dial::LsPt lo{0, 0, 0, in4[4 * i]}, hi{0, 0, 0, in4[4 * i + 1]};
+    const int kg = in4[4 * i + 2], kng = in4[4 * i + 3];
+    const dial::LsGate g = dial::ls_gate(kg, kng);
+    out[i] = (dial::ls_converged(lo, hi, kg, kng) ? 1 : 0) | ((dial::ls_converged_lo(lo, g) || dial::ls_converged_hi(hi, g)) ? 2 : 0);
+  }
+  return 0;
+}
 }
