@@ -728,7 +728,7 @@ static int launch_rollout(dial_ctx* ctx, const dial::RolloutIO& io_in, int B, hi
   // the SIMDs are short of issue slots -- N = 8192: 1.25 -> 1.10 ms, N = 65536: 8.96 -> 6.75 ms (7.15 -> 9.4 M rollouts/s) -- and
   // loses where the launch is one rollout's dependence chain long: a lone pair wavefront needs 46.7 k cycles per env.step against
   // 42.7 k (the DPP / permlane broadcasts sit on the chain, and it waits for the slower of its two rollouts' line searches):
-  // N = 2048 0.380 -> 0.408 ms.  Default: above DIAL_GO2_PAIR_MIN_B rollouts; dial_options.pair_mode 1 = never, 2 = always.
+  // N = 2048 0.380 -> 0.408 ms (final build of round 5: 0.363 -> 0.382).  Default: above DIAL_GO2_PAIR_MIN_B rollouts; dial_options.pair_mode 1 = never, 2 = always.
   // (profiles/r05_ab_pair_kernel.txt, profiles/r05_sections_pair_cycles.txt)
   if (ctx->pair_ok && !tracing && (ctx->opt.pair_mode == 2 || B > DIAL_GO2_PAIR_MIN_B)) {
     dial::RolloutIO io = io_in;
