@@ -46,6 +46,11 @@ _FAST = ["-DDIAL_FUSED_DPP", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Xa
 # two-samples-per-wavefront kernel is compared BIT FOR BIT with the one-sample kernel (tests/test_gpu_parity.py).
 _IEEE = ["-Xarch_device", "-ffp-contract=off"]
 _COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_device", "-fno-slp-vectorize"]
+# per robot family (kern_family.hip -DDIAL_FAMILY=k): LLVM's "max-ilp" machine-scheduling strategy for the Allegro's kernels -- their
+# launch lasts as long as ONE lone wavefront's dependence chain, which the strategy shortens: A/B on one box
+# (profiles/r05_ab_sched_max_ilp.txt) Allegro example 6.67 -> 6.51 ms (-2.5 %); the Go2 (+2 %), the push crate (+2 %) and the H1 (+-0)
+# keep the default strategy.
+_FAMILY_FLAGS = {3: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str:
@@ -59,7 +64,7 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
     fast-math rounding (tests/test_gpu_parity.py: test_ieee_build_needs_no_more_witnesses)."""
     from concurrent.futures import ThreadPoolExecutor
     # every source of the library takes part in the staleness check (a stale .so must never ship silently)
-    srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip"))) + [_abi.HEADER]
+    srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip"))) + [_abi.HEADER, os.path.abspath(__file__)]   # (this file: the flags)
     out = IEEE_LIB_PATH if ieee else LIB_PATH
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
@@ -74,7 +79,7 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
     objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", f"obj_{os.path.basename(out)}_{tag}_{os.getpid()}")
     os.makedirs(objdir, exist_ok=True)
     units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
-    units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"], os.path.join(objdir, f"kern_family_{k}.o"))
+    units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"] + _FAMILY_FLAGS.get(k, []), os.path.join(objdir, f"kern_family_{k}.o"))
               for k in range(N_FAMILIES)]
 
     def compile_unit(u):

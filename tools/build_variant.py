@@ -33,7 +33,7 @@ def main():
     flags = _lib._COMMON + fast + extra
     nfam = int(subprocess.check_output(f"grep -h 'define DIAL_N_FAMILIES' {csrc}/kernel_list.h", shell=True).split()[-1])
     units = [(os.path.join(csrc, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
-    units += [(os.path.join(csrc, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"], os.path.join(objdir, f"kern_family_{k}.o")) for k in range(nfam)]
+    units += [(os.path.join(csrc, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"] + _lib._FAMILY_FLAGS.get(k, []), os.path.join(objdir, f"kern_family_{k}.o")) for k in range(nfam)]
 
     def cc(u):
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + u[1] + ["-c", "-o", u[2], u[0]])
