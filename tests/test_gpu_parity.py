@@ -1114,7 +1114,7 @@ def test_closed_loop_behaviour(example, ticks, N):
     # 2-3 % of the runs lose it within 40 ticks (34 of 1408 at N = 512 over product build, arithmetic variants, plant / planner hybrids and
     # the strict build under a 1-ulp disturbance of the plant; 4 of 64 at the reference's N = 2048); only the two UNDISTURBED strict loops (CPU
     # oracle as plant and planner, libdialhip_ieee.so) kept it in all 320 runs, and the strict build loses it at the common rate once its plant
-    # state is moved by one ulp, once -- and so does the CPU oracle's own loop (1 of 96 with a 1-ulp disturbance per tick).  Through eight recorded drops the plant's steps and the planner's per-rollout rewards are the oracle's,
+    # state is moved by one ulp, once -- and so does the CPU oracle's own loop (3 of 187 with a 1-ulp disturbance per tick).  Through eight recorded drops the plant's steps and the planner's per-rollout rewards are the oracle's,
     # and the oracle's own loop continued from the recorded state tosses the ball the same way (tools/allegro_drop_autopsy.py): the toss is
     # decided by the softmax average of ~25-65 samples, i.e. by the algorithm.  The gate is a RATE over 16 fixed seeds: at most 3 may
     # lose the ball (this build: 2; P(>= 4 of 16) at 2.4 % is 4e-4) -- a kernel that breaks the hand's physics loses it nearly always.
