@@ -134,6 +134,7 @@ def load(path: Optional[str] = None):
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
+    lib.dial_env_reset_batch.argtypes = [vp, fp, fp, fp, fp, fp, ci, vp]
     lib.dial_status.argtypes = [vp]
     lib.dial_set_timing.argtypes = [vp, ci]
     lib.dial_get_rollout_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci)]
@@ -149,7 +150,7 @@ def load(path: Optional[str] = None):
 
 EXPORTED = ("dial_create", "dial_create_sharded", "dial_create_ex", "dial_set_state_trace", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
-            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset",
+            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset", "dial_env_reset_batch",
             "dial_status", "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
@@ -219,6 +220,15 @@ class Context:
         self._check(self.lib.dial_env_reset(self.h, _ptr(qpos), _ptr(qvel), _ptr(state), _ptr(xpos), _ptr(xquat),
                                             _stream()), "dial_env_reset")
         return state, xpos, xquat
+
+    def env_reset_batch(self, qpos, qvel):
+        """n states in one launch: qpos [n, nq], qvel [n, nv] -> packed states [n, state_size]."""
+        import torch
+        n = int(qpos.shape[0])
+        states = torch.zeros((n, self.state_size), dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.dial_env_reset_batch(self.h, _ptr(qpos), _ptr(qvel), _ptr(states), None, None, n, _stream()),
+                    "dial_env_reset_batch")
+        return states
 
     def env_step(self, state, action):
         import torch

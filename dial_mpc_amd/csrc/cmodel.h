@@ -146,6 +146,14 @@ struct Dims {
   static constexpr bool quad_gen = GEN_ && STATIC && !ELL_ && !SQUARE_ && std::is_same<Topo_, TopoGo2>::value;
 #endif
   static constexpr bool phase_tabs = !quad_stage && !rows_stage && !rows_gen && !quad_gen;
+  // the rollout's controls, joint targets and gait clock as tables built once in its prologue (rollout_driver.h; derived.h: Ws::jtab),
+  // the per-step outputs stored by the phases that produce them: the instantiations whose position / velocity stage leaves the A1
+  // temporaries of the workspace unused (the tables live there) and whose control step is ONE physics step (dial_create checks)
+#ifdef DIAL_NO_PRE_CTRL
+  static constexpr bool pre_ctrl = false;
+#else
+  static constexpr bool pre_ctrl = quad_stage;
+#endif
 };
 using DimsGo2 = Dims<true, 19, 18, 12, 14, 13, 5, 5, 4, 12, TopoGo2, true, 192>;
 using DimsH1 = Dims<true, 26, 25, 19, 21, 20, 3, 3, 4, 19, TopoH1, true, 256>;

@@ -398,6 +398,10 @@ struct Ws {
   // (0 = for all ncon); `ovf` = this sample's full-size copy of them in global memory (ws_overflow), used when more touch
   float* ovf;
   int con_cap;
+  // control tables of a whole rollout, built once in its prologue (rollout_driver.h; instantiations with Dims::pre_ctrl):
+  // jtab[t * nu + a] = the joint target act2joint(u_t)[a] of control step t, ztab[t * DIAL_MAX_FEET + f] = the gait clock's foot
+  // height of step t -- neither depends on the state, so K2 / act2joint / get_foot_step leave the per-step dependence chain
+  float *jtab, *ztab;
 };
 
 #if defined(__HIPCC__)
@@ -419,7 +423,7 @@ WS_HD int tri_idx(int i, int j) { return (i * (i + 1)) / 2 + j; }   // i >= j
 // `sq_n`: dimension of the generic solver's dense square `sq` (Dims::NVP).
 WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite,
                    int ncon_all, int nefc_all, int nnode, bool with_L, bool square = false, int ell_jcw = 0, int con_cap = 0,
-                   int sq_n = DIAL_MAX_V) {
+                   int sq_n = DIAL_MAX_V, int tab_steps = 0) {
   int o = 0;
   const bool capped = con_cap > 0 && con_cap < ncon_all && !square && ell_jcw == 0;
   const int ncon = ncon_all;                                            // arrays indexed by the model's contact index
@@ -459,6 +463,9 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   const int u1 = o;
   o = u0;
   WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4)
+  // `tab_steps` = T (instantiations whose position / velocity stage runs in registers and touches none of the A1 temporaries this
+  // region aliases -- Dims::pre_ctrl --, else 0): the rollout's control tables live behind the solver's arrays for its whole length
+  WS_TAKE(jtab, tab_steps * nu) WS_TAKE(ztab, tab_steps * DIAL_MAX_FEET)
   WS_TAKE(cwd, ell * ncon * 6) WS_TAKE(cwa, ell * ncon * 6) WS_TAKE(cwb, ell * ncon * 6) WS_TAKE(ccf, ell * ncon * 4)
   WS_TAKE(vec0, ell * nv) WS_TAKE(vec1, ell * nv)
   const int ls = with_L ? 1 : 0;   // the rest is LDS-solver state; the register solver keeps it in VGPRs

@@ -467,7 +467,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       }
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square,
-                               D::ell ? D::JCW : 0, ctx->con_cap, D::NVP);
+                               D::ell ? D::JCW : 0, ctx->con_cap, D::NVP, (D::pre_ctrl && cfg) ? cfg->Hsample + 1 : 0);
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
 #ifdef DIAL_PROFILE
@@ -481,7 +481,9 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     int urc;
     const auto kind_ok = [&](uint32_t mask) { return ((mask >> task->kind) & 1u) != 0; };   // the robot's own task kinds only
     const bool own = !opt.force_generic;   // the robot's own dimension-specialised instantiation (default)
-    if (own && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>())) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
+    // (Dims::pre_ctrl instantiations run ONE physics step per control step -- every shipped Go2 task; another ratio: the capacity-dimension kernel)
+    if (own && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>()) &&
+        (!DimsGo2::pre_ctrl || task->n_frames == 1)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
     else if (own && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1>())) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
     else if (own && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1Loco>())) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else if (model->cone == DIAL_CONE_ELLIPTIC) {
@@ -1089,12 +1091,12 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
   return DIAL_OK;
 }
 
-int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* state, float* xpos_out,
-                   float* xquat_out, void* stream) {
-  if (!ctx || !state || !qpos || !qvel) return fail(ctx, DIAL_ERR_ARG, "dial_env_reset: null argument");
+static int env_reset_launch(dial_ctx* ctx, const float* qpos, const float* qvel, float* state, float* xpos_out, float* xquat_out,
+                            int n, void* stream, const char* who) {
+  if (!ctx || !state || !qpos || !qvel || n < 1) return fail(ctx, DIAL_ERR_ARG, who);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 #define DIAL_LAUNCH_RESET(D)                                                                        \
-  hipLaunchKernelGGL(env_reset_kernel<D>, dim3(1), dim3(64), ctx->lds_bytes, (hipStream_t)stream,   \
+  hipLaunchKernelGGL(env_reset_kernel<D>, dim3(n), dim3(64), ctx->lds_bytes, (hipStream_t)stream,   \
                      (const CModel<D>*)ctx->dcm, qpos, qvel, state, xpos_out, xquat_out)
   if (ctx->inst == 1) DIAL_LAUNCH_RESET(DimsGo2);
   else if (ctx->inst == 2) DIAL_LAUNCH_RESET(DimsH1);
@@ -1106,6 +1108,14 @@ int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* s
 #undef DIAL_LAUNCH_RESET
   HIP_TRY(ctx, hipGetLastError());
   return DIAL_OK;
+}
+int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* state, float* xpos_out,
+                   float* xquat_out, void* stream) {
+  return env_reset_launch(ctx, qpos, qvel, state, xpos_out, xquat_out, 1, stream, "dial_env_reset: null argument");
+}
+int dial_env_reset_batch(dial_ctx* ctx, const float* qpos, const float* qvel, float* states, float* xpos_out,
+                         float* xquat_out, int n, void* stream) {
+  return env_reset_launch(ctx, qpos, qvel, states, xpos_out, xquat_out, n, stream, "dial_env_reset_batch: null argument or n < 1");
 }
 
 // Internal diagnostics (not part of the public header): wave primitive self-test and the scratch

@@ -1715,10 +1715,28 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
     }
   } else
   w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
+  // (Dims::pre_ctrl rollouts: the step's q / qd rows are stored from here -- Wave::out_io -- instead of by a phase of their own)
+  float *qrow = nullptr, *qdrow = nullptr;
+  if constexpr (M::D::pre_ctrl) {
+    if (w.out_io) {
+      if (w.out_io->qss) qrow = w.out_io->qss + (size_t)w.out_row * dim_nq(m);
+      if (w.out_io->qdss) qdrow = w.out_io->qdss + (size_t)w.out_row * dim_nv(m);
+    }
+  }
   w.items(dim_nj(m), [&](int ji) {
     const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
+    if constexpr (M::D::pre_ctrl) {
+      if (qdrow) {
+        if (m->jnt_type[ji] == DIAL_JNT_FREE) { for (int k = 0; k < 6; k++) qdrow[da + k] = s.qvel[da + k]; }
+        else qdrow[da] = s.qvel[da];
+      }
+    }
     if (m->jnt_type[ji] == DIAL_JNT_FREE) {
-      for (int k = 0; k < 3; k++) s.qpos[qa + k] += dt * s.qvel[da + k];
+      for (int k = 0; k < 3; k++) {
+        const float p = s.qpos[qa + k] + dt * s.qvel[da + k];
+        s.qpos[qa + k] = p;
+        if constexpr (M::D::pre_ctrl) { if (qrow) qrow[qa + k] = p; }
+      }
       float v[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
       // An angular velocity whose SQUARE is below the smallest normal fp32 (|w| < 1.1e-19 rad/s: a body that has come to rest) is
       // no rotation: under the fast-math flags v / sqrt(d) becomes v * v_rsq(d), and v_rsq flushes a denormal d to 0 -> inf -> NaN
@@ -1731,8 +1749,13 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
       dm::quat_mul(qn, q0, qr);
       dm::normalize4(qn);
       for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = qn[k];
+      if constexpr (M::D::pre_ctrl) {
+        if (qrow) { for (int k = 0; k < 4; k++) qrow[qa + 3 + k] = qn[k]; }
+      }
     } else {
-      s.qpos[qa] += dt * s.qvel[da];
+      const float p = s.qpos[qa] + dt * s.qvel[da];
+      s.qpos[qa] = p;
+      if constexpr (M::D::pre_ctrl) { if (qrow) qrow[qa] = p; }
     }
   });
 }
@@ -1757,19 +1780,45 @@ DIAL_DEV float quat_yaw(const float* q) {
 // (atan2 / sin / cos), not their sum.
 // FULL_INFO = false (rollouts): the write-only info fields (done, feet_air_time, last_contact) are not
 // maintained -- nothing reads them inside a rollout (done never terminates one).
-template <bool FULL_INFO, class W, class M>
-DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
+// BaseEnv.act2joint (base_env.py:38-49): normalised action -> joint target, clipped to the physical range
+// (joint_offset: the keyframe pose AllegroReorientEnv.act2joint adds, manipulation.py:107-109; 0 elsewhere)
+template <class M>
+DIAL_DEV float act2joint(const M* m, float act, int a) {
+  float an = (act * m->action_scale + 1.0f) / 2.0f;
+  float jt = (m->joint_range[a][0] + m->joint_offset[a]) + an * (m->joint_range[a][1] - m->joint_range[a][0]);
+  return dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
+}
+// get_foot_step for foot f at the (pre-increment) step counter `step` (function_utils.py:18-43)
+template <class M>
+DIAL_DEV float gait_ztar(const M* m, int f, float step) {
+  return m->gait_amp * foot_step_height(step * m->dt * 2.f * DIAL_PI * m->gait_cadence + DIAL_PI, 2.f * DIAL_PI * m->gait_phase[f], m->gait_duty);
+}
+// PRE (rollouts of the Dims::pre_ctrl instantiations): the joint targets and the gait clock of control step `st` come from the
+// rollout's tables (Ws::jtab / ztab, built in its prologue: rollout_driver.h), and the step's outputs are stored by the phases that
+// produce them (Wave::out_io / out_row: x.pos by the position stage, q / qd by the integrator, the reward by its lane).
+template <bool FULL_INFO, bool PRE = false, class W, class M>
+DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int st = 0) {
   const int nu = dim_nu(m);
   const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO ||
                     m->kind == DIAL_TASK_H1_PUSH_CRATE;
+  static_assert(!PRE || M::D::pre_ctrl, "control tables: carved for the Dims::pre_ctrl instantiations only");
   // act2joint / act2tau (base_env.py:38-66) | desired foot heights from the gait clock (get_foot_step)
+  if constexpr (PRE) {
+    w.items(nu, [&](int a) {
+      const float jt = s.jtab[st * nu + a];
+      float c;
+      if (m->position_control) c = jt;
+      else {
+        float q_err = jt - s.qpos[7 + a];
+        c = dm::clip(m->kp[a] * q_err - m->kd[a] * s.qvel[6 + a], m->tau_range[a][0], m->tau_range[a][1]);
+      }
+      s.ctrl[a] = c;
+    });
+  } else
   w.items(nu + DIAL_MAX_FEET, [&](int it) {
     if (it < nu) {
       const int a = it;
-      float an = (s.act[a] * m->action_scale + 1.0f) / 2.0f;
-      // joint_offset: the keyframe pose AllegroReorientEnv.act2joint adds (manipulation.py:107-109), 0 elsewhere
-      float jt = (m->joint_range[a][0] + m->joint_offset[a]) + an * (m->joint_range[a][1] - m->joint_range[a][0]);
-      jt = dm::clip(jt, m->phys_range[a][0], m->phys_range[a][1]);
+      const float jt = act2joint(m, s.act[a], a);
       float c;
       if (m->position_control) c = jt;
       else {
@@ -1779,15 +1828,13 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
       s.ctrl[a] = c;
     } else {
       const int f = it - nu;
-      if (walk && f < m->nfeet) {
-        const float step = s.info[DIAL_INFO_STEP];
-        s.ztar[f] = m->gait_amp * foot_step_height(step * m->dt * 2.f * DIAL_PI * m->gait_cadence + DIAL_PI,
-                                                   2.f * DIAL_PI * m->gait_phase[f], m->gait_duty);
-      }
+      if (walk && f < m->nfeet) s.ztar[f] = gait_ztar(m, f, s.info[DIAL_INFO_STEP]);
     }
   });
+  const float* const ztar = PRE ? s.ztab + st * DIAL_MAX_FEET : s.ztar;   // this step's desired foot heights
   DIAL_MARK(w, 25);
-  for (int f = 0; f < m->n_frames; f++) {  // pipeline_step
+  const int n_frames = PRE ? 1 : m->n_frames;   // (Dims::pre_ctrl: one physics step per control step, dial_create checks)
+  for (int f = 0; f < n_frames; f++) {  // pipeline_step
 #ifndef DIAL_EMU
     if (w.launder) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // see rollout_driver.h: the step loop
 #endif
@@ -1895,7 +1942,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
           float reward_gaits = 0.f;
   #pragma unroll
           for (int f = 0; f < NF; f++) {
-            const float z_tar = s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
+            const float z_tar = ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
             float fz;
             if (kind == DIAL_TASK_GO2_WALK) {
               float e = (z_tar - zs) / 0.05f;
@@ -2085,6 +2132,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s) {
         info[DIAL_INFO_STAGE] = dm::fminf_(st, (float)(m->n_stage - 1));
       }
       info[DIAL_INFO_REWARD] = reward;
+      if constexpr (PRE) { if (w.out_io && w.out_io->rewss) w.out_io->rewss[w.out_row] = reward; }
     });
   };
   // wave-uniform dispatch on the task kind; a dimension-specialised instantiation only carries its robot's kinds

@@ -7,61 +7,10 @@
 #pragma once
 #include "rollout_body.h"
 #include "philox.h"
+// (struct RolloutIO: rollout_io.h, included by wave.h -- the phases that store a step's outputs name its fields)
 
 namespace dial {
 
-struct RolloutIO {
-  const float* state;        // packed initial state, shared by all samples
-  const float* us;           // [B,T,nu] controls, or nullptr -> build them from nodes
-  const float* eps;          // [n_noise,Hn1,nu] standard-normal draws (nodes mode)
-  const float* Ybar;         // [Hn1,nu]
-  const float* noise_scale;  // [ns]
-  int ns;
-  int n_noise;               // samples with index >= n_noise roll out the mean trajectory Ybar
-  int T, Hn1;
-  float* Y0s;                // out [B,Hn1,nu] (nodes mode) or nullptr
-  float* rewss;              // out [B,T] or nullptr
-  float* rews;               // out [B] mean over T, or nullptr
-  float* qss;                // out [B,T,nq] or nullptr
-  float* qdss;               // out [B,T,nv] or nullptr
-  float* xss;                // out [B,T,(nbody-1)*3] or nullptr
-  unsigned long long* prof;  // DIAL_PROFILE builds: per-section cycle counts of sample 0, else nullptr
-  // in-kernel noise (eps == nullptr && use_rng): Philox keyed by seed, counter = (n_offset + n, quad, rng_iter)
-  int use_rng;
-  uint32_t seed_lo, seed_hi, rng_iter;
-  int n_offset;              // global index of this launch's sample 0 (sample shards)
-  // mean-trajectory relay (GPU launches whose last rollout is the mean trajectory; nullptr / 0 otherwise): the extra
-  // rollout is cut into pieces of `relay_steps` control steps, each run by its own wavefront on a different SIMD
-  float* relay_buf;          // packed state + running reward sum handed from piece to piece
-  int* relay_flag;           // index of the piece that may run
-  int relay_steps;
-  // time-sliced rollout queue (batches beyond the resident set whose rollouts differ in length, rollout_kernel.h): EVERY rollout
-  // is cut into pieces, relay_buf / relay_flag are arrays with one slot per rollout (relay_stride floats apart); 0: the classic
-  // relay of the mean trajectory alone (one slot)
-  int relay_stride;
-  int slice_pieces;          // pieces per rollout (time-sliced queue), else 0
-  // lag-based issue priority (wave.h; models with data-dependent rollout lengths, everything resident): [0] solver iterations,
-  // [1] control steps completed by all rollouts of the launch so far; nullptr: the pseudo-random fair sharing
-  int* work_stat;
-  int relay_base;            // index of the first relay workgroup of the launch
-  int n_first;               // rollout index of the launch's first wavefront (split launches)
-  int* err_word;             // host-visible sticky error word of the context (relay time-out), or nullptr
-  int debug_stall_piece1;    // test hook (DIAL_DEBUG_RELAY_STALL=k): relay piece k - 1 never hands over; 0 = off
-  // generic instantiation: contact cap of the LDS workspace (derived.h: ws_carve) and the per-wavefront overflow areas in
-  // global memory (ovf_words each, indexed by the wavefront's slot in the grid); con_cap = 0: full-size LDS workspace
-  int con_cap;
-  float* ovf;
-  int ovf_words;
-  // diagnostics (dial_set_state_trace; nullptr in production): the packed state [qpos|qvel|qacc_warmstart|info] after every
-  // env.step, trace:[B,T,nstate] -- what the per-transition parity tests restart the oracle from
-  float* trace;
-  // interleaved mean trajectory (rollout-queue launches whose last rollout is the mean trajectory: N + 1 = k x the resident set
-  // + 1 whenever Nsample is a power of two): the mean rollout is NOT a queue item; wavefront q < T of the launch's first round
-  // runs control step q of it between its own steps q and q + 1 (state handed on through relay_buf / relay_flag, T hand-overs
-  // per launch), so that no wavefront slot runs two whole rollouts one after the other -- see rollout_sample
-  int mean_inline;
-  int spread;   // rollout_kernel.h: the spread launch (rollout index = wavefront-in-workgroup x grid + workgroup)
-};
 
 template <class W, class M>
 DIAL_DEV void load_state(W& w, const M* m, const Ws& s, const float* state) {
@@ -139,6 +88,31 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (io.Y0s && relay <= 0) io.Y0s[(size_t)n * Hn1 * nu + it] = v;   // (pieces of one rollout rebuild the same nodes: the first writes them)
     });
   }
+  // Dims::pre_ctrl: K2 (node2u as the constant map W, dial_core.py:92-95,117) and act2joint for ALL T control steps at once -- neither
+  // depends on the state.  Per step the loop below then only runs act2tau.  (Per step, K2 + act2joint + the gait clock were 3.0 k of a
+  // lone Go2 wavefront's 39.3 k cycles per env.step: 12 + 4 busy lanes waiting for scalar loads, LDS round trips and a cosine.)
+  constexpr bool PRE = M::D::pre_ctrl;
+  // the control of step t, actuator a: the same products in the same order as the per-step K2 of the other instantiations
+  const auto node2u = [&](int t, int a) -> float {
+    if (io.us) return io.us[(unsigned)((n * T + t) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
+    float u = 0.f;
+    // the examples' node counts with a compile-time trip count: every LDS fetch is issued up front
+    const auto k2 = [&](auto HN) {
+      DIAL_UNROLL_FULL
+      for (int k = 0; k < decltype(HN)::value; k++) u += cfg->W[t][k] * s.Y[k * nu + a];
+    };
+    if (Hn1 == 5) k2(std::integral_constant<int, 5>{});
+    else if (Hn1 == 6) k2(std::integral_constant<int, 6>{});
+    else if (Hn1 == 7) k2(std::integral_constant<int, 7>{});
+    else for (int k = 0; k < Hn1; k++) u += cfg->W[t][k] * s.Y[k * nu + a];
+    return u;
+  };
+  if constexpr (PRE) {
+    w.items(T * nu, [&](int it) {
+      const int t = it / nu, a = it - t * nu;
+      s.jtab[it] = act2joint(m, node2u(t, a), a);
+    });
+  }
   float rsum = 0.f;
   w.set_rollout(n);
 #ifndef DIAL_EMU
@@ -172,6 +146,15 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   }
   if (relay >= 0 && io.relay_stride == 0) w.hold_priority(3);   // (the lone relay rollout; the sliced queue keeps the fair sharing)
 #endif
+  if constexpr (PRE) {
+    // the gait clock of this (piece of the) rollout: step counter of control step t = the counter now + (t - st_begin), exactly
+    // (env.step adds 1.f per step); the mean trajectory's steps (helper) share the own rollout's counter, both start from io.state
+    const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO || m->kind == DIAL_TASK_H1_PUSH_CRATE;
+    if (walk) w.items((st_end - st_begin) * DIAL_MAX_FEET, [&](int it) {
+      const int dt_ = it / DIAL_MAX_FEET, f = it - dt_ * DIAL_MAX_FEET;
+      if (f < m->nfeet) s.ztab[(st_begin + dt_) * DIAL_MAX_FEET + f] = gait_ztar(m, f, s.info[DIAL_INFO_STEP] + (float)dt_);
+    });
+  }
   // element i of the packed state [qpos | qvel | qacc_warmstart | info] in the LDS workspace
   // (an offset from ONE base pointer, not a select of pointers: keeps the accesses in the LDS address space)
   const auto packed = [&](int i) -> float* {
@@ -197,31 +180,35 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     if (w.launder) { asm volatile("" : "+v"(w.lane)); w.lane_r = w.lane; }   // (and once per physics frame: rollout_body.h env_step)
 #endif
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
-    w.items(nu, [&](int a) {
-      float u;
-      if (io.us) u = io.us[(unsigned)((n * T + st) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
-      else if (mean_now) {   // the mean trajectory's nodes are clip(Ybar): not in this wavefront's LDS (s.Y holds its own rollout's)
-        u = 0.f;
-        for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * dm::clip(io.Ybar[k * nu + a], -1.f, 1.f);
-      } else {
-        // the examples' node counts with a compile-time trip count: the row of W arrives with one or two scalar loads and every
-        // LDS fetch is issued up front.  (A loop whose length is a run-time value waits for one scalar load + one LDS fetch
-        // per node -- K2 cost a lone Go2 wavefront 2.0 k of its 43.7 k cycles per env.step.)  Same products in the same order.
-        u = 0.f;
-        const auto k2 = [&](auto HN) {
-          DIAL_UNROLL_FULL
-          for (int k = 0; k < decltype(HN)::value; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
-        };
-        if (Hn1 == 5) k2(std::integral_constant<int, 5>{});
-        else if (Hn1 == 6) k2(std::integral_constant<int, 6>{});
-        else if (Hn1 == 7) k2(std::integral_constant<int, 7>{});
-        else for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * s.Y[k * nu + a];
+    if constexpr (!PRE) {
+      w.items(nu, [&](int a) {
+        float u;
+        if (mean_now && !io.us) {   // the mean trajectory's nodes are clip(Ybar): not in this wavefront's LDS (s.Y holds its own rollout's)
+          u = 0.f;
+          for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * dm::clip(io.Ybar[k * nu + a], -1.f, 1.f);
+        } else {
+          // (a compile-time trip count for the examples' node counts: the row of W arrives with one or two scalar loads and every
+          //  LDS fetch is issued up front.  A loop whose length is a run-time value waits for one scalar load + one LDS fetch
+          //  per node -- K2 cost a lone Go2 wavefront 2.0 k of its 43.7 k cycles per env.step.)  Same products in the same order.
+          u = node2u(st, a);
+        }
+        s.act[a] = u;
+      });
+    } else {
+#ifndef DIAL_EMU
+      if (mean_now) {   // the table row of step `helper` (the own rollout is past it) takes the mean trajectory's joint targets
+        w.items(nu, [&](int a) {
+          float u = 0.f;
+          for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * dm::clip(io.Ybar[k * nu + a], -1.f, 1.f);
+          s.jtab[st * nu + a] = act2joint(m, u, a);
+        });
       }
-      s.act[a] = u;
-    });
+#endif
+    }
     DIAL_MARK(w, 11);
     const int work0 = w.work;
-    float rew = env_step<false>(w, m, tg, s);
+    if constexpr (PRE) { w.out_io = &io; w.out_row = row * T + st; }   // (the step's outputs are stored by the phases that produce them)
+    float rew = env_step<false, PRE>(w, m, tg, s, st);
     if (mean_now) msum += rew; else rsum += rew;
 #ifndef DIAL_EMU
     if constexpr (M::D::ell) {
@@ -243,20 +230,23 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       }
     }
 #endif
-    // per-step outputs: wave-uniform row pointers (scalar address arithmetic), one pass -- lane i stores element i
-    // of each row that is that long
     const size_t o = (size_t)row * T + st;
-    float* const qrow = io.qss ? io.qss + o * nq : nullptr;
-    float* const qdrow = io.qdss ? io.qdss + o * nv : nullptr;
-    float* const xrow = io.xss ? io.xss + o * nx : nullptr;
-    float* const rrow = io.rewss ? io.rewss + o : nullptr;
-    const int nmax = nx > nq ? nx : nq;   // nv < nq
-    w.items(nmax, [&](int i) {
-      if (qrow && i < nq) qrow[i] = s.qpos[i];
-      if (qdrow && i < nv) qdrow[i] = s.qvel[i];
-      if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
-      if (rrow && i == 0) rrow[0] = rew;
-    });
+    if constexpr (!PRE) {
+      // per-step outputs: wave-uniform row pointers (scalar address arithmetic), one pass -- lane i stores element i
+      // of each row that is that long
+      float* const qrow = io.qss ? io.qss + o * nq : nullptr;
+      float* const qdrow = io.qdss ? io.qdss + o * nv : nullptr;
+      float* const xrow = io.xss ? io.xss + o * nx : nullptr;
+      float* const rrow = io.rewss ? io.rewss + o : nullptr;
+      const int nmax = nx > nq ? nx : nq;   // nv < nq
+      w.items(nmax, [&](int i) {
+        if (qrow && i < nq) qrow[i] = s.qpos[i];
+        if (qdrow && i < nv) qdrow[i] = s.qvel[i];
+        if (xrow && i < nx) xrow[i] = s.xpos[3 + i];
+        if (rrow && i == 0) rrow[0] = rew;
+      });
+    }
+    (void)o;
 #ifndef DIAL_PROFILE   // (profiling builds carry no state trace: the combination trips an LLVM address-space bug in the DimsMax kernel)
     if constexpr (TRACE) { if (io.trace) store_state(w, m, s, io.trace + o * nstate); }
 #endif

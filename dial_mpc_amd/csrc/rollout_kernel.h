@@ -15,7 +15,7 @@
 // wavefront-scope fences, wave.h).
 template <class D, int WPB = 1>
 __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, float* smem, Ws& s, int nnode,
-                                                        int ws_words, int con_cap = 0) {
+                                                        int ws_words, int con_cap = 0, int tab_steps = 0) {
   const CModel<D>* m = gm;
   float* wsbase = smem;
   if constexpr (D::is_static) {
@@ -31,7 +31,7 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   // wave-uniform), so that addresses are SGPR base + lane offset instead of dozens of per-array VGPR bases
   if constexpr (WPB > 1) wsbase += __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * ws_words;
   ws_carve(s, wsbase, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m), dim_ns(m), dim_nc(m),
-           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, D::gen ? con_cap : 0, D::NVP);
+           dim_ne(m), nnode, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, D::gen ? con_cap : 0, D::NVP, D::pre_ctrl ? tab_steps : 0);
   return m;
 }
 
@@ -45,7 +45,7 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
                const dial_cfg* __restrict__ cfg, dial::RolloutIO io, int B, int ws_words, int* __restrict__ next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Ws s;
-  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap);
+  const CModel<D>* m = stage_model<D, WPB>(gm, smem, s, io.Hn1, ws_words, io.con_cap, io.T);
   if constexpr (D::gen)   // this wavefront's overflow area (a slot of the grid, not of the batch: the queue reuses it)
     s.ovf = io.ovf ? io.ovf + (size_t)(blockIdx.x * WPB + (threadIdx.x >> 6)) * io.ovf_words : nullptr;
   // (the wavefront's index in its workgroup as a SCALAR: the rollout index and every row pointer derived from it are wave-uniform;
@@ -158,7 +158,7 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   w.launder = DIAL_PAIR_LAUNDER;
   Ws s;
   ws_carve(s, smem + CMW + (int)(threadIdx.x >> 5) * ws_words, dim_nq(m), dim_nv(m), dim_nu(m), dim_nb(m), dim_nj(m), dim_ng(m),
-           dim_ns(m), dim_nc(m), dim_ne(m), io.Hn1, false, true, 0, 0, D::NVP);
+           dim_ns(m), dim_nc(m), dim_ne(m), io.Hn1, false, true, 0, 0, D::NVP, D::pre_ctrl ? io.T : 0);
 #ifdef DIAL_PROFILE
   w.acc = reinterpret_cast<unsigned long long*>(smem + (CMW + 2 * WPB * ws_words + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
   if ((threadIdx.x & 63) < 32) w.acc[threadIdx.x & 63] = 0;
@@ -208,6 +208,9 @@ env_reset_kernel(const CModel<D>* __restrict__ gm, const float* qpos, const floa
   Wave w;
   w.lane = threadIdx.x;
   w.lane_r = w.lane;
-  dial::env_reset_single(w, m, s, qpos, qvel, state, xpos_out, xquat_out);
+  // (dial_env_reset_batch: workgroup b resets state b of a batch -- rows of qpos / qvel / state / the optional pose outputs)
+  const int b = (int)blockIdx.x, nq = dim_nq(m), nv = dim_nv(m), nb1 = dim_nb(m) - 1;
+  dial::env_reset_single(w, m, s, qpos + (size_t)b * nq, qvel + (size_t)b * nv, state + (size_t)b * (nq + 2 * nv + DIAL_INFO_N),
+                         xpos_out ? xpos_out + (size_t)b * nb1 * 3 : nullptr, xquat_out ? xquat_out + (size_t)b * nb1 * 4 : nullptr);
 }
 

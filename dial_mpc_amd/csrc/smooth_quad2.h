@@ -233,12 +233,16 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     for (int k = 0; k < 12; k++) VA[k] = N[k];
   }
   // the bodies' outputs are complete: stored now
+  // (Dims::pre_ctrl rollouts: this control step's x.pos row goes to HBM from here -- Wave::out_io -- not from a phase of its own)
+  float* xrow = nullptr;
+  if constexpr (M::D::pre_ctrl) { if (w.out_io && w.out_io->xss) xrow = w.out_io->xss + (size_t)w.out_row * ((M::D::NB - 1) * 3); }
   w.items(32, [&](int l) {
     const int d = l & 7, g = l >> 3;
     const bool leg = d >= 1 && d <= 3;
     const int b = leg ? 3 * g + d + 1 : 1;
     if (leg || l == 0) {
       for (int k = 0; k < 3; k++) s.xpos[3 * b + k] = lane_val(PL[k], l);
+      if constexpr (M::D::pre_ctrl) { if (xrow) for (int k = 0; k < 3; k++) xrow[3 * (b - 1) + k] = lane_val(PL[k], l); }
       store4(s.xquat + 4 * b, lane_val(PL[3], l), lane_val(PL[4], l), lane_val(PL[5], l), lane_val(PL[6], l));
       for (int k = 0; k < 3; k++) store2(s.cvel + 6 * b + 2 * k, lane_val(VA[2 * k], l), lane_val(VA[2 * k + 1], l));
     }

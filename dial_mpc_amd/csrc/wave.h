@@ -24,6 +24,7 @@
 //     any intra-phase read-after-write / write-after-write dependence shows up as a mismatch.
 //     This lets the exact kernel logic be verified against the oracle without a GPU.
 #pragma once
+#include "rollout_io.h"
 
 #ifdef DIAL_EMU
 #include <cmath>
@@ -85,6 +86,9 @@ struct Wave {
   static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront, this object is one 32-lane half)
   bool tree_sums = false;                // wave sums in the GPU's association (see emu_row_tree)
   bool launder = false;   // (GPU only: opaque lane id per step, see the HIP Wave)
+  // the control step's rows of the launch's output tensors, for the phases that store what they produce (Dims::pre_ctrl)
+  const dial::RolloutIO* out_io = nullptr;
+  int out_row = 0;
   float* lds = nullptr;
   int lds_words = 0;
   bool check_races = false;
@@ -380,12 +384,21 @@ struct LaneScope {
 #ifdef DIAL_PROFILE
 #define DIAL_NSEC 32
 #define DIAL_MARK(w, id) (w).mark(id)
+#elif defined(DIAL_ISA_MARKS)
+// ISA probes (tools/isa/probe.sh -DDIAL_ISA_MARKS): a comment line per section boundary in the assembly, so that tools/isa/section_hist.py
+// can count the instructions of every section by class; no instruction is emitted
+#define DIAL_MARK(w, id) asm volatile("; DIAL_MARK %0" ::"n"(id))
 #else
 #define DIAL_MARK(w, id)
 #endif
 struct Wave {
   static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront)
   int lane;
+  // The control step's rows of the launch's output tensors (row = rollout x T + step), for the phases that store what they
+  // produce (Dims::pre_ctrl; rollout_driver.h sets them before env_step): one kernarg pointer + one index, not four row pointers
+  // kept live through the solver.  WaveH: the index is a per-lane value (each half has its own rollout).
+  const dial::RolloutIO* out_io = nullptr;
+  int out_row = 0;
 #ifdef DIAL_PROFILE
   // accumulators live in LDS (written by lane 0) so that the profiling build does not eat the scalar
   // registers the measured code is short of

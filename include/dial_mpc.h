@@ -435,6 +435,11 @@ int dial_env_step(dial_ctx* ctx, float* state, const float* action, float* xpos_
  * initialised for the task.  qpos:[nq], qvel:[nv] device pointers.                  */
 int dial_env_reset(dial_ctx* ctx, const float* qpos, const float* qvel, float* state,
                    float* xpos_out, float* xquat_out, void* stream);
+/* The same for n states in ONE launch (one workgroup each): qpos:[n,nq], qvel:[n,nv], states:[n,nstate],
+ * xpos_out:[n,(nbody-1)*3] / xquat_out:[n,(nbody-1)*4] optional.  What a driver uses to seed many synthetic or
+ * randomised start states (the reference jits env.reset and calls it once per state: dial_mpc/core/dial_core.py:222,227). */
+int dial_env_reset_batch(dial_ctx* ctx, const float* qpos, const float* qvel, float* states,
+                         float* xpos_out, float* xquat_out, int n, void* stream);
 
 /* timing hook for bench.py: average duration in ms of the last n launches of the rollout
  * kernel, measured with hipEvents on the launch stream (enable with dial_set_timing).   */

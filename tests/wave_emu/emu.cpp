@@ -26,14 +26,14 @@ struct Runner {
     // DIAL_EMU_CON_CAP=k: the GPU rollout kernel's capped workspace (derived.h: ws_carve) + overflow area, on the host
     if (const char* e = std::getenv("DIAL_EMU_CON_CAP")) con_cap = D::gen ? std::atoi(e) : 0;
     ws_words = ws_carve(s, (float*)0, m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->ncon, m->nefc,
-                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP);
+                        DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP, D::pre_ctrl ? DIAL_MAX_T : 0);
     if (con_cap > 0) ovf_words = ws_overflow(s, (float*)0, m->nv, m->ncon, m->nefc);
   }
   void setup(std::vector<float>& lds, Ws& s, Wave& w, int check_races) const {
     // (the overflow area lives behind the LDS image in the same vector: the race detector then sees both)
     lds.assign(ws_words + ovf_words, 0.f);
     ws_carve(s, lds.data(), cm.nq, cm.nv, cm.nu, cm.nbody, cm.njnt, cm.ngeom, cm.nsite, cm.ncon, cm.nefc,
-             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP);
+             DIAL_MAX_NODE, dial::kNeedL<D>, D::square, D::ell ? D::JCW : 0, con_cap, D::NVP, D::pre_ctrl ? DIAL_MAX_T : 0);
     if (s.con_cap > 0) s.ovf = lds.data() + ws_words;
     w.lds = lds.data();
     w.lds_words = ws_words + ovf_words;
