@@ -1713,30 +1713,21 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
     } else {
       w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
     }
-  } else
-  w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
-  // (Dims::pre_ctrl rollouts: the step's q / qd rows are stored from here -- Wave::out_io -- instead of by a phase of their own)
-  float *qrow = nullptr, *qdrow = nullptr;
-  if constexpr (M::D::pre_ctrl) {
-    if (w.out_io) {
-      if (w.out_io->qss) qrow = w.out_io->qss + (size_t)w.out_row * dim_nq(m);
-      if (w.out_io->qdss) qdrow = w.out_io->qdss + (size_t)w.out_row * dim_nv(m);
-    }
+  } else {
+    // (Dims::pre_ctrl rollouts: the step's qd row is stored from here -- Wave::out_io --, one element per dof lane; the q row by the
+    //  reward phase's idle lanes: the free joint's lane below is the long pole of this stage and should not issue seven stores)
+    float* qdrow = nullptr;
+    if constexpr (M::D::pre_ctrl) { if (w.out_io && w.out_io->qdss) qdrow = w.out_io->qdss + (size_t)w.out_row * dim_nv(m); }
+    w.items(dim_nv(m), [&](int i) {
+      const float v = s.qvel[i] + s.qacc[i] * dt;
+      s.qvel[i] = v;
+      if constexpr (M::D::pre_ctrl) { if (qdrow) qdrow[i] = v; }
+    });
   }
   w.items(dim_nj(m), [&](int ji) {
     const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
-    if constexpr (M::D::pre_ctrl) {
-      if (qdrow) {
-        if (m->jnt_type[ji] == DIAL_JNT_FREE) { for (int k = 0; k < 6; k++) qdrow[da + k] = s.qvel[da + k]; }
-        else qdrow[da] = s.qvel[da];
-      }
-    }
     if (m->jnt_type[ji] == DIAL_JNT_FREE) {
-      for (int k = 0; k < 3; k++) {
-        const float p = s.qpos[qa + k] + dt * s.qvel[da + k];
-        s.qpos[qa + k] = p;
-        if constexpr (M::D::pre_ctrl) { if (qrow) qrow[qa + k] = p; }
-      }
+      for (int k = 0; k < 3; k++) s.qpos[qa + k] += dt * s.qvel[da + k];
       float v[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
       // An angular velocity whose SQUARE is below the smallest normal fp32 (|w| < 1.1e-19 rad/s: a body that has come to rest) is
       // no rotation: under the fast-math flags v / sqrt(d) becomes v * v_rsq(d), and v_rsq flushes a denormal d to 0 -> inf -> NaN
@@ -1749,13 +1740,8 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
       dm::quat_mul(qn, q0, qr);
       dm::normalize4(qn);
       for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = qn[k];
-      if constexpr (M::D::pre_ctrl) {
-        if (qrow) { for (int k = 0; k < 4; k++) qrow[qa + 3 + k] = qn[k]; }
-      }
     } else {
-      const float p = s.qpos[qa] + dt * s.qvel[da];
-      s.qpos[qa] = p;
-      if constexpr (M::D::pre_ctrl) { if (qrow) qrow[qa] = p; }
+      s.qpos[qa] += dt * s.qvel[da];
     }
   });
 }
@@ -1804,16 +1790,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
   static_assert(!PRE || M::D::pre_ctrl, "control tables: carved for the Dims::pre_ctrl instantiations only");
   // act2joint / act2tau (base_env.py:38-66) | desired foot heights from the gait clock (get_foot_step)
   if constexpr (PRE) {
-    w.items(nu, [&](int a) {
-      const float jt = s.jtab[st * nu + a];
-      float c;
-      if (m->position_control) c = jt;
-      else {
-        float q_err = jt - s.qpos[7 + a];
-        c = dm::clip(m->kp[a] * q_err - m->kd[a] * s.qvel[6 + a], m->tau_range[a][0], m->tau_range[a][1]);
-      }
-      s.ctrl[a] = c;
-    });
+    w.jrow = s.jtab + st * nu;   // act2tau runs in the position stage's actuation lanes (smooth_quad.h: MO)
   } else
   w.items(nu + DIAL_MAX_FEET, [&](int it) {
     if (it < nu) {
@@ -2083,10 +2060,14 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
       return out;
     };
     // ---- terms, total in the reference's summation order and info update (one lane; last_ctrl by nu lanes)
-    w.items(1 + nu, [&](int it) {
+    // (PRE: lanes 1 .. nq also store this step's q row -- the integrator's results, one element per lane)
+    float* qrow = nullptr;
+    if constexpr (PRE) { if (w.out_io && w.out_io->qss) qrow = w.out_io->qss + (size_t)w.out_row * dim_nq(m); }
+    w.items(1 + (PRE ? dim_nq(m) : nu), [&](int it) {
       float* info = s.info;
       if (it > 0) {
-        if (!walk) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
+        if (!walk && it <= nu) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
+        if constexpr (PRE) { if (qrow) qrow[it - 1] = s.qpos[it - 1]; }
         return;
       }
       // this step's velocity command, once for all terms (randomize_tasks: the episode's draw -- the only branch left

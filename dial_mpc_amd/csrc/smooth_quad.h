@@ -434,7 +434,19 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       //  LDS round trips under exec masks)
       const int a = m->dof_act[i];
       const int aa = a >= 0 ? a : 0;
-      const float c0 = s.ctrl[aa], lo = m->act_ctrlrange[aa][0], hi = m->act_ctrlrange[aa][1], kp = m->act_kp[aa];
+      float c0 = s.ctrl[aa];
+      const float lo = m->act_ctrlrange[aa][0], hi = m->act_ctrlrange[aa][1], kp = m->act_kp[aa];
+      if constexpr (M::D::pre_ctrl) {
+        if (w.jrow) {   // (rollouts: act2tau by the actuated dof's own lane, from the table's joint target -- no ctrl phase, no LDS round trip)
+          const float jt = w.jrow[aa];
+          if (m->position_control) c0 = jt;
+          else {
+            const float q_err = jt - s.qpos[7 + aa];
+            c0 = dm::clip(m->kp[aa] * q_err - m->kd[aa] * s.qvel[6 + aa], m->tau_range[aa][0], m->tau_range[aa][1]);
+          }
+          if (a >= 0) s.ctrl[aa] = c0;   // (read by the seq-jump task's info update)
+        }
+      }
       const float qp = s.qpos[m->act_qposadr[aa]], gear = m->act_gear[aa];
       const float c = m->act_ctrllimited[aa] ? dm::clip(c0, lo, hi) : c0;
       const float force = m->act_isposition[aa] ? kp * (c - qp) : c;

@@ -89,6 +89,7 @@ struct Wave {
   // the control step's rows of the launch's output tensors, for the phases that store what they produce (Dims::pre_ctrl)
   const dial::RolloutIO* out_io = nullptr;
   int out_row = 0;
+  const float* jrow = nullptr;   // this control step's row of the joint-target table (see the HIP Wave)
   float* lds = nullptr;
   int lds_words = 0;
   bool check_races = false;
@@ -399,6 +400,9 @@ struct Wave {
   // kept live through the solver.  WaveH: the index is a per-lane value (each half has its own rollout).
   const dial::RolloutIO* out_io = nullptr;
   int out_row = 0;
+  // this control step's row of the rollout's joint-target table (Ws::jtab), or nullptr: the position stage's actuation lanes then
+  // run act2tau themselves (base_env.py:51-66) instead of reading s.ctrl from a phase of its own
+  const float* jrow = nullptr;
 #ifdef DIAL_PROFILE
   // accumulators live in LDS (written by lane 0) so that the profiling build does not eat the scalar
   // registers the measured code is short of
