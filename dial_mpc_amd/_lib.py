@@ -50,7 +50,13 @@ _COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_device
 # launch lasts as long as ONE lone wavefront's dependence chain, which the strategy shortens: A/B on one box
 # (profiles/r05_ab_sched_max_ilp.txt) Allegro example 6.67 -> 6.51 ms (-2.5 %); the Go2 (+2 %), the push crate (+2 %) and the H1 (+-0)
 # keep the default strategy.
-_FAMILY_FLAGS = {3: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# Family 4 (the capacity-dimension kernels, DimsMax): SimplifyCFG's common-code sinking is OFF.  A wavefront whose touching contacts
+# exceed the capped LDS workspace runs a second inlined copy of the constraint code on an overflow area in GLOBAL memory
+# (csrc/rollout_body.h: forward_tail); the sinking pass merges instructions of the two copies into one block behind pointer PHIs that
+# mix the LDS and the global address space, and instruction selection then dies with "Illegal instruction detected: V_CMP_NE_U32 0,
+# $src_shared_base" -- rounds 4-5 met this as "the translation unit trips an LLVM bug whenever <some loop> changes shape" and
+# kept old code shapes alive for it; round 6 bisected the pass (tools/isa/llvm_sink_bug.md).
+_FAMILY_FLAGS = {3: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], 4: ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str:
@@ -70,35 +76,50 @@ def build(force: bool = False, verbose: bool = False, ieee: bool = False) -> str
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = _COMMON + (_IEEE if ieee else _FAST) + ([] if ieee else os.environ.get("DIAL_HIPCC_EXTRA", "").split())
-    # objects go to a directory of THIS call (flags hashed into its name, pid-suffixed), the library is linked next to its final
-    # place and moved there atomically: concurrent callers (ranks of a multi-process launch, pytest-xdist workers that all find
-    # a stale tree) never see each other's half-written files
+    # ONE builder at a time per output file (ranks of a multi-process launch, pytest-xdist workers that all find a stale tree): an
+    # exclusive flock on build/<library>.lock, staleness re-checked once the lock is held -- the others find a fresh library.
+    # Objects go to a directory of THIS call (flags hashed into its name, pid-suffixed), the library is linked next to its final place
+    # and moved there atomically; the directory and the temporary are removed whether the build succeeds or not.
+    import fcntl
     import hashlib
     import shutil
+    build_root = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build")
+    os.makedirs(build_root, exist_ok=True)
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:8]
-    objdir = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "build", f"obj_{os.path.basename(out)}_{tag}_{os.getpid()}")
-    os.makedirs(objdir, exist_ok=True)
-    units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
-    units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"] + _FAMILY_FLAGS.get(k, []), os.path.join(objdir, f"kern_family_{k}.o"))
-              for k in range(N_FAMILIES)]
-
-    def compile_unit(u):
-        src, defs, obj = u
-        cmd = [hipcc] + flags + defs + ["-c", "-o", obj, src]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return obj
-    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_unit, units))
+    objdir = os.path.join(build_root, f"obj_{os.path.basename(out)}_{tag}_{os.getpid()}")
     tmp_out = f"{out}.{os.getpid()}.tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp_out, out)
-    shutil.rmtree(objdir, ignore_errors=True)
-    return out
+    with open(os.path.join(build_root, os.path.basename(out) + ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+                return out
+            os.makedirs(objdir, exist_ok=True)
+            units = [(os.path.join(_CSRC, "dial_hip.hip"), [], os.path.join(objdir, "dial_hip.o"))]
+            units += [(os.path.join(_CSRC, "kern_family.hip"), [f"-DDIAL_FAMILY={k}"] + _FAMILY_FLAGS.get(k, []), os.path.join(objdir, f"kern_family_{k}.o"))
+                      for k in range(N_FAMILIES)]
+
+            def compile_unit(u):
+                src, defs, obj = u
+                cmd = [hipcc] + flags + defs + ["-c", "-o", obj, src]
+                if verbose:
+                    print(" ".join(cmd))
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                if r.returncode != 0:   # (the compiler's own words, not just the exit status: a failed unit must be impossible to overlook)
+                    raise DialHipError(f"hipcc failed ({r.returncode}) on {os.path.basename(src)} {' '.join(defs)}:\n{r.stdout[-4000:]}")
+                return obj
+            with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(compile_unit, units))
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out] + objs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp_out, out)
+            return out
+        finally:
+            shutil.rmtree(objdir, ignore_errors=True)
+            if os.path.exists(tmp_out):
+                os.remove(tmp_out)
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load(path: Optional[str] = None):

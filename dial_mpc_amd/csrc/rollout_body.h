@@ -849,18 +849,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       ls_eval3(bitsf(p0.nalpha), bitsf(p0.nalpha), bitsf(p0.nalpha));
       LsPt lo, hi;
       ls_open(p0, point_at(0), lo, hi);
-      if constexpr (M::D::gen) {   // (the capacity-dimension kernel keeps the combined flag: its translation unit trips LLVM's address-space
-        bool swap = true;          //  bug when this loop changes shape, see ls_bracket.h)
-        int ls_iter = 0;
-        for (;;) {
-          const bool done = (ls_iter >= m->ls_iterations) | !swap | ls_converged(lo, hi, kg, kng);
-          if (done) break;
-          ls_eval3(bitsf(lo.nalpha), bitsf(hi.nalpha), 0.5f * (bitsf(lo.alpha) + bitsf(hi.alpha)));   // groups: lo_next, hi_next, mid
-          swap = ls_update_lazy<false>(rule_swap, lo, hi, fbits(bcast(pk[3], 0)), fbits(bcast(pk[3], 16)), fbits(bcast(pk[3], 32)), 0, 16, 32,
-                                       [&](int word, int lane) { return fbits(bcast(pk[word], lane)); });
-          ls_iter++;
-        }
-      } else {
+      {
         const LsGate gate = ls_gate(kg, kng);   // (one scalar compare + branch per loop condition, see solver_reg.h)
         const int max_ls = DM_UNIFORM_I(m->ls_iterations);
         int ls_iter = 0;
@@ -1713,17 +1702,18 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
     } else {
       w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
     }
-  } else {
+  } else if constexpr (M::D::pre_ctrl) {
     // (Dims::pre_ctrl rollouts: the step's qd row is stored from here -- Wave::out_io --, one element per dof lane; the q row by the
     //  reward phase's idle lanes: the free joint's lane below is the long pole of this stage and should not issue seven stores)
     float* qdrow = nullptr;
-    if constexpr (M::D::pre_ctrl) { if (w.out_io && w.out_io->qdss) qdrow = w.out_io->qdss + (size_t)w.out_row * dim_nv(m); }
+    if (w.out_io && w.out_io->qdss) qdrow = w.out_io->qdss + (size_t)w.out_row * dim_nv(m);
     w.items(dim_nv(m), [&](int i) {
       const float v = s.qvel[i] + s.qacc[i] * dt;
       s.qvel[i] = v;
-      if constexpr (M::D::pre_ctrl) { if (qdrow) qdrow[i] = v; }
+      if (qdrow) qdrow[i] = v;
     });
-  }
+  } else
+  w.items(dim_nv(m), [&](int i) { s.qvel[i] += s.qacc[i] * dt; });
   w.items(dim_nj(m), [&](int ji) {
     const int qa = m->jnt_qposadr[ji], da = m->jnt_dofadr[ji];
     if (m->jnt_type[ji] == DIAL_JNT_FREE) {
@@ -1808,7 +1798,6 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
       if (walk && f < m->nfeet) s.ztar[f] = gait_ztar(m, f, s.info[DIAL_INFO_STEP]);
     }
   });
-  const float* const ztar = PRE ? s.ztab + st * DIAL_MAX_FEET : s.ztar;   // this step's desired foot heights
   DIAL_MARK(w, 25);
   const int n_frames = PRE ? 1 : m->n_frames;   // (Dims::pre_ctrl: one physics step per control step, dial_create checks)
   for (int f = 0; f < n_frames; f++) {  // pipeline_step
@@ -1919,7 +1908,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
           float reward_gaits = 0.f;
   #pragma unroll
           for (int f = 0; f < NF; f++) {
-            const float z_tar = ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];
+            const float z_tar = PRE ? s.ztab[st * DIAL_MAX_FEET + f] : s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];   // (PRE: the rollout's gait-clock table)
             float fz;
             if (kind == DIAL_TASK_GO2_WALK) {
               float e = (z_tar - zs) / 0.05f;
@@ -2061,13 +2050,11 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
     };
     // ---- terms, total in the reference's summation order and info update (one lane; last_ctrl by nu lanes)
     // (PRE: lanes 1 .. nq also store this step's q row -- the integrator's results, one element per lane)
-    float* qrow = nullptr;
-    if constexpr (PRE) { if (w.out_io && w.out_io->qss) qrow = w.out_io->qss + (size_t)w.out_row * dim_nq(m); }
     w.items(1 + (PRE ? dim_nq(m) : nu), [&](int it) {
       float* info = s.info;
       if (it > 0) {
         if (!walk && it <= nu) info[DIAL_INFO_LAST_CTRL + it - 1] = s.ctrl[it - 1];
-        if constexpr (PRE) { if (qrow) qrow[it - 1] = s.qpos[it - 1]; }
+        if constexpr (PRE) { if (w.out_io && w.out_io->qss) w.out_io->qss[(size_t)w.out_row * dim_nq(m) + (it - 1)] = s.qpos[it - 1]; }
         return;
       }
       // this step's velocity command, once for all terms (randomize_tasks: the episode's draw -- the only branch left

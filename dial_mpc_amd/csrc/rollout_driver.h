@@ -96,7 +96,8 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   const auto node2u = [&](int t, int a) -> float {
     if (io.us) return io.us[(unsigned)((n * T + t) * nu + a)];   // 32-bit offset from the uniform base: no 64-bit VGPR pair kept live
     float u = 0.f;
-    // the examples' node counts with a compile-time trip count: every LDS fetch is issued up front
+    // the examples' node counts with a compile-time trip count: the row of W arrives with one or two scalar loads and every LDS
+    // fetch is issued up front (a loop whose length is a run-time value waits for one scalar load + one LDS fetch per node)
     const auto k2 = [&](auto HN) {
       DIAL_UNROLL_FULL
       for (int k = 0; k < decltype(HN)::value; k++) u += cfg->W[t][k] * s.Y[k * nu + a];
@@ -187,9 +188,6 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
           u = 0.f;
           for (int k = 0; k < Hn1; k++) u += cfg->W[st][k] * dm::clip(io.Ybar[k * nu + a], -1.f, 1.f);
         } else {
-          // (a compile-time trip count for the examples' node counts: the row of W arrives with one or two scalar loads and every
-          //  LDS fetch is issued up front.  A loop whose length is a run-time value waits for one scalar load + one LDS fetch
-          //  per node -- K2 cost a lone Go2 wavefront 2.0 k of its 43.7 k cycles per env.step.)  Same products in the same order.
           u = node2u(st, a);
         }
         s.act[a] = u;

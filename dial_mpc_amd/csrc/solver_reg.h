@@ -333,14 +333,29 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
   // acc[dof lane i] = (M v)_i, acc[contact lane r] = (J v)_r
   // (a dependent fp32 FMA issues every ~10 cycles on gfx950, an independent one every 2: three partial sums;
   //  the broadcasts run two FMAs ahead of their use)
+  // DIAL_SWEEP_DPP (round 6, default): the entries of v reach every lane as DPP operands of the multiply-adds -- one v_permlane32_swap +
+  // one v_permlane16_swap put v's lanes 0..31 into every row (wave.h: dup_halves, dup_rows), then one v_fmac_f32_dpp per column --
+  // instead of one v_readlane (-> SGPR) + one v_fmac per column: 20 VALU instructions per sweep for 36, and an SGPR-operand FMA
+  // issues no faster than a DPP one (profiles/r06_ubench_issue.txt: 4.2 vs 4.4 cycles, v_readlane 4.5).  Same products, same three
+  // partial sums, same order: bit-identical.
+#ifndef DIAL_SWEEP_DPP
+#define DIAL_SWEEP_DPP 1
+#endif
   auto dotR = [&](const vfloat& v) {
     vfloat acc[3] = {vzero, vzero, vzero};
+#if DIAL_SWEEP_DPP
+    vfloat vlo, vhi, X, Y;
+    w.dup_halves(v, vlo, vhi);
+    w.dup_rows(vlo, X, Y);
+    static_for<0, NV>([&](auto IDX) { constexpr int j = IDX; acc[j % 3] = w.template fma_pick<j>(acc[j % 3], X, Y, R[j]); });
+#else
     float sb[3] = {0.f, 0.f, 0.f};
     static_for<0, NV + 2>([&](auto IDX) {
       constexpr int idx = IDX;
       if constexpr (idx < NV) sb[idx % 3] = bcast(v, idx);
       if constexpr (idx >= 2) acc[(idx - 2) % 3] = acc[(idx - 2) % 3] + R[idx - 2] * sb[(idx - 2) % 3];
     });
+#endif
     return (acc[0] + acc[1]) + acc[2];
   };
   // row-slot product J_r . v: limit rows are +-e_dof, contact rows come out of the sweep
@@ -394,12 +409,23 @@ DIAL_DEV void solver_reg(W& w, const M* m, const Ws& s) {
 #endif
     const vfloat vf = vsel(act, vD * (vzero - vJa), vzero);
     vfloat qfc = vls * vf;  // limit row of the own dof
+#if DIAL_SWEEP_DPP
+    vfloat flo, fhi, fX, fY;   // the contact lanes' forces (lanes 32 ..) within reach of the dof lanes' row broadcasts
+    w.dup_halves(vf, flo, fhi);
+    w.dup_rows(fhi, fX, fY);
+#endif
     static_for<0, NC>([&](auto Cc) {   // J^T f from the dof-major pyramid rows: one 16-byte fetch per contact
       constexpr int c = Cc;
       vfloat jr[4];
       w.per_lane4([&](int l) { return s.Jc + (l < NV ? l : 0) * M::D::T + 4 * c; }, jr[0], jr[1], jr[2], jr[3]);
+#if DIAL_SWEEP_DPP
+      const vfloat t01 = w.template fma_pick<4 * c + 1>(w.template mul_pick<4 * c>(fX, fY, jr[0]), fX, fY, jr[1]);
+      const vfloat t23 = w.template fma_pick<4 * c + 3>(w.template mul_pick<4 * c + 2>(fX, fY, jr[2]), fX, fY, jr[3]);
+      qfc = qfc + (t01 + t23);
+#else
       qfc = qfc + ((jr[0] * bcast(vf, C0 + 4 * c) + jr[1] * bcast(vf, C0 + 4 * c + 1)) +
                    (jr[2] * bcast(vf, C0 + 4 * c + 2) + jr[3] * bcast(vf, C0 + 4 * c + 3)));
+#endif
     });
     const vfloat vgrad = vsel(isdof, vMa - vqfs - qfc, vzero);
     float gn = 0.f;

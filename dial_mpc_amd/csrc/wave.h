@@ -247,9 +247,16 @@ struct Wave {
   void dup_rows(const vfloat& v, vfloat& X, vfloat& Y) {
     for (int l = 0; l < 64; l++) { X.x[l] = v.x[(l & 32) | (l & 15)]; Y.x[l] = v.x[(l & 32) | 16 | (l & 15)]; }
   }
+  // LO = the lower 32 lanes of v in BOTH halves of the wavefront, HI = its upper 32 lanes in both (GPU: one v_permlane32_swap).
+  // One-sample layouts only: dup_halves + dup_rows put any lane of v within reach of every lane's row_newbcast.
+  void dup_halves(const vfloat& v, vfloat& LO, vfloat& HI) {
+    for (int l = 0; l < 64; l++) { LO.x[l] = v.x[l & 31]; HI.x[l] = v.x[32 | (l & 31)]; }
+  }
   // lane K of the own ROW, as a (half-uniform) scalar -- for values every row holds a copy of (GPU: one DPP row_newbcast)
   template <int K>
   float rowbc(const vfloat& v) { return v.x[K]; }
+  template <int K>
+  vfloat mul_pick(const vfloat& X, const vfloat& Y, const vfloat& other) { return other * pick<K>(X, Y); }
   // acc +- other * (lane K of the half, from its duplicated rows X | Y) and 1 / that lane: on the GPU's product build ONE instruction
   // each -- the DPP row broadcast is an operand modifier of v_fmac_f32 / v_rcp_f32 (HIP WaveH below)
   template <int K>
@@ -629,6 +636,13 @@ struct Wave {
     asm("s_nop 1" : "+v"(X), "+v"(Y));   // (the hand-written DPP consumers of X | Y: see fma_pick)
 #endif
   }
+  // LO = the lower 32 lanes of v in both halves of the wavefront, HI = its upper 32 lanes in both (one v_permlane32_swap, gfx950)
+  __device__ __forceinline__ void dup_halves(vfloat v, vfloat& LO, vfloat& HI) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    LO = __builtin_bit_cast(float, r0);
+    HI = __builtin_bit_cast(float, r1);
+  }
   template <int K>
   __device__ __forceinline__ float rowbc(vfloat v) { return row_bcast<K>(v); }
   template <int K>
@@ -659,8 +673,16 @@ struct Wave {
     asm("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(K < 16 ? X : Y), "n"(K & 15));
     return r;
   }
+  template <int K>
+  __device__ __forceinline__ vfloat mul_pick(vfloat X, vfloat Y, vfloat other) {   // other * (lane K): v_mul_f32_dpp
+    vfloat r;
+    asm("v_mul_f32_dpp %0, %1, %2" DIAL_DPP_TAIL : "=v"(r) : "v"(K < 16 ? X : Y), "v"(other), "n"(K & 15));
+    return r;
+  }
 #undef DIAL_DPP_TAIL
 #else
+  template <int K>
+  __device__ __forceinline__ vfloat mul_pick(vfloat X, vfloat Y, vfloat other) { return other * pick<K>(X, Y); }
   template <int K>
   __device__ __forceinline__ vfloat fma_pick(vfloat acc, vfloat X, vfloat Y, vfloat other) { return acc + other * pick<K>(X, Y); }
   template <int K>
