@@ -41,9 +41,24 @@ FLOP_PER_STEP_FALLBACK = {"unitree_go2_trot": 62794.0, "unitree_go2_seq_jump": 6
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3
 SHADER_CLOCK_HZ = 2.4e9           # nominal; the chip clocks to its power budget (MI355X_MICROARCH.md: DVFS), issue fractions are at nominal
-# cycles per wave64 VALU instruction of the rollout kernels' instruction mix with 1 / 2 / 3 / 4 wavefronts on a SIMD
-# (tools/ubench/issue.hip -> profiles/r05_ubench_issue.txt, "rollout-kernel mix" row)
+# cycles per wave64 VALU instruction with 1 / 2 / 3 / 4 wavefronts on a SIMD.  Preferred: the launch's OWN price --
+# profiles/r06_issue_price_<example>[_N<n>].json (tools/isa/price_mix.py: every VALU instruction of the shipped kernel's disassembly
+# priced by its operand form with the rows of profiles/r06_ubench_issue.txt, the hardware's dynamic classes weighted by the committed
+# PMC pass).  Fallback: the hand-composed "rollout-kernel mix" row of the microbenchmark.
 UBENCH_MIX_CYCLES = [5.00, 3.75, 3.54, 3.36]
+
+
+def issue_price(example, n):
+    """-> (cycles per VALU instruction at W = 1..4, source string)"""
+    for name in (f"r06_issue_price_{example}_N{n}.json", f"r06_issue_price_{example}.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            d = json.load(open(p))
+            cyc = d.get("cycles_per_valu_inst_pmc_weighted_W1_W4") or d.get("cycles_per_valu_inst_static_W1_W4")
+            if cyc:
+                kind = "PMC-weighted" if d.get("cycles_per_valu_inst_pmc_weighted_W1_W4") else "static"
+                return cyc, f"profiles/{name} ({kind} per-form price of the shipped kernel, tools/isa/price_mix.py x profiles/r06_ubench_issue.txt)"
+    return UBENCH_MIX_CYCLES, "profiles/r06_ubench_issue.txt (hand-composed mix row)"
 
 
 def resident_waves_per_simd(example, rollouts, n_simd):
@@ -322,15 +337,19 @@ def main():
                "collectives_per_iteration": {"full": 2 if sharded else 0, "lean": 1 if sharded else 0},
                "avg_rollout_kernel_ms": s_kms / max(s_nl, 1)}
         # the VALU-issue fraction of this launch (see `roofline.valu_issue` below), when a PMC pass of exactly this batch is committed
-        pj = os.path.join(ROOT, "profiles", f"r05_pmc_unitree_go2_trot_N{pls.n_local}.json")
-        if os.path.exists(pj) and s_kms > 0:
+        pj = next((os.path.join(ROOT, "profiles", f"{r}_pmc_unitree_go2_trot_N{pls.n_local}.json") for r in ("r06", "r05")
+                   if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_unitree_go2_trot_N{pls.n_local}.json"))), "")
+        if pj and s_kms > 0:
             pc = json.load(open(pj)).get("counters", {})
             n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
             wps = resident_waves_per_simd("unitree_go2_trot", pls.n_local + 1, n_simd)
-            cyc = float(np.interp(wps, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
+            price, price_src = issue_price("unitree_go2_trot", pls.n_local)
+            cyc = float(np.interp(wps, [1, 2, 3, 4], price))
             if pc.get("SQ_INSTS_VALU"):
-                rec["valu_issue_frac"] = pc["SQ_INSTS_VALU"] * cyc / (n_simd * (s_kms / max(s_nl, 1)) * 1e-3 * SHADER_CLOCK_HZ)
-                rec["valu_issue_source"] = f"profiles/{os.path.basename(pj)} x {cyc:.2f} cycles per VALU instruction (profiles/r05_ubench_issue.txt, {wps:.0f} wavefronts per SIMD)"
+                simd_cycles = n_simd * (s_kms / max(s_nl, 1)) * 1e-3 * SHADER_CLOCK_HZ
+                rec["valu_issue_frac"] = pc["SQ_INSTS_VALU"] * cyc / simd_cycles
+                rec["valu_issue_frac_at_2_cycles"] = pc["SQ_INSTS_VALU"] * 2.0 / simd_cycles
+                rec["valu_issue_source"] = f"profiles/{os.path.basename(pj)} x {cyc:.2f} cycles per VALU instruction ({price_src}, {wps:.0f} wavefronts per SIMD)"
         del pls
         return rec
 
@@ -364,7 +383,8 @@ def main():
     # the same command, tools/pmc_passes.sh -> tools/pmc_to_json.py); null when the batch measured there is not the one run here
     traffic, traffic_src, valu_per_step, lane_util, stall = None, None, None, None, None
     valu_issue = None
-    cands = [f"r05_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r05_pmc_{args.example}.json",
+    cands = [f"r06_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r06_pmc_{args.example}.json",
+             f"r05_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r05_pmc_{args.example}.json",
              f"r04_pmc_{args.example}_N{args.nsample_per_gpu}.json", f"r04_pmc_{args.example}.json", f"r03_pmc_{args.example}.json"]
     pmc_path = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
     if pmc_path is not None and world == 1:
@@ -385,10 +405,17 @@ def main():
             if insts and avg_kernel_s > 0:
                 n_simd = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
                 waves_per_simd = resident_waves_per_simd(args.example, n_local, n_simd)
-                cyc = float(np.interp(waves_per_simd, [1, 2, 3, 4], UBENCH_MIX_CYCLES))
-                valu_issue = {"frac": insts * cyc / (n_simd * avg_kernel_s * SHADER_CLOCK_HZ), "valu_insts_per_launch_pmc": insts,
-                              "cycles_per_valu_inst": cyc, "wavefronts_per_simd": waves_per_simd, "simds": n_simd, "clock_hz": SHADER_CLOCK_HZ,
-                              "source": f"profiles/{os.path.basename(pmc_path)} (SQ_INSTS_VALU) x profiles/r05_ubench_issue.txt (mix row) "
+                price, price_src = issue_price(args.example, args.nsample_per_gpu)
+                cyc = float(np.interp(waves_per_simd, [1, 2, 3, 4], price))
+                simd_cycles = n_simd * avg_kernel_s * SHADER_CLOCK_HZ
+                valu_issue = {"frac": insts * cyc / simd_cycles, "frac_at_2_cycles": insts * 2.0 / simd_cycles,
+                              "assumption": "frac: every VALU instruction at the MEASURED issue cost of its operand form at this occupancy; "
+                                            "frac_at_2_cycles: the guide's one wave64 instruction per 2 cycles (MI355X_MICROARCH.md), which only "
+                                            "two-VGPR-source VOP1/VOP2 forms reach on this chip (profiles/r06_ubench_issue.txt)",
+                              "valu_insts_per_launch_pmc": insts, "valu_mix_pmc": pmc.get("valu_mix"),
+                              "cycles_per_valu_inst": cyc, "cycles_per_valu_inst_W1_W4": price, "wavefronts_per_simd": waves_per_simd, "simds": n_simd,
+                              "clock_hz": SHADER_CLOCK_HZ,
+                              "source": f"profiles/{os.path.basename(pmc_path)} (SQ_INSTS_VALU) x {price_src} "
                                         f"/ (SIMDs x this run's average kernel time x nominal clock)"}
     out = {
         "metric": "sample-rollouts/sec (N x H env.steps), Go2 N=2048 H=16" if args.example == "unitree_go2_trot"

@@ -4,6 +4,9 @@ csrc/wave.h (WaveH::fma_pick / rcp_pick: v_fmac_f32_dpp, v_rcp_f32_dpp from inli
 writes a VGPR must be followed by >= 2 wait states before a DPP instruction reads that VGPR as its DPP source.  The compiler's hazard
 recogniser does not look inside inline asm, so the listing is checked instead: for every *_dpp instruction the two preceding issue
 slots (s_nop N counts N + 1) must not hold a VALU write of its src0.  Exit status 1 and a report on any violation.
+Reads compiler listings (probe.sh: `-S`) and disassemblies of the shipped library (tools/isa/disasm_lib.py).  Labels are treated
+CONSERVATIVELY: control flow may join at a label from a block whose tail is not the text above it, so a DPP instruction within the
+first two wait states after a label is reported unless its source was written -- and the hazard thereby covered -- inside the block.
 usage: check_dpp_hazards.py file.s [kernel-name-substring]"""
 import re
 import sys
@@ -22,19 +25,22 @@ def regs(tok):
     return set(range(int(m.group(2)), int(m.group(3)) + 1))
 
 
+HAND_WRITTEN = ("v_fmac_f32_dpp", "v_rcp_f32_dpp", "v_mul_f32_dpp")   # csrc/wave.h: fma_pick / fnma_pick / rcp_pick / mul_pick (inline asm)
 cur, bad, checked = None, [], 0
 window = []   # (wait states this slot provides, set of VGPRs written by a VALU instruction in it, text)
+UNKNOWN = (0, None, "<unknown predecessor at a label>")   # written-set None = "may have written anything"
 for ln, line in enumerate(open(path), 1):
-    m = re.match(r"^(_Z\w+):", line)
+    m = re.match(r"^(_Z\w+|[A-Za-z]\w*_kernel\w*):", line)
     if m:
         cur, window = m.group(1), []
         continue
     if cur is None or want not in cur:
         continue
-    t = line.split(";")[0].strip()
-    if not t or t.startswith(".") or t.endswith(":"):
-        if t.endswith(":"):
-            window = []          # a label: control flow may join here -- conservative would be to flag, but every DPP use follows straight-line code
+    t = line.split(";")[0].split("//")[0].strip()
+    if not t or (t.startswith(".") and not t.endswith(":")):
+        continue
+    if t.endswith(":"):
+        window = [UNKNOWN]       # a label: the other predecessor's tail is unknown -- anything may have been written just before
         continue
     op, _, rest = t.partition(" ")
     ops = [o.strip() for o in rest.split(",")] if rest else []
@@ -44,7 +50,9 @@ for ln, line in enumerate(open(path), 1):
         need, k = 2, len(window) - 1
         while need > 0 and k >= 0:
             ws, written, text = window[k]
-            if written & src0:
+            # (the unknown tail of another predecessor matters for the HAND-WRITTEN forms only: what the compiler emits itself --
+            #  v_mov_b32_dpp, v_add_f32_dpp from builtins -- went through its hazard recogniser with every predecessor in sight)
+            if (written is None and op in HAND_WRITTEN) or (written is not None and (written & src0)):
                 bad.append((cur, ln, t, text))
                 break
             need -= ws

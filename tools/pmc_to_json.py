@@ -36,10 +36,18 @@ if "SQ_INSTS_VALU" in tot:
     d["salu_insts_per_wave_env_step"] = tot.get("SQ_INSTS_SALU", 0) / wave_steps
     d["lds_insts_per_wave_env_step"] = tot.get("SQ_INSTS_LDS", 0) / wave_steps
     d["branch_insts_per_wave_env_step"] = tot.get("SQ_INSTS_BRANCH", 0) / wave_steps
-    mix = {k: tot.get("SQ_INSTS_VALU_" + k, 0.0) / tot["SQ_INSTS_VALU"] for k in ("FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32", "INT32", "CVT")}
-    mix["other (mov, cndmask, cmp, readlane, dpp, bit ops)"] = 1.0 - sum(mix.values())
-    d["valu_mix"] = mix
-    d["valu_full_rate_fp32_frac"] = mix["FMA_F32"] + mix["ADD_F32"] + mix["MUL_F32"]
+    classes = ("FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32", "INT32", "CVT")
+    if all("SQ_INSTS_VALU_" + k in tot for k in classes):
+        mix = {k: tot["SQ_INSTS_VALU_" + k] / tot["SQ_INSTS_VALU"] for k in classes}
+        mix["other (mov, cndmask, cmp, readlane, dpp, bit ops)"] = 1.0 - sum(mix.values())
+        d["valu_mix"] = mix
+        d["valu_full_rate_fp32_frac"] = mix["FMA_F32"] + mix["ADD_F32"] + mix["MUL_F32"]
+    else:   # the per-class pass (tools/pmc_passes.sh: pass 6) was not run: null, never a 0.0 that reads as data
+        d["valu_mix"] = None
+        d["valu_full_rate_fp32_frac"] = None
+if "SQ_THREAD_CYCLES_VALU" not in tot:
+    d["valu_active_lanes_per_inst"] = None
+    d["valu_lane_utilisation"] = None
 if "SQ_THREAD_CYCLES_VALU" in tot and tot.get("SQ_INSTS_VALU"):
     d["valu_active_lanes_per_inst"] = tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"]
     d["valu_lane_utilisation"] = d["valu_active_lanes_per_inst"] / 64.0

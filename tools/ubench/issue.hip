@@ -49,6 +49,15 @@
 #define Q_CNDM "v_cndmask_b32 %0, %0, %4, vcc\n v_mul_f32 %1, %1, %4\n v_cndmask_b32 %2, %2, %5, vcc\n v_mul_f32 %3, %3, %4\n"                  // alternating with v_mul
 #define Q_CNDK "v_cndmask_b32 %0, 0, 1.0, vcc\n v_cndmask_b32 %1, 0, 1.0, vcc\n v_cndmask_b32 %2, 0, 1.0, vcc\n v_cndmask_b32 %3, 0, 1.0, vcc\n"    // constants
 #define Q_CNDD "v_cndmask_b32 %1, %0, %4, vcc\n v_cndmask_b32 %2, %1, %4, vcc\n v_cndmask_b32 %3, %2, %5, vcc\n v_cndmask_b32 %0, %3, %5, vcc\n"     // one dependent chain
+#define Q_CNDN "v_cndmask_b32 %0, %0, %4, vcc\n s_nop 0\n v_cndmask_b32 %2, %2, %5, vcc\n s_nop 0\n"                                      // an s_nop between two
+#define Q_CNDP "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n"                   // pairs: cnd cnd mul mul
+#define Q_CNDE "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, s[20:21]\n v_cndmask_b32 %2, %2, %5, vcc\n v_cndmask_b32 %3, %3, %5, s[20:21]\n"   // VOP2 / VOP3 alternating
+// runs of R consecutive VOP2 v_cndmask inside blocks of 16 instructions (the rest v_mul_f32): where does the penalty start?
+#define B_CND3 "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n "
+#define B_CND4 "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n "
+#define B_CND6 "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n "
+#define B_CND8 "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n "
+#define B_CND12 "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n "
 // packed fp32 (two fp32 per lane and instruction; operands are aligned VGPR pairs)
 #define Q_PKFMA "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
 #define Q_PKMUL "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
@@ -115,6 +124,14 @@ KERNEL(k_cndx, Q_CNDX Q_CNDX Q_CNDX Q_CNDX, "memory")
 KERNEL(k_cndm, Q_CNDM Q_CNDM Q_CNDM Q_CNDM, "memory")
 KERNEL(k_cndk, Q_CNDK Q_CNDK Q_CNDK Q_CNDK, "memory")
 KERNEL(k_cndd, Q_CNDD Q_CNDD Q_CNDD Q_CNDD, "memory")
+KERNEL(k_cndr3, B_CND3, "memory")
+KERNEL(k_cndr4, B_CND4, "memory")
+KERNEL(k_cndr6, B_CND6, "memory")
+KERNEL(k_cndr8, B_CND8, "memory")
+KERNEL(k_cndr12, B_CND12, "memory")
+KERNEL(k_cndn, Q_CNDN Q_CNDN Q_CNDN Q_CNDN, "memory")
+KERNEL(k_cndp, Q_CNDP Q_CNDP Q_CNDP Q_CNDP, "memory")
+KERNEL(k_cnde, Q_CNDE Q_CNDE Q_CNDE Q_CNDE, "s20", "s21")
 KERNEL2(k_pkfma, Q_PKFMA Q_PKFMA Q_PKFMA Q_PKFMA, "memory")
 KERNEL2(k_pkmul, Q_PKMUL Q_PKMUL Q_PKMUL Q_PKMUL, "memory")
 KERNEL2(k_pkadd, Q_PKADD Q_PKADD Q_PKADD Q_PKADD, "memory")
@@ -145,6 +162,9 @@ int main() {
                         {"v_cndmask_b32 d, d, v, vcc (r05: the 23.5-cycle anomaly)", k_cnd}, {"v_cndmask_b32 d, d, v, s[..] (VOP3 mask in SGPRs)", k_cnds},
                         {"v_cndmask_b32 d, v, v, vcc (dst not a source)", k_cndx}, {"v_cndmask_b32 d, 0, 1.0, vcc (constants)", k_cndk},
                         {"v_cndmask_b32 vcc, ONE dependent chain", k_cndd}, {"v_cndmask_b32 vcc alternating with v_mul_f32", k_cndm},
+                        {"v_cndmask_b32 vcc alternating with s_nop 0, per instruction", k_cndn}, {"v_cndmask_b32 vcc in PAIRS (cnd cnd mul mul)", k_cndp},
+                        {"v_cndmask_b32 VOP2 (vcc) alternating with VOP3 (s[..])", k_cnde},
+                        {"runs of 3 VOP2 v_cndmask in blocks of 16 (rest v_mul_f32)", k_cndr3}, {"runs of 4 VOP2 v_cndmask in blocks of 16 (rest v_mul_f32)", k_cndr4}, {"runs of 6 VOP2 v_cndmask in blocks of 16 (rest v_mul_f32)", k_cndr6}, {"runs of 8 VOP2 v_cndmask in blocks of 16 (rest v_mul_f32)", k_cndr8}, {"runs of 12 VOP2 v_cndmask in blocks of 16 (rest v_mul_f32)", k_cndr12},
                         {"v_cmp_lt_f32 -> vcc", k_cmp}, {"v_cmp_lt_f32 -> s[..] (VOP3)", k_cmps}, {"int32 (add / lshl_add / and)", k_int},
                         {"DPP (v_mov_dpp row_shr, v_add_dpp quad_perm)", k_dpp}, {"v_readlane_b32", k_rdl}, {"v_readfirstlane_b32", k_rfl},
                         {"v_writelane_b32 (SGPR spill store)", k_wrl}, {"v_rcp_f32 (transcendental)", k_rcp}, {"v_permlane16_swap_b32", k_swap},
