@@ -290,6 +290,15 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
   };
   // ---- contact Jacobians in the contact frame: Jc[(c,a), i] = frame_a . (jacp_b2 - jacp_b1)(:, i)
   DIAL_MARK(w, 1);
+  {
+  // Row-layout robots (H1 walk / loco): the item -> table-address arithmetic of these two LDS phases is a set of loop invariants of
+  // the T-step loop; hoisted, they were the 11 VGPRs (44 B of scratch) the H1's kernels spilled at the loop entry and re-loaded --
+  // scratch_load + s_waitcnt vmcnt -- in every step right here (ISA of the shipped library, round 6).  An opaque copy of the lane id
+  // for the two phases keeps them local: a dozen integer instructions per step instead of scratch traffic.
+#ifndef DIAL_ROWS_PHASE_SCOPE
+#define DIAL_ROWS_PHASE_SCOPE (kRowsDims<typename M::D> && !M::D::gen && !M::D::ell)   // (the Allegro's kernels never spilled here: measured +0.7 % with it)
+#endif
+  DIAL_LANE_SCOPE_IF(DIAL_ROWS_PHASE_SCOPE, w);
   if constexpr (M::D::ell) {
     // compact rows: J_c is dim x ndof over the dofs that move body1 or body2 (support.jac of both bodies at the contact
     // point, translational rows in the contact frame, then -- condim 6 -- the rotational ones); one item per (contact, dof)
@@ -451,6 +460,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       s.D[r] = 1.f / R;
     }
   });
+  }   // (lane scope of the Jacobian / row phases)
   // ---- smooth.factor_m + forward.fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth (rhs = qfs copy)
   DIAL_MARK(w, 2);
   w.redraw_priority();   // second draw of the physics step (the first: rollout_driver.h), see wave.h
@@ -1149,7 +1159,10 @@ DIAL_DEV void forward(W& w, const M* m, const Ws& s) {
   }
   if constexpr (kRowsDims<typename M::D>) {   // one tree under a free root (H1): the same stage on the row layout (smooth_rows.h)
     forward_smooth_rows(w, m, s);
-    w.items(nc, [&](int c) { collide_contact(m, s, c); });
+    {
+      DIAL_LANE_SCOPE_IF(DIAL_ROWS_PHASE_SCOPE, w);   // (see forward_constraints)
+      w.items(nc, [&](int c) { collide_contact(m, s, c); });
+    }
     forward_constraints(w, m, s, nca, nea);
     return;
   }

@@ -52,13 +52,19 @@ DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
 // the same states.
 template <bool TRACE = false, class W, class M>
 DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_cfg* cfg, const Ws& s,
-                             const RolloutIO& io, int n, int relay = -1, int helper = -1) {
+                             const RolloutIO& io, int n, int relay = -1, int helper = -1, bool init_ws = true) {
   const int nq = dim_nq(m), nv = dim_nv(m), nu = dim_nu(m), nx = (dim_nb(m) - 1) * 3, T = io.T, Hn1 = io.Hn1;
 #ifdef DIAL_PROFILE
   w.tprev = __builtin_readcyclecounter();
 #endif
-  init_world(w, s);
-  init_square(w, m, s);
+  // The workspace entries no phase ever rewrites -- the world body's pose, the structural zeros of the square M / the contact
+  // Jacobian, the fused contacts' frames -- are written by the wavefront's FIRST rollout (piece) only: a queue kernel's later items
+  // find them in place.  (Per item, their lane-derived LDS addresses were loop invariants of the queue's loop, hoisted and spilled:
+  // 4 VGPRs / 20 B of scratch of the Allegro's time-sliced queue kernel, ISA round 6.)
+  if (init_ws) {
+    init_world(w, s);
+    init_square(w, m, s);
+  }
   const int nstate = nq + 2 * nv + DIAL_INFO_N;
   int st_begin = 0, st_end = T;
   if (relay >= 0) { st_begin = relay * io.relay_steps; st_end = st_begin + io.relay_steps < T ? st_begin + io.relay_steps : T; }
@@ -182,6 +188,9 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
 #endif
     // K2: node2u as the constant linear map W (dial_core.py:92-95,117)
     if constexpr (!PRE) {
+      // (row-layout robots: the lanes' addresses into the node array stay inside this phase -- hoisted out of the T-step loop one
+      //  of them was the last VGPR the H1's four-wavefront kernel spilled)
+      DIAL_LANE_SCOPE_IF(kRowsDims<typename M::D> && !M::D::gen, w);
       w.items(nu, [&](int a) {
         float u;
         if (mean_now && !io.us) {   // the mean trajectory's nodes are clip(Ybar): not in this wavefront's LDS (s.Y holds its own rollout's)
@@ -279,7 +288,12 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       if (helper == 0) {
         load_state(w, m, s, io.state);
         msum = 0.f;
-        if (io.Y0s) w.items(Hn1 * nu, [&](int it) { io.Y0s[(size_t)io.n_noise * Hn1 * nu + it] = dm::clip(io.Ybar[it], -1.f, 1.f); });
+        if (io.Y0s) {
+          // (an opaque lane id for this once-per-launch copy: its two lane-derived 64-bit global addresses were hoisted out of the
+          //  queue's rollout loop and spilled -- the 8 B + 8 B of scratch of the Allegro's time-sliced queue kernel, ISA round 6)
+          DIAL_LANE_SCOPE(w);
+          w.items(Hn1 * nu, [&](int it) { io.Y0s[(size_t)io.n_noise * Hn1 * nu + it] = dm::clip(io.Ybar[it], -1.f, 1.f); });
+        }
       } else {
         int timed_out = 0;
         if (w.lane == 0) {   // (bounded like the relay's wait: give up, raise the sticky error, never run on a stale state)

@@ -99,11 +99,15 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
   // profiles/r04_wave_times.txt).  A piece waits for its predecessor's hand-over (rollout_driver.h: the relay protocol, one
   // slot per rollout); predecessors are always EARLIER items, i.e. running or done: no deadlock.
   int q = n - io.n_first;   // queue position of this wavefront's first item (= its grid index)
+  if constexpr (QUEUE) {   // (the workspace's constant entries once per wavefront, not once per queue item: see rollout_sample)
+    dial::init_world(w, s);
+    dial::init_square(w, m, s);
+  }
   for (;;) {
     if constexpr (QUEUE) {
       if (io.slice_pieces > 0) { relay = q / B; n = q - relay * B; }
     }
-    dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay, QUEUE ? helper : -1);
+    dial::rollout_sample<TRACE>(w, m, tg, cfg, s, io, n, relay, QUEUE ? helper : -1, /*init_ws=*/!QUEUE);
     helper = -1;
 #ifdef DIAL_PROFILE
     if (io.prof && w.lane == 0) {   // 100 MHz wall clock; then this rollout's event counters (on-units, solver calls, LS iters, Newton iters)
@@ -169,11 +173,15 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   //  a second instantiation: the code costs registers and a lone wavefront's pace, which batches that do not need it should not pay)
   const int Bq = INLINE ? B - io.mean_inline : B;                  // rollouts the grid / the queue holds
   int helper = INLINE && io.mean_inline && pair < io.T ? pair : -1;   // (first round only)
+  if constexpr (QUEUE) {   // (the workspaces' constant entries once per wavefront, not once per pair drawn from the queue)
+    dial::init_world(w, s);
+    dial::init_square(w, m, s);
+  }
   for (;;) {
     const int n = 2 * pair + w.half + io.n_first;
     // (measured and not kept: the highest issue priority for the odd wavefront of a batch -- N + 1 = 2049 is 1024 full
     //  wavefronts and the mean trajectory alone in the 1025th, which shares a SIMD -- starves its SIMD-mate: 0.408 -> 0.440 ms)
-    if (n < Bq) dial::rollout_sample<false>(w, m, tg, cfg, s, io, n, -1, helper);
+    if (n < Bq) dial::rollout_sample<false>(w, m, tg, cfg, s, io, n, -1, helper, /*init_ws=*/!QUEUE);
     helper = -1;
     if constexpr (!QUEUE) break;
     if (!next) break;

@@ -82,6 +82,7 @@ inline float emu_tree32(const float* v) {     // half-wave sum (WaveH): the two 
 
 #define DIAL_MARK(w, id)
 #define DIAL_LANE_SCOPE(w)
+#define DIAL_LANE_SCOPE_IF(cond, w)
 struct Wave {
   static constexpr bool half2 = false;   // (WaveH below: two samples per wavefront, this object is one 32-lane half)
   bool tree_sums = false;                // wave sums in the GPU's association (see emu_row_tree)
@@ -389,6 +390,16 @@ struct LaneScope {
   __device__ __forceinline__ ~LaneScope() { w.lane = keep; w.lane_r = keep_r; }
 };
 #define DIAL_LANE_SCOPE(w) LaneScope<std::remove_reference_t<decltype(w)>> dial_lane_scope_(w)
+// the same, compiled in only where COND (a compile-time condition) holds
+template <bool COND, class W>
+struct LaneScopeIf {
+  __device__ __forceinline__ explicit LaneScopeIf(W&) {}
+};
+template <class W>
+struct LaneScopeIf<true, W> : LaneScope<W> {
+  __device__ __forceinline__ explicit LaneScopeIf(W& w_) : LaneScope<W>(w_) {}
+};
+#define DIAL_LANE_SCOPE_IF(cond, w) LaneScopeIf<(cond), std::remove_reference_t<decltype(w)>> dial_lane_scope_if_(w)
 #ifdef DIAL_PROFILE
 #define DIAL_NSEC 32
 #define DIAL_MARK(w, id) (w).mark(id)
