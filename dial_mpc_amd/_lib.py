@@ -152,6 +152,9 @@ def load(path: Optional[str] = None):
     lib.dial_rng_fill.argtypes = [vp, u64, u32, ci, ci, fp, vp]
     lib.dial_shard_ybar_rng.argtypes = [vp, fp, ci, u64, u32, fp, fp, ci, fp, vp]
     lib.dial_shard_pack_rewards.argtypes = [vp, fp, ci, ci, ci, fp, vp]
+    lib.dial_shard_ybar_gathered.argtypes = [vp, fp, ci, ci, ci, fp, fp, fp, ci, fp, fp, vp]
+    lib.dial_shard_ybar_gathered_rng.argtypes = [vp, fp, ci, ci, ci, u64, u32, fp, fp, ci, fp, fp, vp]
+    lib.dial_shard_reduce_gathered.argtypes = [vp, fp, ci, ci, ci, ci, ci, ci, fp, fp, vp]
     lib.dial_shift.argtypes = [vp, fp, vp]
     lib.dial_env_step.argtypes = [vp, fp, fp, fp, fp, fp, vp]
     lib.dial_env_reset.argtypes = [vp, fp, fp, fp, fp, fp, vp]
@@ -171,7 +174,8 @@ def load(path: Optional[str] = None):
 
 EXPORTED = ("dial_create", "dial_create_sharded", "dial_create_ex", "dial_set_state_trace", "dial_destroy", "dial_last_error", "dial_rollout", "dial_reverse_once",
             "dial_shard_rollout", "dial_shard_reduce", "dial_shard_ybar", "dial_reverse_once_rng",
-            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards", "dial_shift", "dial_env_step", "dial_env_reset", "dial_env_reset_batch",
+            "dial_shard_rollout_rng", "dial_rng_fill", "dial_shard_ybar_rng", "dial_shard_pack_rewards",
+            "dial_shard_ybar_gathered", "dial_shard_ybar_gathered_rng", "dial_shard_reduce_gathered", "dial_shift", "dial_env_step", "dial_env_reset", "dial_env_reset_batch",
             "dial_status", "dial_set_timing", "dial_get_rollout_ms", "dial_abi_sizes")
 
 
@@ -344,6 +348,21 @@ class Context:
     def shard_pack_rewards(self, gathered, world: int, per: int, n_total: int, rews_all):
         self._check(self.lib.dial_shard_pack_rewards(self.h, _ptr(gathered), world, per, n_total, _ptr(rews_all), _stream()),
                     "dial_shard_pack_rewards")
+
+    # phase B straight from the all-gather's receive buffer (the packing step runs inside the weights kernel; rews_all receives the
+    # packed rewards): two launches per iteration instead of four
+    def shard_ybar_gathered(self, gathered, world: int, per: int, n_total: int, eps_all, Ybar, noise_scale, rews_all, Ybar_out):
+        self._check(self.lib.dial_shard_ybar_gathered(self.h, _ptr(gathered), world, per, n_total, _ptr(eps_all), _ptr(Ybar), _ptr(noise_scale),
+                                                      int(noise_scale.numel()), _ptr(rews_all), _ptr(Ybar_out), _stream()), "dial_shard_ybar_gathered")
+
+    def shard_ybar_gathered_rng(self, gathered, world: int, per: int, n_total: int, seed: int, counter: int, Ybar, noise_scale, rews_all, Ybar_out):
+        self._check(self.lib.dial_shard_ybar_gathered_rng(self.h, _ptr(gathered), world, per, n_total, int(seed), int(counter), _ptr(Ybar),
+                                                          _ptr(noise_scale), int(noise_scale.numel()), _ptr(rews_all), _ptr(Ybar_out), _stream()),
+                    "dial_shard_ybar_gathered_rng")
+
+    def shard_reduce_gathered(self, gathered, world: int, per: int, n_total: int, n_begin: int, n_local: int, include_mean: bool, rews_all, packed_out):
+        self._check(self.lib.dial_shard_reduce_gathered(self.h, _ptr(gathered), world, per, n_total, n_begin, n_local, int(include_mean),
+                                                        _ptr(rews_all), _ptr(packed_out), _stream()), "dial_shard_reduce_gathered")
 
     def packed_size(self) -> int:
         T, Hn1 = self.cfg.Hsample + 1, self.cfg.Hnode + 1

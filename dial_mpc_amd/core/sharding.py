@@ -14,7 +14,8 @@ available everywhere.  The softmax couples all samples through the global std / 
      packed partial weighted sums [Ybar | qbar | qdbar | xbar] (5.4 KB for Go2).
 
 Both messages are KB-sized, i.e. latency-bound on xGMI.  The collective staging buffers are allocated once (``ShardPlan``), results are fresh tensors; an iteration
-is 1 rollout launch + the all-gather + 1 packing launch + 3 K4 launches (+ the all-reduce).  The compute backend is
+is 1 rollout launch + the all-gather + 2 K4 launches (+ the all-reduce): the weights kernel reads the all-gather's receive buffer
+directly (rounds 2-5: a packing launch), the weighted sums finish in the launch that forms them (rounds 1-5: a second launch).  The compute backend is
 passed in as ``ctx`` (``dial_mpc_amd._lib.Context`` in production) so that the partition / collective logic is
 testable with gloo on CPU against a stand-in context.
 """
@@ -58,27 +59,28 @@ def sharded_reverse_once(ctx, dist, rank: int, world: int, N: int, T: int, Hn1: 
     per, n_begin, n_local = plan.per, plan.n_begin, plan.n_local
     # phase A: this rank's rollouts; rewards land in the all-gather send buffer ([0, n_local) noisy, [n_local] mean;
     # rank 0 always holds a full shard, so its mean reward sits in slot `per`, where dial_shard_pack_rewards reads it)
+    mode = 1 if want_bars else 3   # bit 0: with the mean trajectory; bit 1 (DIAL_SHARD_LEAN): no per-step states / nodes are materialised
     if eps is None:
         seed, counter = rng
-        ctx.shard_rollout_rng(packed_state, Ybar_i, noise_scale, seed, counter, n_begin, n_local, True, plan.send)
+        ctx.shard_rollout_rng(packed_state, Ybar_i, noise_scale, seed, counter, n_begin, n_local, mode, plan.send)
     else:
-        ctx.shard_rollout(packed_state, Ybar_i, noise_scale, eps[n_begin:n_begin + n_local], n_local, True, plan.send)
+        ctx.shard_rollout(packed_state, Ybar_i, noise_scale, eps[n_begin:n_begin + n_local], n_local, mode, plan.send)
     dist.all_gather_into_tensor(plan.gathered, plan.send)
     # Results go into FRESH tensors (allocator bookkeeping, no kernel): callers keep `info` dicts across ticks
     # (dial_core.main reads xbar of every tick at the very end), so nothing handed out may alias a buffer the next call
     # writes.  Only the collective's own staging buffers (send / gathered) are reused.
     import torch
     rews_all = torch.empty_like(plan.rews_all)
-    ctx.shard_pack_rewards(plan.gathered, world, per, N, rews_all)
+    # phase B reads the all-gather's receive buffer directly: the weights kernel puts the rewards in order on the way (-> rews_all)
     if not want_bars:
         Ybar = torch.empty_like(plan.Ybar)
         if eps is None:
-            ctx.shard_ybar_rng(rews_all, N, seed, counter, Ybar_i, noise_scale, Ybar)
+            ctx.shard_ybar_gathered_rng(plan.gathered, world, per, N, seed, counter, Ybar_i, noise_scale, rews_all, Ybar)
         else:
-            ctx.shard_ybar(rews_all, N, eps, Ybar_i, noise_scale, Ybar)
+            ctx.shard_ybar_gathered(plan.gathered, world, per, N, eps, Ybar_i, noise_scale, rews_all, Ybar)
         return Ybar, rews_all, None, None, None
     packed = torch.empty_like(plan.packed)
-    ctx.shard_reduce(rews_all, N, n_begin, n_local, rank == 0, packed)
+    ctx.shard_reduce_gathered(plan.gathered, world, per, N, n_begin, n_local, rank == 0, rews_all, packed)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     nq, nv, nx, nu = ctx.nq, ctx.nv, ctx.nx, ctx.nu
     o = 0

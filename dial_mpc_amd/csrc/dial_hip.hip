@@ -37,6 +37,7 @@ DIAL_KERNELS2_GO2(DIAL_X2)
 #undef DIAL_XE
 
 #define WSUM_CHUNKS 64
+#define YB_CHUNKS_HOST 128   // = YB_CHUNKS (defined with its kernel below)
 
 #ifndef DIAL_GO2_LARGE_B
 #define DIAL_GO2_LARGE_B 2304   /* batches above this many rollouts use the large-batch instantiation */
@@ -74,10 +75,23 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // K4a (dial_core.py:121-128): rews [B] (last = mean trajectory) -> softmax weights [B].
 // logp0 = (rews - rew_bar) / std(rews) / temp; std is the population std over all B samples.
+// `gathered` != nullptr (sharded runs): the rewards arrive as the all-gather delivered them -- [world][per + 1]: every rank's noisy
+// samples, then its copy of the mean-trajectory reward -- and are put into the order K4 wants ([n_total noisy | mean], written to
+// `rews_out`) by this kernel's first pass: the packing launch of rounds 2-5 (dial_shard_pack_rewards) is gone from the iteration.
 extern "C" __global__ void __launch_bounds__(WK_THREADS)
-weights_kernel(const float* __restrict__ rews, int B, float temp, float* __restrict__ weights) {
+weights_kernel(const float* __restrict__ rews_in, int B, float temp, float* __restrict__ weights, const float* __restrict__ gathered,
+               int per, float* __restrict__ rews_out) {
   __shared__ float red[WK_THREADS / 64];
   const int tid = threadIdx.x;
+  const float* rews = rews_in;
+  if (gathered) {
+    const int n_total = B - 1;
+    for (int n = tid; n < B; n += WK_THREADS)
+      rews_out[n] = n < n_total ? gathered[(size_t)(n / per) * (per + 1) + (n % per)] : gathered[per];   // (rank 0's mean-trajectory reward: bit-identical on every rank)
+    __threadfence_block();
+    __syncthreads();
+    rews = rews_out;
+  }
   float acc = 0.f, mxr = -INFINITY;
   for (int n = tid; n < B; n += WK_THREADS) { float r = rews[n]; acc += r; mxr = r > mxr ? r : mxr; }
   const float mean = block_sum(acc, red) / (float)B;
@@ -108,6 +122,9 @@ struct WsumArgs { WsumSeg seg[4]; int nseg, Ctot, n_rows, w_begin, mean_row, mea
 
 // Block = 64 columns x 4 wavefronts; wavefront g takes every 4th row of the block's row chunk, the four partial
 // sums are combined in a fixed order through LDS (deterministic, bit-identical on every rank).
+// Two launches.  (Round 6 tried ONE -- the block that draws the last ticket of its column block sums the chunks -- and measured the full
+// iteration 95 us SLOWER at N = 2048: on this multi-XCD part a device-scope release / acquire fence inside a kernel writes back and
+// invalidates the XCD's L2, 1408 blocks each paying for it; a kernel boundary does the same once.  profiles/r06_k4_fusion.txt)
 extern "C" __global__ void __launch_bounds__(256)
 wsum_partial_kernel(WsumArgs a, const float* __restrict__ weights, float* __restrict__ partial) {
   __shared__ float red[4][64];
@@ -140,44 +157,71 @@ wsum_final_kernel(WsumArgs a, const float* __restrict__ partial) {
   int sg = 0;
   for (int k = 1; k < a.nseg; k++) if (c >= a.seg[k].c0) sg = k;
   float acc = 0.f;
+#pragma unroll 16   // (sixteen independent loads in flight; the additions keep their order)
   for (int ch = 0; ch < WSUM_CHUNKS; ch++) acc += partial[(size_t)ch * a.Ctot + c];
   if (a.seg[sg].out) a.seg[sg].out[c - a.seg[sg].c0] = acc;
 }
 
-// Weighted mean of ALL candidate nodes, regenerated from the noise (dial_core.py:110-115,132): two passes with
-// a fixed reduction order.  partial: [YB_CHUNKS, C], C = (Hnode+1)*nu.
+// Weighted mean of ALL candidate nodes, regenerated from the noise (dial_core.py:110-115,132), with a fixed reduction order
+// (bit-identical on every rank).  Round 6: parallel over (row chunk, Philox quad) -- rounds 2-5 ran one 64-thread block
+// per chunk with one thread per COLUMN, i.e. every Philox quad was drawn four times and a rank spent 70 us here at N = 8192 (0.3 ms at
+// cfg 5's N = 65536: more than a third of its rollout launch).
+//   block = 16 row lanes x 16 quads (quad = four consecutive columns = one Philox4x32 draw), grid = (ceil(quads / 16), YB_CHUNKS);
+//   thread (r, q) adds rows r0 + r, r0 + r + 16, ... of its chunk for the quad's four columns; the 16 row lanes are combined in a
+//   fixed order through LDS; a second launch sums the chunks (order 0, 1, ...; see wsum_partial_kernel for why not a ticket).
 #define YB_CHUNKS 128
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(256)
 ybar_partial_kernel(const float* __restrict__ weights, const float* __restrict__ eps, const float* __restrict__ Ybar,
-                    const float* __restrict__ noise_scale, int ns, int n_total, int C, int nu,
-                    float* __restrict__ partial, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  const int k = c / nu, chunk = blockIdx.y, per = (n_total + 1 + YB_CHUNKS - 1) / YB_CHUNKS;
+                    const float* __restrict__ noise_scale, int ns, int n_total, int C, int nu, float* __restrict__ partial,
+                    uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
+  __shared__ float red[16][64];
+  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + ql, c0 = 4 * q;                 // this thread's quad: columns c0 .. c0 + 3
+  const int chunk = blockIdx.y, per = (n_total + 1 + YB_CHUNKS - 1) / YB_CHUNKS;
   const int r0 = chunk * per, r1 = (r0 + per < n_total + 1) ? r0 + per : n_total + 1;
-  const float yb = Ybar[c], sc = noise_scale[ns == 1 ? 0 : k], y0 = Ybar[c - k * nu];
-  float acc = 0.f;
-  for (int n = r0; n < r1; n++) {
-    float e = 0.f;
-    if (n < n_total && k != 0) {
-      if (eps) e = eps[(size_t)n * C + c];
-      else {   // regenerate the sample's noise exactly as the rollout prologue drew it (Philox keyed by seed / iteration / sample / quad)
-        float z[4];
-        dial::normal_quad((uint32_t)n, (uint32_t)(c >> 2), iter, seed_lo, seed_hi, z);
-        e = z[c & 3];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, yb[4] = {0.f, 0.f, 0.f, 0.f}, y0[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+  int kk[4] = {0, 0, 0, 0};
+  if (c0 < C) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c0 + e < C ? c0 + e : C - 1, k = c / nu;
+      kk[e] = k; yb[e] = Ybar[c]; y0[e] = Ybar[c - k * nu]; sc[e] = noise_scale[ns == 1 ? 0 : k];
+    }
+    for (int n = r0 + rl; n < r1; n += 16) {
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n < n_total) {
+        if (eps) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) z[e] = c0 + e < C ? eps[(size_t)n * C + c0 + e] : 0.f;
+        } else {   // the sample's noise exactly as the rollout prologue drew it (Philox keyed by seed / iteration / sample / quad)
+          dial::normal_quad((uint32_t)n, (uint32_t)q, iter, seed_lo, seed_hi, z);
+        }
+      }
+      const float wn = weights[n];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float v = n < n_total ? (kk[e] == 0 ? y0[e] : z[e] * sc[e] + yb[e]) : yb[e];
+        v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+        acc[e] += wn * v;
       }
     }
-    float v = n < n_total ? (k == 0 ? y0 : e * sc + yb) : yb;
-    v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
-    acc += weights[n] * v;
   }
-  partial[(size_t)chunk * C + c] = acc;
+#pragma unroll
+  for (int e = 0; e < 4; e++) red[rl][4 * ql + e] = acc[e];
+  __syncthreads();
+  const int cl = threadIdx.x, c = blockIdx.x * 64 + cl;            // threads 0 .. 63: one column of the block each
+  if (cl < 64 && c < C) {
+    float t = 0.f;
+    for (int r = 0; r < 16; r++) t += red[r][cl];
+    partial[(size_t)chunk * C + c] = t;
+  }
 }
 extern "C" __global__ void __launch_bounds__(64)
 ybar_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ out) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   float acc = 0.f;
+#pragma unroll 16
   for (int ch = 0; ch < YB_CHUNKS; ch++) acc += partial[(size_t)ch * C + c];
   out[c] = acc;
 }
@@ -468,6 +512,11 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
       ctx->ws_words = ws_carve(s, (float*)0, model->nq, model->nv, model->nu, model->nbody, model->njnt,
                                model->ngeom, model->nsite, model->ncon, model->nefc, nnode, dial::kNeedL<D>, D::square,
                                D::ell ? D::JCW : 0, ctx->con_cap, D::NVP, (D::pre_ctrl && cfg) ? cfg->Hsample + 1 : 0);
+#ifdef DIAL_WS_SKEW
+      // measurement switch (round 6, LDS bank conflicts of the two-rollouts-per-wavefront kernels): the workspaces of a workgroup
+      // start DIAL_WS_SKEW words past a multiple of 32 words (= the 32 LDS banks) from each other
+      ctx->ws_words = (ctx->ws_words + 31) / 32 * 32 + DIAL_WS_SKEW;
+#endif
       ctx->lds_bytes = ctx->cm_bytes + (size_t)ws0 * sizeof(float);
       ctx->lds_rollout = ctx->cm_bytes + (size_t)ctx->wpb * ctx->ws_words * sizeof(float);
 #ifdef DIAL_PROFILE
@@ -647,7 +696,9 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     HIP_TRY_CREATE(hipMalloc(&ctx->xss, sizeof(float) * B * T * ctx->nx));
     HIP_TRY_CREATE(hipMalloc(&ctx->weights, sizeof(float) * ctx->W_cap));
     const size_t Ctot = (size_t)ctx->Hn1 * model->nu + T * (model->nq + model->nv + ctx->nx);
-    HIP_TRY_CREATE(hipMalloc(&ctx->partial, sizeof(float) * WSUM_CHUNKS * Ctot));
+    // K4b's partial sums: [chunk][Ctot] (wsum_partial_kernel) or the mean-action kernel's [YB_CHUNKS][C] (ybar_partial_kernel), whichever is larger
+    const size_t part_w = ((Ctot + 63) / 64) * (size_t)WSUM_CHUNKS * 64, part_y = (((size_t)ctx->Hn1 * model->nu + 63) / 64) * (size_t)YB_CHUNKS_HOST * 64;
+    HIP_TRY_CREATE(hipMalloc(&ctx->partial, sizeof(float) * (part_w > part_y ? part_w : part_y)));
     // 32 section / event counters + (profile builds) a start / end timestamp per rollout of the last launch
     HIP_TRY_CREATE(hipMalloc(&ctx->prof, sizeof(unsigned long long) * (32 + 6 * B)));
     HIP_TRY_CREATE(hipMemset(ctx->prof, 0, sizeof(unsigned long long) * (32 + 6 * B)));
@@ -909,11 +960,16 @@ static int shard_rollout_impl(dial_ctx* ctx, const float* state, const float* Yb
     return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
   if (!ctx->has_cfg) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": context was created without a dial_cfg");
   if (ns != 1 && ns != ctx->Hn1) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": noise_scale must have 1 or Hnode+1 entries");
+  // with_mean: bit 0 = roll out the mean trajectory as an extra sample; bit 1 (DIAL_SHARD_LEAN) = the caller wants the mean action only
+  // (dial_shard_ybar*): the rollouts do not materialise their per-step states nor their candidate nodes
+  if (with_mean & 2) store_states = false;
+  const bool lean = (with_mean & 2) != 0;
+  with_mean &= 1;
   const int B = n_local + (with_mean ? 1 : 0);
   if (n_local < 0 || B < 1 || B > ctx->B_cap || n_begin < 0) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": shard larger than Nsample+1");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dial::RolloutIO io{state, nullptr, eps, Ybar_in, noise_scale, ns, n_local, ctx->T, ctx->Hn1,
-                     ctx->Y0s, ctx->rewss, rews_local, store_states ? ctx->qss : nullptr, store_states ? ctx->qdss : nullptr,
+                     lean ? nullptr : ctx->Y0s, ctx->rewss, rews_local, store_states ? ctx->qss : nullptr, store_states ? ctx->qdss : nullptr,
                      store_states ? ctx->xss : nullptr, ctx->prof,
                      use_rng, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter, n_begin};
   return launch_rollout(ctx, io, B, (hipStream_t)stream);
@@ -965,16 +1021,20 @@ static int launch_wsum(dial_ctx* ctx, const float* weights, int n_rows, int w_be
   return DIAL_OK;
 }
 
-int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin, int n_local, int with_mean,
-                      float* packed_out, void* stream) {
-  if (!ctx || !rews_all || !packed_out) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: null argument");
+// gathered != nullptr: the rewards as the all-gather delivered them ([world][per + 1]); the weights kernel puts them in order on the
+// way (-> rews_out).  Otherwise rews_all is read as is.
+static int shard_reduce_impl(dial_ctx* ctx, const float* rews_all, const float* gathered, int world, int per, float* rews_out,
+                             int n_total, int n_begin, int n_local, int with_mean, float* packed_out, void* stream, const char* who) {
+  if (!ctx || (!rews_all && !gathered) || !packed_out) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
+  if (gathered && (!rews_out || world < 1 || per < 1 || n_total < 1 || (long long)world * per < n_total))
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": bad description of the gathered rewards");
   if (!ctx->has_cfg || n_local < 0 || n_local + 1 > ctx->B_cap || n_begin < 0 || n_begin + n_local > n_total)
-    return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: bad shard description");
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": bad shard description");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   // the global weights need n_total+1 floats of ctx->weights
-  if (n_total + 1 > ctx->W_cap) return fail(ctx, DIAL_ERR_ARG, "dial_shard_reduce: n_total exceeds the context's Nsample (create it with Nsample = global sample count)");
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  if (n_total + 1 > ctx->W_cap) return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": n_total exceeds the context's Nsample (create it with Nsample = global sample count)");
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights, gathered, per, rews_out);
   HIP_TRY(ctx, hipGetLastError());
   const dial_model& m = ctx->hm;
   float* Yo = packed_out;
@@ -985,22 +1045,33 @@ int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_b
   // when requested there); it contributes to the partial sums only when with_mean != 0.
   return launch_wsum(ctx, ctx->weights, n_local + 1, n_begin, n_local, with_mean ? n_total : -1, Yo, qo, qdo, xo, st);
 }
+int dial_shard_reduce(dial_ctx* ctx, const float* rews_all, int n_total, int n_begin, int n_local, int with_mean,
+                      float* packed_out, void* stream) {
+  return shard_reduce_impl(ctx, rews_all, nullptr, 0, 0, nullptr, n_total, n_begin, n_local, with_mean, packed_out, stream, "dial_shard_reduce");
+}
+int dial_shard_reduce_gathered(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, int n_begin, int n_local,
+                               int with_mean, float* rews_all_out, float* packed_out, void* stream) {
+  return shard_reduce_impl(ctx, nullptr, gathered, world, per, rews_all_out, n_total, n_begin, n_local, with_mean, packed_out, stream,
+                           "dial_shard_reduce_gathered");
+}
 
-static int shard_ybar_impl(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, int use_rng, uint64_t seed,
+static int shard_ybar_impl(dial_ctx* ctx, const float* rews_all, const float* gathered, int world, int per, float* rews_out,
+                           int n_total, const float* eps_all, int use_rng, uint64_t seed,
                            uint32_t counter, const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out,
                            void* stream, const char* who) {
-  if (!ctx || !rews_all || (!eps_all && !use_rng) || !Ybar_in || !noise_scale || !Ybar_out)
+  if (!ctx || (!rews_all && !gathered) || (!eps_all && !use_rng) || !Ybar_in || !noise_scale || !Ybar_out)
     return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": null argument");
+  if (gathered && (!rews_out || world < 1 || per < 1 || (long long)world * per < n_total))
+    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": bad description of the gathered rewards");
   if (!ctx->has_cfg || n_total + 1 > ctx->W_cap || n_total < 1 || (ns != 1 && ns != ctx->Hn1))
     return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": bad arguments (create the context with Nsample = global sample count)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  const int C = ctx->Hn1 * ctx->hm.nu;
-  if ((size_t)YB_CHUNKS * C > (size_t)WSUM_CHUNKS * ((size_t)C + ctx->T * (ctx->hm.nq + ctx->hm.nv + ctx->nx)))
-    return fail(ctx, DIAL_ERR_ARG, std::string(who) + ": scratch too small");
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights);
+  const int C = ctx->Hn1 * ctx->hm.nu, nquad = (C + 3) / 4;
+  static_assert(YB_CHUNKS == YB_CHUNKS_HOST, "the scratch buffer is sized with YB_CHUNKS_HOST");
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, rews_all, n_total + 1, ctx->hc.temp_sample, ctx->weights, gathered, per, rews_out);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(ybar_partial_kernel, dim3((C + 63) / 64, YB_CHUNKS), dim3(64), 0, st, (const float*)ctx->weights,
+  hipLaunchKernelGGL(ybar_partial_kernel, dim3((nquad + 15) / 16, YB_CHUNKS), dim3(256), 0, st, (const float*)ctx->weights,
                      eps_all, Ybar_in, noise_scale, ns, n_total, C, ctx->hm.nu, ctx->partial,
                      (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter);
   hipLaunchKernelGGL(ybar_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)ctx->partial, C, Ybar_out);
@@ -1010,13 +1081,25 @@ static int shard_ybar_impl(dial_ctx* ctx, const float* rews_all, int n_total, co
 
 int dial_shard_ybar(dial_ctx* ctx, const float* rews_all, int n_total, const float* eps_all, const float* Ybar_in,
                     const float* noise_scale, int ns, float* Ybar_out, void* stream) {
-  return shard_ybar_impl(ctx, rews_all, n_total, eps_all, 0, 0, 0, Ybar_in, noise_scale, ns, Ybar_out, stream, "dial_shard_ybar");
+  return shard_ybar_impl(ctx, rews_all, nullptr, 0, 0, nullptr, n_total, eps_all, 0, 0, 0, Ybar_in, noise_scale, ns, Ybar_out, stream, "dial_shard_ybar");
 }
 
 int dial_shard_ybar_rng(dial_ctx* ctx, const float* rews_all, int n_total, uint64_t seed, uint32_t counter,
                         const float* Ybar_in, const float* noise_scale, int ns, float* Ybar_out, void* stream) {
-  return shard_ybar_impl(ctx, rews_all, n_total, nullptr, 1, seed, counter, Ybar_in, noise_scale, ns, Ybar_out, stream,
+  return shard_ybar_impl(ctx, rews_all, nullptr, 0, 0, nullptr, n_total, nullptr, 1, seed, counter, Ybar_in, noise_scale, ns, Ybar_out, stream,
                          "dial_shard_ybar_rng");
+}
+
+int dial_shard_ybar_gathered(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, const float* eps_all,
+                             const float* Ybar_in, const float* noise_scale, int ns, float* rews_all_out, float* Ybar_out, void* stream) {
+  return shard_ybar_impl(ctx, nullptr, gathered, world, per, rews_all_out, n_total, eps_all, 0, 0, 0, Ybar_in, noise_scale, ns, Ybar_out, stream,
+                         "dial_shard_ybar_gathered");
+}
+
+int dial_shard_ybar_gathered_rng(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, uint64_t seed, uint32_t counter,
+                                 const float* Ybar_in, const float* noise_scale, int ns, float* rews_all_out, float* Ybar_out, void* stream) {
+  return shard_ybar_impl(ctx, nullptr, gathered, world, per, rews_all_out, n_total, nullptr, 1, seed, counter, Ybar_in, noise_scale, ns, Ybar_out,
+                         stream, "dial_shard_ybar_gathered_rng");
 }
 
 int dial_shard_pack_rewards(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, float* rews_all,
@@ -1043,7 +1126,7 @@ static int reverse_once_impl(dial_ctx* ctx, const float* state, const float* Yba
   int rc = shard_rollout_impl(ctx, state, Ybar_in, noise_scale, ns, eps, use_rng, seed, counter, 0, N, 1, rews, stream, who, bars);
   if (rc != DIAL_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights);
+  hipLaunchKernelGGL(weights_kernel, dim3(1), dim3(WK_THREADS), 0, st, (const float*)rews, N + 1, ctx->hc.temp_sample, ctx->weights, (const float*)nullptr, 0, (float*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return launch_wsum(ctx, ctx->weights, N + 1, 0, N, N, Ybar_out, qbar, qdbar, xbar, st, !bars);
 }

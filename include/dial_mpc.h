@@ -389,6 +389,9 @@ int dial_reverse_once(dial_ctx* ctx, const float* state, const float* Ybar_in,
  * its per-sample mean rewards; the caller all-gathers rews over ranks; phase B forms the global
  * weights redundantly on every rank and this rank's partial weighted sums, which the caller
  * all-reduces (sum).  packed_out: [ (Hnode+1)*nu | T*nq | T*nv | T*(nbody-1)*3 ] floats.     */
+/* with_mean: bit 0 = also roll out the mean trajectory (every rank does); bit 1 (DIAL_SHARD_LEAN) = the iteration will be finished by
+ * dial_shard_ybar* (mean action only): the rollouts then write neither their per-step states nor their candidate nodes.       */
+#define DIAL_SHARD_LEAN 2
 int dial_shard_rollout(dial_ctx* ctx, const float* state, const float* Ybar_in,
                        const float* noise_scale, int ns, const float* eps, int n_local,
                        int with_mean, float* rews_local, void* stream);
@@ -422,6 +425,19 @@ int dial_shard_ybar_rng(dial_ctx* ctx, const float* rews_all, int n_total, uint6
  * = [all noisy samples | mean trajectory], the layout dial_shard_reduce / dial_shard_ybar* consume.      */
 int dial_shard_pack_rewards(dial_ctx* ctx, const float* gathered, int world, int per, int n_total,
                             float* rews_all, void* stream);
+/* The sharded iteration's phase B straight from the all-gather's receive buffer (round 6): the packing step runs inside the weights
+ * kernel (rews_all_out:[n_total+1] receives what dial_shard_pack_rewards would have written), so a lean iteration is the rollout
+ * launch + the all-gather + TWO launches (weights, weighted mean action), a full one the rollout + all-gather + two launches
+ * (weights, weighted sums) + the all-reduce.  Same results as dial_shard_pack_rewards followed by dial_shard_ybar[_rng] /
+ * dial_shard_reduce.                                                                                                    */
+int dial_shard_ybar_gathered(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, const float* eps_all,
+                             const float* Ybar_in, const float* noise_scale, int ns, float* rews_all_out, float* Ybar_out,
+                             void* stream);
+int dial_shard_ybar_gathered_rng(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, uint64_t seed,
+                                 uint32_t counter, const float* Ybar_in, const float* noise_scale, int ns,
+                                 float* rews_all_out, float* Ybar_out, void* stream);
+int dial_shard_reduce_gathered(dial_ctx* ctx, const float* gathered, int world, int per, int n_total, int n_begin,
+                               int n_local, int with_mean, float* rews_all_out, float* packed_out, void* stream);
 
 /* K5. MBDPI.shift (dial_core.py:160-166): Y:[Hnode+1,nu] in place. */
 int dial_shift(dial_ctx* ctx, float* Y, void* stream);

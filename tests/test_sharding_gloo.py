@@ -55,6 +55,15 @@ class FakeCtx:
         g = gathered.numpy().reshape(world, per + 1)
         rews_all.copy_(torch.from_numpy(np.concatenate([g[:, :per].reshape(-1)[:n_total], g[0, per:per + 1]])))
 
+    # the fused entry points of round 6 (phase B straight from the all-gather's receive buffer)
+    def shard_ybar_gathered(self, gathered, world, per, n_total, eps_all, Ybar, noise_scale, rews_all, Ybar_out):
+        self.shard_pack_rewards(gathered, world, per, n_total, rews_all)
+        self.shard_ybar(rews_all, n_total, eps_all, Ybar, noise_scale, Ybar_out)
+
+    def shard_reduce_gathered(self, gathered, world, per, n_total, n_begin, n_local, include_mean, rews_all, packed_out):
+        self.shard_pack_rewards(gathered, world, per, n_total, rews_all)
+        self.shard_reduce(rews_all, n_total, n_begin, n_local, include_mean, packed_out)
+
     def shard_ybar(self, rews_all, n_total, eps_all, Ybar, noise_scale, Ybar_out):
         r = rews_all.numpy().astype(np.float32)
         logp = (r - r[-1]) / r.std() / np.float32(self.cfg.temp_sample)
