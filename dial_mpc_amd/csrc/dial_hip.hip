@@ -50,12 +50,28 @@ DIAL_KERNELS2_GO2(DIAL_X2)
 // Deterministic block reductions (1024 threads = 16 wavefronts): DPP butterfly inside each wavefront, then a
 // fixed-order sum of the 16 partials.  The order never depends on timing => bit-identical on every rank.
 #define WK_THREADS 1024
+#ifndef DIAL_K4_FP64
+#define DIAL_K4_FP64 0   // measurement switch: the softmax statistics in fp64 (see weights_kernel)
+#endif
 __device__ __forceinline__ float block_sum(float v, float* red) {
   const int tid = threadIdx.x;
   float ws = dialwave::wave_sum_dpp(v);
   if ((tid & 63) == 0) red[tid >> 6] = ws;
   __syncthreads();
   float r = 0.f;
+#pragma unroll
+  for (int k = 0; k < WK_THREADS / 64; k++) r += red[k];
+  __syncthreads();
+  return r;
+}
+// the same in fp64 (the softmax's mean / variance / normaliser: see weights_kernel): xor-butterfly inside the wavefront (the same
+// association in every lane), then the fixed-order sum of the 16 partials
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  const int tid = threadIdx.x;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
 #pragma unroll
   for (int k = 0; k < WK_THREADS / 64; k++) r += red[k];
   __syncthreads();
@@ -92,6 +108,28 @@ weights_kernel(const float* __restrict__ rews_in, int B, float temp, float* __re
     __syncthreads();
     rews = rews_out;
   }
+#if DIAL_K4_FP64
+  // (-DDIAL_K4_FP64=1, a measurement switch of round 6: mean, variance and normaliser in fp64, the logits from an fp64 1 / (std temp).
+  //  Closer to the exact softmax of the same rewards -- and therefore FURTHER from the reference's fp32 arithmetic, which the oracle
+  //  restates: the chained-plan replay test left its gate with it (acts 3.18e-3 off after five ticks vs the 3e-3 allowed).  What the
+  //  peaked-softmax sensitivity needed was the mean rewards themselves correctly rounded: rollout_driver.h sums them in fp64.)
+  __shared__ double redd[WK_THREADS / 64];
+  double accd = 0.0;
+  float mxr = -INFINITY;
+  for (int n = tid; n < B; n += WK_THREADS) { float r = rews[n]; accd += (double)r; mxr = r > mxr ? r : mxr; }
+  const double mean = block_sum_d(accd, redd) / (double)B;
+  const float rmax = block_max(mxr, red);
+  accd = 0.0;
+  for (int n = tid; n < B; n += WK_THREADS) { double d = (double)rews[n] - mean; accd += d * d; }
+  const double stdd = sqrt(block_sum_d(accd, redd) / (double)B);
+  const float stdv = (float)stdd;
+  const float rew_bar = rews[B - 1];
+  const double inv = 1.0 / (stdd * (double)temp);
+  const double mxd = ((double)rmax - (double)rew_bar) * inv;   // max of logp0: the map r -> logp0 is increasing
+  accd = 0.0;
+  for (int n = tid; n < B; n += WK_THREADS) { const float l = (float)(((double)rews[n] - (double)rew_bar) * inv - mxd); accd += (double)expf(l); }
+  const float den = (float)block_sum_d(accd, redd);
+#else   // the reference's own arithmetic: fp32 throughout (dial_core.py:126-128)
   float acc = 0.f, mxr = -INFINITY;
   for (int n = tid; n < B; n += WK_THREADS) { float r = rews[n]; acc += r; mxr = r > mxr ? r : mxr; }
   const float mean = block_sum(acc, red) / (float)B;
@@ -104,14 +142,20 @@ weights_kernel(const float* __restrict__ rews_in, int B, float temp, float* __re
   acc = 0.f;
   for (int n = tid; n < B; n += WK_THREADS) { float l = (rews[n] - rew_bar) / stdv / temp; acc += expf(l - mx); }
   const float den = block_sum(acc, red);
+#endif
   // std(rews) == 0 (all rewards identical): the reference divides 0 by 0 (dial_core.py:126) and every weight, hence
   // Ybar, becomes NaN.  Kept bug-compatible and DEFINED: the NaN is written as a bit pattern, because the device
   // code is compiled with -fno-honor-nans and a floating-point 0/0 would be undefined there.
   const bool degenerate = stdv == 0.f;
   uint32_t* wbits = reinterpret_cast<uint32_t*>(weights);
   for (int n = tid; n < B; n += WK_THREADS) {
+#if DIAL_K4_FP64
+    const float l = (float)(((double)rews[n] - (double)rew_bar) * inv - mxd);
+    const float wv = expf(l) / den;
+#else
     float l = (rews[n] - rew_bar) / stdv / temp;
     const float wv = expf(l - mx) / den;
+#endif
     wbits[n] = degenerate ? 0x7fc00000u : __builtin_bit_cast(uint32_t, wv);
   }
 }
@@ -522,7 +566,7 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
 #ifdef DIAL_PROFILE
       ctx->lds_rollout += 16 + (size_t)ctx->wpb * 32 * sizeof(unsigned long long);
 #endif
-      hipError_t e = hipMalloc(&ctx->dcm, sizeof(CModel<D>));
+      hipError_t e = hipMalloc(&ctx->dcm, (sizeof(CModel<D>) + 15) / 16 * 16);   // (the kernels stage it with 16-byte copies)
       if (e == hipSuccess) e = hipMemcpy(ctx->dcm, h, sizeof(CModel<D>), hipMemcpyHostToDevice);
       delete h;
       return e == hipSuccess ? DIAL_OK : DIAL_ERR_HIP;

@@ -36,6 +36,28 @@ DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
   });
 }
 
+#ifndef DIAL_RSUM_FP64
+#define DIAL_RSUM_FP64 1   // A/B switch: 0 = the fp32 running reward sum of rounds 1-5
+#endif
+#if DIAL_RSUM_FP64
+using rsum_t = double;
+#else
+using rsum_t = float;
+#endif
+// the running reward sum (fp64) in two 32-bit words of a hand-over slot (the slots are 4-byte aligned)
+#ifndef DIAL_EMU
+DIAL_DEV void store_sum(float* p, double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  reinterpret_cast<uint32_t*>(p)[0] = (uint32_t)b;
+  reinterpret_cast<uint32_t*>(p)[1] = (uint32_t)(b >> 32);
+}
+DIAL_DEV double load_sum(const float* p) {
+  const uint32_t lo = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t hi = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+#endif
+
 // `relay` >= 0: this wavefront runs piece `relay` of the mean-trajectory rollout (RolloutIO::relay_*): it prepares
 // everything that does not depend on its predecessor, waits for the predecessor's state, runs its control steps at the
 // highest issue priority and hands the state on.  Every piece is a different wavefront on a different SIMD, so the
@@ -120,7 +142,11 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       s.jtab[it] = act2joint(m, node2u(t, a), a);
     });
   }
-  float rsum = 0.f;
+  // the rollout's reward sum in fp64 (round 6): the mean reward then is the correctly rounded mean of the T fp32 step rewards.  With
+  // rewards near 10 (seq-jump: alive x 10) an fp32 running sum was up to 2.7 ulp off, and at an effective sample size of 1 .. 2 the
+  // softmax turns one ulp of a mean reward into 1.5e-4 of logit (tools/k4_sensitivity.py): the device's Ybar left its 1e-4 gate
+  // against the fp64 K4 of its own rollouts
+  rsum_t rsum = 0;
   w.set_rollout(n);
 #ifndef DIAL_EMU
   float* const rbuf = io.relay_buf ? io.relay_buf + (size_t)n * io.relay_stride : nullptr;   // this rollout's hand-over slot
@@ -149,7 +175,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     load_state(w, m, s, rbuf);
-    rsum = __hip_atomic_load(rbuf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rsum = load_sum(rbuf + nstate);
   }
   if (relay >= 0 && io.relay_stride == 0) w.hold_priority(3);   // (the lone relay rollout; the sliced queue keeps the fair sharing)
 #endif
@@ -172,7 +198,8 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   bool mean_now = false;   // this pass of the loop runs the mean trajectory's step `helper`, not an own step
   // the parked state: element l + k * KSTRIDE of the packed state in register k of (logical) lane l
   constexpr int KSTRIDE = W::half2 ? 32 : 64, NKEEP = W::half2 ? 4 : 2;
-  float keep[NKEEP] = {}, msum = 0.f;
+  float keep[NKEEP] = {};
+  rsum_t msum = 0;
   (void)packed; (void)keep; (void)msum;
   for (int st_own = st_begin; mean_now || st_own < st_end;) {
     const int st = mean_now ? helper : st_own;    // control step this pass runs ...
@@ -216,7 +243,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     const int work0 = w.work;
     if constexpr (PRE) { w.out_io = &io; w.out_row = row * T + st; }   // (the step's outputs are stored by the phases that produce them)
     float rew = env_step<false, PRE>(w, m, tg, s, st);
-    if (mean_now) msum += rew; else rsum += rew;
+    if (mean_now) msum += (rsum_t)rew; else rsum += (rsum_t)rew;
 #ifndef DIAL_EMU
     if constexpr (M::D::ell) {
       if (io.work_stat && relay < 0) {   // once per control step: add own work to the launch totals, compare rates, set the level
@@ -263,11 +290,11 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       // hand the mean trajectory on (or finish it), then resume the own rollout from the parked state
       if (helper + 1 < T) {
         store_state(w, m, s, io.relay_buf);
-        w.items(1, [&](int) { io.relay_buf[nstate] = msum; });
+        w.items(1, [&](int) { store_sum(io.relay_buf + nstate, msum); });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (w.lane == 0) __hip_atomic_store(io.relay_flag, helper + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        if (io.rews) { const float mean = msum / (float)T; w.items(1, [&](int) { io.rews[row] = mean; }); }
+        if (io.rews) { const float mean = (float)(msum / (rsum_t)T); w.items(1, [&](int) { io.rews[row] = mean; }); }
         if (w.lane == 0) __hip_atomic_store(io.relay_flag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
       }
       w.items(KSTRIDE, [&](int l) {
@@ -287,7 +314,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
       bool ok = true;
       if (helper == 0) {
         load_state(w, m, s, io.state);
-        msum = 0.f;
+        msum = 0;
         if (io.Y0s) {
           // (an opaque lane id for this once-per-launch copy: its two lane-derived 64-bit global addresses were hoisted out of the
           //  queue's rollout loop and spilled -- the 8 B + 8 B of scratch of the Allegro's time-sliced queue kernel, ISA round 6)
@@ -313,7 +340,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           load_state(w, m, s, io.relay_buf);
-          msum = __hip_atomic_load(io.relay_buf + nstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          msum = load_sum(io.relay_buf + nstate);
         }
       }
       mean_now = ok;   // (!ok: the predecessor never came -- the own rollout resumes, its state is still in the workspace)
@@ -331,7 +358,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   if (relay >= 0 && relay + 1 == io.debug_stall_piece1) return;   // test hook: a piece that never hands over (its successors time out)
   if (relay >= 0 && st_end < T) {   // hand over: state, running sum, then the flag (release)
     store_state(w, m, s, rbuf);
-    w.items(1, [&](int) { rbuf[nstate] = rsum; });
+    w.items(1, [&](int) { store_sum(rbuf + nstate, rsum); });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (w.lane == 0) __hip_atomic_store(rflag, relay + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
@@ -339,7 +366,7 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
   if (relay >= 0 && w.lane == 0) __hip_atomic_store(rflag, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // last piece: re-arm
 #endif
   if (io.rews) {
-    const float mean = rsum / (float)T;
+    const float mean = (float)(rsum / (rsum_t)T);
     w.items(1, [&](int) { io.rews[n] = mean; });
   }
 }

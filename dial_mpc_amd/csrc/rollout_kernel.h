@@ -20,9 +20,11 @@ __device__ __forceinline__ const CModel<D>* stage_model(const CModel<D>* gm, flo
   float* wsbase = smem;
   if constexpr (D::is_static) {
     constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspace 16-B aligned
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
+    // 16-byte copies (the constants are padded to a multiple of 16 B on both sides: dial_create allocates CMW words): a quarter of
+    // the load / store / loop instructions of the 4-byte copy, every wavefront of every launch runs this
+    const uint4* src = reinterpret_cast<const uint4*>(gm);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < CMW / 4; i += 64 * WPB) dst[i] = src[i];
     __syncthreads();
     m = reinterpret_cast<const CModel<D>*>(smem);
     wsbase = smem + CMW;
@@ -148,9 +150,9 @@ rollout_kernel2(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CMW = (int)((sizeof(CModel<D>) + 15) / 16) * 4;   // words, keeps the workspaces 16-B aligned
   {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(CModel<D>) / 4); i += 64 * WPB) dst[i] = src[i];
+    const uint4* src = reinterpret_cast<const uint4*>(gm);   // (16-byte copies, see stage_model)
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < CMW / 4; i += 64 * WPB) dst[i] = src[i];
     __syncthreads();   // (the only workgroup-level barrier: phase boundaries are wavefront-scope fences, wave.h)
   }
   const CModel<D>* m = reinterpret_cast<const CModel<D>*>(smem);

@@ -413,8 +413,18 @@ def distribution_parity(o32, s0, us, Y0s, got, product, temp, members=32, noise_
     rep["gpu"]["ess_rel"] = abs(g["ess"] / ref["ess"] - 1)
     rep["gpu"]["outside"] = outside(got)
     # what the kernels themselves emitted (K4 on the device) must be the fp64 K4 of their own rollouts ...
-    for nme, atol in (("Ybar", 1e-4), ("qbar", 1e-4), ("xbar", 1e-4), ("qdbar", 2e-3)):
-        assert np.allclose(np.asarray(product[nme], np.float64).reshape(-1), g[nme], atol=atol), nme
+    # Floor: the fixed 1e-4 / 2e-3 of rounds 1-5 -- or, where the softmax is so peaked that it is smaller than what ONE ulp of an fp32
+    # mean reward does, that: the API hands the mean rewards over as fp32 (like the reference), a correctly rounded one is half an ulp
+    # off, one ulp of reward is ulp / (std temp) of logit, i.e. of relative weight, and a weighted mean moves by that times the spread of
+    # its rows.  seq-jump (rewards near 10: alive x 10; N = 1024, temp 0.05, std 0.13): 1.5e-4 of logit per ulp at an effective sample
+    # size of 1.7 -- round 6's rounding lottery drew exactly such a batch (tools/k4_sensitivity.py) and an fp32 running reward sum, 2.7
+    # ulp off, put the device's Ybar 1.17e-4 from the fp64 K4.  (The kernels now sum the rewards in fp64: <= 0.5 ulp.)
+    rews64 = np.asarray(got[0], np.float64).mean(1)
+    dl = float(np.spacing(np.float32(np.abs(rews64).max()))) / max(float(rews64.std()) * float(temp), 1e-30)
+    B_ = rews64.shape[0]
+    for nme, atol, rows in (("Ybar", 1e-4, Y0s), ("qbar", 1e-4, got[1]), ("xbar", 1e-4, got[3]), ("qdbar", 2e-3, got[2])):
+        spread = float(np.abs(np.asarray(rows, np.float64).reshape(B_, -1) - g[nme]).max())
+        assert np.allclose(np.asarray(product[nme], np.float64).reshape(-1), g[nme], atol=max(atol, dl * spread)), (nme, dl, spread)
     # ... and sit inside the oracle's jitter envelope
     rep["ratio"] = {nme: rep["gpu"][nme] / max(env_d[nme], 1e-30) for nme in names + ("ess_rel",)}
     if not check:                  # surveys (tools/transition_survey.py) print the report instead
