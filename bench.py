@@ -283,11 +283,16 @@ def main():
     # here / :262-264 upstream); at world > 1 a lean iteration is ONE collective (all-gather of the rewards), a full one two
     # (+ all-reduce of the packed partial sums).  `value` stays the full iteration; these are reported next to it.
     plan_pat = tuple([False] * (dial_config.Ndiffuse - 1) + [True])
-    lean_steps = max(10, args.steps // 2)
+    # (the SAME iteration indices as the full run -- same warm-up, same count, each run restarts from a zero plan: where the rollouts'
+    #  length depends on the iterate (the Allegro's solver runs to convergence, and the first iterations of an annealing run from a zero
+    #  plan are its longest) a run over fewer iterations averages over a different stretch: round 5 reported the Allegro example's lean
+    #  iteration SLOWER than its full one, 6.80 vs 6.57 ms, with 15 + 3 iterations against 30 + 3: profiles/r06_allegro_iteration_times.txt)
+    lean_steps = args.steps
+    lean_warm = args.warmup
     lean_pat, plan_run = ((True,), (True,)) if args.full_only else ((False,), plan_pat)
-    el_lean, k_lean, nl_lean = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, 3 if not args.full_only else 0,
+    el_lean, k_lean, nl_lean = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, lean_warm if not args.full_only else 0,
                                                 eps_pool if args.host_noise else None, pattern=lean_pat)
-    el_plan, _, _ = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, 3 if not args.full_only else 0,
+    el_plan, _, _ = timed_iterations(mbdpi, states, lean_steps if not args.full_only else 1, lean_warm if not args.full_only else 0,
                                      eps_pool if args.host_noise else None, pattern=plan_run)
     if args.full_only:
         el_lean, el_plan, lean_steps = 0.0, 0.0, 1     # (not measured in this mode)

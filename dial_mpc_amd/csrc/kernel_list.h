@@ -19,8 +19,8 @@
 #endif
 // Round 5: TWO samples per wavefront (rollout_kernel2, wave.h: WaveH).  Small batches: one wavefront per workgroup (7.3 KB of
 // constants + 2 x 8.9 KB), N + 1 = 2049 rollouts = 1025 wavefronts = ONE per SIMD; large ones: the rollout queue over workgroups
-// of DIAL_GO2_PAIR_WPB wavefronts (78.5 KB: two per CU = two wavefronts = four rollouts per SIMD).  Compiled for two wavefronts
-// per SIMD (<= 256 VGPRs; the kernel uses ~236, no scratch).
+// of DIAL_GO2_PAIR_WPB wavefronts (76.5 KB: two per CU = two wavefronts = four rollouts per SIMD).  Compiled for two wavefronts
+// per SIMD (<= 256 VGPRs; round 6: the plain grid uses 199, the queue 244, no scratch -- tools/isa/disasm_lib.py prints the table).
 #ifndef DIAL_GO2_PAIR_WPB
 #define DIAL_GO2_PAIR_WPB 4
 #endif

@@ -343,10 +343,15 @@ typedef struct dial_options {
                                  workgroup after workgroup (some CUs with 16 wavefronts, some with 8) instead of being dealt
                                  round-robin over the whole resident grid                                                     */
   int32_t pair_mode;          /* Go2: TWO rollouts per wavefront, one per 32-lane half (rollout_kernel2).  0 = for batches beyond
-                                 4608 rollouts, where the SIMDs are short of issue slots (N = 65536: 7.15 -> 9.4 M rollouts/s);
-                                 1 = never (the one-rollout-per-wavefront kernels at any batch size); 2 = always.  The same
-                                 arithmetic in the same order per rollout: bit-identical on the build without fused multiply-add
-                                 contraction, at rounding level (which products the compiler fuses) on the product build.       */
+                                 DIAL_GO2_PAIR_MIN_B = 2304 rollouts (the one-sample kernels' resident set), where the SIMDs are short of
+                                 issue slots (N = 65536: 7.2 -> 10.2 M rollouts/s); 1 = never (the one-rollout-per-wavefront kernels
+                                 at any batch size); 2 = always.  The same arithmetic in the same order per rollout: bit-identical on the
+                                 build without fused multiply-add contraction, at rounding level (which products the compiler fuses) on
+                                 the product build.  CONSEQUENCE (product build): the kernel family is chosen from the batch a call
+                                 launches, so a rollout's bits depend on it -- the same N sharded over ranks whose shards fall on the
+                                 other side of 2304 (N = 4096 over 2 or 4 ranks) equals the fused run at rounding level, not bit for
+                                 bit; ranks of one run always agree with each other (same shard size).  pair_mode 1 or 2 on every
+                                 context restores bit-equality across shardings.                                                  */
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for

@@ -407,7 +407,7 @@ def test_full_size_oracle_parity(example, N, H):
             print(f"   per transition along 96 GPU trajectories x {H + 1} steps: direct {100 * osc['direct_share']:.2f} % (worst "
                   f"{osc['direct_worst']:.2f} x gate), witnessed {osc['witnessed']} {osc['witness_ulp']}, unwitnessed {len(osc['unwitnessed'])}")
         # (the chaotic env's product outputs -- Ybar / qbar / qdbar / xbar, the reward distribution -- are gated against the oracle's
-        #  32-member jitter envelope in test_default_rule_distribution_parity_full_size: same model, same inputs)
+        #  12-member jitter envelope in test_default_rule_distribution_parity_full_size: same model, same inputs)
         if not chaotic:
             # product outputs: the few knife-edge rollouts carry softmax weight ~1/N each, so the aggregates stay comparable
             assert _close(out["Ybar"].cpu().numpy(), ro["Ybar"], agg_tol(example, "Ybar"))
@@ -622,7 +622,7 @@ def test_two_samples_per_wavefront_is_bit_identical(example, N, H, per_rollout):
 
 @pytest.mark.parametrize("gate", ["rollout", "stagewise", "full_size", "stress", "converged", "distribution"])
 def test_pair_kernel_passes_the_oracle_gates(gate, monkeypatch):
-    """By default the Go2 runs two rollouts per wavefront only for batches beyond 4608 rollouts; here the oracle gates of this file
+    """By default the Go2 runs two rollouts per wavefront only for batches beyond DIAL_GO2_PAIR_MIN_B = 2304 rollouts; here the oracle gates of this file
     run on that kernel at THEIR sizes (dial_options.pair_mode = 2 for every context they create): per rollout and step under the
     per-rollout-comparable rule, the full BASELINE sizes, perturbed states, the converged solver and the distribution-level gate
     of the shipped rule."""

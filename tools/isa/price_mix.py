@@ -14,7 +14,7 @@ VERDICT r5 item 2: the issue ceiling `SQ_INSTS_VALU x cycles / (SIMDs x time x c
     executed: cycles per VALU instruction = sum_c (PMC share of class c) x (static average cost of class c).  Within a class the
     static distribution stands in for the dynamic one (there is no per-opcode counter); between classes the weights are measured.
 
-usage: price_mix.py <ubench_issue.txt> <listing.s> <kernel-name-substring> [pmc.json] [out.json]
+usage: price_mix.py <ubench_issue.txt> <listing.s> <kernel-name-regex> [pmc.json] [out.json]
 """
 import collections
 import json
@@ -130,7 +130,7 @@ def census(listing, want):
         m = re.match(r"^(\w[\w$.]*):", line)
         if m and not m.group(1).startswith((".L", "L")):
             cur = m.group(1)
-            on = want in cur
+            on = re.search(want, cur) is not None     # (`want`: a regular expression over the mangled kernel name)
             continue
         if not on:
             continue
