@@ -87,6 +87,127 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (k < m->con_dim[c]) f(m->con_adr[c] + k);
     });
   };
+  // ================================================================ ROW layout of the contributing units (round 6)
+  // With <= 8 contributing units (the rule: 2.4 on average with the ball in the hand) lane 8 idx + k owns ROW k of unit ulist[idx]
+  // (a limit row is a one-row unit), and everything that walked a unit's <= 6 rows serially in ONE lane -- the zone / force / weight
+  // evaluation of every Newton iteration, the two warm-start costs of every solve, the line search's per-unit coefficients -- is one
+  // pass of straight-line code per row lane plus sums over aligned groups of eight lanes (three DPP steps: wave.h seg8_sumN).  The
+  // row's Jaref lives in a register of its lane for the whole solve (the LDS copy is kept for the dof-side consumers).  The unit-lane
+  // code below stays as the path for more than 8 units.  Lone rollout: zones 3.2 k -> , line-search set-up 5.3 k -> , warm start
+  // 7.2 k -> cycles (profiles/r06_sections_allegro_reorient_cycles.txt); sums over a unit's rows associate differently: rounding level.
+  const bool r8 = n_on <= 8;
+  // per row lane: [0] row index (-1: idle lane), [1] friction factor of the row (k = 0: mu; limit row: 1), [2] D of the row, [3] mu of the
+  // unit (0: limit row), [4] Dm of the unit, [5] kind: 0 idle, 1 limit row, 2 contact row 0, 3 contact row k > 0, [6] the unit's contact (-1)
+  vfloat RL[7];
+  if (r8) w.per_lane_n(RL, [&](int l, float* o) {
+    for (int k = 0; k < 7; k++) o[k] = 0.f;
+    o[0] = -1.f; o[6] = -1.f;
+    const int idx = l >> 3, k = l & 7;
+    if (idx >= n_on) return;
+    const int u = (int)s.ulist[idx];
+    if (u < NL) {
+      if (k != 0) return;
+      o[0] = (float)u; o[1] = 1.f; o[2] = s.D[u]; o[5] = 1.f;
+      return;
+    }
+    const int c = u - NL, dim = m->con_dim[c], r0 = m->con_adr[c];
+    if (k >= dim) return;
+    const float mu = m->con_friction[c][0] * mu_scale;
+    o[0] = (float)(r0 + k);
+    o[1] = k == 0 ? mu : m->con_friction[c][k > 0 ? k - 1 : 0];
+    o[2] = s.D[r0 + k];
+    o[3] = mu;
+    o[4] = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL);
+    o[5] = k == 0 ? 2.f : 3.f;
+    o[6] = (float)c;
+  });
+  // J_r . vec for the row of every lane (two vectors at once when vecB != nullptr): the inner product of row_products below
+  auto row_products_r8 = [&](const float* vecA, const float* vecB, vfloat& outA, vfloat& outB) {
+    vfloat ab[2];
+    w.per_lane_n(ab, [&](int l, float* o) {
+      o[0] = 0.f; o[1] = 0.f;
+      const int kind = (int)lane_val(RL[5], l);
+      if (kind == 0) return;
+      const int r = (int)lane_val(RL[0], l);
+      if (kind == 1) {
+        const int dof = m->jnt_dofadr[m->lim_jnt[r]];
+        o[0] = s.lsign[r] * vecA[dof];
+        if (vecB) o[1] = s.lsign[r] * vecB[dof];
+        return;
+      }
+      const int c = (int)lane_val(RL[6], l), k = l & 7, nd = m->con_ndof[c];
+      const float* J = s.Jc + m->con_joff[c] + k * nd;
+      const uint32_t* dw = reinterpret_cast<const uint32_t*>(m->con_dof[c]);
+      const uint32_t dws[3] = {dw[0], dw[1], dw[2]};
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int t = 0; t < (NCD + 1) / 2; t++) {
+        const bool on = 2 * t < nd;
+        float j0, j1;
+        load2(J + (on ? 2 * t : 0), j0, j1);
+        const int i0 = (int)((dws[(2 * t) >> 2] >> (8 * ((2 * t) & 3))) & 255u), i1 = (int)((dws[(2 * t + 1) >> 2] >> (8 * ((2 * t + 1) & 3))) & 255u);
+        const int g0 = on ? i0 : 0, g1 = on ? i1 : 0;
+        float ta = a + j0 * vecA[g0];
+        ta = ta + j1 * vecA[g1];
+        a = on ? ta : a;
+        if (vecB) { float tb = b + j0 * vecB[g0]; tb = tb + j1 * vecB[g1]; b = on ? tb : b; }
+      }
+      o[0] = a; o[1] = b;
+    });
+    outA = ab[0]; outB = ab[1];
+  };
+  // the unit evaluation in the row layout: vja = the row values; returns every lane's share of the cost (their wave sum is the total).
+  // STORE: forces, zone, Hessian weights -- what unit_cost(.., true) writes for the contributing units
+  auto unit_eval_r8 = [&](const vfloat& vja, bool store) -> vfloat {
+    vfloat t[2];   // tangential part |U_1..|^2 and the normal part U_0 of the lane's unit, in every lane of its group of eight
+    w.per_lane_n(t, [&](int l, float* o) {
+      const int kind = (int)lane_val(RL[5], l);
+      const float U = lane_val(vja, l) * lane_val(RL[1], l);
+      o[0] = kind == 3 ? U * U : 0.f;
+      o[1] = (kind == 1 || kind == 2) ? U : 0.f;
+    });
+    w.seg8_sumN(t);
+    const vfloat out = w.per_lane([&](int l) -> float {
+      const int kind = (int)lane_val(RL[5], l);
+      if (kind == 0) return 0.f;
+      const float jr = lane_val(vja, l), fr = lane_val(RL[1], l), Dk = lane_val(RL[2], l), mu = lane_val(RL[3], l), Dm = lane_val(RL[4], l);
+      const float U = jr * fr, N = lane_val(t[1], l);
+      float tsqr = lane_val(t[0], l);
+      tsqr = tsqr >= DM_FLT_MIN ? tsqr : 0.f;   // (denormal = zero, as in unit_cost)
+      const float T = DM_SQRT(tsqr);
+      const bool bottom = (tsqr <= 0.f && N < 0.f) || (tsqr > 0.f && mu * N + T <= 0.f);
+      const bool middle = tsqr > 0.f && N < mu * T && mu * N + T > 0.f;
+      const float nmt = N - mu * T;
+      float cost = 0.f;
+      if (bottom) cost = 0.5f * Dk * jr * jr;
+      else if (middle && kind == 2) cost = 0.5f * Dm * nmt * nmt;
+      if (store) {
+        const int r = (int)lane_val(RL[0], l), c = (int)lane_val(RL[6], l), k = l & 7;
+        float f = 0.f;
+        if (bottom) f = -Dk * jr;
+        else if (middle) { const float fn = -Dm * nmt * mu; f = kind == 2 ? fn : -fn / T * U * fr; }
+        s.frc[r] = f;
+        if (kind >= 2) {
+          if (kind == 2) s.lsign[r] = bottom ? 2.f : (middle ? 1.f : 0.f);
+          if (bottom) s.cwd[6 * c + k] = Dk;
+          else if (middle) {
+            s.cwa[6 * c + k] = fr; s.cwb[6 * c + k] = U;
+            if (kind == 2) {
+              const float Tg = dm::fmaxf_(T, MJ_MINVAL), TTT = dm::fmaxf_(Tg * Tg * Tg, MJ_MINVAL);
+              s.ccf[4 * c] = Dm;
+              s.ccf[4 * c + 1] = -mu / Tg;               // c0
+              s.ccf[4 * c + 2] = mu * mu - mu * N / Tg;  // c1
+              s.ccf[4 * c + 3] = mu * N / TTT;           // c2
+            }
+          }
+        }
+      }
+      return cost;
+    });
+    return out;
+  };
+  vfloat vJaR = vzero;   // the row lanes' Jaref (r8)
+
   // ---- unit evaluation: cost of limit row / contact u at the row values ja[]; STORE additionally writes the forces,
   // the zone (lsign of the contact's first row doubles as storage) and the Hessian weights
   auto unit_cost = [&](int u, const float* ja, const float* aref_or_null, bool store) -> float {
@@ -188,14 +309,26 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
 
   // ---- warm-start selection: cost at qacc_warmstart vs cost at qacc_smooth
   w.items(NV, [&](int i) { s.vec0[i] = s.warm[i]; s.vec1[i] = s.qas[i]; });
-  row_products(s.vec0, s.Jaref, s.vec1, s.jv);     // J warm, J qacc_smooth (aref subtracted on the fly below)
+  vfloat jaW = vzero, jaS = vzero;   // (r8) J warm - aref, J qacc_smooth - aref of the lane's row
+  if (r8) {
+    row_products_r8(s.vec0, s.vec1, jaW, jaS);
+    const vfloat ar = w.per_lane([&](int l) { return lane_val(RL[5], l) != 0.f ? s.aref[(int)lane_val(RL[0], l)] : 0.f; });
+    jaW = jaW - ar; jaS = jaS - ar;
+  } else {
+    row_products(s.vec0, s.Jaref, s.vec1, s.jv);     // J warm, J qacc_smooth (aref subtracted on the fly below)
+  }
   const vfloat maW = mul_m(s.vec0), maS = mul_m(s.vec1);
   float cw, gw, cs, gs;
   {
     vfloat t[4];
-    t[0] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, s.aref, false) : 0.f; });
+    if (r8) {
+      t[0] = unit_eval_r8(jaW, false);
+      t[2] = unit_eval_r8(jaS, false);
+    } else {
+      t[0] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, s.aref, false) : 0.f; });
+      t[2] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.jv, s.aref, false) : 0.f; });
+    }
     t[1] = (maW - vqfs) * (vwarm - vqas);
-    t[2] = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.jv, s.aref, false) : 0.f; });
     t[3] = (maS - vqfs) * (vqas - vqas);
     float r[4];
     w.vsumN(t, r);
@@ -205,7 +338,17 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   const bool use_warm = cost_w < cost_s;
   vfloat vqacc = use_warm ? vwarm : vqas;
   vfloat vMa = use_warm ? maW : maS;
-  for_on_rows([&](int r) { s.Jaref[r] = (use_warm ? s.Jaref[r] : s.jv[r]) - s.aref[r]; });
+  if (r8) {
+    vJaR = use_warm ? jaW : jaS;
+    // the LDS copy (H's limit rows read it) and the forces of the limit rows that are OFF (D = 0: not in the list, never written
+    // by the row lanes; J^T f reads the limit row of every dof)
+    w.items(64 + NL, [&](int it) {
+      if (it < 64) { if (lane_val(RL[5], it) != 0.f) s.Jaref[(int)lane_val(RL[0], it)] = lane_val(vJaR, it); }
+      else if (s.D[it - 64] == 0.f) s.frc[it - 64] = 0.f;
+    });
+  } else {
+    for_on_rows([&](int r) { s.Jaref[r] = (use_warm ? s.Jaref[r] : s.jv[r]) - s.aref[r]; });
+  }
   float cost = use_warm ? cost_w : cost_s;
   float gauss = use_warm ? 0.5f * gw : 0.5f * gs;
   float prev_cost = INFINITY;
@@ -218,7 +361,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   int niter = 0;
   for (;;) {
     // ---- _update_constraint: zones, forces, Hessian weights (unit lanes); cost
-    const vfloat ucost = w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, nullptr, true) : 0.f; });
+    const vfloat ucost = r8 ? unit_eval_r8(vJaR, true) : w.per_lane([&](int l) { return l < NU_ ? unit_cost(l, s.Jaref, nullptr, true) : 0.f; });
     w.fence();
     DIAL_MARK(w, 12);
     // ---- J^T f per dof lane: own limit row + the contacts that move the dof
@@ -322,7 +465,9 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     // ---- solver._linesearch
     w.begin_region();
     w.items(NV, [&](int i) { s.vec0[i] = lane_val(vsearch, i); });
-    row_products(s.vec0, s.jv, nullptr, nullptr);
+    vfloat vjvR = vzero, vdummy = vzero;   // (r8) J search of the lane's row
+    if (r8) row_products_r8(s.vec0, nullptr, vjvR, vdummy);
+    else row_products(s.vec0, s.jv, nullptr, nullptr);
     const vfloat vmv = mul_m(s.vec0);
     float sn2, s1, s2;
     {
@@ -343,6 +488,29 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       return l < NU_ ? l : -1;
     };
     vfloat L[10];
+    if (r8) {
+      // the units' coefficients from their row lanes: partial terms per row, sums over the group of eight, then every line-search
+      // lane (g, j) fetches unit j's ten words from lane 8 j (ds_bpermute)
+      vfloat P[8];   // q0 q1 q2 | uu uv vv | u0 v0
+      w.per_lane_n(P, [&](int l, float* o) {
+        for (int k = 0; k < 8; k++) o[k] = 0.f;
+        const int kind = (int)lane_val(RL[5], l);
+        if (kind == 0) return;
+        const float ja = lane_val(vJaR, l), jv = lane_val(vjvR, l), d = lane_val(RL[2], l), f = lane_val(RL[1], l);
+        o[0] = 0.5f * ja * ja * d; o[1] = jv * ja * d; o[2] = 0.5f * jv * jv * d;
+        if (kind == 3) { const float a = ja * f, b = jv * f; o[3] = a * a; o[4] = a * b; o[5] = b * b; }
+        if (kind == 1) { o[6] = ja; o[7] = jv; }                  // limit row: (Jaref, jv)
+        if (kind == 2) { o[6] = ja * f; o[7] = jv * f; }          // contact: (Jaref_0 mu, jv_0 mu)   (f = mu on row 0)
+      });
+      w.seg8_sumN(P);
+      const vfloat src[10] = {P[6], P[7], P[3], P[4], P[5], RL[4], RL[3], P[0], P[1], P[2]};
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        const vfloat g = w.gather64(src[k], [&](int l) { return 8 * (l & 15); });
+        L[k] = w.per_lane([&](int l) { return (l < 48 && (l & 15) < n_on) ? lane_val(g, l) : 0.f; });
+      }
+      // (s.jv keeps the rows' J search for nothing but the profile build's dumps; the Jaref update below runs in the row lanes)
+    } else
     w.per_lane_n(L, [&](int l, float* o) {
       for (int k = 0; k < 10; k++) o[k] = 0.f;
       const int u = unit_of_lane(l);
@@ -483,7 +651,12 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     if (improved) {
       vqacc = vqacc + vsearch * alpha;
       vMa = vMa + vmv * alpha;
-      for_on_rows([&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
+      if (r8) {
+        vJaR = vJaR + vjvR * alpha;
+        w.items(64, [&](int l) { if (lane_val(RL[5], l) != 0.f) s.Jaref[(int)lane_val(RL[0], l)] = lane_val(vJaR, l); });
+      } else {
+        for_on_rows([&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
+      }
     }
     niter++;
     w.work++;

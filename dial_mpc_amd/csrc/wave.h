@@ -236,6 +236,21 @@ struct Wave {
   // K independent 16-lane sums (results replicated in every lane of the group)
   template <int K>
   void row16_sumN(vfloat (&v)[K]) { for (int k = 0; k < K; k++) v[k] = row16_sum(v[k]); }
+  // K independent sums within every aligned group of EIGHT lanes, replicated in the group's lanes (GPU: quad_perm xor 1, xor 2,
+  // row_half_mirror -- the association (((a0+a1)+(a2+a3)) + ((a7+a6)+(a5+a4))) is reproduced here)
+  template <int K>
+  void seg8_sumN(vfloat (&v)[K]) {
+    for (int k = 0; k < K; k++) {
+      vfloat s1, s2, s3;
+      for (int l = 0; l < 64; l++) s1.x[l] = v[k].x[l] + v[k].x[l ^ 1];
+      for (int l = 0; l < 64; l++) s2.x[l] = s1.x[l] + s1.x[l ^ 2];
+      for (int l = 0; l < 64; l++) s3.x[l] = s2.x[l] + s2.x[(l & ~7) | (7 - (l & 7))];
+      v[k] = s3;
+    }
+  }
+  // value of lane src(l), per lane (GPU: ds_bpermute); src outside 0..63 is the caller's bug
+  template <class F>
+  vfloat gather64(const vfloat& v, F src) { vfloat r; for (int l = 0; l < 64; l++) r.x[l] = v.x[src(l) & 63]; return r; }
   // wave-uniform sum of a register value over all 64 lanes (idle lanes must hold 0)
   float vsum(const vfloat& v) { if (tree_sums) return emu_tree64(v.x); float s = 0.f; for (int l = 0; l < 64; l++) s += v.x[l]; return s; }
   template <int K>
@@ -629,6 +644,17 @@ struct Wave {
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x140>(v[k]);
   }
+  template <int K>
+  __device__ __forceinline__ void seg8_sumN(vfloat (&v)[K]) {   // sums within aligned groups of eight lanes, K chains interleaved
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0xb1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x4e>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = dialwave::dpp_add<0x141>(v[k]);
+  }
+  template <class F>
+  __device__ __forceinline__ vfloat gather64(vfloat v, F src) { return __shfl(v, src(lane) & 63, 64); }   // ds_bpermute_b32
   __device__ __forceinline__ void row16_sum3(vfloat& a, vfloat& b, vfloat& c) {   // stage-interleaved: no DPP hazard stalls
     a = dialwave::dpp_add<0xb1>(a); b = dialwave::dpp_add<0xb1>(b); c = dialwave::dpp_add<0xb1>(c);
     a = dialwave::dpp_add<0x4e>(a); b = dialwave::dpp_add<0x4e>(b); c = dialwave::dpp_add<0x4e>(c);

@@ -107,6 +107,21 @@ def _gate(example, orc, state, g, got, product, cfg, nstate):
     for k in ("Ybar", "qbar", "qdbar", "xbar"):     # (the exporter writes no qdbar: the fp64 K4 of the file's own rollouts stands in)
         prod[k] = np.asarray(prod[k], np.float64).reshape(-1) if k in prod else own[k]
     dist = distribution_parity(orc, state, us, Y0s, got, prod, float(cfg.temp_sample), members=8, scale_peaked=4.0)
+    # Quantitative floors (`max_frac=1.0` alone would let ANY share diverge as long as every divergence has a witness):
+    #  (a) the share of rollouts that needed a witness is bounded by what the oracle's OWN 1-ulp jitter ensemble shows (distribution_parity
+    #      asserts gpu.outside <= 1.5 x the ensemble's worst member + 0.02; restated here so that the report carries the numbers);
+    #  (b) the witnesses are rounding-level: at least half of them at <= 4 ulp of per-step jitter, at most a tenth need the full 64;
+    #  (c) what is reported: the share that matched step by step without any witness.
+    B = rep["rollouts"]
+    mags = [d["witness"][1] for d in rep["details"] if d["witness"] is not None and d["witness"][0] != "restart"]
+    direct_share = 1.0 - rep["outside_tol"] / B
+    floor = 1.0 - (1.5 * dist["envelope_max"]["outside"] + 0.02)
+    assert direct_share >= min(floor, 0.99), (direct_share, floor, dist["envelope_max"]["outside"])
+    if len(mags) >= 8:
+        assert np.median(mags) <= 4 and np.mean(np.asarray(mags) >= 64) <= 0.10 + 2.0 / len(mags), (np.bincount(np.asarray(mags, int)).tolist(),)
+    print(f"{example}: {100 * direct_share:.1f} % of {B} rollouts match step by step (oracle's own 1-ulp ensemble: worst member "
+          f"{100 * (1 - dist['envelope_max']['outside']):.1f} %); {rep['witnessed']} needed a witness, jitter magnitudes (ulp) "
+          f"{dict(zip(*np.unique(mags, return_counts=True))) if mags else {}}; unwitnessed {rep.get('unwitnessed', 0)}")
     return rep, dist
 
 
