@@ -15,6 +15,9 @@ namespace dial {
 template <class W, class M>
 DIAL_DEV void load_state(W& w, const M* m, const Ws& s, const float* state) {
   const int nq = dim_nq(m), nv = dim_nv(m);
+  // (the Allegro's queue kernels: the lanes' 64-bit addresses into the hand-over slot are loop invariants of the queue's loop over rollout
+  //  pieces -- hoisted and spilled; an opaque lane id keeps them inside the call)
+  DIAL_LANE_SCOPE_IF(M::D::ell, w);
   w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
     float v = state[i];
     if (i < nq) s.qpos[i] = v;
@@ -26,6 +29,7 @@ DIAL_DEV void load_state(W& w, const M* m, const Ws& s, const float* state) {
 template <class W, class M>
 DIAL_DEV void store_state(W& w, const M* m, const Ws& s, float* state) {
   const int nq = dim_nq(m), nv = dim_nv(m);
+  DIAL_LANE_SCOPE_IF(M::D::ell, w);   // (see load_state)
   w.items(nq + 2 * nv + DIAL_INFO_N, [&](int i) {
     float v;
     if (i < nq) v = s.qpos[i];

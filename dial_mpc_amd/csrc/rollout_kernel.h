@@ -79,10 +79,15 @@ rollout_kernel(const CModel<D>* __restrict__ gm, const dial_task* __restrict__ t
 #ifndef DIAL_LAUNDER_STATIC
 #define DIAL_LAUNDER_STATIC 0   // A/B switch: the opaque lane id per step for EVERY instantiation
 #endif
+#ifndef DIAL_LAUNDER_ELL_QUEUE
+#define DIAL_LAUNDER_ELL_QUEUE 0   // A/B switch (round 6): an opaque lane id per control step / physics frame for the Allegro's queue kernels -- 7 spilled
+                                   // VGPRs -> 0, but cfg 4 +3 % (9.72 -> 10.0 ms) and the queue is no longer bit-identical to the plain launch: off
+#endif
 #ifndef DIAL_LAUNDER_H1
 #define DIAL_LAUNDER_H1 0       // A/B switch: the opaque lane id per step for the H1's 25-dof kernels (10 spilled VGPRs without it, 1 with)
 #endif
-  w.launder = D::gen || OCC >= 4 || DIAL_LAUNDER_STATIC || (DIAL_LAUNDER_H1 && std::is_same<typename D::Topo, TopoH1>::value);   // (see wave.h)
+  w.launder = D::gen || OCC >= 4 || DIAL_LAUNDER_STATIC || (DIAL_LAUNDER_H1 && std::is_same<typename D::Topo, TopoH1>::value) ||
+              (DIAL_LAUNDER_ELL_QUEUE && D::ell && QUEUE);   // (see wave.h)
 #ifdef DIAL_PROFILE
   w.acc = reinterpret_cast<unsigned long long*>(smem + (ws_words * WPB + (D::is_static ? (int)((sizeof(CModel<D>) + 15) / 16) * 4 : 0) + 2) / 2 * 2) + 32 * (threadIdx.x >> 6);
   if (w.lane < 32) w.acc[w.lane] = 0;

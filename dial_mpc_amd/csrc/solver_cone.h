@@ -96,46 +96,48 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   // code below stays as the path for more than 8 units.  Lone rollout: zones 3.2 k -> , line-search set-up 5.3 k -> , warm start
   // 7.2 k -> cycles (profiles/r06_sections_allegro_reorient_cycles.txt); sums over a unit's rows associate differently: rounding level.
   const bool r8 = n_on <= 8;
-  // per row lane: [0] row index (-1: idle lane), [1] friction factor of the row (k = 0: mu; limit row: 1), [2] D of the row, [3] mu of the
-  // unit (0: limit row), [4] Dm of the unit, [5] kind: 0 idle, 1 limit row, 2 contact row 0, 3 contact row k > 0, [6] the unit's contact (-1)
-  vfloat RL[7];
+  // per row lane: [0] row index | kind << 7 | (contact + 1) << 10 as an exact float (kind: 0 idle, 1 limit row, 2 contact row 0, 3 contact
+  // row k > 0; one register instead of three: the queue kernel sits on the 168-VGPR budget), [1] friction factor of the row (k = 0: mu;
+  // limit row: 1), [2] D of the row, [3] mu of the unit (0: limit row), [4] Dm of the unit
+  vfloat RL[5];
+  const auto rl_kind = [&](int l) { return ((int)lane_val(RL[0], l) >> 7) & 7; };
+  const auto rl_row = [&](int l) { return (int)lane_val(RL[0], l) & 127; };
+  const auto rl_con = [&](int l) { return ((int)lane_val(RL[0], l) >> 10) - 1; };
+  static_assert(D::NE <= 128 && D::NC < 1000, "packed row code");
   if (r8) w.per_lane_n(RL, [&](int l, float* o) {
-    for (int k = 0; k < 7; k++) o[k] = 0.f;
-    o[0] = -1.f; o[6] = -1.f;
+    for (int k = 0; k < 5; k++) o[k] = 0.f;
     const int idx = l >> 3, k = l & 7;
     if (idx >= n_on) return;
     const int u = (int)s.ulist[idx];
     if (u < NL) {
       if (k != 0) return;
-      o[0] = (float)u; o[1] = 1.f; o[2] = s.D[u]; o[5] = 1.f;
+      o[0] = (float)(u | (1 << 7)); o[1] = 1.f; o[2] = s.D[u];
       return;
     }
     const int c = u - NL, dim = m->con_dim[c], r0 = m->con_adr[c];
     if (k >= dim) return;
     const float mu = m->con_friction[c][0] * mu_scale;
-    o[0] = (float)(r0 + k);
+    o[0] = (float)((r0 + k) | ((k == 0 ? 2 : 3) << 7) | ((c + 1) << 10));
     o[1] = k == 0 ? mu : m->con_friction[c][k > 0 ? k - 1 : 0];
     o[2] = s.D[r0 + k];
     o[3] = mu;
     o[4] = s.D[r0] / dm::fmaxf_(mu * mu * (1.f + mu * mu), MJ_MINVAL);
-    o[5] = k == 0 ? 2.f : 3.f;
-    o[6] = (float)c;
   });
   // J_r . vec for the row of every lane (two vectors at once when vecB != nullptr): the inner product of row_products below
   auto row_products_r8 = [&](const float* vecA, const float* vecB, vfloat& outA, vfloat& outB) {
     vfloat ab[2];
     w.per_lane_n(ab, [&](int l, float* o) {
       o[0] = 0.f; o[1] = 0.f;
-      const int kind = (int)lane_val(RL[5], l);
+      const int kind = rl_kind(l);
       if (kind == 0) return;
-      const int r = (int)lane_val(RL[0], l);
+      const int r = rl_row(l);
       if (kind == 1) {
         const int dof = m->jnt_dofadr[m->lim_jnt[r]];
         o[0] = s.lsign[r] * vecA[dof];
         if (vecB) o[1] = s.lsign[r] * vecB[dof];
         return;
       }
-      const int c = (int)lane_val(RL[6], l), k = l & 7, nd = m->con_ndof[c];
+      const int c = rl_con(l), k = l & 7, nd = m->con_ndof[c];
       const float* J = s.Jc + m->con_joff[c] + k * nd;
       const uint32_t* dw = reinterpret_cast<const uint32_t*>(m->con_dof[c]);
       const uint32_t dws[3] = {dw[0], dw[1], dw[2]};
@@ -161,14 +163,14 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   auto unit_eval_r8 = [&](const vfloat& vja, bool store) -> vfloat {
     vfloat t[2];   // tangential part |U_1..|^2 and the normal part U_0 of the lane's unit, in every lane of its group of eight
     w.per_lane_n(t, [&](int l, float* o) {
-      const int kind = (int)lane_val(RL[5], l);
+      const int kind = rl_kind(l);
       const float U = lane_val(vja, l) * lane_val(RL[1], l);
       o[0] = kind == 3 ? U * U : 0.f;
       o[1] = (kind == 1 || kind == 2) ? U : 0.f;
     });
     w.seg8_sumN(t);
     const vfloat out = w.per_lane([&](int l) -> float {
-      const int kind = (int)lane_val(RL[5], l);
+      const int kind = rl_kind(l);
       if (kind == 0) return 0.f;
       const float jr = lane_val(vja, l), fr = lane_val(RL[1], l), Dk = lane_val(RL[2], l), mu = lane_val(RL[3], l), Dm = lane_val(RL[4], l);
       const float U = jr * fr, N = lane_val(t[1], l);
@@ -182,7 +184,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       if (bottom) cost = 0.5f * Dk * jr * jr;
       else if (middle && kind == 2) cost = 0.5f * Dm * nmt * nmt;
       if (store) {
-        const int r = (int)lane_val(RL[0], l), c = (int)lane_val(RL[6], l), k = l & 7;
+        const int r = rl_row(l), c = rl_con(l), k = l & 7;
         float f = 0.f;
         if (bottom) f = -Dk * jr;
         else if (middle) { const float fn = -Dm * nmt * mu; f = kind == 2 ? fn : -fn / T * U * fr; }
@@ -312,7 +314,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
   vfloat jaW = vzero, jaS = vzero;   // (r8) J warm - aref, J qacc_smooth - aref of the lane's row
   if (r8) {
     row_products_r8(s.vec0, s.vec1, jaW, jaS);
-    const vfloat ar = w.per_lane([&](int l) { return lane_val(RL[5], l) != 0.f ? s.aref[(int)lane_val(RL[0], l)] : 0.f; });
+    const vfloat ar = w.per_lane([&](int l) { return rl_kind(l) != 0 ? s.aref[rl_row(l)] : 0.f; });
     jaW = jaW - ar; jaS = jaS - ar;
   } else {
     row_products(s.vec0, s.Jaref, s.vec1, s.jv);     // J warm, J qacc_smooth (aref subtracted on the fly below)
@@ -343,7 +345,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
     // the LDS copy (H's limit rows read it) and the forces of the limit rows that are OFF (D = 0: not in the list, never written
     // by the row lanes; J^T f reads the limit row of every dof)
     w.items(64 + NL, [&](int it) {
-      if (it < 64) { if (lane_val(RL[5], it) != 0.f) s.Jaref[(int)lane_val(RL[0], it)] = lane_val(vJaR, it); }
+      if (it < 64) { if (rl_kind(it) != 0) s.Jaref[rl_row(it)] = lane_val(vJaR, it); }
       else if (s.D[it - 64] == 0.f) s.frc[it - 64] = 0.f;
     });
   } else {
@@ -494,7 +496,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       vfloat P[8];   // q0 q1 q2 | uu uv vv | u0 v0
       w.per_lane_n(P, [&](int l, float* o) {
         for (int k = 0; k < 8; k++) o[k] = 0.f;
-        const int kind = (int)lane_val(RL[5], l);
+        const int kind = rl_kind(l);
         if (kind == 0) return;
         const float ja = lane_val(vJaR, l), jv = lane_val(vjvR, l), d = lane_val(RL[2], l), f = lane_val(RL[1], l);
         o[0] = 0.5f * ja * ja * d; o[1] = jv * ja * d; o[2] = 0.5f * jv * jv * d;
@@ -653,7 +655,7 @@ DIAL_DEV void solver_cone(W& w, const M* m, const Ws& s) {
       vMa = vMa + vmv * alpha;
       if (r8) {
         vJaR = vJaR + vjvR * alpha;
-        w.items(64, [&](int l) { if (lane_val(RL[5], l) != 0.f) s.Jaref[(int)lane_val(RL[0], l)] = lane_val(vJaR, l); });
+        w.items(64, [&](int l) { if (rl_kind(l) != 0) s.Jaref[rl_row(l)] = lane_val(vJaR, l); });
       } else {
         for_on_rows([&](int r) { s.Jaref[r] += s.jv[r] * alpha; });
       }

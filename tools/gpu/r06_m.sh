@@ -4,7 +4,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; export GRAFT_REPO_ROOT=$ROOT; OUT=$ROOT/gpurun_out/r06m; mkdir -p $OUT; cd $ROOT
 timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "allegro or Allegro" > $OUT/pytest_allegro.txt 2>&1; grep -E "passed|failed|error" $OUT/pytest_allegro.txt | tail -3
 ab() { ex=$1; shift
-  for rep in 1 2 3; do for lib in libdialhip_preR8.so libdialhip.so; do
+  for rep in 1 2 3; do for lib in libdialhip_nolaunder.so libdialhip.so; do
     DIAL_HIP_LIB=$ROOT/dial_mpc_amd/csrc/$lib python bench.py --example $ex --warmup 5 --no-cpu-baseline --ticks 2 --no-strong-cfg5 "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$ex $*', '$lib', 'kernel_ms', round(d['roofline']['avg_kernel_ms'],4), 'ms/step', round(d['ms_per_step'],4))"
   done; done
