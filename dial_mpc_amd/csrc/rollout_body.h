@@ -1705,9 +1705,15 @@ DIAL_DEV void euler(W& w, const M* m, const Ws& s) {
       // implicit joint damping (forward.euler): qacc <- (M + dt diag(damping))^-1 (qfrc_smooth + qfrc_constraint);
       // qacc_warmstart keeps the solver's solution.  M + dt B has M's sparsity: the tree elimination order applies.
       constexpr int NV = M::D::NV, S = M::D::S;
-      w.items(NV * S, [&](int e) {
-        const int i = e / S, j = e - i * S;
-        s.H[e] = s.M[e] + (i == j ? dt * m->dof_damping[i] : 0.f);
+      // M + dt B: 16-byte copies, the damping on the chunk that holds the row's diagonal (round 6: was one ELEMENT per item, nine
+      // passes of the wavefront over the 22 x 24 square in every physics sub-step; cfg 4: -1.5 % per iteration, profiles/r06_ab_allegro_issue_bound.txt)
+      w.items(NV * S / 4, [&](int e) {
+        const int i = (4 * e) / S, j0 = 4 * e - i * S;
+        float a = s.M[4 * e], b = s.M[4 * e + 1], c2 = s.M[4 * e + 2], d2 = s.M[4 * e + 3];
+        const float add = dt * m->dof_damping[i];
+        const int dj = i - j0;   // position of the diagonal inside the chunk, if 0 .. 3
+        a += dj == 0 ? add : 0.f; b += dj == 1 ? add : 0.f; c2 += dj == 2 ? add : 0.f; d2 += dj == 3 ? add : 0.f;
+        store4(s.H + 4 * e, a, b, c2, d2);
       });
       const vfloat rhs = w.per_lane([&](int l) { return l < NV ? s.qfs[l] + s.qfc[l] : 0.f; });
       const vfloat x = reg_chol<typename M::D>(w, m, s.H, rhs, s.H);
