@@ -182,6 +182,9 @@ void static_for(F&& f) {
 }
 
 // What only the generic instantiation carries (box narrow phases and the crate task: include/dial_mpc.h).  An EMPTY base for
+#define DIAL_KBI_WORDS 12   /* rows of the impedance table: nine words, padded to whole 16-byte fetches */
+#define DIAL_KBI_ROWS 8     /* distinct (solref, solimp) rows a dimension-specialised instantiation holds */
+
 // the dimension-specialised instantiations: their constants live in LDS, which is on the residency edge.
 template <class D, bool GENERIC = D::gen>
 struct CModelGeneric {};
@@ -193,7 +196,8 @@ struct CModelGeneric<D, true> {
   float crate_region[6], head_vec[3];
   // dry friction (joint frictionloss): rows [nlim, nlim + nfri) of the constraint list, and the push-crate task's contacts
   int32_t nfri, fri_dof[DIAL_MAX_FRI], dof_frirow[D::NV];
-  float fri_loss[DIAL_MAX_FRI], fri_solref[DIAL_MAX_FRI][2], fri_solimp[DIAL_MAX_FRI][5];
+  float fri_loss[DIAL_MAX_FRI];
+  uint8_t fri_kbi[(DIAL_MAX_FRI + 3) & ~3];   // row of CModel::kbi_tab
   int32_t pc_foot_contact[2][2], pc_wanted[2], pc_n_unwanted, pc_unwanted[16];
   float pc_wanted_zmax;
 };
@@ -228,7 +232,16 @@ struct CModel : CModelGeneric<D_> {
   uint8_t shared_child[4][4];
   // ---- joints
   int32_t jnt_type[D::NJ], jnt_qposadr[D::NJ], jnt_dofadr[D::NJ], jnt_bodyid[D::NJ];
-  float jnt_pos[D::NJ][3], jnt_axis[D::NJ][3], jnt_range[D::NJ][2], jnt_solref[D::NJ][2], jnt_solimp[D::NJ][5];
+  float jnt_pos[D::NJ][3], jnt_axis[D::NJ][3], jnt_range[D::NJ][2];
+  // The position-independent part of constraint._kbi (k, b, the impedance curve's constants) of the limit rows / contacts / dry-friction
+  // rows, evaluated ONCE on the host from solref / solimp / timestep (derived.h: kbi_row) instead of in every physics step by every row
+  // lane: k b dmin dmax | 1/width mid 1/mid^(p-1) 1/(1-mid)^(p-1) | power -- round 6, ~35 issue slots (five of them v_rcp) per call.
+  // Rows with the same solref / solimp share one table row (a robot has two or three distinct ones; the constants live in LDS, which
+  // is on the residency edge: DESIGN.md 5c) -- jnt_kbi / con_kbi / fri_kbi hold the row's index.  More distinct rows than NKBI: the
+  // capacity-dimension kernel (dial_create: kbi_unique_rows).
+  static constexpr int NKBI = D::is_static ? DIAL_KBI_ROWS : D::NJ + D::NC + DIAL_MAX_FRI;
+  alignas(16) float kbi_tab[NKBI][DIAL_KBI_WORDS];
+  uint8_t jnt_kbi[(D::NJ + 3) & ~3], con_kbi[(D::NC + 3) & ~3];
   float jnt_margin[D::NJ], qpos0[D::NQ];
   // ---- dofs
   int32_t dof_bodyid[D::NV], dof_jntid[D::NV], dof_act[D::NV], dof_limrow[D::NV];
@@ -250,7 +263,9 @@ struct CModel : CModelGeneric<D_> {
   int32_t site_bodyid[D::NSA];
   float site_pos[D::NSA][3], site_quat[D::NSA][4];
   int32_t con_kind[D::NC], con_geom1[D::NC], con_geom2[D::NC], con_body1[D::NC], con_body2[D::NC];
-  float con_friction[D::NC][5], con_solref[D::NC][2], con_solimp[D::NC][5], con_margin[D::NC];
+  float con_friction[D::NC][5], con_margin[D::NC];
+  // pyramidal cones: the rows' invweight (_efc_contact_pyramidal) | elliptic: body_invweight0[body1] + [body2], the same / impratio
+  float con_invw[D::NC][D::ell ? 2 : 1];
   // elliptic models: rows / dofs of every contact and the contacts of every dof (static, from the body tree)
   int32_t cone, eulerdamp;
   int32_t con_dim[D::NCE], con_adr[D::NCE];      // condim and first constraint row

@@ -2,6 +2,8 @@
 // structs into the dimension-specialised CModel<D>, and the per-wavefront LDS workspace layout.
 // Internal to the library (not ABI).
 #pragma once
+#include <cmath>
+#include <cstring>
 #include "cmodel.h"
 
 #define DIAL_MAX_TRI ((DIAL_MAX_V * (DIAL_MAX_V + 1)) / 2)
@@ -161,6 +163,42 @@ static inline bool ell_fits(const dial_model* m, const dial_derived* dv) {
 }
 
 // Host: capacity-sized ABI structs -> CModel<D>.  The caller has checked dims_match<D>() for static D.
+// constraint._kbi's position-independent part for one row (CModel::jnt_kbi / con_kbi / fri_kbi), in the reference's own fp32 order of
+// operations and with true divisions (the device evaluated the same expressions with v_rcp in every step)
+static inline void kbi_row(float* o, const float* solref, const float* solimp, float timestep) {
+  const float MINIMP = 0.0001f, MAXIMP = 0.9999f, MINVAL = 1e-15f;
+  const auto clipf = [](float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); };
+  volatile float timeconst = solref[0] > 2.f * timestep ? solref[0] : 2.f * timestep, dampratio = solref[1];   // (volatile: no fast-math re-association on the host)
+  volatile float dmin = clipf(solimp[0], MINIMP, MAXIMP), dmax = clipf(solimp[1], MINIMP, MAXIMP);
+  volatile float width = solimp[2] > MINVAL ? solimp[2] : MINVAL, mid = clipf(solimp[3], MINIMP, MAXIMP);
+  volatile float power = solimp[4] > 1.f ? solimp[4] : 1.f;
+  volatile float d2 = dmax * dmax;
+  volatile float den = d2 * timeconst; den = den * timeconst; den = den * dampratio; den = den * dampratio;
+  volatile float k = 1.f / den, dt = dmax * timeconst, b = 2.f / dt;
+  if (solref[0] <= 0.f) k = -solref[0] / d2;
+  if (solref[1] <= 0.f) b = -solref[1] / dmax;
+  volatile float omm = 1.f - mid;
+  o[0] = k; o[1] = b; o[2] = dmin; o[3] = dmax; o[4] = 1.f / width; o[5] = mid;
+  if (power == 2.f) { o[6] = 1.f / mid; o[7] = 1.f / omm; }
+  else { volatile float pa = std::pow((float)mid, (float)power - 1.f), pb = std::pow((float)omm, (float)power - 1.f); o[6] = 1.f / pa; o[7] = 1.f / pb; }
+  o[8] = power; o[9] = 0.f; o[10] = 0.f; o[11] = 0.f;
+}
+
+// distinct (solref, solimp) rows among the model's limit rows, contacts and dry-friction rows (CModel::kbi_tab's occupancy)
+static inline int kbi_unique_rows(const dial_model* m) {
+  int n = 0;
+  static thread_local float ref[DIAL_MAX_JNT + DIAL_MAX_CON + DIAL_MAX_FRI][7];
+  const auto intern = [&](const float* solref, const float* solimp) {
+    float key[7] = {solref[0], solref[1], solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
+    for (int r = 0; r < n; r++) if (memcmp(ref[r], key, sizeof(key)) == 0) return;
+    memcpy(ref[n++], key, sizeof(key));
+  };
+  for (int l = 0; l < m->nlim; l++) { const int j = m->lim_jnt[l]; intern(m->jnt_solref[j], m->jnt_solimp[j]); }
+  for (int c = 0; c < m->ncon; c++) intern(m->con_solref[c], m->con_solimp[c]);
+  for (int q = 0; q < m->nfri && q < DIAL_MAX_FRI; q++) intern(m->fri_solref[q], m->fri_solimp[q]);
+  return n;
+}
+
 template <class D>
 static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_task* t, const dial_derived* dv) {
   CModel<D>& o = *c;
@@ -250,8 +288,8 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     o.jnt_type[j] = m->jnt_type[j]; o.jnt_qposadr[j] = m->jnt_qposadr[j]; o.jnt_dofadr[j] = m->jnt_dofadr[j];
     o.jnt_bodyid[j] = m->jnt_bodyid[j]; o.jnt_margin[j] = m->jnt_margin[j];
     for (int k = 0; k < 3; k++) { o.jnt_pos[j][k] = m->jnt_pos[j][k]; o.jnt_axis[j][k] = m->jnt_axis[j][k]; }
-    for (int k = 0; k < 2; k++) { o.jnt_range[j][k] = m->jnt_range[j][k]; o.jnt_solref[j][k] = m->jnt_solref[j][k]; }
-    for (int k = 0; k < 5; k++) o.jnt_solimp[j][k] = m->jnt_solimp[j][k];
+    for (int k = 0; k < 2; k++) o.jnt_range[j][k] = m->jnt_range[j][k];
+    o.jnt_kbi[j] = 0;
   }
   for (int i = 0; i < m->nq; i++) o.qpos0[i] = m->qpos0[i];
   for (int i = 0; i < m->nv; i++) {
@@ -302,8 +340,31 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
   for (int cidx = 0; cidx < m->ncon; cidx++) {
     o.con_kind[cidx] = m->con_kind[cidx]; o.con_geom1[cidx] = m->con_geom1[cidx]; o.con_geom2[cidx] = m->con_geom2[cidx];
     o.con_body1[cidx] = m->con_body1[cidx]; o.con_body2[cidx] = m->con_body2[cidx]; o.con_margin[cidx] = m->con_margin[cidx];
-    for (int k = 0; k < 5; k++) { o.con_friction[cidx][k] = m->con_friction[cidx][k]; o.con_solimp[cidx][k] = m->con_solimp[cidx][k]; }
-    for (int k = 0; k < 2; k++) o.con_solref[cidx][k] = m->con_solref[cidx][k];
+    for (int k = 0; k < 5; k++) o.con_friction[cidx][k] = m->con_friction[cidx][k];
+    {   // constraint._efc_contact_pyramidal / _elliptic: the rows' inverse weights, in the reference's own order of operations
+      const float t = m->body_invweight0[m->con_body1[cidx]][0] + m->body_invweight0[m->con_body2[cidx]][0], mu = m->con_friction[cidx][0];
+      if constexpr (D::ell) { o.con_invw[cidx][0] = t; o.con_invw[cidx][1] = t / m->impratio; }
+      else {
+        float invweight = t + mu * mu * t;
+        invweight = invweight * 2.f * mu * mu / m->impratio;
+        o.con_invw[cidx][0] = invweight;
+      }
+    }
+  }
+  {   // the impedance table: one row per distinct (solref, solimp) among the limit rows, the contacts and the dry-friction rows
+    int n = 0;
+    float ref[CModel<D>::NKBI][7];
+    const auto intern = [&](const float* solref, const float* solimp) -> uint8_t {
+      float key[7] = {solref[0], solref[1], solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
+      for (int r = 0; r < n; r++) if (memcmp(ref[r], key, sizeof(key)) == 0) return (uint8_t)r;
+      if (n >= CModel<D>::NKBI) return 0;   // (dial_create has checked kbi_unique_rows() against the instantiation's capacity)
+      memcpy(ref[n], key, sizeof(key));
+      kbi_row(o.kbi_tab[n], solref, solimp, m->timestep);
+      return (uint8_t)n++;
+    };
+    for (int l = 0; l < m->nlim; l++) { const int j = m->lim_jnt[l]; o.jnt_kbi[j] = intern(m->jnt_solref[j], m->jnt_solimp[j]); }
+    for (int c = 0; c < m->ncon; c++) o.con_kbi[c] = intern(m->con_solref[c], m->con_solimp[c]);
+    if constexpr (D::gen) for (int q = 0; q < m->nfri && q < DIAL_MAX_FRI; q++) o.fri_kbi[q] = intern(m->fri_solref[q], m->fri_solimp[q]);
   }
   o.cone = m->cone; o.eulerdamp = m->eulerdamp;
   if constexpr (D::gen) {
@@ -320,8 +381,6 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int q = 0; q < m->nfri && q < DIAL_MAX_FRI; q++) {
       o.fri_dof[q] = m->fri_dof[q]; o.fri_loss[q] = m->fri_loss[q];
       o.dof_frirow[m->fri_dof[q]] = m->nlim + q;
-      for (int k = 0; k < 2; k++) o.fri_solref[q][k] = m->fri_solref[q][k];
-      for (int k = 0; k < 5; k++) o.fri_solimp[q][k] = m->fri_solimp[q][k];
     }
     for (int f = 0; f < 2; f++) { o.pc_wanted[f] = t->pc_wanted[f]; for (int k = 0; k < 2; k++) o.pc_foot_contact[f][k] = t->pc_foot_contact[f][k]; }
     o.pc_n_unwanted = t->pc_n_unwanted;

@@ -573,14 +573,17 @@ int dial_create_ex(dial_ctx** out, const dial_model* model, const dial_task* tas
     };
     int urc;
     const auto kind_ok = [&](uint32_t mask) { return ((mask >> task->kind) & 1u) != 0; };   // the robot's own task kinds only
-    const bool own = !opt.force_generic;   // the robot's own dimension-specialised instantiation (default)
+    // the robot's own dimension-specialised instantiation (default) -- unless the model has more distinct (solref, solimp) rows than
+    // their impedance table holds (CModel::kbi_tab; the shipped robots have two or three)
+    const bool kbi_ok = kbi_unique_rows(model) <= DIAL_KBI_ROWS;
+    const bool own = !opt.force_generic && kbi_ok;
     // (Dims::pre_ctrl instantiations run ONE physics step per control step -- every shipped Go2 task; another ratio: the capacity-dimension kernel)
     if (own && dims_match<DimsGo2>(model) && derived_fits<DimsGo2>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsGo2>()) &&
         (!DimsGo2::pre_ctrl || task->n_frames == 1)) { ctx->inst = 1; ctx->wpb = 1; urc = upload(DimsGo2{}); }
     else if (own && dims_match<DimsH1>(model) && derived_fits<DimsH1>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1>())) { ctx->inst = 2; ctx->wpb = 3; urc = upload(DimsH1{}); }
     else if (own && dims_match<DimsH1Loco>(model) && derived_fits<DimsH1Loco>(&ctx->hd) && kind_ok(dial::task_kind_mask<DimsH1Loco>())) { ctx->inst = 3; ctx->wpb = 2; urc = upload(DimsH1Loco{}); }
     else if (model->cone == DIAL_CONE_ELLIPTIC) {
-      if (!(dims_match<DimsAllegro>(model) && ell_fits<DimsAllegro>(model, &ctx->hd))) {
+      if (!(kbi_ok && dims_match<DimsAllegro>(model) && ell_fits<DimsAllegro>(model, &ctx->hd))) {
         dial_destroy(ctx);
         return fail(nullptr, DIAL_ERR_UNSUPPORTED, "dial_create: elliptic-cone models need a dimension-specialised instantiation (built: Allegro hand)");
       }

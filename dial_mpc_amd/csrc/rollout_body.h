@@ -140,25 +140,22 @@ DIAL_DEV void solve_spd(W& w, const M* m, const Ws& s, const float* A, float* rh
 }
 
 // ---------------------------------------------------------------- constraint._kbi
-template <class M>
-DIAL_DEV void kbi(const M* m, const float* solref, const float* solimp, float pos, float& k, float& b,
-                  float& imp) {
-  float timeconst = dm::fmaxf_(solref[0], 2.f * m->timestep), dampratio = solref[1];
-  float dmin = dm::clip(solimp[0], MJ_MINIMP, MJ_MAXIMP), dmax = dm::clip(solimp[1], MJ_MINIMP, MJ_MAXIMP);
-  float width = dm::fmaxf_(MJ_MINVAL, solimp[2]), mid = dm::clip(solimp[3], MJ_MINIMP, MJ_MAXIMP);
-  float power = dm::fmaxf_(1.f, solimp[4]);
-  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-  b = 2.f / (dmax * timeconst);
-  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
-  if (solref[1] <= 0.f) b = -solref[1] / dmax;
-  float x = dm::absf(pos) / width;
+// (round 6: k, b and the curve's constants come from the row's table -- CModel::kbi_tab, derived.h: kbi_row -- the
+//  per-step part is what depends on the position)
+DIAL_DEV void kbi(const float* t, float pos, float& k, float& b, float& imp) {
+  float t0, t1, dmin, dmax, rwidth, mid, rmid, r1mm;
+  load4(t, t0, t1, dmin, dmax);
+  load4(t + 4, rwidth, mid, rmid, r1mm);
+  const float power = t[8];
+  k = t0; b = t1;
+  float x = dm::absf(pos) * rwidth;
   float ia, ib;
   if (power == 2.f) {          // MuJoCo's default solimp power: x^2 / mid, no transcendental needed
-    ia = (1.f / mid) * (x * x);
-    ib = 1.f - (1.f / (1.f - mid)) * ((1.f - x) * (1.f - x));
+    ia = rmid * (x * x);
+    ib = 1.f - r1mm * ((1.f - x) * (1.f - x));
   } else {
-    ia = (1.f / DM_POW(mid, power - 1.f)) * DM_POW(x, power);
-    ib = 1.f - (1.f / DM_POW(1.f - mid, power - 1.f)) * DM_POW(1.f - x, power);
+    ia = rmid * DM_POW(x, power);
+    ib = 1.f - r1mm * DM_POW(1.f - x, power);
   }
   float yv = x < mid ? ia : ib;
   float im = dmin + yv * (dmax - dmin);
@@ -385,7 +382,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         s.lsign[r] = sgn;
         if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
         float k_, b_, imp;
-        kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+        kbi(m->kbi_tab[m->jnt_kbi[ji]], pos, k_, b_, imp);
         const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
         s.aref[r] = -b_ * (sgn * s.qvel[da]) - k_ * imp * pos;
         s.D[r] = 1.f / R;
@@ -397,11 +394,10 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         return;
       }
       const float pos = s.cdist[c] - m->con_margin[c];
-      const float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
+      const float t = m->con_invw[c][0], iw1 = m->con_invw[c][1];   // (the bodies' inverse weights, summed | / impratio: derived.h)
       const float f0 = m->con_friction[c][0];
       float k_, b_, imp;
-      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
-      const float iw1 = t / m->impratio;
+      kbi(m->kbi_tab[m->con_kbi[c]], pos, k_, b_, imp);
       for (int j = 0; j < dim; j++) {
         float invw = j == 0 ? t : iw1;
         if (j >= 2) { const float fj = m->con_friction[c][j - 1]; invw = iw1 * (f0 * f0) / (fj * fj); }
@@ -422,7 +418,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       s.lsign[r] = sgn;
       if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
       float k_, b_, imp;
-      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      kbi(m->kbi_tab[m->jnt_kbi[ji]], pos, k_, b_, imp);
       float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
       float vel = sgn * s.qvel[da];
       s.aref[r] = -b_ * vel - k_ * imp * pos;
@@ -432,7 +428,7 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
         const int q = r - nl, da = m->fri_dof[q];
         s.lsign[r] = 1.f;
         float k_, b_, imp;
-        kbi(m, m->fri_solref[q], m->fri_solimp[q], 0.f, k_, b_, imp);
+        kbi(m->kbi_tab[m->fri_kbi[q]], 0.f, k_, b_, imp);
         const float R = dm::fmaxf_(m->dof_invweight0[da] * (1.f - imp) / imp, MJ_MINVAL);
         s.aref[r] = -b_ * s.qvel[da];
         s.D[r] = 1.f / R;
@@ -442,12 +438,9 @@ DIAL_DEV void forward_constraints(W& w, const M* m, const Ws& s, int nca, int ne
       s.lsign[r] = 0.f;
       float pos = s.cdist[c] - m->con_margin[c];
       if (!(pos < 0.f)) { s.D[r] = 0.f; s.aref[r] = 0.f; return; }
-      float t = m->body_invweight0[m->con_body1[c]] + m->body_invweight0[m->con_body2[c]];
-      float mu = m->con_friction[c][0];
-      float invweight = t + mu * mu * t;
-      invweight = invweight * 2.f * mu * mu / m->impratio;
+      const float invweight = m->con_invw[c][0];   // (_efc_contact_pyramidal's row weight: a model constant, derived.h)
       float k_, b_, imp;
-      kbi(m, m->con_solref[c], m->con_solimp[c], pos, k_, b_, imp);
+      kbi(m->kbi_tab[m->con_kbi[c]], pos, k_, b_, imp);
       float R = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
       float vel;
       if constexpr (M::D::square) {

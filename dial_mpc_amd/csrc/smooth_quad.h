@@ -343,11 +343,9 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       if (d != 3) return;
       const float mu1 = m->con_friction[r][0], mu2 = m->con_friction[r][1];
       const float pos = lane_val(CP[3], l) - m->con_margin[r];
-      const float t = m->body_invweight0[m->con_body1[r]] + m->body_invweight0[m->con_body2[r]];
-      float invweight = t + mu1 * mu1 * t;
-      invweight = invweight * 2.f * mu1 * mu1 / m->impratio;
+      const float invweight = m->con_invw[r][0];   // (_efc_contact_pyramidal's row weight: a model constant, derived.h)
       float k_, b_, imp;
-      kbi(m, m->con_solref[r], m->con_solimp[r], pos, k_, b_, imp);
+      kbi(m->kbi_tab[m->con_kbi[r]], pos, k_, b_, imp);
       const float Rr = dm::fmaxf_(invweight * (1.f - imp) / imp, MJ_MINVAL);
       const float va[3] = {lane_val(VA[0], l), lane_val(VA[1], l), lane_val(VA[2], l)};
       const float off[3] = {lane_val(CP[0], l) - com[0], lane_val(CP[1], l) - com[1], lane_val(CP[2], l) - com[2]};
@@ -373,7 +371,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       const float pos = dm::fminf_(dist_min, dist_max) - m->jnt_margin[ji];
       const float sgn = dist_min < dist_max ? 1.f : -1.f;
       float k_, b_, imp;
-      kbi(m, m->jnt_solref[ji], m->jnt_solimp[ji], pos, k_, b_, imp);
+      kbi(m->kbi_tab[m->jnt_kbi[ji]], pos, k_, b_, imp);
       const float Rr = dm::fmaxf_(m->dof_invweight0[i] * (1.f - imp) / imp, MJ_MINVAL);
       const bool on = pos < 0.f;
       s.lsign[lr] = sgn;

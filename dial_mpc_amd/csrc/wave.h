@@ -55,6 +55,7 @@ inline float bcast(const vfloat& v, int lane) { return v.x[lane]; }
 inline float lane_val(const vfloat& v, int lane) { return v.x[lane]; }
 // two consecutive floats from an 8-byte aligned address (one ds_read_b64 on the GPU)
 inline void load2(const float* p, float& a, float& b) { a = p[0]; b = p[1]; }
+inline void load4(const float* p, float& a, float& b, float& c, float& d) { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
 // two / four consecutive floats to an 8- / 16-byte aligned address (one ds_write_b64 / b128 on the GPU)
 inline void store2(float* p, float a, float b) { p[0] = a; p[1] = b; }
 inline void store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
@@ -384,6 +385,7 @@ __device__ __forceinline__ float bcast(vfloat v, int lane) {
 }
 __device__ __forceinline__ float lane_val(vfloat v, int) { return v; }
 __device__ __forceinline__ void load2(const float* p, float& a, float& b) { const float2 t = *reinterpret_cast<const float2*>(p); a = t.x; b = t.y; }
+__device__ __forceinline__ void load4(const float* p, float& a, float& b, float& c, float& d) { const float4 t = *reinterpret_cast<const float4*>(p); a = t.x; b = t.y; c = t.z; d = t.w; }
 __device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }

@@ -800,7 +800,9 @@ def test_default_rule_distribution_parity_full_size(example, N, H):
     ctx = _lib.Context(model, task, cfg)
     trace_dev = ctx.set_state_trace(N + 1)          # the device's own packed state after every env.step (diagnostics)
     o32 = O.Oracle(model, task, cfg, np.float32)
-    for seed in (0, 1):
+    # (the Allegro from its example's initial state only: a seed is 48 s of oracle time on the GPU box's host cores, and its perturbed states
+    #  are the subject of test_stress_parity_perturbed_states and test_full_size_oracle_parity; the suite's budget is 420 s)
+    for seed in ((0,) if example == "allegro_reorient" else (0, 1)):
         q, qd = (env._init_q, np.zeros(model.nv)) if seed == 0 else perturbed_state(env, seed)
         s0, _, _ = o32.env_reset(q, qd)
         eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=seed, Ybar_scale=0.2)
