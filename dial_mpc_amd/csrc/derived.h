@@ -8,6 +8,7 @@
 
 #define DIAL_MAX_TRI ((DIAL_MAX_V * (DIAL_MAX_V + 1)) / 2)
 #define DIAL_MAX_HITEM 512
+#define DIAL_ZTAB_W 8   /* words per control step of Ws::ztab */
 
 struct dial_derived {
   int32_t nlevel;                          // max body depth
@@ -332,6 +333,10 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 3; k++) { o.geom_pos[g][k] = m->geom_pos[g][k]; o.geom_size[g][k] = m->geom_size[g][k]; }
     for (int k = 0; k < 4; k++) o.geom_quat[g][k] = m->geom_quat[g][k];
   }
+  {   // (math.quat_to_3x3's third column, dmath.h: quat_to_mat)
+    const float w = m->geom_quat[0][0], x = m->geom_quat[0][1], y = m->geom_quat[0][2], z = m->geom_quat[0][3];
+    o.geom0_normal[0] = 2.f * (x * z + w * y); o.geom0_normal[1] = 2.f * (y * z - w * x); o.geom0_normal[2] = w * w - x * x - y * y + z * z;
+  }
   for (int s = 0; s < m->nsite; s++) {
     o.site_bodyid[s] = m->site_bodyid[s];
     for (int k = 0; k < 3; k++) o.site_pos[s][k] = m->site_pos[s][k];
@@ -458,8 +463,9 @@ struct Ws {
   float* ovf;
   int con_cap;
   // control tables of a whole rollout, built once in its prologue (rollout_driver.h; instantiations with Dims::pre_ctrl):
-  // jtab[t * nu + a] = the joint target act2joint(u_t)[a] of control step t, ztab[t * DIAL_MAX_FEET + f] = the gait clock's foot
-  // height of step t -- neither depends on the state, so K2 / act2joint / get_foot_step leave the per-step dependence chain
+  // jtab[t * nu + a] = the joint target act2joint(u_t)[a] of control step t, ztab[t * DIAL_ZTAB_W + f] = the gait clock's foot
+  // height of step t (f < 4) and the step's ramped velocity targets (4, 5: v_x, v_y; 6: yaw rate; 7: yaw) -- none depends on the
+  // state, so K2 / act2joint / get_foot_step / the ramps leave the per-step dependence chain
   float *jtab, *ztab;
 };
 
@@ -524,7 +530,7 @@ WS_HD int ws_carve(Ws& s, float* base, int nq, int nv, int nu, int nbody, int nj
   WS_TAKE(H, ntri) WS_TAKE(jv, nefc) WS_TAKE(frc, nefc + 4)
   // `tab_steps` = T (instantiations whose position / velocity stage runs in registers and touches none of the A1 temporaries this
   // region aliases -- Dims::pre_ctrl --, else 0): the rollout's control tables live behind the solver's arrays for its whole length
-  WS_TAKE(jtab, tab_steps * nu) WS_TAKE(ztab, tab_steps * DIAL_MAX_FEET)
+  WS_TAKE(jtab, tab_steps * nu) WS_TAKE(ztab, tab_steps * DIAL_ZTAB_W)
   WS_TAKE(cwd, ell * ncon * 6) WS_TAKE(cwa, ell * ncon * 6) WS_TAKE(cwb, ell * ncon * 6) WS_TAKE(ccf, ell * ncon * 4)
   WS_TAKE(vec0, ell * nv) WS_TAKE(vec1, ell * nv)
   const int ls = with_L ? 1 : 0;   // the rest is LDS-solver state; the register solver keeps it in VGPRs

@@ -1920,7 +1920,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
           float reward_gaits = 0.f;
   #pragma unroll
           for (int f = 0; f < NF; f++) {
-            const float z_tar = PRE ? s.ztab[st * DIAL_MAX_FEET + f] : s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];   // (PRE: the rollout's gait-clock table)
+            const float z_tar = PRE ? s.ztab[st * DIAL_ZTAB_W + f] : s.ztar[f], zs = s.spos[3 * m->feet_site[f] + 2];   // (PRE: the rollout's gait-clock table)
             float fz;
             if (kind == DIAL_TASK_GO2_WALK) {
               float e = (z_tar - zs) / 0.05f;
@@ -1973,9 +1973,14 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
         float rot_t[4] = {tq[0], tq[1], tq[2], tq[3]};
         const float yaw = quat_yaw(rot_t);
         if (walk) {
-          const float a2 = cmd[5];
-          const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
-          const float d_yaw = yaw - (yaw_tar0 + avt * dt * step);
+          float yaw_tar;
+          if constexpr (PRE) yaw_tar = s.ztab[st * DIAL_ZTAB_W + DIAL_MAX_FEET + 3];   // (the rollout's table of ramped targets)
+          else {
+            const float a2 = cmd[5];
+            const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+            yaw_tar = yaw_tar0 + avt * dt * step;
+          }
+          const float d_yaw = yaw - yaw_tar;
           // atan2(sin d, cos d) wraps d to (-pi, pi]; d - 2 pi rint(d / 2 pi) is the same angle without trig
           const float wy = d_yaw - 6.283185307179586f * DM_RINT(d_yaw * 0.15915494309189535f);
           out = -(wy * wy);
@@ -1994,7 +1999,10 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
             for (int k = 0; k < 3; k++) vel[k] = tv[3 + k] - cr[k];
             dm::inv_rotate(vb, vel, rot_t);
             float vt[2];
-            for (int k = 0; k < 2; k++) { const float v = cmd[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+            for (int k = 0; k < 2; k++) {
+              if constexpr (PRE) vt[k] = s.ztab[st * DIAL_ZTAB_W + DIAL_MAX_FEET + k];
+              else { const float v = cmd[k]; vt[k] = dm::fminf_(v * step * dt / m->ramp_up_time, v); }
+            }
             const float e0 = vb[0] - vt[0], e1 = vb[1] - vt[1];
             out = -(e0 * e0 + e1 * e1);
           } else {
@@ -2009,8 +2017,10 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
               }
               out = -e3;
             } else {
-              const float a2 = cmd[5];
-              const float ea = ab[2] - dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+              float avt;
+              if constexpr (PRE) avt = s.ztab[st * DIAL_ZTAB_W + DIAL_MAX_FEET + 2];
+              else { const float a2 = cmd[5]; avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2); }
+              const float ea = ab[2] - avt;
               out = -(ea * ea);
             }
           }
@@ -2072,7 +2082,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
       // this step's velocity command, once for all terms (randomize_tasks: the episode's draw -- the only branch left
       // between here and the end of the phase)
       float cmd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (walk) step_cmd(m, tg, info[DIAL_INFO_STEP], cmd);
+      if (walk && !PRE) step_cmd(m, tg, info[DIAL_INFO_STEP], cmd);   // (PRE: the targets come from the rollout's table)
       float r[9];
       r[0] = term(std::integral_constant<int, 0>{}, cmd);
       r[1] = term(std::integral_constant<int, 1>{}, cmd);
@@ -2098,7 +2108,7 @@ DIAL_DEV float env_step(W& w, const M* m, const dial_task* tg, const Ws& s, int 
       } else {                                      // unitree_go2_env.py:485-496
         reward = r[3] * 1.0f + r[1] * 1.0f + r[2] * 0.3f + r[0] * 0.1f - r[4] * 0.1f + 1.0f * 10.0f;
       }
-      if (walk) {
+      if (walk && !PRE) {   // (info.vel_tar / ang_vel_tar: written for the caller of env.step; no walking reward reads them back)
         for (int k = 0; k < 3; k++) {
           const float v = cmd[k], a = cmd[3 + k];
           info[DIAL_INFO_VEL_TAR + k] = dm::fminf_(v * step * dt / m->ramp_up_time, v);

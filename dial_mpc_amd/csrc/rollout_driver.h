@@ -187,9 +187,20 @@ DIAL_DEV void rollout_sample(W& w, const M* m, const dial_task* tg, const dial_c
     // the gait clock of this (piece of the) rollout: step counter of control step t = the counter now + (t - st_begin), exactly
     // (env.step adds 1.f per step); the mean trajectory's steps (helper) share the own rollout's counter, both start from io.state
     const bool walk = m->kind == DIAL_TASK_GO2_WALK || m->kind == DIAL_TASK_H1_WALK || m->kind == DIAL_TASK_H1_LOCO || m->kind == DIAL_TASK_H1_PUSH_CRATE;
-    if (walk) w.items((st_end - st_begin) * DIAL_MAX_FEET, [&](int it) {
-      const int dt_ = it / DIAL_MAX_FEET, f = it - dt_ * DIAL_MAX_FEET;
-      if (f < m->nfeet) s.ztab[(st_begin + dt_) * DIAL_MAX_FEET + f] = gait_ztar(m, f, s.info[DIAL_INFO_STEP] + (float)dt_);
+    // ... and the step's ramped velocity targets (unitree_go2_env.py:190-215; the expressions the reward lane evaluated in every step)
+    static_assert(DIAL_ZTAB_W == DIAL_MAX_FEET + 4, "ztab row: foot heights | v_x v_y yaw-rate yaw targets");
+    if (walk) w.items((st_end - st_begin) * DIAL_ZTAB_W, [&](int it) {
+      const int dt_ = it / DIAL_ZTAB_W, f = it - dt_ * DIAL_ZTAB_W;
+      const float step = s.info[DIAL_INFO_STEP] + (float)dt_;
+      float* row = s.ztab + (st_begin + dt_) * DIAL_ZTAB_W;
+      if (f < DIAL_MAX_FEET) { if (f < m->nfeet) row[f] = gait_ztar(m, f, step); return; }
+      float cmd[6];
+      step_cmd(m, tg, step, cmd);
+      const float dt = m->dt;
+      if (f < DIAL_MAX_FEET + 2) { const float v = cmd[f - DIAL_MAX_FEET]; row[f] = dm::fminf_(v * step * dt / m->ramp_up_time, v); return; }
+      const float a2 = cmd[5];
+      const float avt = dm::fminf_(a2 * step * dt / m->ramp_up_time, a2);
+      row[f] = f == DIAL_MAX_FEET + 2 ? avt : s.info[DIAL_INFO_YAW_TAR] + avt * dt * step;
     });
   }
   // element i of the packed state [qpos | qvel | qacc_warmstart | info] in the LDS workspace

@@ -302,13 +302,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
   //     are structural zeros written once per kernel (init_quad);
   //   * leg lanes: their joint's limit row.
   if constexpr (FUSED) {
-    float pn[3];
-    {
-      const float gq[4] = {m->geom_quat[0][0], m->geom_quat[0][1], m->geom_quat[0][2], m->geom_quat[0][3]};
-      float mat[9];
-      dm::quat_to_mat(mat, gq);
-      pn[0] = mat[2]; pn[1] = mat[5]; pn[2] = mat[8];
-    }
+    const float pn[3] = {m->geom0_normal[0], m->geom0_normal[1], m->geom0_normal[2]};   // (the floor's normal: a model constant, derived.h)
     const float fr[9] = {s.cframe[0], s.cframe[1], s.cframe[2], s.cframe[3], s.cframe[4], s.cframe[5], s.cframe[6], s.cframe[7], s.cframe[8]};
     vfloat CP[4];   // contact point (3), distance
     w.per_lane_n(CP, [&](int l, float* o) {
