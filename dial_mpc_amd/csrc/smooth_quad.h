@@ -211,13 +211,16 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     float velT[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};
     float accT[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
     for (int j = 0; j < 3; j++) {
-      float cdd[6];
-      dm::motion_cross(cdd, vs, cdT[j]);
-      for (int k = 0; k < 6; k++) { accT[k] += cdd[k] * qv[3 + j]; velT[k] += cdT[j][k] * qv[3 + j]; }
+      // cdof_dot of the trunk's rotational dof j = motion_cross(vs, cdof): vs has no angular part, so it is (0, vs.lin x cdof.ang).
+      // (Spelled out: handed the explicit zeros the compiler kept their SIGNS alive -- fifteen v_bfi copysigns and a dozen
+      //  subtractions of signed zeros per step, in every lane.)
+      float cl[3];
+      dm::cross3(cl, vs + 3, cdT[j]);
+      for (int k = 0; k < 3; k++) accT[3 + k] += cl[k] * qv[3 + j];
+      for (int k = 0; k < 6; k++) velT[k] += cdT[j][k] * qv[3 + j];
     }
     w.per_lane_n(VA, [&](int l, float* o) {
-      const bool trunk = (l & 15) == 0;
-      for (int k = 0; k < 6; k++) { o[k] = trunk ? velT[k] : 0.f; o[6 + k] = trunk ? accT[k] : 0.f; }
+      for (int k = 0; k < 6; k++) { o[k] = velT[k]; o[6 + k] = accT[k]; }   // the trunk's, in EVERY lane: the sums below start from it
     });
   }
   const vfloat QVL = w.per_lane([&](int l) {
@@ -225,28 +228,24 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     const bool leg = d >= 1 && d <= 3, tdof = r == 0 && d >= 4 && d <= 9;
     return s.qvel[leg ? 3 * r + d + 5 : (tdof ? d - 4 : 0)];   // this dof lane's velocity
   });
-  // Round 6: the same recurrences -- cvel_d = cvel_{d-1} + cdof_d qvel_d, cdof_dot_d = cvel_{d-1} x cdof_d, cacc_d = cacc_{d-1} +
-  // cdof_dot_d qvel_d -- as two sweeps with the motion cross product formed ONCE in between, from the parent's final velocity,
-  // instead of in every round of one combined sweep (a lane at depth d recomputed it three times, twice from a velocity that was
-  // not final yet): 42 vector instructions less per step.  Same operands, same expressions, same contraction: bit-identical.
-  // (Also tried: the products cdof qvel / cdof_dot qvel formed once and rounded before the additions -- one v_add_f32_dpp per
-  //  component and round, 60 instructions less, headline kernel 0.349 -> 0.344 ms -- but the product build's rounding lottery then
-  //  drew a seq-jump batch that left the distribution gate; not kept.)
+  // The recurrences cvel_d = cvel_{d-1} + cdof_d qvel_d, cdof_dot_d = cvel_{d-1} x cdof_d, cacc_d = cacc_{d-1} + cdof_dot_d qvel_d down a
+  // leg of depth 3.  Round 6, second form: a lane at depth d needs trunk + P_{d-2} + P_{d-1} + P_d with P = cdof qvel of the lanes below
+  // it in its row -- the products are formed ONCE (zero outside the leg lanes) and added through two DPP-operand additions (row_shr:2,
+  // row_shr:1: both read the products themselves, no round waits for the one before) and one multiply-add, in the order the recurrence
+  // adds them: 25 vector instructions per sweep where three rounds of shift + multiply-add + select were 54.  The ancestors' products
+  // are rounded before they are added (they were fused into their own lanes' sums): rounding level, covered by the oracle parity tests.
   {
-    DIAL_UNROLL_FULL
-    for (int it = 0; it < 3; it++) {
-      vfloat Q[6], N[6];
+    const vfloat QL = w.per_lane([&](int l) { const int d = l & 15; return (d >= 1 && d <= 3) ? lane_val(QVL, l) : 0.f; });
+    const auto chain_sum = [&](vfloat* acc, const vfloat* cd) {   // acc[k] (the trunk's value in every lane) -> the body's, leg lanes
+      vfloat P[6], P1[6], P2[6];
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) Q[k] = w.template row_shr<1>(VA[k]);
-      w.per_lane_n(N, [&](int l, float* o) {
-        const int d = l & 15;
-        const bool leg = d >= 1 && d <= 3;
-        const float qv = lane_val(QVL, l);
-        for (int k = 0; k < 6; k++) { const float v = lane_val(Q[k], l) + lane_val(CD[k], l) * qv; o[k] = leg ? v : lane_val(VA[k], l); }
-      });
+      for (int k = 0; k < 6; k++) P[k] = cd[k] * QL;
       DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) VA[k] = N[k];
-    }
+      for (int k = 0; k < 6; k++) { P2[k] = w.template row_shr<2>(P[k]); P1[k] = w.template row_shr<1>(P[k]); }
+      DIAL_UNROLL_FULL
+      for (int k = 0; k < 6; k++) acc[k] = vfma(cd[k], QL, (acc[k] + P2[k]) + P1[k]);
+    };
+    chain_sum(VA, CD);
     vfloat VP[6], CDD[6];   // the parent's (final) velocity; cdof_dot
     DIAL_UNROLL_FULL
     for (int k = 0; k < 6; k++) VP[k] = w.template row_shr<1>(VA[k]);
@@ -255,20 +254,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
       const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
       dm::motion_cross(o, vp, cd);
     });
-    DIAL_UNROLL_FULL
-    for (int it = 0; it < 3; it++) {
-      vfloat Q[6], N[6];
-      DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) Q[k] = w.template row_shr<1>(VA[6 + k]);
-      w.per_lane_n(N, [&](int l, float* o) {
-        const int d = l & 15;
-        const bool leg = d >= 1 && d <= 3;
-        const float qv = lane_val(QVL, l);
-        for (int k = 0; k < 6; k++) { const float a = lane_val(Q[k], l) + lane_val(CDD[k], l) * qv; o[k] = leg ? a : lane_val(VA[6 + k], l); }
-      });
-      DIAL_UNROLL_FULL
-      for (int k = 0; k < 6; k++) VA[6 + k] = N[k];
-    }
+    chain_sum(VA + 6, CDD);
   }
   // the bodies' outputs are complete: stored now (fewer registers to carry through the rest of the stage)
   // (Dims::pre_ctrl rollouts: this control step's x.pos row goes to HBM from here -- Wave::out_io -- not from a phase of its own)

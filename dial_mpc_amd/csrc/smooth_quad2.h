@@ -195,14 +195,14 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     const float vs[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};   // the rotational dofs see the velocity after the translational ones
     float velT[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};
     float accT[6] = {0.f, 0.f, 0.f, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
-    for (int j = 0; j < 3; j++) {
-      float cdd[6];
-      dm::motion_cross(cdd, vs, cdT[j]);
-      for (int k = 0; k < 6; k++) { accT[k] += cdd[k] * qv[3 + j]; velT[k] += cdT[j][k] * qv[3 + j]; }
+    for (int j = 0; j < 3; j++) {   // (vs has no angular part: cdof_dot = (0, vs.lin x cdof.ang), spelled out -- see smooth_quad.h)
+      float cl[3];
+      dm::cross3(cl, vs + 3, cdT[j]);
+      for (int k = 0; k < 3; k++) accT[3 + k] += cl[k] * qv[3 + j];
+      for (int k = 0; k < 6; k++) velT[k] += cdT[j][k] * qv[3 + j];
     }
     w.per_lane_n(VA, [&](int l, float* o) {
-      const bool trunk = (l & 7) == 0;
-      for (int k = 0; k < 6; k++) { o[k] = trunk ? velT[k] : 0.f; o[6 + k] = trunk ? accT[k] : 0.f; }
+      for (int k = 0; k < 6; k++) { o[k] = velT[k]; o[6 + k] = accT[k]; }   // the trunk's, in EVERY lane: the sums below start from it
     });
   }
   const vfloat QVL = w.per_lane([&](int l) {
@@ -210,27 +210,29 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
     const bool leg = d >= 1 && d <= 3, mrow = (g == 0 && d >= 4 && d <= 6) || (d == 7 && g < 3);
     return s.qvel[leg ? 3 * g + d + 5 : (mrow ? (d == 7 ? g : d - 1) : 0)];   // this dof lane's velocity
   });
-  DIAL_UNROLL_FULL
-  for (int it = 0; it < 3; it++) {
-    vfloat Q[12], N[12];
+  // the leg recurrences as sums of the products of the lanes below (smooth_quad.h has the account; the same expressions, so that the
+  // two kernels stay bit-identical in the strict-IEEE build: a leg's lanes d = 1 .. 3 sit above a lane whose product is zero here too)
+  {
+    const vfloat QL = w.per_lane([&](int l) { const int d = l & 7; return (d >= 1 && d <= 3) ? lane_val(QVL, l) : 0.f; });
+    const auto chain_sum = [&](vfloat* acc, const vfloat* cd) {
+      vfloat P[6], P1[6], P2[6];
+      DIAL_UNROLL_FULL
+      for (int k = 0; k < 6; k++) P[k] = cd[k] * QL;
+      DIAL_UNROLL_FULL
+      for (int k = 0; k < 6; k++) { P2[k] = w.template row_shr<2>(P[k]); P1[k] = w.template row_shr<1>(P[k]); }
+      DIAL_UNROLL_FULL
+      for (int k = 0; k < 6; k++) acc[k] = vfma(cd[k], QL, (acc[k] + P2[k]) + P1[k]);
+    };
+    chain_sum(VA, CD);
+    vfloat VP[6], CDD[6];
     DIAL_UNROLL_FULL
-    for (int k = 0; k < 12; k++) Q[k] = w.template row_shr<1>(VA[k]);
-    w.per_lane_n(N, [&](int l, float* o) {
-      const int d = l & 7;
-      const bool leg = d >= 1 && d <= 3;
-      const float vp[6] = {lane_val(Q[0], l), lane_val(Q[1], l), lane_val(Q[2], l), lane_val(Q[3], l), lane_val(Q[4], l), lane_val(Q[5], l)};
+    for (int k = 0; k < 6; k++) VP[k] = w.template row_shr<1>(VA[k]);
+    w.per_lane_n(CDD, [&](int l, float* o) {
+      const float vp[6] = {lane_val(VP[0], l), lane_val(VP[1], l), lane_val(VP[2], l), lane_val(VP[3], l), lane_val(VP[4], l), lane_val(VP[5], l)};
       const float cd[6] = {lane_val(CD[0], l), lane_val(CD[1], l), lane_val(CD[2], l), lane_val(CD[3], l), lane_val(CD[4], l), lane_val(CD[5], l)};
-      const float qv = lane_val(QVL, l);
-      float cdd[6];
-      dm::motion_cross(cdd, vp, cd);
-      for (int k = 0; k < 6; k++) {
-        const float a = lane_val(Q[6 + k], l) + cdd[k] * qv, v = vp[k] + cd[k] * qv;
-        o[k] = leg ? v : lane_val(VA[k], l);
-        o[6 + k] = leg ? a : lane_val(VA[6 + k], l);
-      }
+      dm::motion_cross(o, vp, cd);
     });
-    DIAL_UNROLL_FULL
-    for (int k = 0; k < 12; k++) VA[k] = N[k];
+    chain_sum(VA + 6, CDD);
   }
   // the bodies' outputs are complete: stored now
   // (Dims::pre_ctrl rollouts: this control step's x.pos row goes to HBM from here -- Wave::out_io -- not from a phase of its own)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call s: ramped velocity targets in the control table + floor normal as a model constant -- Go2 parity tests + A/B against the build before
+# round 6, call s: Go2 changes -- parity tests + A/B against the build before (libdialhip_base.so)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; export GRAFT_REPO_ROOT=$ROOT; OUT=$ROOT/gpurun_out/r06s; mkdir -p $OUT; cd $ROOT
 timeout 900 python -m pytest tests -x -q -m gpu -k "go2 or Go2 or pair or sharded or planner or closed_loop or crate" > $OUT/pytest_go2.txt 2>&1; grep -E "passed|failed|error" $OUT/pytest_go2.txt | tail -4
