@@ -260,6 +260,7 @@ struct CModel : CModelGeneric<D_> {
   // ---- geoms / sites / contacts / limits / actuators
   int32_t geom_bodyid[D::NG];
   float geom_pos[D::NG][3], geom_quat[D::NG][4], geom_size[D::NG][3];
+  int32_t quad_site_is_geom;             // quadruped stage: every foot's site sits at its foot geom's centre (site_pos[1 + r] == geom_pos[1 + r]): one rotation serves both
   float geom0_normal[3];                 // third column of geom 0's rotation (the floor plane's normal: smooth_quad.h evaluated it per step)
   int32_t site_bodyid[D::NSA];
   float site_pos[D::NSA][3], site_quat[D::NSA][4];

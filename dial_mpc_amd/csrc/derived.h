@@ -333,6 +333,12 @@ static inline void fill_cmodel(CModel<D>* c, const dial_model* m, const dial_tas
     for (int k = 0; k < 3; k++) { o.geom_pos[g][k] = m->geom_pos[g][k]; o.geom_size[g][k] = m->geom_size[g][k]; }
     for (int k = 0; k < 4; k++) o.geom_quat[g][k] = m->geom_quat[g][k];
   }
+  o.quad_site_is_geom = 0;
+  if constexpr (D::quad_stage) {
+    bool same = m->nsite >= 5 && m->ngeom >= 5;
+    for (int r = 1; same && r <= 4; r++) for (int k = 0; k < 3; k++) same = same && m->site_pos[r][k] == m->geom_pos[r][k];
+    o.quad_site_is_geom = same ? 1 : 0;
+  }
   {   // (math.quat_to_3x3's third column, dmath.h: quat_to_mat)
     const float w = m->geom_quat[0][0], x = m->geom_quat[0][1], y = m->geom_quat[0][2], z = m->geom_quat[0][3];
     o.geom0_normal[0] = 2.f * (x * z + w * y); o.geom0_normal[1] = 2.f * (y * z - w * x); o.geom0_normal[2] = w * w - x * x - y * y + z * z;

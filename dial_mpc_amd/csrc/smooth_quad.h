@@ -22,6 +22,10 @@
 #include "derived.h"
 #include "dmath.h"
 
+#ifndef DIAL_NO_SITE_SHORTCUT
+#define DIAL_NO_SITE_SHORTCUT 0   /* measurement switch: rotate the foot geom's centre even when it is the foot site's */
+#endif
+
 namespace dial {
 
 template <class D>
@@ -102,6 +106,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
   DIAL_MARK(w, 0);
   // ---- local_to_global: inertial frames (all bodies), the foot geom and site (calf lanes), the trunk's site (trunk lanes)
   vfloat F[22];   // xipos(3) ximat(9) | mass-weighted xipos(3), mass | site(3) | foot geom centre(3)
+  const bool site_is_geom = FUSED && DM_UNIFORM_I(m->quad_site_is_geom) != 0 && !DIAL_NO_SITE_SHORTCUT;
   w.per_lane_n(F, [&](int l, float* o) {
     const int d = l & 15, r = l >> 4;
     const bool leg = d >= 1 && d <= 3, counted = leg || l == 0;
@@ -118,8 +123,11 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     dm::quat_to_mat(mat, qi);
     dm::rotate(ts, sp, q);
     if constexpr (FUSED) {
-      const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
-      dm::rotate(tg, gp, q);
+      if (site_is_geom) { tg[0] = ts[0]; tg[1] = ts[1]; tg[2] = ts[2]; }   // (the foot site IS the foot geom's centre: wave-uniform, one rotation less)
+      else {
+        const float gp[3] = {m->geom_pos[gs][0], m->geom_pos[gs][1], m->geom_pos[gs][2]};
+        dm::rotate(tg, gp, q);
+      }
     }
     for (int k = 0; k < 3; k++) {
       const float xi = p[k] + t3[k];
@@ -377,17 +385,18 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     for (int k = 0; k < 6; k++) X[10 + k] = T[k];
   }
   // ---- subtree sums (smooth.crb, rne backward): leaf-to-root along the legs, then the trunk = own + the four hips
-  DIAL_UNROLL_FULL
-  for (int it = 0; it < 2; it++) {
-    vfloat Q[16], N[16];
+  // Round 6, second form.  The lanes above a calf hold zeros, so with T = X + shl1(X) (thigh + calf in the thigh lane, the calf's own in
+  // the calf lane) R = X + shl1(T) is hip + (thigh + calf), thigh + calf, calf in the three leg lanes -- the association of the two
+  // masked rounds this replaces (bit-identical), as 32 DPP-operand additions instead of 2 x 16 x (shift, add, select).  The trunk
+  // copies (d = 0) and the lanes past the calf end up with sums nobody reads: the trunk's own terms are taken first.
+  float X0[16];   // the trunk's own terms, taken before the sums below overwrite lane 0
+  for (int k = 0; k < 16; k++) X0[k] = bcast(X[k], 0);
+  {
+    vfloat T[16];
     DIAL_UNROLL_FULL
-    for (int k = 0; k < 16; k++) Q[k] = w.template row_shl<1>(X[k]);
-    w.per_lane_n(N, [&](int l, float* o) {
-      const bool on = (l & 15) == 2 - it;
-      for (int k = 0; k < 16; k++) o[k] = on ? lane_val(X[k], l) + lane_val(Q[k], l) : lane_val(X[k], l);
-    });
+    for (int k = 0; k < 16; k++) T[k] = X[k] + w.template row_shl<1>(X[k]);
     DIAL_UNROLL_FULL
-    for (int k = 0; k < 16; k++) X[k] = N[k];
+    for (int k = 0; k < 16; k++) X[k] = X[k] + w.template row_shl<1>(T[k]);
   }
   float XT[16];   // the trunk's composite inertia and subtree force
   {
@@ -398,7 +407,7 @@ DIAL_DEV void forward_smooth_quad(W& w, const M* m, const Ws& s) {
     });
     float hs[16];
     w.vsumN(H, hs);
-    for (int k = 0; k < 16; k++) XT[k] = bcast(X[k], 0) + hs[k];
+    for (int k = 0; k < 16; k++) XT[k] = X0[k] + hs[k];
   }
   DIAL_MARK(w, 22);
   // ---- F_i = crb cdof_i, M = F . cdof over the ancestors (support.make_m), qfrc_smooth = passive - bias + actuator
