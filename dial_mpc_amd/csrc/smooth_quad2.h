@@ -355,7 +355,8 @@ DIAL_DEV void forward_smooth_quad2(W& w, const M* m, const Ws& s) {
   // ---- subtree sums (smooth.crb, rne backward): leaf-to-root along the legs, then the trunk = own + the four hips
   // Round 6, second form.  The lanes above a calf hold zeros, so with T = X + shl1(X) (thigh + calf in the thigh lane, the calf's own in
   // the calf lane) R = X + shl1(T) is hip + (thigh + calf), thigh + calf, calf in the three leg lanes -- the association of the two
-  // masked rounds this replaces (bit-identical), as 32 DPP-operand additions instead of 2 x 16 x (shift, add, select).  The trunk
+  // masked rounds this replaces, as 32 DPP-operand additions instead of 2 x 16 x (shift, add, select).  (Same sums on paper; the outputs
+  // of the two builds differ in the last bits of the laterally symmetric components -- tools/gpu/bit_compare_steps.py -- so: rounding level.)  The trunk
   // copies (d = 0) and the lanes past the calf end up with sums nobody reads: the trunk's own terms are taken first.
   float X0[16];   // the trunk's own terms (the row's lane 0), taken before the sums below overwrite that lane
   DIAL_UNROLL_FULL
