@@ -320,8 +320,8 @@ typedef struct dial_ctx dial_ctx; /* opaque; one per (device, model, task, cfg).
  * variables: the way a launch is put on the chip depends on (model, task, cfg, these options) and nothing else.        */
 typedef struct dial_options {
   int32_t force_generic;      /* 1: capacity-dimension (generic) kernel instantiation instead of the robot's own -- what a user model
-                                 that is none of the seven runs on.  Its price, measured once with the Go2 (round 6, N = 2048 H = 16): 1.087
-                                 ms per iteration against 0.363 ms on the robot's own kernel, i.e. 3.0 x (run-time dimensions, packed
+                                 that is none of the seven runs on.  Its price, measured once with the Go2 (round 6, N = 2048 H = 16): 1.076
+                                 ms per iteration against 0.347 ms on the robot's own kernel, i.e. 3.1 x (run-time dimensions, packed
                                  triangles, the LDS phase version of the position stage; profiles/r06_bench_go2_on_capacity_dimension_kernel.json) */
   int32_t con_cap;            /* generic instantiation, models with many candidate contacts: touching contacts the LDS
                                  workspace of a rollout wavefront holds (samples beyond run on an overflow area in global
