@@ -935,6 +935,50 @@ def test_async_planner_replay_matches_oracle_restatement():
             assert dev_k["acts"] <= 3e-3 and dev_k["tau"] <= 0.1 and dev_k["refs"] <= 3e-3, (dev_k, env_k)
 
 
+def test_impedance_table_rows_and_the_capacity_fallback():
+    """Round 6: constraint._kbi's constant part comes from a host-built table whose rows are shared by (solref, solimp) value
+    (CModel::kbi_tab, at most DIAL_KBI_ROWS = 8 in a robot's own instantiation).  (1) A Go2 whose limit rows use THREE distinct, non-default
+    parameter sets -- one with solimp power 3 (the transcendental branch) and one with a direct-stiffness solref (negative entries) --
+    still runs on its own kernel and matches the oracle, which evaluates _kbi per call from the raw parameters.  (2) Twelve distinct
+    sets exceed the table: dial_create falls back to the capacity-dimension kernel (another LDS footprint) and the results still match."""
+    import copy
+    import oracle as O
+    from dial_mpc_amd import _lib
+    dc, env, model0, task, cfg = setup_case("unitree_go2_trot", 64, 8, per_rollout=True)
+    ctx0 = _lib.Context(model0, task, cfg)
+    lds_own = ctx0.lib.dial_lds_bytes(ctx0.h)
+    del ctx0
+    for case in ("three sets", "twelve sets"):
+        model = copy.deepcopy(model0)
+        for l in range(model.nlim):
+            j = model.lim_jnt[l]
+            if case == "twelve sets":
+                model.jnt_solimp[j][0] = 0.9 - 0.002 * l          # every limited joint its own row
+            elif l % 3 == 1:
+                model.jnt_solimp[j][4] = 3.0                      # power 3: pow() branch
+                model.jnt_solimp[j][2] = 0.002
+            elif l % 3 == 2:
+                model.jnt_solref[j][0], model.jnt_solref[j][1] = -800.0, -40.0   # direct stiffness / damping
+        ctx = _lib.Context(model, task, cfg)
+        lds = ctx.lib.dial_lds_bytes(ctx.h)
+        assert (lds == lds_own) == (case == "three sets"), (case, lds, lds_own)
+        o32 = O.Oracle(model, task, cfg, np.float32)
+        # a state with several joints past their limits, so that the rows matter
+        q = np.array(env._init_q, np.float64)
+        for l in range(0, model.nlim, 2):
+            j = model.lim_jnt[l]
+            q[model.jnt_qposadr[j]] = model.jnt_range[j][1] + 0.02
+        s0, _, _ = o32.env_reset(q, np.zeros(model.nv))
+        eps, sigma, Ybar = seeded_inputs(dc, model.nu, seed=0)
+        ref = o32.reverse_once(s0, Ybar, sigma, eps, full=True)
+        out = ctx.reverse_once(_dev(s0), _dev(Ybar), _dev(sigma), _dev(eps))
+        err_r = float(np.abs(out["rews"].cpu().numpy() - ref["rews"]).max())
+        err_y = float(np.abs(out["Ybar"].cpu().numpy() - ref["Ybar"]).max())
+        print(f"{case}: LDS {lds} B (own kernel {lds_own}), max|rews - oracle| = {err_r:.3g}, max|Ybar - oracle| = {err_y:.3g}")
+        assert err_r < 1e-3 and err_y < 1e-3, (case, err_r, err_y)
+        del ctx
+
+
 @pytest.mark.parametrize("N,world", [(2048, 2), (2048, 4), (1001, 4), (37, 4), (5, 4), (2048, 1), (16384, 2)])
 def test_sharded_kernels_at_world_2_and_4_on_one_gpu(N, world):
     """The HIP kernels of the sharded path at world > 1, driven on ONE GPU: one dial_create_sharded context per pseudo-rank
