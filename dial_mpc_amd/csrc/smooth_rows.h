@@ -295,10 +295,11 @@ DIAL_DEV void forward_smooth_rows(W& w, const M* m, const Ws& s) {
     const float qv[6] = {s.qvel[0], s.qvel[1], s.qvel[2], s.qvel[3], s.qvel[4], s.qvel[5]};
     const float vs[6] = {0.f, 0.f, 0.f, qv[0], qv[1], qv[2]};   // the rotational dofs see the velocity after the translational ones
     for (int k = 0; k < 3; k++) { velT[k] = 0.f; velT[3 + k] = qv[k]; accT[k] = 0.f; accT[3 + k] = -m->gravity[k]; }
-    for (int j = 0; j < 3; j++) {
-      float cdd[6];
-      dm::motion_cross(cdd, vs, cdT[j]);
-      for (int k = 0; k < 6; k++) { accT[k] += cdd[k] * qv[3 + j]; velT[k] += cdT[j][k] * qv[3 + j]; }
+    for (int j = 0; j < 3; j++) {   // (vs has no angular part: cdof_dot = (0, vs.lin x cdof.ang), spelled out -- see smooth_quad.h)
+      float cl[3];
+      dm::cross3(cl, vs + 3, cdT[j]);
+      for (int k = 0; k < 3; k++) accT[3 + k] += cl[k] * qv[3 + j];
+      for (int k = 0; k < 6; k++) velT[k] += cdT[j][k] * qv[3 + j];
     }
   }
   w.per_lane_n(V, [&](int l, float* o) {
