@@ -358,7 +358,11 @@ typedef struct dial_options {
 } dial_options;
 
 /* host pointers; copies model/task/cfg to the device and allocates scratch for
- * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable. */
+ * cfg->Nsample+1 rollouts.  Fails with DIAL_ERR_HIP when no HIP device is usable.
+ * Which kernel instantiation runs is decided here from (model, task, options): the robot's own dimension-specialised one when the
+ * model matches it -- dimensions, topology, task kind, one physics step per control step for the Go2's, and at most eight distinct
+ * (solref, solimp) parameter sets among its limit rows / contacts / dry-friction rows (their impedance constants live in a shared
+ * table of the staged model constants) -- otherwise the capacity-dimension instantiation (options.force_generic has its price). */
 int dial_create(dial_ctx** out, const dial_model* model, const dial_task* task,
                 const dial_cfg* cfg, int device);
 /* Same, for one rank of a sample-sharded run: the rollout scratch is sized for n_local_cap (+1 mean-trajectory)
